@@ -1,0 +1,110 @@
+"""ctypes binding of libdqoraster.so (include/dqo_raster.h).  Shared by the drop-in packages in this directory.
+
+There is NO CPU fallback: if the HIP library is missing or a tensor is not on the GPU the call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdqoraster.so")
+
+c_f = ctypes.c_float
+c_i32 = ctypes.c_int32
+c_vp = ctypes.c_void_p
+
+
+class DqoRastParams(ctypes.Structure):
+    _fields_ = [("P", c_i32), ("D", c_i32), ("M", c_i32), ("W", c_i32), ("H", c_i32), ("prefiltered", c_i32), ("debug", c_i32),
+                ("tanfovx", c_f), ("tanfovy", c_f), ("cx", c_f), ("cy", c_f), ("scale_modifier", c_f), ("color_sigma", c_f),
+                ("opaque_threshold", c_f), ("depth_threshold", c_f), ("normal_threshold", c_f), ("T_threshold", c_f)]
+
+
+class DqoRastInputs(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("bg", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp",
+                                    "viewmatrix", "projmatrix", "campos", "tile_mask")]
+
+
+class DqoRastOutputs(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("out_color", "out_depth", "out_hit_color", "out_hit_depth", "out_hit_color_weight",
+                                    "out_hit_depth_weight", "out_T", "n_touched", "radii")]
+
+
+class DqoRastCtx(ctypes.Structure):
+    _fields_ = [("geom", c_vp), ("geom_bytes", ctypes.c_size_t), ("binning", c_vp), ("binning_bytes", ctypes.c_size_t),
+                ("image", c_vp), ("image_bytes", ctypes.c_size_t), ("inst_capacity", ctypes.c_int64)]
+
+
+class DqoRastGrads(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("dL_dmeans3D", "dL_dsh", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dcov3D",
+                                    "dL_dmeans2D")]
+
+
+class DqoRastHeader(ctypes.Structure):
+    _fields_ = [("num_rendered", ctypes.c_uint32), ("num_tiles", ctypes.c_uint32), ("overflow", ctypes.c_uint32),
+                ("max_tile_count", ctypes.c_uint32), ("num_visible", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3)]
+
+
+EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_rast_geom_bytes", "dqo_rast_image_bytes", "dqo_rast_binning_bytes",
+           "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
+           "dqo_rast_forward", "dqo_rast_backward", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
+           "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam")
+
+_lib = None
+
+
+def lib():
+    """Load libdqoraster.so (built by `make -C dqo-map_amd/csrc` / __graft_entry__.build()).  Fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()). "
+                               "There is no CPU fallback for this operator.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.dqo_last_error.restype = ctypes.c_char_p
+        for n in ("dqo_rast_geom_bytes", "dqo_rast_image_bytes", "dqo_rast_binning_bytes", "dqo_rast_backward_workspace_bytes",
+                  "dqo_knn3_workspace_bytes"):
+            getattr(L, n).restype = ctypes.c_size_t
+        L.dqo_rast_geom_bytes.argtypes = [c_i32, c_i32, c_i32]
+        L.dqo_rast_image_bytes.argtypes = [c_i32, c_i32]
+        L.dqo_rast_binning_bytes.argtypes = [ctypes.c_int64]
+        L.dqo_rast_backward_workspace_bytes.argtypes = [ctypes.c_int64]
+        L.dqo_knn3_workspace_bytes.argtypes = [c_i32]
+        P = ctypes.POINTER
+        L.dqo_rast_forward_prepare.argtypes = [P(DqoRastParams), P(DqoRastInputs), P(DqoRastOutputs), P(DqoRastCtx), c_vp]
+        L.dqo_rast_forward_render.argtypes = L.dqo_rast_forward_prepare.argtypes
+        L.dqo_rast_forward.argtypes = L.dqo_rast_forward_prepare.argtypes
+        L.dqo_rast_read_header.argtypes = [P(DqoRastCtx), P(DqoRastHeader), c_vp]
+        L.dqo_rast_backward.argtypes = [P(DqoRastParams), P(DqoRastInputs), P(DqoRastCtx), c_vp, c_vp, c_vp, P(DqoRastGrads), c_vp,
+                                        ctypes.c_size_t, c_vp]
+        L.dqo_mark_visible.argtypes = [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
+        L.dqo_knn3.argtypes = [c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
+        L.dqo_quadric_iou_fwd_bwd.argtypes = [c_i32] + [c_vp] * 12
+        L.dqo_quadric_adam.argtypes = [c_i32, c_i32] + [c_vp] * 9
+        if L.dqo_abi_version() != 1:
+            raise RuntimeError("libdqoraster.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().dqo_last_error().decode() or f"libdqoraster error {rc}")
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None / empty tensor -> NULL, like an empty tensor's data_ptr in the reference)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and t.numel() > 0 and not t.is_cuda:
+            raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path. Got a tensor on "
+                               f"{t.device}.")
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,174 @@
+// extern "C" entry points of libdqoraster.so (declared in include/dqo_raster.h): argument validation, buffer-size
+// queries and launches.  No allocation, no synchronisation (except dqo_rast_read_header), no exceptions.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "dqo_common.h"
+
+static thread_local char g_err[512] = "";
+
+void dqo_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int dqo_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s);
+int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void* ws, size_t ws_bytes, hipStream_t s);
+size_t dqo_knn3_ws_bytes(int P);
+int dqo_launch_quadric_iou(int B, const float* axes, const float* R, const float* center, const float* P34, const float* obs,
+                           float* bbox, float* loss, int32_t* valid, float* g_axes, float* g_R, float* g_center, hipStream_t s);
+int dqo_launch_quadric_adam(int n_obj, int n_iters, const int32_t* view_offset, const float* P34_views, const float* obs_views,
+                            const int32_t* view_schedule, float* axes, float* R, float* center, float* loss_hist, hipStream_t s);
+
+extern "C" {
+
+#define DQO_API __attribute__((visibility("default")))
+
+DQO_API int dqo_abi_version(void) { return DQO_ABI_VERSION; }
+DQO_API const char* dqo_last_error(void) { return g_err; }
+
+DQO_API size_t dqo_rast_geom_bytes(int32_t P, int32_t W, int32_t H) {
+    (void)W;
+    (void)H;
+    return dqo_geom_layout(nullptr, P < 0 ? 0 : P).total;
+}
+DQO_API size_t dqo_rast_image_bytes(int32_t W, int32_t H) { return dqo_image_layout(nullptr, W, H).total; }
+DQO_API size_t dqo_rast_binning_bytes(int64_t cap) { return dqo_bin_layout(nullptr, cap < 0 ? 0 : cap).total; }
+DQO_API size_t dqo_rast_backward_workspace_bytes(int64_t cap) { return sizeof(DqoGradRec) * (size_t)(cap < 0 ? 0 : cap) + 256; }
+
+static int check_common(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx) {
+    DQO_CHECK_ARG(p && in && ctx, "null params / inputs / ctx");
+    DQO_CHECK_ARG(p->P >= 0 && p->W > 0 && p->H > 0, "bad sizes P=%d W=%d H=%d", p->P, p->W, p->H);
+    DQO_CHECK_ARG(p->D >= 0 && p->D <= 3, "sh degree %d out of range 0..3", p->D);
+    DQO_CHECK_ARG((p->W + DQO_TILE - 1) / DQO_TILE < 65536 && (p->H + DQO_TILE - 1) / DQO_TILE < 65536, "image too large");
+    DQO_CHECK_ARG(in->viewmatrix && in->projmatrix && in->campos && in->bg, "viewmatrix/projmatrix/campos/bg must be given");
+    if (p->P > 0) {
+        DQO_CHECK_ARG(in->means3D && in->opacities, "means3D / opacities missing");
+        DQO_CHECK_ARG((in->shs != nullptr) != (in->colors_precomp != nullptr),
+                      "Please provide excatly one of either SHs or precomputed colors!");
+        DQO_CHECK_ARG(in->cov3D_precomp == nullptr,
+                      "cov3D_precomp is not supported by the depth rasteriser: its blend kernel reads scales/rotations (forward.cu:780)");
+        DQO_CHECK_ARG(in->scales && in->rotations, "scales and rotations are required");
+        if (in->shs) DQO_CHECK_ARG(p->M >= (p->D + 1) * (p->D + 1), "sh has %d coefficients, degree %d needs %d", p->M, p->D, (p->D + 1) * (p->D + 1));
+        if (in->colors_precomp == nullptr && p->M == 0) {
+            // rasterizer_impl.cu:267-270 analogue
+            dqo_set_error("For non-RGB, provide precomputed Gaussian colors!");
+            return DQO_ERR_INVALID_ARG;
+        }
+    }
+    DQO_CHECK_ARG(ctx->geom && ctx->geom_bytes >= dqo_rast_geom_bytes(p->P, p->W, p->H), "geom buffer too small (%zu < %zu)",
+                  ctx->geom_bytes, dqo_rast_geom_bytes(p->P, p->W, p->H));
+    DQO_CHECK_ARG(ctx->image && ctx->image_bytes >= dqo_rast_image_bytes(p->W, p->H), "image buffer too small (%zu < %zu)",
+                  ctx->image_bytes, dqo_rast_image_bytes(p->W, p->H));
+    return DQO_OK;
+}
+
+static int check_outputs(const DqoRastParams* p, const DqoRastOutputs* o) {
+    DQO_CHECK_ARG(o, "null outputs");
+    DQO_CHECK_ARG(o->out_color && o->out_depth && o->out_hit_color && o->out_hit_depth && o->out_hit_color_weight &&
+                      o->out_hit_depth_weight && o->out_T,
+                  "null image output");
+    if (p->P > 0) DQO_CHECK_ARG(o->n_touched && o->radii, "null n_touched / radii");
+    return DQO_OK;
+}
+
+DQO_API int dqo_rast_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, void* stream) {
+    int rc = check_common(p, in, ctx);
+    if (rc) return rc;
+    rc = check_outputs(p, out);
+    if (rc) return rc;
+    return dqo_launch_forward_prepare(p, in, out, ctx, (hipStream_t)stream);
+}
+
+DQO_API int dqo_rast_read_header(const DqoRastCtx* ctx, DqoRastHeader* host_out, void* stream) {
+    DQO_CHECK_ARG(ctx && ctx->geom && host_out, "null ctx / out");
+    uint32_t buf[128];
+    DQO_CHECK_HIP(hipMemcpyAsync(buf, ctx->geom, sizeof(buf), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DQO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    memcpy(host_out, buf, sizeof(DqoRastHeader));
+    const uint32_t* counters = buf + 64;  // second 256-byte slot of the geom buffer
+    // after `prepare` only the counters are valid; `render` fills the header proper
+    host_out->num_rendered = counters[0];
+    host_out->num_visible = counters[1];
+    return host_out->overflow ? DQO_ERR_OVERFLOW : DQO_OK;
+}
+
+DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, void* stream) {
+    int rc = check_common(p, in, ctx);
+    if (rc) return rc;
+    rc = check_outputs(p, out);
+    if (rc) return rc;
+    DQO_CHECK_ARG(ctx->inst_capacity >= 0 && ctx->inst_capacity < (int64_t)0xffffffffll, "bad inst_capacity");
+    DQO_CHECK_ARG(ctx->inst_capacity == 0 || ctx->binning, "null binning buffer");
+    if (ctx->binning_bytes < dqo_rast_binning_bytes(ctx->inst_capacity)) {
+        dqo_set_error("binning buffer too small (%zu < %zu)", ctx->binning_bytes, dqo_rast_binning_bytes(ctx->inst_capacity));
+        return DQO_ERR_WORKSPACE;
+    }
+    return dqo_launch_forward_render(p, in, out, ctx, (hipStream_t)stream);
+}
+
+DQO_API int dqo_rast_forward(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, void* stream) {
+    int rc = dqo_rast_forward_prepare(p, in, out, ctx, stream);
+    if (rc) return rc;
+    return dqo_rast_forward_render(p, in, out, ctx, stream);
+}
+
+DQO_API int dqo_rast_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
+                              const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* g, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(p, in, ctx);
+    if (rc) return rc;
+    DQO_CHECK_ARG(g, "null grads");
+    if (p->P == 0) return DQO_OK;  // rasterize_points.cu:208
+    DQO_CHECK_ARG(dL_dcolor && dL_ddepth, "null upstream gradients");
+    DQO_CHECK_ARG(g->dL_dmeans3D && g->dL_dcolors && g->dL_dopacity && g->dL_dscales && g->dL_drotations && g->dL_dcov3D && g->dL_dmeans2D,
+                  "null gradient output");
+    DQO_CHECK_ARG(p->M == 0 || g->dL_dsh, "null dL_dsh");
+    DQO_CHECK_ARG(ctx->binning || ctx->inst_capacity == 0, "null binning buffer");
+    if (ws_bytes < dqo_rast_backward_workspace_bytes(ctx->inst_capacity) || (ws == nullptr && ctx->inst_capacity > 0)) {
+        dqo_set_error("backward workspace too small (%zu < %zu)", ws_bytes, dqo_rast_backward_workspace_bytes(ctx->inst_capacity));
+        return DQO_ERR_WORKSPACE;
+    }
+    return dqo_launch_backward(p, in, ctx, dL_dcolor, dL_ddepth, hit_image, g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+DQO_API int dqo_mark_visible(int32_t P, const float* means3D, const float* view, const float* proj, uint8_t* present, void* stream) {
+    DQO_CHECK_ARG(P >= 0, "bad P");
+    if (P == 0) return DQO_OK;
+    DQO_CHECK_ARG(means3D && view && proj && present, "null pointer");
+    return dqo_launch_mark_visible(P, means3D, view, proj, present, (hipStream_t)stream);
+}
+
+DQO_API size_t dqo_knn3_workspace_bytes(int32_t P) { return dqo_knn3_ws_bytes(P < 0 ? 0 : P); }
+
+DQO_API int dqo_knn3(int32_t P, const float* xyz, float* mean_d2, int32_t* idx3, void* ws, size_t ws_bytes, void* stream) {
+    DQO_CHECK_ARG(P >= 0, "bad P");
+    if (P == 0) return DQO_OK;
+    DQO_CHECK_ARG(xyz && mean_d2 && idx3, "null pointer");
+    if (ws == nullptr || ws_bytes < dqo_knn3_ws_bytes(P)) {
+        dqo_set_error("knn workspace too small (%zu < %zu)", ws_bytes, dqo_knn3_ws_bytes(P));
+        return DQO_ERR_WORKSPACE;
+    }
+    return dqo_launch_knn3(P, xyz, mean_d2, idx3, ws, ws_bytes, (hipStream_t)stream);
+}
+
+DQO_API int dqo_quadric_iou_fwd_bwd(int32_t B, const float* axes, const float* R, const float* center, const float* P34, const float* obs,
+                                    float* bbox, float* loss, int32_t* valid, float* g_axes, float* g_R, float* g_center, void* stream) {
+    DQO_CHECK_ARG(B >= 0, "bad B");
+    if (B == 0) return DQO_OK;
+    DQO_CHECK_ARG(axes && R && center && P34 && obs && bbox && loss && valid && g_axes && g_R && g_center, "null pointer");
+    return dqo_launch_quadric_iou(B, axes, R, center, P34, obs, bbox, loss, valid, g_axes, g_R, g_center, (hipStream_t)stream);
+}
+
+DQO_API int dqo_quadric_adam(int32_t n_obj, int32_t n_iters, const int32_t* view_offset, const float* P34_views, const float* obs_views,
+                             const int32_t* view_schedule, float* axes, float* R, float* center, float* loss_hist, void* stream) {
+    DQO_CHECK_ARG(n_obj >= 0 && n_iters >= 0, "bad sizes");
+    if (n_obj == 0 || n_iters == 0) return DQO_OK;
+    DQO_CHECK_ARG(view_offset && P34_views && obs_views && view_schedule && axes && R && center, "null pointer");
+    return dqo_launch_quadric_adam(n_obj, n_iters, view_offset, P34_views, obs_views, view_schedule, axes, R, center, loss_hist,
+                                   (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// Shared device/host definitions for libdqoraster.so (gfx950 only: wave64, 160 KB LDS, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dqo_raster.h"
+
+#define DQO_TILE 16  // reference BLOCK_X = BLOCK_Y = 16 (cuda_rasterizer/config.h:15-16); part of the op's semantics
+#define DQO_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------------------------
+void dqo_set_error(const char* fmt, ...);
+#define DQO_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            dqo_set_error(__VA_ARGS__);   \
+            return DQO_ERR_INVALID_ARG;   \
+        }                                 \
+    } while (0)
+#define DQO_CHECK_HIP(expr)                                                          \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            dqo_set_error("%s failed: %s", #expr, hipGetErrorString(e_));            \
+            return DQO_ERR_LAUNCH;                                                   \
+        }                                                                            \
+    } while (0)
+#define DQO_CHECK_LAUNCH() DQO_CHECK_HIP(hipGetLastError())
+
+static inline size_t dqo_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- context buffer layouts (private) -------------------------------------------------------------------------
+// geom buffer: header + per-Gaussian SoA tables, every table 256-B aligned.
+struct DqoGeomLayout {
+    DqoRastHeader* header;   // 256 B reserved
+    uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator), [1] visible count, [2] max tile count
+    float4* conic_opacity;   // [P] (conic.x, conic.y, conic.z, opacity)           forward.cu:343
+    float4* xy_depth;        // [P] (pix.x, pix.y, depth = p_view.z, bits(radius))  forward.cu:339-341
+    float4* rgb_smax;        // [P] (r, g, b, max(scale)*scale_mod)                 forward.cu:333-335, 73
+    float4* normal_c;        // [P] (n_c.xyz, n_c . p_c)   surfel normal in camera space, hoisted out of the blend loop
+    float4* point_c;         // [P] (p_c.xyz, unused)      forward.cu:782-783
+    uint32_t* rect;          // [P] packed tile rect: minx | miny<<8 | maxx<<16 | maxy<<24 (tile grid <= 255x255) — else rect16
+    uint2* rect16;           // [P] (minx | maxx<<16, miny | maxy<<16)
+    uint32_t* tiles_touched; // [P]
+    uint32_t* slot_base;     // [P] first gaussian-major instance slot of this Gaussian
+    uint8_t* clamped;        // [P] bit0..2 = SH colour channel clamped at 0 (forward.cu:151-153)
+    size_t total;
+};
+
+static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
+    DqoGeomLayout L;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += dqo_align_up(bytes, 256);
+        return r;
+    };
+    L.header = (DqoRastHeader*)take(256);
+    L.counters = (uint32_t*)take(256);
+    L.conic_opacity = (float4*)take(sizeof(float4) * P);
+    L.xy_depth = (float4*)take(sizeof(float4) * P);
+    L.rgb_smax = (float4*)take(sizeof(float4) * P);
+    L.normal_c = (float4*)take(sizeof(float4) * P);
+    L.point_c = (float4*)take(sizeof(float4) * P);
+    L.rect = nullptr;
+    L.rect16 = (uint2*)take(sizeof(uint2) * P);
+    L.tiles_touched = (uint32_t*)take(sizeof(uint32_t) * P);
+    L.slot_base = (uint32_t*)take(sizeof(uint32_t) * P);
+    L.clamped = (uint8_t*)take(P);
+    L.total = (size_t)(p - (char*)base);
+    return L;
+}
+
+// image buffer: per-tile tables + per-pixel forward->backward state.
+struct DqoImageLayout {
+    uint32_t* tile_count;   // [T] instances per tile (atomic histogram, K1)
+    uint32_t* tile_cursor;  // [T] emit cursor
+    uint2* ranges;          // [T] [start, end) into the sorted list (rasterizer_impl.cu:120-142)
+    uint32_t* tile_walk;    // [T] entries the backward must walk = max over pixels of max(n_contrib, hit position)
+    uint32_t* tile_order;   // [T] tile ids, active tiles first (row-major), rasterizer_impl.cu:353-365
+    float* final_T;         // [HW] end_T  (forward.cu:849)
+    uint32_t* n_contrib;    // [HW] last contributor, 1-based (forward.cu:850)
+    uint32_t* hit_pos;      // [HW] 1-based list position of the Gaussian that fixed the depth, 0 if none
+    size_t total;
+};
+
+static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
+    DqoImageLayout L;
+    const size_t gx = (W + DQO_TILE - 1) / DQO_TILE, gy = (H + DQO_TILE - 1) / DQO_TILE;
+    const size_t T = gx * gy, HW = (size_t)W * H;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += dqo_align_up(bytes, 256);
+        return r;
+    };
+    L.tile_count = (uint32_t*)take(4 * T);
+    L.tile_cursor = (uint32_t*)take(4 * T);
+    L.ranges = (uint2*)take(8 * T);
+    L.tile_walk = (uint32_t*)take(4 * T);
+    L.tile_order = (uint32_t*)take(4 * T);
+    L.final_T = (float*)take(4 * HW);
+    L.n_contrib = (uint32_t*)take(4 * HW);
+    L.hit_pos = (uint32_t*)take(4 * HW);
+    L.total = (size_t)(p - (char*)base);
+    return L;
+}
+
+// binning buffer: per-instance tables.
+struct DqoBinLayout {
+    uint64_t* keys;       // [cap] unsorted (depth bits << 32 | gaussian id), grouped per tile segment
+    uint32_t* slots;      // [cap] unsorted gaussian-major slot of the instance
+    uint32_t* point_list; // [cap] sorted gaussian ids   (binningState.point_list)
+    uint32_t* slot_list;  // [cap] sorted slots (where the backward stores this instance's gradient record)
+    size_t total;
+};
+
+static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap) {
+    DqoBinLayout L;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += dqo_align_up(bytes, 256);
+        return r;
+    };
+    L.keys = (uint64_t*)take(8 * (size_t)cap);
+    L.slots = (uint32_t*)take(4 * (size_t)cap);
+    L.point_list = (uint32_t*)take(4 * (size_t)cap);
+    L.slot_list = (uint32_t*)take(4 * (size_t)cap);
+    L.total = (size_t)(p - (char*)base);
+    return L;
+}
+
+// Per-instance gradient record written by the backward blend kernel (one per (tile, Gaussian) instance), summed per
+// Gaussian in a fixed order by the per-Gaussian backward kernel: bitwise reproducible, no float atomics.
+struct __attribute__((aligned(16))) DqoGradRec {
+    float dcolor[3];   // dL/d rgb
+    float dmean2D[2];  // dL/d pixel-space mean (already scaled by W/2, H/2)
+    float dconic[3];   // dL/d conic (xx, xy, yy)
+    float dopacity;
+    float dmean3D[3];  // depth-hit gradient (backward.cu:1034-1036, 1061-1063)
+    float drot[4];     // depth-hit gradient (backward.cu:1053-1056)
+};
+static_assert(sizeof(DqoGradRec) == 64, "record must be one 64-byte line");
+
+// Per-view constants.  Scalars travel by value (kernarg -> SGPRs); the matrices stay device pointers because the
+// reference API hands them over as device tensors (no host read, no sync) — kernels fetch them with scalar loads.
+struct DqoView {
+    const float* view;    // [16]
+    const float* proj;    // [16]
+    const float* campos;  // [3]
+    const float* bg;      // [3]
+    float tanfovx, tanfovy, focal_x, focal_y, cx, cy;
+    float scale_mod, color_sigma, opaque_thr, depth_thr, normal_thr, T_thr;
+    int W, H, gx, gy;
+    int P, D, M;
+};
+
+static inline DqoView dqo_make_view(const DqoRastParams* p, const DqoRastInputs* in) {
+    DqoView v;
+    v.view = in->viewmatrix;
+    v.proj = in->projmatrix;
+    v.campos = in->campos;
+    v.bg = in->bg;
+    v.tanfovx = p->tanfovx;
+    v.tanfovy = p->tanfovy;
+    v.focal_y = p->H / (2.0f * p->tanfovy);  // rasterizer_impl.cu:245-246
+    v.focal_x = p->W / (2.0f * p->tanfovx);
+    v.cx = p->cx;
+    v.cy = p->cy;
+    v.scale_mod = p->scale_modifier;
+    v.color_sigma = p->color_sigma;
+    v.opaque_thr = p->opaque_threshold;
+    v.depth_thr = p->depth_threshold;
+    v.normal_thr = p->normal_threshold;
+    v.T_thr = p->T_threshold;
+    v.W = p->W;
+    v.H = p->H;
+    v.gx = (p->W + DQO_TILE - 1) / DQO_TILE;
+    v.gy = (p->H + DQO_TILE - 1) / DQO_TILE;
+    v.P = p->P;
+    v.D = p->D;
+    v.M = p->M;
+    return v;
+}
+
+// launchers (defined in the .hip files)
+int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);
+int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);
+int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
+                        const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* g, void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,285 @@
+"""Drop-in replacement for DQO-MAP's `diff_gaussian_rasterization_depth` package on MI355X.
+
+Same public surface as /root/reference/submodules/diff-gaussian-rasterizer-depth/diff_gaussian_rasterization_depth/
+__init__.py: `GaussianRasterizationSettings` (:288-307, same field names / order / defaults), `GaussianRasterizer`
+(:310-376, `.forward(...)`, `.markVisible(...)`), `rasterize_gaussians` (:29-50) and the autograd Function
+`_RasterizeGaussians` (:53-285) with the same 9-tuple of outputs and the same gradient slots, so SLAM/render.py:8-13
+imports and calls it unchanged.  Below the Python surface the pybind module `_C_depth` (ext.cpp:15-19) is replaced by
+the C ABI of libdqoraster.so (include/dqo_raster.h) called through ctypes with raw device pointers.
+
+Differences that are not visible to callers:
+  * the three context tensors (geomBuffer, binningBuffer, imgBuffer) keep their role (opaque uint8 tensors saved for
+    backward) but have this library's layout;
+  * the forward does ONE 4-byte device->host read (the instance count N, to size the binning buffer exactly as the
+    reference does at rasterizer_impl.cu:307) instead of the reference's two reads plus a host loop over all tiles;
+    `set_sync_mode("lazy")` removes even that one (capacity carried over from the previous call, overflow detected
+    and raised at the next synchronisation point — never silent);
+  * `tile_mask=None` is accepted and means "all tiles" (the reference requires a tensor).
+There is no CPU path: tensors must live on the GPU and the HIP library must be built.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+import _dqo_native as N
+
+_sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy": reuse / grow the previous capacity, no sync
+_cap_hint = {}
+_pending = []          # lazy mode: (event, pinned header tensor, key) of forwards not yet verified
+
+
+def set_sync_mode(mode):
+    """'exact' (default, one 4-byte D2H read per forward) or 'lazy' (no host synchronisation in the forward)."""
+    global _sync_mode
+    if mode not in ("exact", "lazy"):
+        raise ValueError(mode)
+    _sync_mode = mode
+    _pending.clear()
+
+
+def _verify_pending(block):
+    """Lazy mode: check the headers of earlier forwards; raise if one of them overflowed its instance capacity."""
+    keep = []
+    for ev, host, key, cap in _pending:
+        if not block and not ev.query():
+            keep.append((ev, host, key, cap))
+            continue
+        ev.synchronize()
+        n, overflow = int(host[0]), int(host[2])
+        _cap_hint[key] = max(_cap_hint.get(key, 0), int(n * 1.25) + 4096)
+        if overflow:
+            _pending[:] = keep
+            raise RuntimeError(f"diff_gaussian_rasterization_depth (lazy mode): a previous forward produced {n} Gaussian-tile "
+                               f"instances but only {cap} fitted its binning buffer; its outputs are invalid. The capacity has "
+                               "been raised — re-run that iteration (or use set_sync_mode('exact')).")
+    _pending[:] = keep
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected scalar type Float but found {t.dtype} ({name})")
+    return t.contiguous()
+
+
+def rasterize_gaussians(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, raster_settings):
+    return _RasterizeGaussians.apply(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask,
+                                     raster_settings)
+
+
+def _params(rs, P, M):
+    return N.DqoRastParams(P=P, D=int(rs.sh_degree), M=M, W=int(rs.image_width), H=int(rs.image_height),
+                           prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx),
+                           tanfovy=float(rs.tanfovy), cx=float(rs.cx), cy=float(rs.cy), scale_modifier=float(rs.scale_modifier),
+                           color_sigma=float(rs.color_sigma), opaque_threshold=float(rs.opaque_threshold),
+                           depth_threshold=float(rs.depth_threshold), normal_threshold=float(rs.normal_threshold),
+                           T_threshold=float(rs.T_threshold))
+
+
+def _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask):
+    return N.DqoRastInputs(bg=N.ptr(rs.bg), means3D=N.ptr(means3D), shs=N.ptr(sh), colors_precomp=N.ptr(colors_precomp),
+                           opacities=N.ptr(opacities), scales=N.ptr(scales), rotations=N.ptr(rotations),
+                           cov3D_precomp=N.ptr(cov3Ds_precomp), viewmatrix=N.ptr(rs.viewmatrix), projmatrix=N.ptr(rs.projmatrix),
+                           campos=N.ptr(rs.campos), tile_mask=N.ptr(tile_mask))
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, raster_settings):
+        rs = raster_settings
+        lib = N.lib()
+        if means3D.ndimension() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:67-70
+        N.require_gpu(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, rs.bg, rs.viewmatrix,
+                      rs.projmatrix, rs.campos)
+        if not means3D.is_cuda:
+            raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+        dev = means3D.device
+        means3D, opacities = _f32(means3D, "means3D"), _f32(opacities, "opacities")
+        sh, colors_precomp = _f32(sh, "sh"), _f32(colors_precomp, "colors_precomp")
+        scales, rotations, cov3Ds_precomp = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3Ds_precomp, "cov3D_precomp")
+        bg, view, proj, campos = (_f32(rs.bg, "bg"), _f32(rs.viewmatrix, "viewmatrix"), _f32(rs.projmatrix, "projmatrix"),
+                                  _f32(rs.campos, "campos"))
+        rs = rs._replace(bg=bg, viewmatrix=view, projmatrix=proj, campos=campos)
+        if tile_mask is not None:
+            if tile_mask.dtype != torch.int32:
+                raise RuntimeError(f"expected scalar type Int but found {tile_mask.dtype} (tile_mask)")
+            tile_mask = tile_mask.contiguous()
+        P = means3D.size(0)
+        H, W = int(rs.image_height), int(rs.image_width)
+        M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:105-109
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            stream = N.current_stream()
+            color = torch.empty((3, H, W), **f32)
+            depth = torch.empty((1, H, W), **f32)
+            hit_color = torch.empty((1, H, W), **i32)
+            hit_depth = torch.empty((1, H, W), **i32)
+            hit_color_weight = torch.empty((1, H, W), **f32)
+            hit_depth_weight = torch.empty((1, H, W), **f32)
+            T_map = torch.empty((1, H, W), **f32)
+            n_touched = torch.empty((P,), **i32)
+            radii = torch.empty((P,), **i32)
+            geomBuffer = torch.empty((lib.dqo_rast_geom_bytes(P, W, H),), **u8)
+            imgBuffer = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
+            params = _params(rs, P, M)
+            inputs = _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask)
+            outputs = N.DqoRastOutputs(out_color=color.data_ptr(), out_depth=depth.data_ptr(), out_hit_color=hit_color.data_ptr(),
+                                       out_hit_depth=hit_depth.data_ptr(), out_hit_color_weight=hit_color_weight.data_ptr(),
+                                       out_hit_depth_weight=hit_depth_weight.data_ptr(), out_T=T_map.data_ptr(),
+                                       n_touched=N.ptr(n_touched), radii=N.ptr(radii))
+            cctx = N.DqoRastCtx(geom=geomBuffer.data_ptr(), geom_bytes=geomBuffer.numel(), binning=None, binning_bytes=0,
+                                image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(), inst_capacity=0)
+            N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
+                                                 ctypes.byref(cctx), stream))
+            key = (dev.index, P, W, H)
+            if _sync_mode == "exact":
+                hdr = N.DqoRastHeader()
+                N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))  # the one D2H read
+                num_rendered = int(hdr.num_rendered)
+                cap = max(num_rendered, 1)
+            else:
+                _verify_pending(block=False)
+                cap = _cap_hint.get(key)
+                if cap is None:  # first call for this shape: measure once
+                    hdr = N.DqoRastHeader()
+                    N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))
+                    cap = _cap_hint[key] = int(hdr.num_rendered * 1.25) + 4096
+                num_rendered = -1
+            binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
+            cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
+            N.check(lib.dqo_rast_forward_render(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
+                                                ctypes.byref(cctx), stream))
+            if _sync_mode == "lazy":
+                host = torch.empty((8,), dtype=torch.int32).pin_memory()
+                host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                _pending.append((ev, host, key, cap))
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.inst_capacity = cap
+        ctx.M = M
+        ctx.save_for_backward(colors_precomp, hit_depth, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer, opacities, tile_mask if tile_mask is not None else torch.empty(0))
+        ctx.mark_non_differentiable(hit_color, hit_depth, n_touched, radii)
+        return (color, depth, hit_color, hit_depth, hit_color_weight, hit_depth_weight, T_map, n_touched, radii)
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_depth, grad_hit_color, grad_hit_depth, grad_hit_color_weight,
+                 grad_hit_depth_weight, grad_T_map, grad_n_touched, _):
+        # only grad_out_color and grad_out_depth are consumed, exactly like the reference (__init__.py:176-238; F6)
+        rs = ctx.raster_settings
+        lib = N.lib()
+        (colors_precomp, hit_depth, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer,
+         opacities, tile_mask) = ctx.saved_tensors
+        if tile_mask.numel() == 0:
+            tile_mask = None
+        if _sync_mode == "lazy":
+            _verify_pending(block=True)
+        P, M = means3D.size(0), ctx.M
+        H, W = int(rs.image_height), int(rs.image_width)
+        dev = means3D.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, H, W), **f32)
+        if grad_out_depth is None:
+            grad_out_depth = torch.zeros((1, H, W), **f32)
+        grad_out_color, grad_out_depth = _f32(grad_out_color, "grad_out_color"), _f32(grad_out_depth, "grad_out_depth")
+        with torch.cuda.device(dev):
+            stream = N.current_stream()
+            g_means3D = torch.empty((P, 3), **f32)
+            g_means2D = torch.empty((P, 3), **f32)
+            g_colors = torch.empty((P, 3), **f32)
+            g_opacity = torch.empty((P, 1), **f32)
+            g_cov3D = torch.empty((P, 6), **f32)
+            g_sh = torch.empty((P, M, 3), **f32)
+            g_scales = torch.empty((P, 3), **f32)
+            g_rot = torch.empty((P, 4), **f32)
+            if P > 0:
+                cap = ctx.inst_capacity
+                ws = torch.empty((lib.dqo_rast_backward_workspace_bytes(cap),), dtype=torch.uint8, device=dev)
+                params = _params(rs, P, M)
+                inputs = _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask)
+                cctx = N.DqoRastCtx(geom=geomBuffer.data_ptr(), geom_bytes=geomBuffer.numel(), binning=binningBuffer.data_ptr(),
+                                    binning_bytes=binningBuffer.numel(), image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(),
+                                    inst_capacity=cap)
+                grads = N.DqoRastGrads(dL_dmeans3D=g_means3D.data_ptr(), dL_dsh=N.ptr(g_sh), dL_dcolors=g_colors.data_ptr(),
+                                       dL_dopacity=g_opacity.data_ptr(), dL_dscales=g_scales.data_ptr(),
+                                       dL_drotations=g_rot.data_ptr(), dL_dcov3D=g_cov3D.data_ptr(), dL_dmeans2D=g_means2D.data_ptr())
+                N.check(lib.dqo_rast_backward(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(cctx),
+                                              grad_out_color.data_ptr(), grad_out_depth.data_ptr(), hit_depth.data_ptr(),
+                                              ctypes.byref(grads), ws.data_ptr(), ws.numel(), stream))
+        # gradient slots of the reference (__init__.py:273-283); inputs handed over as empty tensors get None
+        def slot(g, inp):
+            return g if inp.numel() != 0 else None
+        return (g_means3D, slot(g_sh, sh), slot(g_colors, colors_precomp), g_opacity.view_as(opacities) if opacities.numel() else None,
+                slot(g_scales, scales), slot(g_rot, rotations), slot(g_cov3D, cov3Ds_precomp), None, None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    opaque_threshold: float
+    normal_threshold: float
+    depth_threshold: float
+    prefiltered: bool
+    debug: bool
+    cx: float
+    cy: float
+    color_sigma: float = 3.0
+    T_threshold: float = 0.0001
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # frustum test of rasterizer_impl.cu:54-66 for the camera in raster_settings
+        with torch.no_grad():
+            rs = self.raster_settings
+            N.require_gpu(positions, rs.viewmatrix, rs.projmatrix)
+            if not positions.is_cuda:
+                raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+            positions = _f32(positions, "positions")
+            P = positions.size(0)
+            visible = torch.zeros((P,), dtype=torch.bool, device=positions.device)
+            with torch.cuda.device(positions.device):
+                N.check(N.lib().dqo_mark_visible(P, N.ptr(positions), N.ptr(_f32(rs.viewmatrix, "viewmatrix")),
+                                                 N.ptr(_f32(rs.projmatrix, "projmatrix")), N.ptr(visible), N.current_stream()))
+        return visible
+
+    def forward(self, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                tile_mask=None, normal_w=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        # normal_w is accepted and ignored, as in the reference (__init__.py:335)
+        return rasterize_gaussians(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, tile_mask,
+                                   raster_settings)

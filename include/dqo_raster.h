@@ -1,0 +1,178 @@
+/*
+ * dqo_raster.h — C ABI of libdqoraster.so: the MI355X (gfx950) drop-in for DQO-MAP's mapping hot path.
+ *
+ * Every entry point replaces one binding of the reference's three CUDA extensions (paths relative to
+ * /root/reference):
+ *
+ *   dqo_rast_forward_*   <- _C_depth.rasterize_gaussians           submodules/diff-gaussian-rasterizer-depth/ext.cpp:16,
+ *                                                                  rasterize_points.cu:37-155, cuda_rasterizer/rasterizer.h:35-73
+ *   dqo_rast_backward    <- _C_depth.rasterize_gaussians_backward  ext.cpp:17, rasterize_points.cu:157-249, rasterizer.h:75-105
+ *   dqo_mark_visible     <- _C_depth.mark_visible                  ext.cpp:18, rasterize_points.cu:251-270, rasterizer.h:27-33
+ *   dqo_knn3             <- simple_knn._C.distCUDA2                submodules/simple-knn/ext.cpp:15-17, spatial.cu:15-28
+ *   dqo_quadric_*        <- Ellipsoid_tensor.forward + bboxes_iou + the Adam loop of Object_Optimize_only
+ *                                                                  SLAM/multiprocess/quadrics.py:285-290, 2018-2091, 2144-2220, 2234-2298
+ *   dqo_accumulate_gaussian_error <- cuda_utils._C.accumulate_gaussian_error   submodules/cuda_utils/ext.cpp, map_process.cu:33-245
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers (tensor.data_ptr()), sizes, no torch / C++ types; all memory is caller-owned.
+ *   - every launch goes to the caller's stream (`hipStream_t` passed as void*); no hipMalloc/hipFree, no host
+ *     synchronisation inside any entry point except dqo_rast_read_header (explicitly a D2H read).
+ *   - return value: 0 on success, negative DqoStatus on error; dqo_last_error() gives the message (thread-local).
+ *     The reference throws C++ exceptions -> Python RuntimeError (rasterize_points.cu:67-70); the Python shim does the same.
+ *   - fp32 everywhere, matrices in the reference's row-vector convention (flat 16 floats, auxiliary.h:59-77).
+ */
+#ifndef DQO_RASTER_H_
+#define DQO_RASTER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQO_ABI_VERSION 1
+
+typedef enum DqoStatus {
+    DQO_OK = 0,
+    DQO_ERR_INVALID_ARG = -1,  /* bad shape / null pointer / unsupported combination */
+    DQO_ERR_WORKSPACE = -2,    /* a caller-provided buffer is too small */
+    DQO_ERR_LAUNCH = -3,       /* hipLaunch / hipMemsetAsync failed (message holds hipGetErrorString) */
+    DQO_ERR_OVERFLOW = -4      /* instance capacity exceeded (reported by dqo_rast_read_header) */
+} DqoStatus;
+
+/* Scalar settings: GaussianRasterizationSettings, diff_gaussian_rasterization_depth/__init__.py:288-307. */
+typedef struct DqoRastParams {
+    int32_t P;              /* number of Gaussians (means3D.size(0)) */
+    int32_t D;              /* active SH degree 0..3 */
+    int32_t M;              /* SH coefficients per Gaussian (sh.size(1)); 0 when colours are precomputed */
+    int32_t W, H;           /* image size */
+    int32_t prefiltered;    /* accepted, unused (reference only traps on it) */
+    int32_t debug;          /* accepted, unused */
+    float tanfovx, tanfovy;
+    float cx, cy;           /* principal point in pixels */
+    float scale_modifier;
+    float color_sigma;      /* radius = ceil(color_sigma * sqrt(lambda_max)) */
+    float opaque_threshold; /* alpha of the first Gaussian that fixes the depth */
+    float depth_threshold;  /* hit_depth_threshold */
+    float normal_threshold; /* hit_normal_threshold = cos(angle) */
+    float T_threshold;
+} DqoRastParams;
+
+/* Borrowed device inputs.  Exactly one of (shs, colors_precomp) is non-NULL.  scales and rotations are required: the
+ * reference's blend kernel dereferences them unconditionally (forward.cu:780), so cov3D_precomp-only calls are rejected
+ * with DQO_ERR_INVALID_ARG instead of faulting. */
+typedef struct DqoRastInputs {
+    const float* bg;             /* [3] */
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3] or NULL */
+    const float* opacities;      /* [P] */
+    const float* scales;         /* [P,3] */
+    const float* rotations;      /* [P,4] (r,x,y,z), already normalised by the caller */
+    const float* cov3D_precomp;  /* must be NULL */
+    const float* viewmatrix;     /* [16] */
+    const float* projmatrix;     /* [16] */
+    const float* campos;         /* [3] */
+    const int32_t* tile_mask;    /* [ceil(H/16) * ceil(W/16)], non-zero = render; NULL = all ones */
+} DqoRastInputs;
+
+/* Caller-allocated outputs; the forward writes EVERY element (masked / empty tiles get the reference's initial
+ * fills: colour 0, depth 0, ids 0, weights 0, T 1 — rasterize_points.cu:79-89), so torch.empty is enough. */
+typedef struct DqoRastOutputs {
+    float* out_color;            /* [3,H,W] */
+    float* out_depth;            /* [1,H,W] */
+    int32_t* out_hit_color;      /* [1,H,W] id of the max-weight colour contributor, -1 if none */
+    int32_t* out_hit_depth;      /* [1,H,W] id of the Gaussian that fixed the depth, -1 if none */
+    float* out_hit_color_weight; /* [1,H,W] */
+    float* out_hit_depth_weight; /* [1,H,W] */
+    float* out_T;                /* [1,H,W] */
+    int32_t* n_touched;          /* [P] */
+    int32_t* radii;              /* [P] */
+} DqoRastOutputs;
+
+/* Forward->backward context: the three opaque byte buffers the reference keeps as geomBuffer / binningBuffer /
+ * imgBuffer (rasterize_points.cu:93-98).  Layout is private to this library; sizes come from the functions below. */
+typedef struct DqoRastCtx {
+    void* geom;
+    size_t geom_bytes;
+    void* binning;
+    size_t binning_bytes;
+    void* image;
+    size_t image_bytes;
+    int64_t inst_capacity; /* number of (Gaussian, tile) instances `binning` can hold */
+} DqoRastCtx;
+
+/* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206). */
+typedef struct DqoRastGrads {
+    float* dL_dmeans3D;   /* [P,3] */
+    float* dL_dsh;        /* [P,M,3] (NULL when M == 0) */
+    float* dL_dcolors;    /* [P,3] */
+    float* dL_dopacity;   /* [P,1] */
+    float* dL_dscales;    /* [P,3] */
+    float* dL_drotations; /* [P,4] */
+    float* dL_dcov3D;     /* [P,6] */
+    float* dL_dmeans2D;   /* [P,3] (x,y used; z = 0) */
+} DqoRastGrads;
+
+/* Host-visible copy of the device header kept at the start of ctx.geom. */
+typedef struct DqoRastHeader {
+    uint32_t num_rendered;   /* N: (Gaussian, tile) instances */
+    uint32_t num_tiles;      /* active (non-empty, unmasked) tiles */
+    uint32_t overflow;       /* non-zero: N exceeded inst_capacity, results of this forward are invalid */
+    uint32_t max_tile_count; /* longest per-tile list */
+    uint32_t num_visible;    /* Gaussians with radius > 0 */
+    uint32_t reserved[3];
+} DqoRastHeader;
+
+int dqo_abi_version(void);
+const char* dqo_last_error(void);
+
+size_t dqo_rast_geom_bytes(int32_t P, int32_t W, int32_t H);
+size_t dqo_rast_image_bytes(int32_t W, int32_t H);
+size_t dqo_rast_binning_bytes(int64_t inst_capacity);
+size_t dqo_rast_backward_workspace_bytes(int64_t inst_capacity);
+
+/* Stage 1 (per-Gaussian preprocess + per-tile counts + offsets).  Needs ctx.geom and ctx.image; leaves N in the
+ * device header.  rasterizer_impl.cu:272-307 (K1, K2). */
+int dqo_rast_forward_prepare(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
+/* D2H read of the header (the ONLY synchronising call; replaces the reference's cudaMemcpy at rasterizer_impl.cu:307). */
+int dqo_rast_read_header(const DqoRastCtx*, DqoRastHeader* host_out, void* hipStream);
+/* Stage 2 (instance emit, per-tile sort, blend).  Needs ctx.binning with inst_capacity >= N, otherwise the device
+ * header's overflow flag is raised and no instance is written out of bounds.  rasterizer_impl.cu:309-440 (K3-K6). */
+int dqo_rast_forward_render(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
+/* Both stages back to back, no host synchronisation (caller guarantees / later checks capacity). */
+int dqo_rast_forward(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
+
+/* rasterizer_impl.cu:445-564 (K7-K9).  `hit_image` is out_hit_depth of the forward ([H*W]); workspace holds the
+ * per-instance gradient records. */
+int dqo_rast_backward(const DqoRastParams*, const DqoRastInputs*, const DqoRastCtx*, const float* dL_dout_color,
+                      const float* dL_dout_depth, const int32_t* hit_image, DqoRastGrads*, void* workspace,
+                      size_t workspace_bytes, void* hipStream);
+
+int dqo_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* hipStream);
+
+/* Exact 3-NN: mean of the 3 smallest squared distances and the 3 neighbour indices (ascending distance, ties by
+ * Morton order, INT_MAX / FLT_MAX when fewer than 3 other points exist). */
+size_t dqo_knn3_workspace_bytes(int32_t P);
+int dqo_knn3(int32_t P, const float* xyz, float* mean_d2, int32_t* idx3, void* workspace, size_t workspace_bytes,
+             void* hipStream);
+
+/* Batched dual-quadric residual over B independent (object, view) pairs: loss = 1 - IoU(obs, bbox(ellipsoid, P34)),
+ * with gradients.  valid[b] = 0 when loss == 1 (the reference skips that Adam step). */
+int dqo_quadric_iou_fwd_bwd(int32_t B, const float* axes, const float* R, const float* center, const float* P34,
+                            const float* obs_bbox, float* bbox, float* loss, int32_t* valid, float* g_axes, float* g_R,
+                            float* g_center, void* hipStream);
+/* Object_Optimize_only inner loops for n_obj objects in ONE launch: n_iters Adam steps each (lr .01/.001/.01,
+ * betas .9/.999, eps 1e-15), view picked by view_schedule[obj][it] (negative = from the end).  Parameters are updated
+ * in place; loss_hist [n_obj, n_iters] may be NULL.  Views of object o are P34_views / obs_views rows
+ * [view_offset[o], view_offset[o+1]). */
+int dqo_quadric_adam(int32_t n_obj, int32_t n_iters, const int32_t* view_offset, const float* P34_views,
+                     const float* obs_views, const int32_t* view_schedule, float* axes, float* R, float* center,
+                     float* loss_hist, void* hipStream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQO_RASTER_H_ */

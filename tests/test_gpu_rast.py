@@ -1,0 +1,148 @@
+"""GPU parity tests (run on the MI355X box): the HIP rasteriser, called through the drop-in Python operator and therefore
+through the C ABI of libdqoraster.so, against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from dqo_harness import scenes
+import util_rast as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import _dqo_native
+    _dqo_native.lib()  # fails loudly if the HIP extension is missing
+    return torch
+
+
+def _check(oracle, cam, sc, dL, **kw):
+    """HIP vs fp32 oracle (forward, 1e-4) and vs fp64 oracle as truth for gradients (see util_rast.compare_grads)."""
+    h, hg = U.run_hip(cam, sc, dL=dL, **kw)
+    o, r, og = U.run_oracle(oracle, cam, sc, dL=dL, **kw)
+    st = U.compare_forward(h, r)
+    _, _, og64 = U.run_oracle(oracle, cam, sc, dL=dL, dtype=np.float64, **kw)
+    gs = U.compare_grads(hg, og, og64)
+    print("fwd", st, "grads (rel-to-max, q99)", gs)
+    return h, r, o
+
+
+def _dL(cam, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.normal(size=(3, cam.H, cam.W)).astype(np.float32), rng.normal(size=(1, cam.H, cam.W)).astype(np.float32)
+
+
+@pytest.mark.parametrize("P", [3000, 10000])
+def test_forward_backward_cfg1(torch_cuda, oracle, P):
+    cam, sc = scenes.make_config(1, P=P)
+    _check(oracle, cam, sc, _dL(cam))
+
+
+def test_forward_backward_room_sh_rest(torch_cuda, oracle):
+    """Surfel room (cfg-2 layout at reduced P), non-zero higher-order SH, non-zero background."""
+    cam, sc = scenes.make_config(2, P=20000)
+    rng = np.random.default_rng(5)
+    sc["shs"][:, 1:, :] = rng.normal(0, 0.05, sc["shs"][:, 1:, :].shape).astype(np.float32)
+    _check(oracle, cam, sc, _dL(cam, 1), bg=(0.1, 0.2, 0.3))
+
+
+def test_tile_mask_and_colors_precomp(torch_cuda, oracle):
+    cam, sc = scenes.make_config(1, P=4000)
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    mask = (np.random.default_rng(2).uniform(size=(gy, gx)) < 0.6).astype(np.int32)
+    cp = np.random.default_rng(3).uniform(0, 1, (4000, 3)).astype(np.float32)
+    h, r, o = _check(oracle, cam, sc, _dL(cam, 2), tile_mask=mask, colors_precomp=cp)
+    pm = np.repeat(np.repeat(mask, 16, 0), 16, 1)[:cam.H, :cam.W].astype(bool)
+    assert (h["color"][:, ~pm] == 0).all() and (h["T_map"][0][~pm] == 1).all() and (h["hit_depth"][0][~pm] == 0).all()
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_lower_sh_degree(torch_cuda, oracle, deg):
+    cam, sc = scenes.make_config(1, P=2000)
+    sc["shs"][:, 1:, :] = np.random.default_rng(7).normal(0, 0.1, sc["shs"][:, 1:, :].shape).astype(np.float32)
+    _check(oracle, cam, sc, _dL(cam, 3), sh_degree=deg)
+
+
+def test_binning_exact(torch_cuda, oracle):
+    """Integer / index work is bit-exact: radii, instance count, per-tile sorted id lists, ranges."""
+    import torch
+    import ctypes
+    import _dqo_native as N
+    from diff_gaussian_rasterization_depth import _RasterizeGaussians
+    cam, sc = scenes.make_config(1, P=6000)
+    o, r, _ = U.run_oracle(oracle, cam, sc)
+    rs = U.raster_settings_torch(cam, "cuda")
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device="cuda")
+
+    class Ctx:  # minimal stand-in for the autograd ctx to get at the saved buffers
+        def save_for_backward(self, *a):
+            self.saved = a
+
+        def mark_non_differentiable(self, *a):
+            pass
+
+    c = Ctx()
+    out = _RasterizeGaussians.forward(c, t(sc["xyz"]), t(sc["shs"]), torch.Tensor([]), t(sc["opacity"]), t(sc["scales"]),
+                                      t(sc["rotations"]), torch.Tensor([]), None, rs)
+    assert c.num_rendered == o.N
+    geom, binning, img = c.saved[8], c.saved[9], c.saved[10]
+    Nn = o.N
+    T = ((cam.W + 15) // 16) * ((cam.H + 15) // 16)
+    al = lambda n: (n + 255) // 256 * 256
+    # binning layout: keys u64[cap] | slots u32[cap] | point_list u32[cap] | slot_list u32[cap], each 256-B aligned
+    off_pl = al(8 * Nn) + al(4 * Nn)
+    pl = binning[off_pl:off_pl + 4 * Nn].view(torch.int32).cpu().numpy().astype(np.uint32)
+    np.testing.assert_array_equal(pl, o.ctx("point_list"))
+    # image layout: tile_count | tile_cursor | ranges ...
+    off_rg = 2 * al(4 * T)
+    rg = img[off_rg:off_rg + 8 * T].view(torch.int32).cpu().numpy().reshape(T, 2).astype(np.uint32)
+    np.testing.assert_array_equal(rg, o.ctx("ranges"))
+    np.testing.assert_array_equal(out[8].cpu().numpy(), r["radii"])
+
+
+def test_empty_and_tiny(torch_cuda, oracle):
+    import torch
+    cam, sc = scenes.make_config(1, P=50)
+    e = {k: v[:0] for k, v in sc.items()}
+    h, _ = U.run_hip(cam, e)
+    assert (h["color"] == 0).all() and (h["T_map"] == 1).all() and (h["hit_depth"] == 0).all()
+    _check(oracle, cam, sc, _dL(cam, 4))
+
+
+def test_mark_visible(torch_cuda, oracle):
+    import torch
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    cam, sc = scenes.make_config(2, P=20000)
+    rast = GaussianRasterizer(U.raster_settings_torch(cam, "cuda"))
+    vis = rast.markVisible(torch.tensor(sc["xyz"], device="cuda")).cpu().numpy()
+    np.testing.assert_array_equal(vis, oracle.mark_visible(sc["xyz"], cam.world_view_transform, cam.full_proj_transform))
+
+
+def test_errors(torch_cuda):
+    import torch
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    cam, sc = scenes.make_config(1, P=10)
+    rast = GaussianRasterizer(U.raster_settings_torch(cam, "cuda"))
+    t = lambda a: torch.tensor(a, device="cuda")
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        rast(means3D=t(sc["xyz"]), opacities=t(sc["opacity"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        rast(means3D=t(sc["xyz"]), opacities=t(sc["opacity"]), shs=t(sc["shs"]))
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        rast(means3D=t(sc["xyz"]).reshape(-1), opacities=t(sc["opacity"]), shs=t(sc["shs"]), scales=t(sc["scales"]),
+             rotations=t(sc["rotations"]))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        rast(means3D=torch.tensor(sc["xyz"]), opacities=t(sc["opacity"]), shs=t(sc["shs"]), scales=t(sc["scales"]),
+             rotations=t(sc["rotations"]))
+
+
+def test_backward_deterministic(torch_cuda):
+    """No float atomics in the backward: two runs are bitwise identical (the reference's is order-dependent, B10)."""
+    cam, sc = scenes.make_config(1, P=5000)
+    dL = _dL(cam, 6)
+    _, g1 = U.run_hip(cam, sc, dL=dL)
+    _, g2 = U.run_hip(cam, sc, dL=dL)
+    for k in g1:
+        np.testing.assert_array_equal(g1[k], g2[k])

@@ -1,0 +1,134 @@
+"""Helpers shared by the GPU parity tests: run the HIP operator (through the drop-in Python surface, i.e. through the C ABI)
+and the CPU oracle on the same seeded inputs."""
+import math
+
+import numpy as np
+
+NT60 = math.cos(math.radians(60.0))
+
+
+def raster_settings_torch(cam, device, sh_degree=3, bg=(0, 0, 0), **kw):
+    import torch
+    from diff_gaussian_rasterization_depth import GaussianRasterizationSettings
+    d = dict(opaque_threshold=0.6, depth_threshold=1.0, normal_threshold=NT60, color_sigma=3.0, T_threshold=1e-4, scale_modifier=1.0)
+    d.update(kw)
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=device)
+    return GaussianRasterizationSettings(
+        image_height=cam.H, image_width=cam.W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=t(bg), scale_modifier=d["scale_modifier"],
+        viewmatrix=t(cam.world_view_transform), projmatrix=t(cam.full_proj_transform), sh_degree=sh_degree, campos=t(cam.camera_center),
+        opaque_threshold=d["opaque_threshold"], normal_threshold=d["normal_threshold"], depth_threshold=d["depth_threshold"],
+        prefiltered=False, debug=False, cx=cam.cx, cy=cam.cy, color_sigma=d["color_sigma"], T_threshold=d["T_threshold"])
+
+
+def oracle_settings(ol, cam, sh_degree=3, bg=(0, 0, 0), **kw):
+    d = dict(opaque_threshold=0.6, depth_threshold=1.0, normal_threshold=NT60, color_sigma=3.0, T_threshold=1e-4, scale_modifier=1.0)
+    d.update(kw)
+    return ol.RastSettings(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, sh_degree=sh_degree, bg=bg, **d)
+
+
+def run_hip(cam, sc, device="cuda", tile_mask=None, colors_precomp=None, dL=None, sh_degree=3, bg=(0, 0, 0), **kw):
+    """Returns (outputs dict of numpy arrays, grads dict or None)."""
+    import torch
+    from diff_gaussian_rasterization_depth import GaussianRasterizer
+    rs = raster_settings_torch(cam, device, sh_degree=sh_degree, bg=bg, **kw)
+    rast = GaussianRasterizer(rs)
+    req = dL is not None
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=device, requires_grad=req)
+    xyz, opac, scales, rots = t(sc["xyz"]), t(sc["opacity"]), t(sc["scales"]), t(sc["rotations"])
+    shs = t(sc["shs"]) if colors_precomp is None else None
+    cp = t(colors_precomp) if colors_precomp is not None else None
+    tm = None if tile_mask is None else torch.tensor(np.ascontiguousarray(tile_mask, np.int32), device=device)
+    out = rast(means3D=xyz, opacities=opac, shs=shs, colors_precomp=cp, scales=scales, rotations=rots, tile_mask=tm)
+    names = ("color", "depth", "hit_color", "hit_depth", "hit_color_weight", "hit_depth_weight", "T_map", "n_touched", "radii")
+    res = {k: v.detach().cpu().numpy() for k, v in zip(names, out)}
+    grads = None
+    if req:
+        gC = torch.tensor(np.ascontiguousarray(dL[0], np.float32), device=device)
+        gD = torch.tensor(np.ascontiguousarray(dL[1], np.float32), device=device)
+        loss = (out[0] * gC).sum() + (out[1] * gD).sum()
+        loss.backward()
+        grads = dict(means3D=xyz.grad, opacity=opac.grad, scales=scales.grad, rotations=rots.grad)
+        if shs is not None:
+            grads["sh"] = shs.grad
+        else:
+            grads["colors"] = cp.grad
+        grads = {k: v.detach().cpu().numpy() for k, v in grads.items()}
+    return res, grads
+
+
+def run_oracle(ol, cam, sc, tile_mask=None, colors_precomp=None, dL=None, sh_degree=3, bg=(0, 0, 0), dtype=np.float32, **kw):
+    o = ol.OracleRasterizer(dtype)
+    st = oracle_settings(ol, cam, sh_degree=sh_degree, bg=bg, **kw)
+    r = o.forward(st, sc["xyz"], sc["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
+                  shs=None if colors_precomp is not None else sc["shs"], colors_precomp=colors_precomp, scales=sc["scales"],
+                  rotations=sc["rotations"], tile_mask=tile_mask)
+    res = dict(color=r.color, depth=r.depth, hit_color=r.hit_color, hit_depth=r.hit_depth, hit_color_weight=r.hit_color_weight,
+               hit_depth_weight=r.hit_depth_weight, T_map=r.T_map, n_touched=r.n_touched, radii=r.radii)
+    grads = None
+    if dL is not None:
+        g = o.backward(dL[0], dL[1])
+        grads = dict(means3D=g.means3D, opacity=g.opacity, scales=g.scales, rotations=g.rotations)
+        if colors_precomp is None:
+            grads["sh"] = g.sh
+        else:
+            grads["colors"] = g.colors
+    return o, res, grads
+
+
+def compare_forward(h, o, max_mismatch_frac=1e-3, tol=1e-4):
+    """Parity bar of BASELINE.json north_star: RGB/depth within 1e-4; discrete maps bit-exact up to a mismatch budget
+    (a 1-ulp difference in exp() can flip an alpha >= threshold decision; such pixels are excluded from the continuous
+    comparison and counted)."""
+    HW = h["depth"].size
+    bad = (h["hit_depth"] != o["hit_depth"]) | (h["hit_color"] != o["hit_color"])
+    # a flipped contributor decision also shows up as a jump in T: exclude those pixels as well
+    bad |= np.abs(h["T_map"] - o["T_map"]) > 1e-3
+    frac = bad.sum() / HW
+    assert frac <= max_mismatch_frac, f"index-map mismatch {frac:.2e} over budget"
+    ok = ~bad[0]
+    stats = {}
+    for k in ("color", "depth", "hit_color_weight", "hit_depth_weight", "T_map"):
+        d = np.abs(h[k] - o[k])[:, ok]
+        stats[k] = float(d.max()) if d.size else 0.0
+        assert stats[k] <= tol, f"{k}: max abs diff {stats[k]:.3e} > {tol}"
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    nt = np.abs(h["n_touched"].astype(np.int64) - o["n_touched"].astype(np.int64))
+    assert nt.sum() <= max(8, 4 * bad.sum()), f"n_touched differs by {nt.sum()} counts"
+    stats["mismatch_px"] = int(bad.sum())
+    return stats
+
+
+def compare_grads(hg, og, og64=None, rtol=1e-3):
+    """Gradients within 1e-3 (north_star).
+
+    Metric: max abs error relative to the tensor's max magnitude, and the 99th percentile of the per-Gaussian (row)
+    relative error.  The thin surfels of this workload (scale ratio 10:1, cov2D inverse with denom^2) make a handful of
+    scale / rotation gradients ill-conditioned in fp32: the fp32 ORACLE itself then sits up to ~2e-2 away from its own
+    fp64 instantiation.  When the fp64 oracle is supplied it is the truth and the bar is
+        err(HIP, fp64) <= max(1e-3, 3 x err(fp32 oracle, fp64))
+    i.e. the kernel must be as accurate as a float32 evaluation of the reference algorithm can be; without it the HIP
+    result is compared to the fp32 oracle at 1e-3 directly."""
+    stats = {}
+
+    def errs(a, truth):
+        scale = np.abs(truth).max() + 1e-30
+        tmax = np.abs(a - truth).max() / scale
+        rows_t = truth.reshape(truth.shape[0], -1) if truth.ndim > 1 else truth.reshape(-1, 1)
+        rows_a = a.reshape(rows_t.shape)
+        rel = np.abs(rows_a - rows_t).max(1) / (np.abs(rows_t).max(1) + 1e-3 * scale)
+        return tmax, (float(np.quantile(rel, 0.99)) if rel.size else 0.0)
+
+    for k in og:
+        a, b = hg[k].reshape(og[k].shape).astype(np.float64), og[k].astype(np.float64)
+        if og64 is None:
+            tmax, q99 = errs(a, b)
+            lim_max = lim_q = rtol
+        else:
+            t = og64[k].reshape(og[k].shape).astype(np.float64)
+            tmax, q99 = errs(a, t)
+            omax, oq99 = errs(b, t)
+            lim_max, lim_q = max(rtol, 3 * omax), max(rtol, 3 * oq99)
+        stats[k] = (float(tmax), q99)
+        assert tmax <= lim_max, f"grad {k}: rel-to-max error {tmax:.3e} > {lim_max:.3e}"
+        assert q99 <= lim_q, f"grad {k}: 99% row-wise error {q99:.3e} > {lim_q:.3e}"
+    return stats
