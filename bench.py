@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Mapping-iteration benchmark of the MI355X rasteriser path (BASELINE.json metric).
+
+One step = one mapping iteration of DQO-MAP's local_optimize loop (SLAM/multiprocess/mapper.py:531-605) on synthetic
+data of BASELINE config 3: activations -> rasteriser forward -> loss (0.8 L1 colour + 1.0 depth L1 on the object masks,
+mapper.py:836-875) -> rasteriser backward -> Adam step over the six parameter groups (gaussian_pointcloud.py:331-378).
+500k Gaussians, 1200x680, 8 object ids; inputs resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg 3] [--P 500000]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank owns its own object
+shard (weak scaling: fixed Gaussians per GPU, per-object losses on disjoint masks), the only exchange is one packed
+all-reduce of the per-iteration loss scalars.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dqo-map_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cfg", type=int, default=3)
+    ap.add_argument("--P", type=int, default=None)
+    ap.add_argument("--sync-mode", default="lazy", choices=("lazy", "exact"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-P", type=int, default=100_000)
+    return ap.parse_args()
+
+
+def object_masks(cam, hit_ids, obj_id, n_objects, device):
+    """Per-object screen masks (16-px tile granularity): a pixel belongs to the object of the Gaussian that
+    fixes its depth in the initial render; the shard's render mask is the union of its objects' masks."""
+    ids = hit_ids[0].long().clamp(min=0)
+    pix_obj = obj_id[ids]
+    pix_obj[hit_ids[0] < 0] = -1
+    return pix_obj
+
+
+def build_problem(args, rank, world, device):
+    from dqo_harness import scenes, mapping
+    cfgd = dict(scenes.CONFIGS[args.cfg])
+    P = args.P or cfgd["P"]
+    # weak scaling: every rank gets its own shard of P Gaussians (distinct objects / seed), same camera and image size
+    cfgd["seed"] = cfgd["seed"] + 1000 * rank
+    if args.cfg == 1:
+        cam, scene = scenes.make_config(1, P=P)
+    else:
+        cam = scenes.replica_camera(cfgd["W"], cfgd["H"], cfgd["fx"], cfgd["fx"], cfgd["cx"], cfgd["cy"])
+        scene = scenes.surfel_room(cfgd["seed"], P, n_objects=cfgd["n_objects"], rest_sigma=cfgd["rest_sigma"])
+    params = mapping.GaussianParams(scene, device)
+    settings = mapping.make_settings(cam, device)
+    # target = render of a perturbed copy, so the gradients are non-trivial
+    rng = np.random.default_rng(cfgd["seed"] + 7)
+    pert = dict(scene)
+    pert["xyz"] = (scene["xyz"] + rng.normal(0, 0.004, scene["xyz"].shape)).astype(np.float32)
+    pert["shs"] = scene["shs"].copy()
+    pert["shs"][:, 0, :] += rng.normal(0, 0.15, (P, 3)).astype(np.float32)
+    with torch.no_grad():
+        tgt = mapping.render(settings, mapping.GaussianParams(pert, device).activated())
+        gt_color, gt_depth = tgt["render"].clone(), tgt["depth"].clone()
+        pix_obj = object_masks(cam, tgt["depth_index_map"], params.obj_id, cfgd["n_objects"], device)
+        render_mask = pix_obj >= 0  # union of the object masks of this shard
+    return cam, scene, params, settings, gt_color, gt_depth, render_mask, cfgd, P
+
+
+def make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world):
+    from dqo_harness import mapping
+
+    def step():
+        out = mapping.render(settings, params.activated())
+        loss, parts = mapping.mapping_loss(out, gt_color, gt_depth, render_mask=render_mask)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        loss_buf[0], loss_buf[1], loss_buf[2] = parts["total_loss"], parts["color_loss"], parts["depth_loss"]
+        if world > 1:
+            # the path's only exchange: one packed fp32 all-reduce of the quantities shared across object shards
+            torch.distributed.all_reduce(loss_buf)
+        return out
+
+    return step
+
+
+def cpu_baseline(args, cam, scene, P_sample):
+    """Single-thread CPU oracle (kind 'port': the reference has no CPU renderer) on a bounded sample of the
+    same workload: ONE forward + backward at the same image size with the first P_sample Gaussians of the scene."""
+    from oracle import oracle_lib as ol
+    ol.build()
+    sub = {k: v[:P_sample] for k, v in scene.items()}
+    st = ol.RastSettings(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, normal_threshold=float(np.cos(np.deg2rad(60.0))))
+    o = ol.OracleRasterizer(np.float32)
+    t0 = time.time()
+    r = o.forward(st, sub["xyz"], sub["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
+                  shs=sub["shs"], scales=sub["scales"], rotations=sub["rotations"])
+    t1 = time.time()
+    o.backward(np.ones((3, cam.H, cam.W), np.float32), np.ones((1, cam.H, cam.W), np.float32))
+    t2 = time.time()
+    return dict(value=1.0 / (t2 - t0), unit="iter/s", cores=1, kind="port",
+                sample=f"1 iteration (raster fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s, no loss/Adam) of the single-thread C++ oracle on "
+                       f"the first {P_sample} Gaussians of the workload at {cam.W}x{cam.H} (N={r.num_rendered} instances)")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")  # RCCL on ROCm
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP rasteriser has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    import _dqo_native as N
+    import diff_gaussian_rasterization_depth as dgr
+    from dqo_harness import mapping
+    N.lib()
+    dgr.set_sync_mode(args.sync_mode)
+
+    cam, scene, params, settings, gt_color, gt_depth, render_mask, cfgd, P = build_problem(args, rank, world, device)
+    opt = mapping.make_optimizer(params)
+    loss_buf = torch.zeros(4, device=device)
+    step = make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world)
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if args.sync_mode == "lazy":
+        dgr._verify_pending(block=True)  # raises if any timed iteration overflowed its instance capacity
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # workload statistics of the last iteration (reported next to every timing)
+    n_vis = int((out["radii"] > 0).sum().item())
+    stats = dict(P=P, P_visible=n_vis)
+
+    roofline = None
+    kernels = None
+    if rank == 0 and not args.no_roofline:
+        # per-kernel durations with HIP events on the launch stream, over the same step function
+        N.profile_enable(True)
+        N.profile_collect(reset=True)
+        torch.cuda.synchronize()
+        ksteps = min(args.steps, 20)
+        for _ in range(ksteps):
+            step()
+        torch.cuda.synchronize()
+        prof = N.profile_collect(reset=True)
+        N.profile_enable(False)
+        kernels = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items()}  # average microseconds per launch
+        # read N / active tiles of the current state
+        cap = dgr._cap_hint.get((device.index, P, cam.W, cam.H))
+        stats["kernel_us"] = kernels
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        dom_name, dom_ms = dom[0], dom[1][0] / max(dom[1][1], 1)
+        # instance count from a fresh exact forward
+        dgr.set_sync_mode("exact")
+        with torch.no_grad():
+            o2 = mapping.render(settings, params.activated())
+        dgr.set_sync_mode(args.sync_mode)
+        n_inst = dgr.last_num_rendered()
+        HWa = cam.W * cam.H
+        stats.update(N_instances=n_inst)
+        # algorithmic bytes per launch: what the kernel must move at minimum
+        alg = {
+            "preprocess_kernel": 236 * n_vis + 12 * (P - n_vis) + 4 * P,             # read params of visible, xyz of culled; radii
+            "emit_kernel": 12 * n_inst,                                              # key + slot per instance
+            "tile_sort_kernel": 12 * n_inst + 8 * n_inst,                            # read key+slot, write id+slot
+            "blend_forward_kernel": 28 * n_inst + 36 * HWa,                          # id + xy + conic/opacity gather; 9 output planes
+            "blend_backward_kernel": 40 * n_inst + 16 * HWa,                         # + rgb gather; dL_dcolor + dL_ddepth
+            "gaussian_backward_kernel": 236 * 2 * n_vis,                             # re-read params, write grads
+        }
+        bytes_dom = alg.get(dom_name, 0)
+        achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, avg_launch_us=round(dom_ms * 1e3, 2),
+                        algorithmic_bytes=int(bytes_dom))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, cam, scene, min(args.cpu_sample_P, P))
+
+    if rank == 0:
+        value = world * args.steps / dt
+        line = {
+            "metric": "mapping iters/sec (fwd+bwd raster) @ 500k Gaussians 1200x680",
+            "value": round(value, 3), "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg{args.cfg}: surfel room, {P} Gaussians/GPU, {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, "
+                                   "SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 depth L1), raster fwd+bwd + fused Adam (6 groups)",
+                       "shards": world, "sync_mode": args.sync_mode, **stats},
+            "loss": [round(float(x), 6) for x in loss_buf.tolist()[:3]],
+        }
+        if roofline is not None:
+            line["roofline"] = roofline
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,11 @@ class DqoRastHeader(ctypes.Structure):
                 ("max_tile_count", ctypes.c_uint32), ("num_visible", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3)]
 
 
-EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_rast_geom_bytes", "dqo_rast_image_bytes", "dqo_rast_binning_bytes",
+class DqoProfileEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("total_ms", ctypes.c_double), ("calls", ctypes.c_uint32)]
+
+
+EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_rast_geom_bytes", "dqo_rast_image_bytes", "dqo_rast_binning_bytes",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
            "dqo_rast_forward", "dqo_rast_backward", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
            "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam")
@@ -80,6 +84,8 @@ def lib():
         L.dqo_knn3.argtypes = [c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
         L.dqo_quadric_iou_fwd_bwd.argtypes = [c_i32] + [c_vp] * 12
         L.dqo_quadric_adam.argtypes = [c_i32, c_i32] + [c_vp] * 9
+        L.dqo_profile_enable.argtypes = [ctypes.c_int]
+        L.dqo_profile_collect.argtypes = [P(DqoProfileEntry), ctypes.c_int, ctypes.c_int]
         if L.dqo_abi_version() != 1:
             raise RuntimeError("libdqoraster.so ABI version mismatch")
         _lib = L
@@ -108,3 +114,14 @@ def require_gpu(*tensors):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_enable(on):
+    lib().dqo_profile_enable(1 if on else 0)
+
+
+def profile_collect(reset=True):
+    """{kernel name: (total_ms, calls)} of every launch bracketed since the last reset (synchronises)."""
+    buf = (DqoProfileEntry * 64)()
+    n = lib().dqo_profile_collect(buf, 64, 1 if reset else 0)
+    return {buf[i].name.decode(): (buf[i].total_ms, buf[i].calls) for i in range(n)}

@@ -23,9 +23,72 @@ int dqo_launch_quadric_iou(int B, const float* axes, const float* R, const float
 int dqo_launch_quadric_adam(int n_obj, int n_iters, const int32_t* view_offset, const float* P34_views, const float* obs_views,
                             const int32_t* view_schedule, float* axes, float* R, float* center, float* loss_hist, hipStream_t s);
 
+// ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -------------------------------
+#include <map>
+#include <string>
+#include <vector>
+int g_dqo_profile_on = 0;
+namespace {
+struct Pending {
+    std::string name;
+    hipEvent_t start, stop;
+};
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_event_pool;
+std::map<std::string, std::pair<double, uint32_t>> g_profile_acc;
+hipEvent_t take_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+void dqo_profile_before(const char* name, hipStream_t s) {
+    Pending p{name, take_event(), take_event()};
+    hipEventRecord(p.start, s);
+    g_pending.push_back(p);
+}
+void dqo_profile_after(hipStream_t s) { hipEventRecord(g_pending.back().stop, s); }
+
 extern "C" {
 
 #define DQO_API __attribute__((visibility("default")))
+
+DQO_API int dqo_profile_enable(int on) {
+    g_dqo_profile_on = on ? 1 : 0;
+    return DQO_OK;
+}
+
+// Waits for every bracketed launch recorded so far, accumulates elapsed times per kernel name and copies up to
+// max_entries accumulated rows out (returns the number of rows).  reset != 0 clears the accumulators afterwards.
+DQO_API int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset) {
+    for (auto& p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            auto& a = g_profile_acc[p.name];
+            a.first += ms;
+            a.second += 1;
+        }
+        g_event_pool.push_back(p.start);
+        g_event_pool.push_back(p.stop);
+    }
+    g_pending.clear();
+    int n = 0;
+    for (auto& kv : g_profile_acc) {
+        if (n >= max_entries || out == nullptr) break;
+        strncpy(out[n].name, kv.first.c_str(), sizeof(out[n].name) - 1);
+        out[n].name[sizeof(out[n].name) - 1] = 0;
+        out[n].total_ms = kv.second.first;
+        out[n].calls = kv.second.second;
+        n++;
+    }
+    if (reset) g_profile_acc.clear();
+    return n;
+}
 
 DQO_API int dqo_abi_version(void) { return DQO_ABI_VERSION; }
 DQO_API const char* dqo_last_error(void) { return g_err; }

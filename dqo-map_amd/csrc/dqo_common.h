@@ -29,6 +29,18 @@ void dqo_set_error(const char* fmt, ...);
 
 static inline size_t dqo_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- optional per-kernel timing (dqo_profile_enable): HIP events recorded on the launch stream around every kernel ----
+extern int g_dqo_profile_on;
+void dqo_profile_before(const char* name, hipStream_t s);
+void dqo_profile_after(hipStream_t s);
+#define DQO_LAUNCH(name, kernel, grid, block, stream, ...)                       \
+    do {                                                                         \
+        if (g_dqo_profile_on) dqo_profile_before(name, stream);                  \
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);         \
+        if (g_dqo_profile_on) dqo_profile_after(stream);                         \
+        DQO_CHECK_LAUNCH();                                                      \
+    } while (0)
+
 // ---- context buffer layouts (private) -------------------------------------------------------------------------
 // geom buffer: header + per-Gaussian SoA tables, every table 256-B aligned.
 struct DqoGeomLayout {
@@ -74,6 +86,7 @@ static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
 // image buffer: per-tile tables + per-pixel forward->backward state.
 struct DqoImageLayout {
     uint32_t* tile_count;   // [T] instances per tile (atomic histogram, K1)
+    uint32_t* tile_flag;    // [T] 1 = some Gaussian's reference rect covers the tile but all such instances were culled as dead
     uint32_t* tile_cursor;  // [T] emit cursor
     uint2* ranges;          // [T] [start, end) into the sorted list (rasterizer_impl.cu:120-142)
     uint32_t* tile_walk;    // [T] entries the backward must walk = max over pixels of max(n_contrib, hit position)
@@ -95,6 +108,7 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
         return r;
     };
     L.tile_count = (uint32_t*)take(4 * T);
+    L.tile_flag = (uint32_t*)take(4 * T);  // directly after tile_count: both are zeroed by one memset
     L.tile_cursor = (uint32_t*)take(4 * T);
     L.ranges = (uint2*)take(8 * T);
     L.tile_walk = (uint32_t*)take(4 * T);

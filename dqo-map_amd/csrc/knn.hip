@@ -259,27 +259,19 @@ int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void
     (void)ws_bytes;
     KnnWs w = knn_ws(ws, P);
     const int P2 = next_pow2(P < SORT_RUN ? SORT_RUN : P);
-    hipLaunchKernelGGL(bbox_kernel, dim3(1), dim3(1024), 0, s, P, xyz, w.bbox);
-    DQO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(morton_kernel, dim3((P2 + 255) / 256), dim3(256), 0, s, P, P2, xyz, w.bbox, w.keys);
-    DQO_CHECK_LAUNCH();
+    DQO_LAUNCH("bbox_kernel", bbox_kernel, dim3(1), dim3(1024), s, P, xyz, w.bbox);
+    DQO_LAUNCH("morton_kernel", morton_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
     const int runs = P2 / SORT_RUN;
-    hipLaunchKernelGGL(bitonic_lds_kernel, dim3(runs), dim3(SORT_T), 0, s, w.keys, SORT_RUN, 1);
-    DQO_CHECK_LAUNCH();
+    DQO_LAUNCH("bitonic_lds_kernel", bitonic_lds_kernel, dim3(runs), dim3(SORT_T), s, w.keys, SORT_RUN, 1);
     for (int k = SORT_RUN * 2; k <= P2; k <<= 1) {
         for (int j = k >> 1; j >= SORT_RUN; j >>= 1) {
-            hipLaunchKernelGGL(bitonic_global_kernel, dim3((P2 / 2 + 255) / 256), dim3(256), 0, s, w.keys, P2 / 2, k, j);
-            DQO_CHECK_LAUNCH();
+            DQO_LAUNCH("bitonic_global_kernel", bitonic_global_kernel, dim3((P2 / 2 + 255) / 256), dim3(256), s, w.keys, P2 / 2, k, j);
         }
-        hipLaunchKernelGGL(bitonic_lds_kernel, dim3(runs), dim3(SORT_T), 0, s, w.keys, k, 0);
-        DQO_CHECK_LAUNCH();
+        DQO_LAUNCH("bitonic_lds_kernel", bitonic_lds_kernel, dim3(runs), dim3(SORT_T), s, w.keys, k, 0);
     }
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, xyz, w.keys, w.sorted);
-    DQO_CHECK_LAUNCH();
+    DQO_LAUNCH("gather_sorted_kernel", gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), s, P, xyz, w.keys, w.sorted);
     const int nb = (P + KNN_BOX - 1) / KNN_BOX;
-    hipLaunchKernelGGL(box_minmax_kernel, dim3(nb), dim3(256), 0, s, P, w.sorted, w.boxes);
-    DQO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_scan_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, w.sorted, w.boxes, mean_d2, idx3);
-    DQO_CHECK_LAUNCH();
+    DQO_LAUNCH("box_minmax_kernel", box_minmax_kernel, dim3(nb), dim3(256), s, P, w.sorted, w.boxes);
+    DQO_LAUNCH("knn_scan_kernel", knn_scan_kernel, dim3((P + 255) / 256), dim3(256), s, P, w.sorted, w.boxes, mean_d2, idx3);
     return DQO_OK;
 }

@@ -234,16 +234,14 @@ __global__ void quadric_adam_kernel(int n_obj, int n_iters, const int32_t* __res
 
 int dqo_launch_quadric_iou(int B, const float* axes, const float* R, const float* center, const float* P34, const float* obs,
                            float* bbox, float* loss, int32_t* valid, float* g_axes, float* g_R, float* g_center, hipStream_t s) {
-    hipLaunchKernelGGL(quadric_iou_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, axes, R, center, P34, obs, bbox, loss, valid, g_axes,
+    DQO_LAUNCH("quadric_iou_kernel", quadric_iou_kernel, dim3((B + 63) / 64), dim3(64), s, B, axes, R, center, P34, obs, bbox, loss, valid, g_axes,
                        g_R, g_center);
-    DQO_CHECK_LAUNCH();
     return DQO_OK;
 }
 
 int dqo_launch_quadric_adam(int n_obj, int n_iters, const int32_t* view_offset, const float* P34_views, const float* obs_views,
                             const int32_t* view_schedule, float* axes, float* R, float* center, float* loss_hist, hipStream_t s) {
-    hipLaunchKernelGGL(quadric_adam_kernel, dim3((n_obj + 63) / 64), dim3(64), 0, s, n_obj, n_iters, view_offset, P34_views, obs_views,
+    DQO_LAUNCH("quadric_adam_kernel", quadric_adam_kernel, dim3((n_obj + 63) / 64), dim3(64), s, n_obj, n_iters, view_offset, P34_views, obs_views,
                        view_schedule, axes, R, center, loss_hist);
-    DQO_CHECK_LAUNCH();
     return DQO_OK;
 }

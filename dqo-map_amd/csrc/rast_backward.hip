@@ -14,6 +14,7 @@
 //   * gaussian_backward_kernel sums each Gaussian's contiguous records in a fixed order (bitwise reproducible) and
 //     finishes the chain rule (cov2D, projection, SH, cov3D) in the same pass.
 #include "dqo_common.h"
+#include "dqo_cull.h"
 
 namespace {
 
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     __shared__ float4 s_rgb[BWD_THREADS];
     __shared__ int s_id[BWD_THREADS];
     __shared__ uint32_t s_slot[BWD_THREADS];
+    __shared__ uint32_t s_qmask[BWD_THREADS];
     __shared__ float4 s_rec[BWD_THREADS * 4];  // 64 records x 64 B
 
     const int tile = img.tile_order[blockIdx.x];
@@ -112,11 +114,22 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
         const int pos = L - 1 - (b * BWD_THREADS + lane);
         if (pos >= 0) {
             const int id = (int)bin.point_list[range.x + pos];
+            const float4 co = g.conic_opacity[id];
+            const float4 xy = g.xy_depth[id];
             s_id[lane] = id;
             s_slot[lane] = bin.slot_list[range.x + pos];
-            s_co[lane] = g.conic_opacity[id];
-            s_xy[lane] = g.xy_depth[id];
+            s_co[lane] = co;
+            s_xy[lane] = xy;
             s_rgb[lane] = g.rgb_smax[id];
+            // quadrants (= the lane's four pixels) the splat can reach at all (dqo_cull.h)
+            const float qthr = dqo_q_threshold(co.w);
+            uint32_t qm = 0;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                const float x0 = (float)(tile_x * DQO_TILE + (q & 1) * 8), y0 = (float)(tile_y * DQO_TILE + (q >> 1) * 8);
+                qm |= dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, qthr, x0, y0, x0 + 7.f, y0 + 7.f) ? (1u << q) : 0u;
+            }
+            s_qmask[lane] = qm;
         }
         __syncthreads();
         const int batch = min(BWD_THREADS, L - b * BWD_THREADS);
@@ -127,9 +140,11 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
             const float4 cs = s_rgb[j];
             float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
             bool any_color = false, any_hit = false;
+            const uint32_t qm = s_qmask[j];
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
                 any_hit |= (hit_pos[q] == c + 1);
+                if (!((qm >> q) & 1u)) continue;  // wave-uniform: quadrant q is out of the splat's reach
                 if (c < last_contrib[q]) {
                     const float dx = xy.x - pixfx[q], dy = xy.y - pixfy[q];
                     const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
@@ -554,11 +569,9 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity);
     const int T = v.gx * v.gy;
     DqoGradRec* recs = (DqoGradRec*)ws;
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(T), dim3(BWD_THREADS), 0, s, v, g, img, bin, in->scales, in->rotations, dL_dcolor,
+    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(T), dim3(BWD_THREADS), s, v, g, img, bin, in->scales, in->rotations, dL_dcolor,
                        dL_ddepth, recs, (int64_t)ctx->inst_capacity);
-    DQO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), 0, s, v, g, in->means3D, in->scales, in->rotations,
+    DQO_LAUNCH("gaussian_backward_kernel", gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), s, v, g, in->means3D, in->scales, in->rotations,
                        in->shs, recs, *gr);
-    DQO_CHECK_LAUNCH();
     return DQO_OK;
 }

@@ -12,6 +12,7 @@
 // needs per Gaussian is precomputed once into 16-byte SoA records (the reference rebuilds the quaternion rotation and
 // four uncoalesced gathers per (pixel, Gaussian) pair, forward.cu:779-791).
 #include "dqo_common.h"
+#include "dqo_cull.h"
 
 namespace {
 
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
                                                                 const float* __restrict__ shs,
                                                                 const float* __restrict__ colors_precomp,
                                                                 const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
-                                                                uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii_out,
+                                                                uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
+                                                                int32_t* __restrict__ radii_out,
                                                                 int32_t* __restrict__ n_touched_out) {
 #pragma clang fp contract(off)
     __shared__ uint32_t s_wave_sum[K1_THREADS / 64];
@@ -208,13 +210,22 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
             g.normal_c[idx] = make_float4(ncx, ncy, ncz, npc);
             g.point_c[idx] = make_float4(tvx, tvy, tvz, 0.f);
             g.clamped[idx] = (uint8_t)clampbits;
-            // tiles_touched + per-tile histogram, forward.cu:344-353
+            // tiles_touched + per-tile histogram, forward.cu:344-353 — restricted to the tiles whose pixels the splat can
+            // actually reach (dqo_cull.h: output-invariant, the dropped instances are no-ops in the reference's lists)
+            const float qthr = dqo_q_threshold(opacities[idx]);
             for (int y = rminy; y < rmaxy; y++)
                 for (int x = rminx; x < rmaxx; x++) {
                     const int t = y * v.gx + x;
-                    if (tile_mask == nullptr || tile_mask[t]) {
+                    if (tile_mask != nullptr && !tile_mask[t]) continue;
+                    if (dqo_splat_hits_rect(pixx, pixy, conx, cony, conz, qthr, (float)(x * DQO_TILE), (float)(y * DQO_TILE),
+                                            (float)(x * DQO_TILE + DQO_TILE - 1), (float)(y * DQO_TILE + DQO_TILE - 1))) {
                         ntouch++;
                         atomicAdd(&tile_count[t], 1u);
+                    } else if (tile_flag[t] == 0u) {
+                        // the reference would list this Gaussian here, so the tile is an ACTIVE tile there even if every
+                        // one of its instances is dead: it must be rendered (ids -1, colour = bg), not left at the
+                        // never-rendered fills.  Idempotent racy store; most lanes see the 1 and skip it.
+                        tile_flag[t] = 1u;
                     }
                 }
         } while (false);
@@ -355,13 +366,19 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, int gx, const int32_t*
     if (ntouch == 0) return;
     const uint2 r = g.rect16[idx];
     const int rminx = r.x & 0xffff, rmaxx = r.x >> 16, rminy = r.y & 0xffff, rmaxy = r.y >> 16;
-    const uint32_t depth_bits = __float_as_uint(g.xy_depth[idx].z);
+    const float4 xyd = g.xy_depth[idx];
+    const float4 co = g.conic_opacity[idx];
+    const float qthr = dqo_q_threshold(co.w);
+    const uint32_t depth_bits = __float_as_uint(xyd.z);
     const uint64_t key = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
     uint32_t slot = g.slot_base[idx];
     for (int y = rminy; y < rmaxy; y++)
         for (int x = rminx; x < rmaxx; x++) {
             const int t = y * gx + x;
-            if (tile_mask == nullptr || tile_mask[t]) {
+            // same predicate, same inputs, same IEEE ops as the count pass in preprocess_kernel
+            if ((tile_mask == nullptr || tile_mask[t]) &&
+                dqo_splat_hits_rect(xyd.x, xyd.y, co.x, co.y, co.z, qthr, (float)(x * DQO_TILE), (float)(y * DQO_TILE),
+                                    (float)(x * DQO_TILE + DQO_TILE - 1), (float)(y * DQO_TILE + DQO_TILE - 1))) {
                 const uint32_t pos = atomicAdd(&tile_cursor[t], 1u);
                 if ((int64_t)pos < capacity) {
                     bin.keys[pos] = key;
@@ -478,6 +495,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
     __shared__ float4 s_rgb[BLEND_THREADS];
     __shared__ int s_id[BLEND_THREADS];
     __shared__ int s_cnt[BLEND_THREADS];
+    __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_walk;
 
     const int tile = img.tile_order[blockIdx.x];
@@ -493,14 +511,17 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
     const int n = (int)(range.y - range.x);
 
     if (n == 0) {
-        // masked or empty tile: the reference's torch::full initial values (rasterize_points.cu:79-89)
+        // masked or empty tile: the reference's torch::full initial values (rasterize_points.cu:79-89).  A tile that is
+        // active in the reference but whose instances were all culled as dead is rendered with an empty list instead:
+        // colour = bg, ids = -1 (forward.cu:724-725, 852-860).
+        const bool rendered = img.tile_flag[tile] != 0u;
         if (inside) {
-            out.out_color[pix_id] = 0.f;
-            out.out_color[HW + pix_id] = 0.f;
-            out.out_color[2 * HW + pix_id] = 0.f;
+            out.out_color[pix_id] = rendered ? v.bg[0] : 0.f;
+            out.out_color[HW + pix_id] = rendered ? v.bg[1] : 0.f;
+            out.out_color[2 * HW + pix_id] = rendered ? v.bg[2] : 0.f;
             out.out_depth[pix_id] = 0.f;
-            out.out_hit_depth[pix_id] = 0;
-            out.out_hit_color[pix_id] = 0;
+            out.out_hit_depth[pix_id] = rendered ? -1 : 0;
+            out.out_hit_color[pix_id] = rendered ? -1 : 0;
             out.out_hit_color_weight[pix_id] = 0.f;
             out.out_hit_depth_weight[pix_id] = 0.f;
             out.out_T[pix_id] = 1.f;
@@ -515,7 +536,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
     const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
     bool done = !inside;
     float T = 1.0f, end_T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0, hit_pos = 0;
+    uint32_t last_contributor = 0, hit_pos = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float depth_ = 0.f;
     bool hit_gaussian = false;
@@ -541,18 +562,30 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
         const int progress = i * BLEND_THREADS + tid;
         if (progress < n) {
             const int id = (int)bin.point_list[range.x + progress];
+            const float4 co = g.conic_opacity[id];
+            const float4 xy = g.xy_depth[id];
             s_id[tid] = id;
-            s_co[tid] = g.conic_opacity[id];
-            s_xy[tid] = g.xy_depth[id];
+            s_co[tid] = co;
+            s_xy[tid] = xy;
             s_rgb[tid] = g.rgb_smax[id];
+            // which of the four 8x8 quadrants (= waves) the splat can reach at all (dqo_cull.h)
+            const float qthr = dqo_q_threshold(co.w);
+            uint32_t qm = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float x0 = (float)(tile_x * DQO_TILE + (q & 1) * 8), y0 = (float)(tile_y * DQO_TILE + (q >> 1) * 8);
+                qm |= dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, qthr, x0, y0, x0 + 7.f, y0 + 7.f) ? (1u << q) : 0u;
+            }
+            s_qmask[tid] = qm;
         }
         __syncthreads();
         const int batch = min(BLEND_THREADS, toDo);
         for (int j = 0; j < batch; j++) {
             if (__ballot(!done) == 0) break;  // whole wave finished
+            if (!((s_qmask[j] >> wave) & 1u)) continue;  // wave-uniform: this quadrant is out of the splat's reach
             bool contributes_half = false;
             if (!done) {
-                contributor++;
+                const uint32_t contributor = (uint32_t)(i * BLEND_THREADS + j + 1);  // the reference's running counter
                 const float4 xy = s_xy[j];
                 const float4 co = s_co[j];
                 const float dx = xy.x - pixfx, dy = xy.y - pixfy;
@@ -652,13 +685,12 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     const int T = v.gx * v.gy;
     DQO_CHECK_HIP(hipMemsetAsync(g.header, 0, 512, s));  // header + counters
-    DQO_CHECK_HIP(hipMemsetAsync(img.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    DQO_CHECK_HIP(hipMemsetAsync(img.tile_count, 0, (size_t)((char*)(img.tile_flag + T) - (char*)img.tile_count), s));
     if (p->P > 0) {
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;
-        hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(K1_THREADS), 0, s, v, in->means3D, in->scales, in->rotations,
-                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, img.tile_count, out->radii, out->n_touched);
-        DQO_CHECK_LAUNCH();
+        DQO_LAUNCH("preprocess_kernel", preprocess_kernel, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
+                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, img.tile_count, img.tile_flag, out->radii, out->n_touched);
     }
     return DQO_OK;
 }
@@ -669,23 +701,18 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity);
     const int T = v.gx * v.gy;
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, T, img, g, (int64_t)ctx->inst_capacity);
-    DQO_CHECK_LAUNCH();
+    DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, (int64_t)ctx->inst_capacity);
     if (p->P > 0) {
-        hipLaunchKernelGGL(emit_kernel, dim3((p->P + 255) / 256), dim3(256), 0, s, p->P, v.gx, in->tile_mask, g, img.tile_cursor, bin,
+        DQO_LAUNCH("emit_kernel", emit_kernel, dim3((p->P + 255) / 256), dim3(256), s, p->P, v.gx, in->tile_mask, g, img.tile_cursor, bin,
                            (int64_t)ctx->inst_capacity);
-        DQO_CHECK_LAUNCH();
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(SORT_THREADS), 0, s, img, bin);
-        DQO_CHECK_LAUNCH();
+        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(T), dim3(SORT_THREADS), s, img, bin);
     }
-    hipLaunchKernelGGL(blend_forward_kernel, dim3(T), dim3(BLEND_THREADS), 0, s, v, g, img, bin, *out);
-    DQO_CHECK_LAUNCH();
+    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(T), dim3(BLEND_THREADS), s, v, g, img, bin, *out);
     return DQO_OK;
 }
 
 int dqo_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s) {
     if (P <= 0) return DQO_OK;
-    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, proj, present);
-    DQO_CHECK_LAUNCH();
+    DQO_LAUNCH("mark_visible_kernel", mark_visible_kernel, dim3((P + 255) / 256), dim3(256), s, P, means3D, view, proj, present);
     return DQO_OK;
 }

@@ -28,6 +28,12 @@ import _dqo_native as N
 _sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy": reuse / grow the previous capacity, no sync
 _cap_hint = {}
 _pending = []          # lazy mode: (event, pinned header tensor, key) of forwards not yet verified
+_last = {"num_rendered": None, "num_visible": None}
+
+
+def last_num_rendered():
+    """Instance count N of the most recent forward that ran in 'exact' mode (statistics for benchmarks)."""
+    return _last["num_rendered"]
 
 
 def set_sync_mode(mode):
@@ -141,6 +147,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))  # the one D2H read
                 num_rendered = int(hdr.num_rendered)
                 cap = max(num_rendered, 1)
+                _last["num_rendered"], _last["num_visible"] = num_rendered, int(hdr.num_visible)
             else:
                 _verify_pending(block=False)
                 cap = _cap_hint.get(key)

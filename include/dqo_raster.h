@@ -11,7 +11,6 @@
  *   dqo_knn3             <- simple_knn._C.distCUDA2                submodules/simple-knn/ext.cpp:15-17, spatial.cu:15-28
  *   dqo_quadric_*        <- Ellipsoid_tensor.forward + bboxes_iou + the Adam loop of Object_Optimize_only
  *                                                                  SLAM/multiprocess/quadrics.py:285-290, 2018-2091, 2144-2220, 2234-2298
- *   dqo_accumulate_gaussian_error <- cuda_utils._C.accumulate_gaussian_error   submodules/cuda_utils/ext.cpp, map_process.cu:33-245
  *
  * Conventions
  *   - plain C: raw DEVICE pointers (tensor.data_ptr()), sizes, no torch / C++ types; all memory is caller-owned.
@@ -127,6 +126,17 @@ typedef struct DqoRastHeader {
 
 int dqo_abi_version(void);
 const char* dqo_last_error(void);
+
+/* Optional per-kernel timing (measurement only; the reference has nothing comparable — it times whole frames with
+ * time.time(), utils/monitor.py:22-37).  While enabled every kernel launch of this library is bracketed by HIP events
+ * recorded on the launch stream; dqo_profile_collect waits for them and returns accumulated milliseconds per kernel. */
+typedef struct DqoProfileEntry {
+    char name[48];
+    double total_ms;
+    uint32_t calls;
+} DqoProfileEntry;
+int dqo_profile_enable(int on);
+int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset);
 
 size_t dqo_rast_geom_bytes(int32_t P, int32_t W, int32_t H);
 size_t dqo_rast_image_bytes(int32_t W, int32_t H);

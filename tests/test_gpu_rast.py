@@ -86,20 +86,46 @@ def test_binning_exact(torch_cuda, oracle):
     c = Ctx()
     out = _RasterizeGaussians.forward(c, t(sc["xyz"]), t(sc["shs"]), torch.Tensor([]), t(sc["opacity"]), t(sc["scales"]),
                                       t(sc["rotations"]), torch.Tensor([]), None, rs)
-    assert c.num_rendered == o.N
     geom, binning, img = c.saved[8], c.saved[9], c.saved[10]
-    Nn = o.N
-    T = ((cam.W + 15) // 16) * ((cam.H + 15) // 16)
+    Nn = c.num_rendered
+    assert 0 < Nn <= o.N
+    gx = (cam.W + 15) // 16
+    T = gx * ((cam.H + 15) // 16)
     al = lambda n: (n + 255) // 256 * 256
     # binning layout: keys u64[cap] | slots u32[cap] | point_list u32[cap] | slot_list u32[cap], each 256-B aligned
     off_pl = al(8 * Nn) + al(4 * Nn)
     pl = binning[off_pl:off_pl + 4 * Nn].view(torch.int32).cpu().numpy().astype(np.uint32)
-    np.testing.assert_array_equal(pl, o.ctx("point_list"))
-    # image layout: tile_count | tile_cursor | ranges ...
-    off_rg = 2 * al(4 * T)
+    # image layout: tile_count | tile_flag | tile_cursor | ranges ...
+    off_rg = 3 * al(4 * T)
     rg = img[off_rg:off_rg + 8 * T].view(torch.int32).cpu().numpy().reshape(T, 2).astype(np.uint32)
-    np.testing.assert_array_equal(rg, o.ctx("ranges"))
     np.testing.assert_array_equal(out[8].cpu().numpy(), r["radii"])
+    # Per tile the HIP list is the oracle's (= reference's) list with the dead entries removed, in the same order:
+    # every instance the HIP binning dropped must be a provable no-op (alpha < 1/255 or power > 0 on every pixel of the
+    # tile, evaluated with the blend loop's own fp32 arithmetic), so all outputs are unchanged (dqo_cull.h).
+    opl, org = o.ctx("point_list"), o.ctx("ranges")
+    m2d, con = o.ctx("means2D"), o.ctx("conic_opacity")
+    dropped = kept = 0
+    for t in range(T):
+        mine = pl[rg[t, 0]:rg[t, 1]]
+        ref = opl[org[t, 0]:org[t, 1]]
+        it = iter(ref)
+        assert all(any(x == y for y in it) for x in mine), f"tile {t}: HIP list is not an ordered sub-list of the reference list"
+        gone = np.setdiff1d(ref, mine)
+        kept += len(mine)
+        dropped += len(gone)
+        if len(gone):
+            ty, tx = divmod(t, gx)
+            ys, xs = np.mgrid[ty * 16:min(cam.H, ty * 16 + 16), tx * 16:min(cam.W, tx * 16 + 16)]
+            xs, ys = xs.astype(np.float32).ravel(), ys.astype(np.float32).ravel()
+            dx = m2d[gone, 0][:, None] - xs[None]
+            dy = m2d[gone, 1][:, None] - ys[None]
+            A, B, C, op = (con[gone, k][:, None] for k in range(4))
+            power = np.float32(-0.5) * (A * dx * dx + C * dy * dy) - B * dx * dy
+            alpha = np.minimum(np.float32(0.99), op * np.exp(power))
+            live = (power <= 0) & (alpha >= np.float32(1.0 / 255.0))
+            assert not live.any(), f"tile {t}: dropped a live instance"
+    assert kept == Nn and kept + dropped == o.N
+    print(f"binning: kept {kept} of {o.N} reference instances ({dropped / o.N:.1%} dead entries culled)")
 
 
 def test_empty_and_tiny(torch_cuda, oracle):
