@@ -87,10 +87,11 @@ def make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, 
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
-        loss_buf[0], loss_buf[1], loss_buf[2] = parts["total_loss"], parts["color_loss"], parts["depth_loss"]
-        if world > 1:
-            # the path's only exchange: one packed fp32 all-reduce of the quantities shared across object shards
-            torch.distributed.all_reduce(loss_buf)
+        loss_buf.put("total", parts["total_loss"])
+        loss_buf.put("color", parts["color_loss"])
+        loss_buf.put("depth", parts["depth_loss"])
+        # the path's only exchange: ONE packed fp32 all-reduce of the quantities shared across object shards
+        loss_buf.reduce()
         return out
 
     return step
@@ -136,7 +137,8 @@ def main():
 
     cam, scene, params, settings, gt_color, gt_depth, render_mask, cfgd, P = build_problem(args, rank, world, device)
     opt = mapping.make_optimizer(params)
-    loss_buf = torch.zeros(4, device=device)
+    from dqo_harness.sharding import PackedAllReduce
+    loss_buf = PackedAllReduce([("total", 1), ("color", 1), ("depth", 1)], device)
     step = make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world)
 
     def sync_all():
@@ -219,7 +221,7 @@ def main():
             "config": {"workload": f"cfg{args.cfg}: surfel room, {P} Gaussians/GPU, {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, "
                                    "SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 depth L1), raster fwd+bwd + fused Adam (6 groups)",
                        "shards": world, "sync_mode": args.sync_mode, **stats},
-            "loss": [round(float(x), 6) for x in loss_buf.tolist()[:3]],
+            "loss": [round(float(x) / world, 6) for x in loss_buf.buf.tolist()[:3]],
         }
         if roofline is not None:
             line["roofline"] = roofline
