@@ -195,7 +195,7 @@ def main():
         # algorithmic bytes per launch: what the kernel must move at minimum
         alg = {
             "preprocess_kernel": 236 * n_vis + 12 * (P - n_vis) + 4 * P,             # read params of visible, xyz of culled; radii
-            "emit_kernel": 12 * n_inst,                                              # key + slot per instance
+            "bin_emit_kernel": 12 * n_inst, "bin_count_kernel": 16 * n_inst,                                              # key + slot per instance
             "tile_sort_kernel": 12 * n_inst + 8 * n_inst,                            # read key+slot, write id+slot
             "blend_forward_kernel": 28 * n_inst + 36 * HWa,                          # id + xy + conic/opacity gather; 9 output planes
             "blend_backward_kernel": 40 * n_inst + 16 * HWa,                         # + rgb gather; dL_dcolor + dL_ddepth

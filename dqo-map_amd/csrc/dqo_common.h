@@ -126,6 +126,7 @@ struct DqoBinLayout {
     uint32_t* slots;      // [cap] unsorted gaussian-major slot of the instance
     uint32_t* point_list; // [cap] sorted gaussian ids   (binningState.point_list)
     uint32_t* slot_list;  // [cap] sorted slots (where the backward stores this instance's gradient record)
+    uint8_t* live;        // [cap] per sorted instance: 4-bit mask of the tile quadrants in which the forward acted on it
     size_t total;
 };
 
@@ -141,6 +142,7 @@ static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap) {
     L.slots = (uint32_t*)take(4 * (size_t)cap);
     L.point_list = (uint32_t*)take(4 * (size_t)cap);
     L.slot_list = (uint32_t*)take(4 * (size_t)cap);
+    L.live = (uint8_t*)take((size_t)cap);
     L.total = (size_t)(p - (char*)base);
     return L;
 }

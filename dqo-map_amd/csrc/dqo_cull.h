@@ -51,3 +51,10 @@ __device__ __forceinline__ bool dqo_splat_hits_rect(float mx, float my, float A,
     const float margin = 0.05f + 0.01f * qthr + 4.0e-6f * tmax;
     return !(qmin > qthr + margin);  // NaN-safe: keeps the entry
 }
+
+// exp(power) of the blend loops (forward.cu:770, backward.cu:943).  One v_exp_f32 (|rel err| ~1e-7 for power in [-5.6, 0],
+// the only range that survives the 1/255 cut) instead of the ~15-instruction libm expf; forward and backward share it so
+// the backward reproduces the forward's alpha bit for bit.
+__device__ __forceinline__ float dqo_gauss(float power) { return __expf(power); }
+// 1/x by v_rcp_f32 (1 ulp) for the T / (1 - alpha) recurrences of the backward (backward.cu:948, 980)
+__device__ __forceinline__ float dqo_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -1,7 +1,7 @@
 // Backward pass of the depth-aware Gaussian rasteriser for gfx950 (MI355X).
 //
 // Replaces (semantics, not structure) /root/reference/submodules/diff-gaussian-rasterizer-depth/
-//   cuda_rasterizer/backward.cu:808-1066  renderCUDA_flat (+propagateRotationGrad :100-148)  -> blend_backward_kernel
+//   cuda_rasterizer/backward.cu:808-1066  renderCUDA_flat (+propagateRotationGrad :100-148)  -> blend_backward_kernel (rast_backward_blend.hip)
 //   cuda_rasterizer/backward.cu:273-422   computeCov2DCUDA                                    \
 //   cuda_rasterizer/backward.cu:492-548   preprocessCUDA (+SH bwd :152-268, cov3D bwd :426-487)/ -> gaussian_backward_kernel
 //
@@ -17,273 +17,6 @@
 #include "dqo_cull.h"
 
 namespace {
-
-// ---- wave64 sum via DPP (no LDS traffic): 4 steps inside each 16-lane row, 2 row broadcasts, result in lane 63 ----
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);       // row_half_mirror
-    v += dpp_mov<0x140>(v);       // row_mirror          -> every lane holds its row's sum
-    v += dpp_mov<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
-    v += dpp_mov<0x143, 0xC>(v);  // row_bcast31 into rows 2,3 -> lanes 48..63 hold the wave total
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-__device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
-#pragma clang fp contract(off)
-    float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
-    const float n = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
-    return make_float3(rx * n, ry * n, rz * n);
-}
-
-constexpr int BWD_THREADS = 64;  // one wave per tile
-constexpr int PPL = 4;           // pixels per lane (the four 8x8 quadrants of the tile)
-
-__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
-                                                                     DqoBinLayout bin, const float* __restrict__ scales,
-                                                                     const float* __restrict__ rotations,
-                                                                     const float* __restrict__ dL_dpixels,
-                                                                     const float* __restrict__ dL_ddepths,
-                                                                     DqoGradRec* __restrict__ recs, int64_t capacity) {
-    __shared__ float4 s_co[BWD_THREADS];
-    __shared__ float4 s_xy[BWD_THREADS];
-    __shared__ float4 s_rgb[BWD_THREADS];
-    __shared__ int s_id[BWD_THREADS];
-    __shared__ uint32_t s_slot[BWD_THREADS];
-    __shared__ uint32_t s_qmask[BWD_THREADS];
-    __shared__ float4 s_rec[BWD_THREADS * 4];  // 64 records x 64 B
-
-    const int tile = img.tile_order[blockIdx.x];
-    const uint2 range = img.ranges[tile];
-    const int n = (int)(range.y - range.x);
-    if (n == 0) return;
-    const int L = min((int)img.tile_walk[tile], n);
-    const int lane = threadIdx.x;
-    const int tile_x = tile % v.gx, tile_y = tile / v.gx;
-    const size_t HW = (size_t)v.W * v.H;
-
-    float view[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) view[i] = v.view[i];
-    const float bg0 = v.bg[0], bg1 = v.bg[1], bg2 = v.bg[2];
-    const float ddelx_dx = 0.5f * v.W, ddely_dy = 0.5f * v.H;
-
-    // per-pixel state, 4 pixels per lane
-    float pixfx[PPL], pixfy[PPL];
-    float T[PPL], T_final[PPL];
-    int last_contrib[PPL], hit_pos[PPL];
-    float acc0[PPL], acc1[PPL], acc2[PPL], lc0[PPL], lc1[PPL], lc2[PPL], last_alpha[PPL];
-    float dp0[PPL], dp1[PPL], dp2[PPL], ddep[PPL], bgdot[PPL];
-    uint32_t pxs[PPL], pys[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; q++) {
-        const uint32_t px = tile_x * DQO_TILE + (q & 1) * 8 + (lane & 7);
-        const uint32_t py = tile_y * DQO_TILE + (q >> 1) * 8 + (lane >> 3);
-        const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
-        const size_t pid = (size_t)v.W * py + px;
-        pxs[q] = px, pys[q] = py;
-        pixfx[q] = (float)px, pixfy[q] = (float)py;
-        T_final[q] = inside ? img.final_T[pid] : 0.f;
-        T[q] = T_final[q];
-        last_contrib[q] = inside ? (int)img.n_contrib[pid] : 0;
-        hit_pos[q] = inside ? (int)img.hit_pos[pid] : 0;
-        dp0[q] = inside ? dL_dpixels[pid] : 0.f;
-        dp1[q] = inside ? dL_dpixels[HW + pid] : 0.f;
-        dp2[q] = inside ? dL_dpixels[2 * HW + pid] : 0.f;
-        ddep[q] = inside ? dL_ddepths[pid] : 0.f;
-        bgdot[q] = bg0 * dp0[q] + bg1 * dp1[q] + bg2 * dp2[q];
-        acc0[q] = acc1[q] = acc2[q] = 0.f;
-        lc0[q] = lc1[q] = lc2[q] = 0.f;
-        last_alpha[q] = 0.f;
-    }
-
-    // entries [L, n) were never reached by any pixel of the tile: zero records
-    for (int e = L * 4 + lane; e < n * 4; e += BWD_THREADS) {
-        const uint32_t slot = bin.slot_list[range.x + (e >> 2)];
-        if ((int64_t)slot < capacity) reinterpret_cast<float4*>(recs + slot)[e & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
-    const int rounds = (L + BWD_THREADS - 1) / BWD_THREADS;
-    for (int b = 0; b < rounds; b++) {
-        // batch b covers list positions L-1-b*64 ... (descending); lane l stages position L-1-(b*64+l)
-        __syncthreads();
-        const int pos = L - 1 - (b * BWD_THREADS + lane);
-        if (pos >= 0) {
-            const int id = (int)bin.point_list[range.x + pos];
-            const float4 co = g.conic_opacity[id];
-            const float4 xy = g.xy_depth[id];
-            s_id[lane] = id;
-            s_slot[lane] = bin.slot_list[range.x + pos];
-            s_co[lane] = co;
-            s_xy[lane] = xy;
-            s_rgb[lane] = g.rgb_smax[id];
-            // quadrants (= the lane's four pixels) the splat can reach at all (dqo_cull.h)
-            const float qthr = dqo_q_threshold(co.w);
-            uint32_t qm = 0;
-#pragma unroll
-            for (int q = 0; q < PPL; q++) {
-                const float x0 = (float)(tile_x * DQO_TILE + (q & 1) * 8), y0 = (float)(tile_y * DQO_TILE + (q >> 1) * 8);
-                qm |= dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, qthr, x0, y0, x0 + 7.f, y0 + 7.f) ? (1u << q) : 0u;
-            }
-            s_qmask[lane] = qm;
-        }
-        __syncthreads();
-        const int batch = min(BWD_THREADS, L - b * BWD_THREADS);
-        for (int j = 0; j < batch; j++) {
-            const int c = L - 1 - (b * BWD_THREADS + j);  // 0-based list position; the reference's `contributor` after --
-            const float4 co = s_co[j];
-            const float4 xy = s_xy[j];
-            const float4 cs = s_rgb[j];
-            float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
-            bool any_color = false, any_hit = false;
-            const uint32_t qm = s_qmask[j];
-#pragma unroll
-            for (int q = 0; q < PPL; q++) {
-                any_hit |= (hit_pos[q] == c + 1);
-                if (!((qm >> q) & 1u)) continue;  // wave-uniform: quadrant q is out of the splat's reach
-                if (c < last_contrib[q]) {
-                    const float dx = xy.x - pixfx[q], dy = xy.y - pixfy[q];
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    if (power <= 0.0f) {
-                        const float G = expf(power);
-                        const float alpha = fminf(0.99f, co.w * G);
-                        if (alpha >= 1.0f / 255.0f) {
-                            any_color = true;
-                            T[q] = T[q] / (1.f - alpha);
-                            const float dchannel_dcolor = alpha * T[q];
-                            const float la = last_alpha[q];
-                            acc0[q] = la * lc0[q] + (1.f - la) * acc0[q];
-                            acc1[q] = la * lc1[q] + (1.f - la) * acc1[q];
-                            acc2[q] = la * lc2[q] + (1.f - la) * acc2[q];
-                            lc0[q] = cs.x, lc1[q] = cs.y, lc2[q] = cs.z;
-                            float dL_dalpha = (cs.x - acc0[q]) * dp0[q] + (cs.y - acc1[q]) * dp1[q] + (cs.z - acc2[q]) * dp2[q];
-                            r_c0 += dchannel_dcolor * dp0[q];
-                            r_c1 += dchannel_dcolor * dp1[q];
-                            r_c2 += dchannel_dcolor * dp2[q];
-                            dL_dalpha *= T[q];
-                            last_alpha[q] = alpha;
-                            dL_dalpha += (-T_final[q] / (1.f - alpha)) * bgdot[q];
-                            const float dL_dG = co.w * dL_dalpha;
-                            const float gdx = G * dx, gdy = G * dy;
-                            const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                            const float dG_ddely = -gdy * co.z - gdx * co.y;
-                            r_mx += dL_dG * dG_ddelx * ddelx_dx;
-                            r_my += dL_dG * dG_ddely * ddely_dy;
-                            r_ka += -0.5f * gdx * dx * dL_dG;
-                            r_kb += -0.5f * gdx * dy * dL_dG;
-                            r_kc += -0.5f * gdy * dy * dL_dG;
-                            r_op += G * dL_dalpha;
-                        }
-                    }
-                }
-            }
-            float t_c0 = 0.f, t_c1 = 0.f, t_c2 = 0.f, t_mx = 0.f, t_my = 0.f, t_ka = 0.f, t_kb = 0.f, t_kc = 0.f, t_op = 0.f;
-            if (__ballot(any_color)) {
-                t_c0 = wave_sum(r_c0);
-                t_c1 = wave_sum(r_c1);
-                t_c2 = wave_sum(r_c2);
-                t_mx = wave_sum(r_mx);
-                t_my = wave_sum(r_my);
-                t_ka = wave_sum(r_ka);
-                t_kb = wave_sum(r_kb);
-                t_kc = wave_sum(r_kc);
-                t_op = wave_sum(r_op);
-            }
-            float t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_q0 = 0.f, t_q1 = 0.f, t_q2 = 0.f, t_q3 = 0.f;
-            if (__ballot(any_hit)) {
-                // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth)
-                float h_m0 = 0.f, h_m1 = 0.f, h_m2 = 0.f, h_q0 = 0.f, h_q1 = 0.f, h_q2 = 0.f, h_q3 = 0.f;
-                const int id = s_id[j];
-                const float4 n_np = g.normal_c[id];
-                const float4 pc = g.point_c[id];
-                const float sx = scales[3 * id], sy = scales[3 * id + 1], sz = scales[3 * id + 2];
-                const float4 qt = reinterpret_cast<const float4*>(rotations)[id];
-                const float scale_max = fmaxf(fmaxf(sx, sy), sz);  // raw scales, quirk B6 (backward.cu:1009)
-                const int axis = (sx <= sy && sx <= sz) ? 0 : ((sy <= sx && sy <= sz) ? 1 : 2);
-#pragma unroll
-                for (int q = 0; q < PPL; q++) {
-                    if (hit_pos[q] == c + 1) {
-#pragma clang fp contract(off)
-                        const float3 ray = pixel_ray_b(pxs[q], pys[q], v.focal_x, v.focal_y, v.cx, v.cy);
-                        const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
-                        // hit_point.z as stored by the forward (forward.cu:784-786, 808)
-                        const float den_f = ray.x * n_np.x + ray.y * n_np.y + ray.z * n_np.z;
-                        const float t = (float)((double)n_np.w / ((double)den_f + 1e-8));
-                        const float hit_z = t * ray.z;
-                        const float angle_distance = fabsf(nr_f);
-                        const float depth_distance = fabsf(hit_z - pc.z);
-                        const float dL_ddi = ddep[q];
-                        if (depth_distance <= v.depth_thr * scale_max && angle_distance >= v.normal_thr) {
-                            const float nr = (float)((double)nr_f + 1e-8);
-                            const float inv_nr = 1.f / nr, inv_nr2 = inv_nr * inv_nr;
-                            const float np = n_np.x * pc.x + n_np.y * pc.y + n_np.z * pc.z;
-                            const float dpx = ray.z * n_np.x * inv_nr, dpy = ray.z * n_np.y * inv_nr, dpz = ray.z * n_np.z * inv_nr;
-                            h_m0 += dL_ddi * (dpx * view[0] + dpy * view[1] + dpz * view[2]);
-                            h_m1 += dL_ddi * (dpx * view[4] + dpy * view[5] + dpz * view[6]);
-                            h_m2 += dL_ddi * (dpx * view[8] + dpy * view[9] + dpz * view[10]);
-                            const float n1c = ray.z * (nr * pc.x - np * ray.x) * inv_nr2;
-                            const float n2c = ray.z * (nr * pc.y - np * ray.y) * inv_nr2;
-                            const float n3c = ray.z * (nr * pc.z - np * ray.z) * inv_nr2;
-                            const float n1w = n1c * view[0] + n2c * view[1] + n3c * view[2];
-                            const float n2w = n1c * view[4] + n2c * view[5] + n3c * view[6];
-                            const float n3w = n1c * view[8] + n2c * view[9] + n3c * view[10];
-                            // propagateRotationGrad, backward.cu:100-148: d(column `axis` of R(q)) / dq
-                            const float q0 = qt.x, q1 = qt.y, q2 = qt.z, q3 = qt.w;
-                            float d0[3], d1[3], d2[3], d3[3];
-                            if (axis == 0) {
-                                d0[0] = 0, d0[1] = 2 * q3, d0[2] = -2 * q2;
-                                d1[0] = 0, d1[1] = 2 * q2, d1[2] = 2 * q3;
-                                d2[0] = -4 * q2, d2[1] = 2 * q1, d2[2] = -2 * q0;
-                                d3[0] = -4 * q3, d3[1] = 2 * q0, d3[2] = 2 * q1;
-                            } else if (axis == 1) {
-                                d0[0] = -2 * q3, d0[1] = 0, d0[2] = 2 * q1;
-                                d1[0] = 2 * q2, d1[1] = -4 * q1, d1[2] = 2 * q0;
-                                d2[0] = 2 * q1, d2[1] = 0, d2[2] = 2 * q3;
-                                d3[0] = -2 * q0, d3[1] = -4 * q3, d3[2] = 2 * q2;
-                            } else {
-                                d0[0] = 2 * q2, d0[1] = -2 * q1, d0[2] = 0;
-                                d1[0] = 2 * q3, d1[1] = -2 * q0, d1[2] = -4 * q1;
-                                d2[0] = 2 * q0, d2[1] = 2 * q3, d2[2] = -4 * q2;
-                                d3[0] = 2 * q1, d3[1] = 2 * q2, d3[2] = 0;
-                            }
-                            h_q0 += dL_ddi * (n1w * d0[0] + n2w * d0[1] + n3w * d0[2]);
-                            h_q1 += dL_ddi * (n1w * d1[0] + n2w * d1[1] + n3w * d1[2]);
-                            h_q2 += dL_ddi * (n1w * d2[0] + n2w * d2[1] + n3w * d2[2]);
-                            h_q3 += dL_ddi * (n1w * d3[0] + n2w * d3[1] + n3w * d3[2]);
-                        } else {
-                            h_m0 += dL_ddi * view[2];
-                            h_m1 += dL_ddi * view[6];
-                            h_m2 += dL_ddi * view[10];
-                        }
-                    }
-                }
-                t_m0 = wave_sum(h_m0);
-                t_m1 = wave_sum(h_m1);
-                t_m2 = wave_sum(h_m2);
-                t_q0 = wave_sum(h_q0);
-                t_q1 = wave_sum(h_q1);
-                t_q2 = wave_sum(h_q2);
-                t_q3 = wave_sum(h_q3);
-            }
-            if (lane == 0) {
-                s_rec[j * 4 + 0] = make_float4(t_c0, t_c1, t_c2, t_mx);
-                s_rec[j * 4 + 1] = make_float4(t_my, t_ka, t_kb, t_kc);
-                s_rec[j * 4 + 2] = make_float4(t_op, t_m0, t_m1, t_m2);
-                s_rec[j * 4 + 3] = make_float4(t_q0, t_q1, t_q2, t_q3);
-            }
-        }
-        __syncthreads();
-        // write the batch's records: 4 lanes per 64-byte record, each record one contiguous row
-        for (int e = lane; e < batch * 4; e += BWD_THREADS) {
-            const uint32_t slot = s_slot[e >> 2];
-            if ((int64_t)slot < capacity) reinterpret_cast<float4*>(recs + slot)[e & 3] = s_rec[e];
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Per-Gaussian backward: sum the instance records, then K8 (cov2D) + K9 (projection, SH, cov3D) in one pass.
@@ -558,6 +291,10 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
 
 }  // namespace
 
+int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
+                              const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
+                              DqoGradRec* recs, int64_t capacity, hipStream_t s);
+
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                         const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* gr, void* ws, size_t ws_bytes, hipStream_t s) {
     (void)hit_image;  // the hit Gaussian is recovered from its list position kept in the image context
@@ -569,8 +306,8 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity);
     const int T = v.gx * v.gy;
     DqoGradRec* recs = (DqoGradRec*)ws;
-    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(T), dim3(BWD_THREADS), s, v, g, img, bin, in->scales, in->rotations, dL_dcolor,
-                       dL_ddepth, recs, (int64_t)ctx->inst_capacity);
+    int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, (int64_t)ctx->inst_capacity, s);
+    if (rc) return rc;
     DQO_LAUNCH("gaussian_backward_kernel", gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), s, v, g, in->means3D, in->scales, in->rotations,
                        in->shs, recs, *gr);
     return DQO_OK;

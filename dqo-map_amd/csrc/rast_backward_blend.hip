@@ -1,0 +1,299 @@
+// Backward blend kernel (K7) for gfx950 — replaces /root/reference/submodules/diff-gaussian-rasterizer-depth/
+// cuda_rasterizer/backward.cu:808-1066 (renderCUDA_flat) and :100-148 (propagateRotationGrad).
+//
+// Structure: one 16x16 tile per 256-thread block = four wave64, each wave owns one 8x8 pixel quadrant (1 pixel per lane).
+// The tile's list is walked back to front in batches of 128 entries staged in LDS as 16-byte records together with a 4-bit
+// quadrant mask (dqo_cull.h): a wave skips — wave-uniformly, for the price of one LDS read — every entry that cannot reach
+// its quadrant, and every entry behind the last position any of its 64 pixels needs.  For the entries it does process, each
+// lane evaluates its pixel, the nine colour-path sums (and the seven depth-hit sums when a lane's depth was fixed by this
+// entry) are reduced across the wave with DPP, and lane 0 parks them in the wave's own LDS slot.  After the batch the four
+// slots of every entry are added in a fixed order and stored as ONE 64-byte record at the instance's gaussian-major slot.
+// No global float atomics (the reference: ~10 per (pixel, Gaussian) pair + 3-7 per hit pixel), bitwise reproducible.
+#include "dqo_common.h"
+#include "dqo_cull.h"
+
+namespace {
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// wave64 sum, result broadcast as a wave-uniform value
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);       // row_half_mirror
+    v += dpp_mov<0x140>(v);       // row_mirror          -> every lane holds its row's sum
+    v += dpp_mov<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
+    v += dpp_mov<0x143, 0xC>(v);  // row_bcast31 into rows 2,3 -> lanes 48..63 hold the wave total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
+#pragma clang fp contract(off)
+    float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
+    const float n = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
+    return make_float3(rx * n, ry * n, rz * n);
+}
+
+constexpr int BWD_THREADS = 256;
+constexpr int BWD_BATCH = 128;
+
+__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+                                                                     DqoBinLayout bin, const float* __restrict__ scales,
+                                                                     const float* __restrict__ rotations,
+                                                                     const float* __restrict__ dL_dpixels,
+                                                                     const float* __restrict__ dL_ddepths,
+                                                                     DqoGradRec* __restrict__ recs, int64_t capacity) {
+    __shared__ float4 s_co[BWD_BATCH];
+    __shared__ float4 s_xy[BWD_BATCH];
+    __shared__ float4 s_rgb[BWD_BATCH];
+    __shared__ int s_id[BWD_BATCH];
+    __shared__ uint32_t s_slot[BWD_BATCH];
+    __shared__ uint32_t s_qmask[BWD_BATCH];
+    __shared__ uint8_t s_list[4][BWD_BATCH];
+    __shared__ float4 s_part[4][BWD_BATCH][4];  // [wave][entry][4 x float4] = 32 KB
+
+    const int tile = img.tile_order[blockIdx.x];
+    const uint2 range = img.ranges[tile];
+    const int n = (int)(range.y - range.x);
+    if (n == 0) return;
+    const int L = min((int)img.tile_walk[tile], n);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int tile_x = tile % v.gx, tile_y = tile / v.gx;
+    const size_t HW = (size_t)v.W * v.H;
+
+    const uint32_t px = tile_x * DQO_TILE + (wave & 1) * 8 + (lane & 7);
+    const uint32_t py = tile_y * DQO_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
+    const size_t pid = (size_t)v.W * py + px;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const float T_final = inside ? img.final_T[pid] : 0.f;
+    float T = T_final;
+    const int last_contrib = inside ? (int)img.n_contrib[pid] : 0;
+    const int hit_pos = inside ? (int)img.hit_pos[pid] : 0;
+    const float dp0 = inside ? dL_dpixels[pid] : 0.f;
+    const float dp1 = inside ? dL_dpixels[HW + pid] : 0.f;
+    const float dp2 = inside ? dL_dpixels[2 * HW + pid] : 0.f;
+    const float ddep = inside ? dL_ddepths[pid] : 0.f;
+    const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    const float ddelx_dx = 0.5f * v.W, ddely_dy = 0.5f * v.H;
+    // entries at list positions >= wave_need are of no interest to any pixel of this wave
+    int wave_need = max(last_contrib, hit_pos);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_need = max(wave_need, __shfl_xor(wave_need, off));
+
+    // entries [L, n) were never reached by any pixel of the tile: zero records
+    for (int e = L * 4 + tid; e < n * 4; e += BWD_THREADS) {
+        const uint32_t slot = bin.slot_list[range.x + (e >> 2)];
+        if ((int64_t)slot < capacity) reinterpret_cast<float4*>(recs + slot)[e & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const int rounds = (L + BWD_BATCH - 1) / BWD_BATCH;
+    for (int b = 0; b < rounds; b++) {
+        __syncthreads();  // previous batch fully consumed (records written) before LDS is reused
+        // batch b covers list positions L-1-b*128 ... descending; thread t < 128 stages position L-1-(b*128+t)
+        if (tid < BWD_BATCH) {
+            const int pos = L - 1 - (b * BWD_BATCH + tid);
+            if (pos >= 0) {
+                const int id = (int)bin.point_list[range.x + pos];
+                const float4 co = g.conic_opacity[id];
+                const float4 xy = g.xy_depth[id];
+                s_id[tid] = id;
+                s_slot[tid] = bin.slot_list[range.x + pos];
+                s_co[tid] = co;
+                s_xy[tid] = xy;
+                s_rgb[tid] = g.rgb_smax[id];
+                // exact live mask recorded by the forward: quadrants in which some pixel blended this entry or took it
+                // as its depth hit — precisely the (pixel, entry) pairs the reference's backward does work for
+                s_qmask[tid] = (uint32_t)bin.live[range.x + pos];
+            }
+        }
+        {
+            float4* pz = &s_part[0][0][0];
+#pragma unroll
+            for (int k = 0; k < (4 * BWD_BATCH * 4) / BWD_THREADS; k++) pz[k * BWD_THREADS + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        const int batch = min(BWD_BATCH, L - b * BWD_BATCH);
+        // per-wave compaction: entries of this batch that are live in this wave's quadrant (forward's live mask) and not
+        // behind everything this wave's pixels ever looked at, in walk order
+        int cnt = 0;
+#pragma unroll
+        for (int base = 0; base < BWD_BATCH; base += 64) {
+            const int jj = base + lane;
+            const bool lv = jj < batch && ((s_qmask[jj] >> wave) & 1u) && (L - 1 - (b * BWD_BATCH + jj) < wave_need);
+            const unsigned long long mm = __ballot(lv);
+            if (lv) s_list[wave][cnt + (int)__popcll(mm & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            cnt += (int)__popcll(mm);
+        }
+        // software-pipelined walk: next entry's records are fetched from LDS while the current one is processed
+        int j_nx = cnt > 0 ? (int)s_list[wave][0] : 0;
+        float4 co_nx = s_co[j_nx], xy_nx = s_xy[j_nx], cs_nx = s_rgb[j_nx];
+        for (int k = 0; k < cnt; k++) {
+            const int j = j_nx;
+            const float4 co = co_nx, xy = xy_nx, cs_cur = cs_nx;
+            if (k + 1 < cnt) {
+                j_nx = (int)s_list[wave][k + 1];
+                co_nx = s_co[j_nx];
+                xy_nx = s_xy[j_nx];
+                cs_nx = s_rgb[j_nx];
+            }
+            const int c = L - 1 - (b * BWD_BATCH + j);  // 0-based list position == the reference's `contributor` after its --
+            float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
+            bool did_color = false;
+            if (c < last_contrib) {
+                const float dx = xy.x - pixfx, dy = xy.y - pixfy;
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                if (power <= 0.0f) {
+                    const float G = dqo_gauss(power);
+                    const float alpha = fminf(0.99f, co.w * G);
+                    if (alpha >= 1.0f / 255.0f) {
+                        const float4 cs = cs_cur;
+                        did_color = true;
+                        const float inv_1ma = dqo_rcp(1.f - alpha);
+                        T = T * inv_1ma;
+                        const float dchannel_dcolor = alpha * T;
+                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                        lc0 = cs.x, lc1 = cs.y, lc2 = cs.z;
+                        float dL_dalpha = (cs.x - acc0) * dp0 + (cs.y - acc1) * dp1 + (cs.z - acc2) * dp2;
+                        r_c0 = dchannel_dcolor * dp0;
+                        r_c1 = dchannel_dcolor * dp1;
+                        r_c2 = dchannel_dcolor * dp2;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final * inv_1ma) * bgdot;  // end_T, not the running T (quirk B2)
+                        const float dL_dG = co.w * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                        const float dG_ddely = -gdy * co.z - gdx * co.y;
+                        r_mx = dL_dG * dG_ddelx * ddelx_dx;
+                        r_my = dL_dG * dG_ddely * ddely_dy;
+                        r_ka = -0.5f * gdx * dx * dL_dG;
+                        r_kb = -0.5f * gdx * dy * dL_dG;
+                        r_kc = -0.5f * gdy * dy * dL_dG;
+                        r_op = G * dL_dalpha;
+                    }
+                }
+            }
+            const bool is_hit = (hit_pos == c + 1);
+            const bool any_color = __ballot(did_color) != 0ull;
+            const bool any_hit = __ballot(is_hit) != 0ull;
+            if (!any_color && !any_hit) continue;
+            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0, o3 = o0;
+            if (any_color) {
+                o0.x = wave_sum(r_c0);
+                o0.y = wave_sum(r_c1);
+                o0.z = wave_sum(r_c2);
+                o0.w = wave_sum(r_mx);
+                o1.x = wave_sum(r_my);
+                o1.y = wave_sum(r_ka);
+                o1.z = wave_sum(r_kb);
+                o1.w = wave_sum(r_kc);
+                o2.x = wave_sum(r_op);
+            }
+            if (any_hit) {
+                // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth)
+                float h_m0 = 0.f, h_m1 = 0.f, h_m2 = 0.f, h_q0 = 0.f, h_q1 = 0.f, h_q2 = 0.f, h_q3 = 0.f;
+                if (is_hit) {
+#pragma clang fp contract(off)
+                    const int id = s_id[j];
+                    const float4 n_np = g.normal_c[id];
+                    const float4 pc = g.point_c[id];
+                    const float sx = scales[3 * id], sy = scales[3 * id + 1], sz = scales[3 * id + 2];
+                    const float4 qt = reinterpret_cast<const float4*>(rotations)[id];
+                    const float scale_max = fmaxf(fmaxf(sx, sy), sz);  // raw scales, quirk B6 (backward.cu:1009)
+                    const int axis = (sx <= sy && sx <= sz) ? 0 : ((sy <= sx && sy <= sz) ? 1 : 2);
+                    const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
+                    const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
+                    // hit_point.z exactly as the forward computed it (forward.cu:784-786)
+                    const float den_f = ray.x * n_np.x + ray.y * n_np.y + ray.z * n_np.z;
+                    const float t = (float)((double)n_np.w / ((double)den_f + 1e-8));
+                    const float hit_z = t * ray.z;
+                    const float angle_distance = fabsf(nr_f);
+                    const float depth_distance = fabsf(hit_z - pc.z);
+                    const float* view = v.view;
+                    if (depth_distance <= v.depth_thr * scale_max && angle_distance >= v.normal_thr) {
+                        const float nr = (float)((double)nr_f + 1e-8);
+                        const float inv_nr = 1.f / nr, inv_nr2 = inv_nr * inv_nr;
+                        const float np = n_np.x * pc.x + n_np.y * pc.y + n_np.z * pc.z;
+                        const float dpx = ray.z * n_np.x * inv_nr, dpy = ray.z * n_np.y * inv_nr, dpz = ray.z * n_np.z * inv_nr;
+                        h_m0 = ddep * (dpx * view[0] + dpy * view[1] + dpz * view[2]);
+                        h_m1 = ddep * (dpx * view[4] + dpy * view[5] + dpz * view[6]);
+                        h_m2 = ddep * (dpx * view[8] + dpy * view[9] + dpz * view[10]);
+                        const float n1c = ray.z * (nr * pc.x - np * ray.x) * inv_nr2;
+                        const float n2c = ray.z * (nr * pc.y - np * ray.y) * inv_nr2;
+                        const float n3c = ray.z * (nr * pc.z - np * ray.z) * inv_nr2;
+                        const float n1w = n1c * view[0] + n2c * view[1] + n3c * view[2];
+                        const float n2w = n1c * view[4] + n2c * view[5] + n3c * view[6];
+                        const float n3w = n1c * view[8] + n2c * view[9] + n3c * view[10];
+                        // propagateRotationGrad, backward.cu:100-148: d(column `axis` of R(q)) / dq
+                        const float q0 = qt.x, q1 = qt.y, q2 = qt.z, q3 = qt.w;
+                        float d0[3], d1[3], d2[3], d3[3];
+                        if (axis == 0) {
+                            d0[0] = 0, d0[1] = 2 * q3, d0[2] = -2 * q2;
+                            d1[0] = 0, d1[1] = 2 * q2, d1[2] = 2 * q3;
+                            d2[0] = -4 * q2, d2[1] = 2 * q1, d2[2] = -2 * q0;
+                            d3[0] = -4 * q3, d3[1] = 2 * q0, d3[2] = 2 * q1;
+                        } else if (axis == 1) {
+                            d0[0] = -2 * q3, d0[1] = 0, d0[2] = 2 * q1;
+                            d1[0] = 2 * q2, d1[1] = -4 * q1, d1[2] = 2 * q0;
+                            d2[0] = 2 * q1, d2[1] = 0, d2[2] = 2 * q3;
+                            d3[0] = -2 * q0, d3[1] = -4 * q3, d3[2] = 2 * q2;
+                        } else {
+                            d0[0] = 2 * q2, d0[1] = -2 * q1, d0[2] = 0;
+                            d1[0] = 2 * q3, d1[1] = -2 * q0, d1[2] = -4 * q1;
+                            d2[0] = 2 * q0, d2[1] = 2 * q3, d2[2] = -4 * q2;
+                            d3[0] = 2 * q1, d3[1] = 2 * q2, d3[2] = 0;
+                        }
+                        h_q0 = ddep * (n1w * d0[0] + n2w * d0[1] + n3w * d0[2]);
+                        h_q1 = ddep * (n1w * d1[0] + n2w * d1[1] + n3w * d1[2]);
+                        h_q2 = ddep * (n1w * d2[0] + n2w * d2[1] + n3w * d2[2]);
+                        h_q3 = ddep * (n1w * d3[0] + n2w * d3[1] + n3w * d3[2]);
+                    } else {
+                        h_m0 = ddep * view[2];
+                        h_m1 = ddep * view[6];
+                        h_m2 = ddep * view[10];
+                    }
+                }
+                o2.y = wave_sum(h_m0);
+                o2.z = wave_sum(h_m1);
+                o2.w = wave_sum(h_m2);
+                o3.x = wave_sum(h_q0);
+                o3.y = wave_sum(h_q1);
+                o3.z = wave_sum(h_q2);
+                o3.w = wave_sum(h_q3);
+            }
+            if (lane == 0) {
+                s_part[wave][j][0] = o0;
+                s_part[wave][j][1] = o1;
+                s_part[wave][j][2] = o2;
+                s_part[wave][j][3] = o3;
+            }
+        }
+        __syncthreads();
+        // fixed-order sum of the four quadrant partials, one 64-byte record per instance (4 lanes per record)
+        for (int e = tid; e < batch * 4; e += BWD_THREADS) {
+            const int j = e >> 2, k = e & 3;
+            const float4 a = s_part[0][j][k], b4 = s_part[1][j][k], c4 = s_part[2][j][k], d4 = s_part[3][j][k];
+            const float4 r = make_float4(((a.x + b4.x) + c4.x) + d4.x, ((a.y + b4.y) + c4.y) + d4.y, ((a.z + b4.z) + c4.z) + d4.z,
+                                         ((a.w + b4.w) + c4.w) + d4.w);
+            const uint32_t slot = s_slot[j];
+            if ((int64_t)slot < capacity) reinterpret_cast<float4*>(recs + slot)[k] = r;
+        }
+    }
+}
+
+}  // namespace
+
+int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
+                              const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
+                              DqoGradRec* recs, int64_t capacity, hipStream_t s) {
+    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(T), dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
+               dL_dcolor, dL_ddepth, recs, capacity);
+    return DQO_OK;
+}

@@ -62,12 +62,9 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
                                                                 const float* __restrict__ shs,
                                                                 const float* __restrict__ colors_precomp,
                                                                 const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
-                                                                uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
                                                                 int32_t* __restrict__ radii_out,
                                                                 int32_t* __restrict__ n_touched_out) {
 #pragma clang fp contract(off)
-    __shared__ uint32_t s_wave_sum[K1_THREADS / 64];
-    __shared__ uint32_t s_block_base;
     __shared__ uint32_t s_visible;
     const int tid = threadIdx.x;
     const int P = v.P;
@@ -78,15 +75,12 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
     if (tid == 0) s_visible = 0;
     __syncthreads();
 
-    uint32_t touch[K1_ITEMS];
     uint32_t nvis = 0;
 #pragma unroll 1
     for (int it = 0; it < K1_ITEMS; it++) {
         const int idx = blockIdx.x * (K1_THREADS * K1_ITEMS) + it * K1_THREADS + tid;
-        touch[it] = 0;
         if (idx >= P) continue;
         int radius = 0;
-        uint32_t ntouch = 0;
         int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
         do {
             const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
@@ -210,65 +204,16 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
             g.normal_c[idx] = make_float4(ncx, ncy, ncz, npc);
             g.point_c[idx] = make_float4(tvx, tvy, tvz, 0.f);
             g.clamped[idx] = (uint8_t)clampbits;
-            // tiles_touched + per-tile histogram, forward.cu:344-353 — restricted to the tiles whose pixels the splat can
-            // actually reach (dqo_cull.h: output-invariant, the dropped instances are no-ops in the reference's lists)
-            const float qthr = dqo_q_threshold(opacities[idx]);
-            for (int y = rminy; y < rmaxy; y++)
-                for (int x = rminx; x < rmaxx; x++) {
-                    const int t = y * v.gx + x;
-                    if (tile_mask != nullptr && !tile_mask[t]) continue;
-                    if (dqo_splat_hits_rect(pixx, pixy, conx, cony, conz, qthr, (float)(x * DQO_TILE), (float)(y * DQO_TILE),
-                                            (float)(x * DQO_TILE + DQO_TILE - 1), (float)(y * DQO_TILE + DQO_TILE - 1))) {
-                        ntouch++;
-                        atomicAdd(&tile_count[t], 1u);
-                    } else if (tile_flag[t] == 0u) {
-                        // the reference would list this Gaussian here, so the tile is an ACTIVE tile there even if every
-                        // one of its instances is dead: it must be rendered (ids -1, colour = bg), not left at the
-                        // never-rendered fills.  Idempotent racy store; most lanes see the 1 and skip it.
-                        tile_flag[t] = 1u;
-                    }
-                }
         } while (false);
         radii_out[idx] = radius;
         n_touched_out[idx] = 0;
-        g.tiles_touched[idx] = ntouch;
         g.rect16[idx] = make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16));
-        touch[it] = ntouch;
         nvis += radius > 0 ? 1u : 0u;
     }
-    // ---- gaussian-major slot allocation: block-wide exclusive scan of the 4x256 counts, one atomic per block ----
-    uint32_t mine = 0;
-#pragma unroll
-    for (int it = 0; it < K1_ITEMS; it++) mine += touch[it];
-    const uint32_t lane = lane_id(), wave = tid >> 6;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= (uint32_t)off) incl += o;
-    }
-    if (lane == 63) s_wave_sum[wave] = incl;
+    // visible count for the header (statistics only)
     if (nvis) atomicAdd(&s_visible, nvis);
     __syncthreads();
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < K1_THREADS / 64; w++) {
-            const uint32_t t = s_wave_sum[w];
-            s_wave_sum[w] = tot;
-            tot += t;
-        }
-        s_block_base = tot ? atomicAdd(&g.counters[0], tot) : 0u;
-        if (s_visible) atomicAdd(&g.counters[1], s_visible);
-    }
-    __syncthreads();
-    // thread-major order inside the block: thread t owns [base + excl(t), +mine), its 4 items consecutively
-    uint32_t base = s_block_base + s_wave_sum[wave] + (incl - mine);
-#pragma unroll
-    for (int it = 0; it < K1_ITEMS; it++) {
-        const int idx = blockIdx.x * (K1_THREADS * K1_ITEMS) + it * K1_THREADS + tid;
-        if (idx < P) g.slot_base[idx] = base;
-        base += touch[it];
-    }
+    if (tid == 0 && s_visible) atomicAdd(&g.counters[1], s_visible);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -351,42 +296,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         h.reserved[0] = h.reserved[1] = h.reserved[2] = 0;
         *g.header = h;
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Instance emit: one 8-byte key per (Gaussian, unmasked tile) into the tile's segment (duplicateWithKeys,
-// rasterizer_impl.cu:70-115).  Segment order is arbitrary; the per-tile sort below restores the reference's total order
-// (depth bits ascending, ties by ascending Gaussian id = the stable radix sort of emission order).
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
-                                                   uint32_t* __restrict__ tile_cursor, DqoBinLayout bin, int64_t capacity) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const uint32_t ntouch = g.tiles_touched[idx];
-    if (ntouch == 0) return;
-    const uint2 r = g.rect16[idx];
-    const int rminx = r.x & 0xffff, rmaxx = r.x >> 16, rminy = r.y & 0xffff, rmaxy = r.y >> 16;
-    const float4 xyd = g.xy_depth[idx];
-    const float4 co = g.conic_opacity[idx];
-    const float qthr = dqo_q_threshold(co.w);
-    const uint32_t depth_bits = __float_as_uint(xyd.z);
-    const uint64_t key = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
-    uint32_t slot = g.slot_base[idx];
-    for (int y = rminy; y < rmaxy; y++)
-        for (int x = rminx; x < rmaxx; x++) {
-            const int t = y * gx + x;
-            // same predicate, same inputs, same IEEE ops as the count pass in preprocess_kernel
-            if ((tile_mask == nullptr || tile_mask[t]) &&
-                dqo_splat_hits_rect(xyd.x, xyd.y, co.x, co.y, co.z, qthr, (float)(x * DQO_TILE), (float)(y * DQO_TILE),
-                                    (float)(x * DQO_TILE + DQO_TILE - 1), (float)(y * DQO_TILE + DQO_TILE - 1))) {
-                const uint32_t pos = atomicAdd(&tile_cursor[t], 1u);
-                if ((int64_t)pos < capacity) {
-                    bin.keys[pos] = key;
-                    bin.slots[pos] = slot;
-                }
-                slot++;
-            }
-        }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -496,6 +405,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
     __shared__ int s_id[BLEND_THREADS];
     __shared__ int s_cnt[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
+    __shared__ uint8_t s_list[4][BLEND_THREADS];
     __shared__ uint32_t s_walk;
 
     const int tile = img.tile_order[blockIdx.x];
@@ -544,20 +454,23 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
     float color_weight_max = -1.f, hit_color_weight = 0.f, hit_depth_weight = 0.f;
 
     s_cnt[tid] = 0;
+    int flushed_upto = 0;  // index of the batch currently held in LDS
     if (tid == 0) s_walk = 0;
     const int rounds = (n + BLEND_THREADS - 1) / BLEND_THREADS;
     int toDo = n;
     for (int i = 0; i < rounds; i++, toDo -= BLEND_THREADS) {
         // also orders the previous round's LDS reads before this round's staging writes
         if (__syncthreads_and(done)) break;
-        // flush the n_touched counts of the previous batch (forward.cu:833-835: one count per pair with T' > 0.5)
+        // flush the previous batch: n_touched counts (forward.cu:833-835: one count per pair with T' > 0.5) and the
+        // 4-bit live mask (which quadrants had a lane this entry acted on) that lets the backward skip dead pairs
         if (i > 0) {
-            const int c = s_cnt[tid];
-            if (c) {
-                atomicAdd(&out.n_touched[s_id[tid]], c);
-                s_cnt[tid] = 0;
-            }
+            const uint32_t wd = (uint32_t)s_cnt[tid];
+            const int prev = (i - 1) * BLEND_THREADS + tid;
+            if (prev < n) bin.live[range.x + prev] = (uint8_t)(wd >> 28);
+            if (wd & 0x0fffffffu) atomicAdd(&out.n_touched[s_id[tid]], (int)(wd & 0x0fffffffu));
+            s_cnt[tid] = 0;
         }
+        flushed_upto = i;
         __syncthreads();
         const int progress = i * BLEND_THREADS + tid;
         if (progress < n) {
@@ -580,18 +493,38 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
         }
         __syncthreads();
         const int batch = min(BLEND_THREADS, toDo);
-        for (int j = 0; j < batch; j++) {
+        // per-wave compaction: the entries of this batch that can reach this wave's quadrant, in list order
+        int cnt = 0;
+#pragma unroll
+        for (int base = 0; base < BLEND_THREADS; base += 64) {
+            const int jj = base + lane;
+            const bool lv = jj < batch && ((s_qmask[jj] >> wave) & 1u);
+            const unsigned long long mm = __ballot(lv);
+            if (lv) s_list[wave][cnt + (int)__popcll(mm & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            cnt += (int)__popcll(mm);
+        }
+        // software-pipelined walk: the next entry's records are fetched from LDS while the current one is blended
+        int j = cnt > 0 ? (int)s_list[wave][0] : 0;
+        float4 xy = s_xy[j], co = s_co[j];
+        for (int k = 0; k < cnt; k++) {
             if (__ballot(!done) == 0) break;  // whole wave finished
-            if (!((s_qmask[j] >> wave) & 1u)) continue;  // wave-uniform: this quadrant is out of the splat's reach
-            bool contributes_half = false;
+            const int j_cur = j;
+            const float4 xy_cur = xy, co_cur = co;
+            if (k + 1 < cnt) {
+                j = (int)s_list[wave][k + 1];
+                xy = s_xy[j];
+                co = s_co[j];
+            }
+            bool contributes_half = false, lane_live = false;
             if (!done) {
+                const int j = j_cur;
                 const uint32_t contributor = (uint32_t)(i * BLEND_THREADS + j + 1);  // the reference's running counter
-                const float4 xy = s_xy[j];
-                const float4 co = s_co[j];
+                const float4 xy = xy_cur;
+                const float4 co = co_cur;
                 const float dx = xy.x - pixfx, dy = xy.y - pixfy;
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                 if (power <= 0.0f) {
-                    const float alpha = fminf(0.99f, co.w * expf(power));
+                    const float alpha = fminf(0.99f, co.w * dqo_gauss(power));
                     if (alpha >= 1.0f / 255.0f) {
                         const float4 cs = s_rgb[j];
                         if (!hit_gaussian && alpha >= v.opaque_thr) {
@@ -605,6 +538,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
                             const float depth_distance = fabsf(h.hit_z - xy.z);
                             depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy.z;
                             hit_gaussian = true;
+                            lane_live = true;
                         }
                         const float test_T = T * (1.f - alpha);
                         if (test_T < v.T_thr && hit_gaussian) {
@@ -621,6 +555,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
                                     hit_color_weight = w;
                                 }
                                 contributes_half = test_T > 0.5f;
+                                lane_live = true;
                                 last_contributor = contributor;
                                 end_T = test_T;
                             }
@@ -629,14 +564,19 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
                     }
                 }
             }
+            // one LDS atomic per (wave, entry): low 28 bits count the T' > 0.5 pairs, bit 28+wave marks the quadrant live
             const unsigned long long m = __ballot(contributes_half);
-            if (m && lane == 0) atomicAdd(&s_cnt[j], (int)__popcll(m));
+            const unsigned long long lv = __ballot(lane_live);
+            if (lv && lane == 0) atomicAdd(&s_cnt[j_cur], (int)((uint32_t)__popcll(m) | (1u << (28 + wave))));
         }
     }
     __syncthreads();
     {
-        const int c = s_cnt[tid];
-        if (c) atomicAdd(&out.n_touched[s_id[tid]], c);
+        // the last batch that was staged (index flushed_upto) has not been flushed yet
+        const uint32_t wd = (uint32_t)s_cnt[tid];
+        const int prev = flushed_upto * BLEND_THREADS + tid;
+        if (prev < n) bin.live[range.x + prev] = (uint8_t)(wd >> 28);
+        if (wd & 0x0fffffffu) atomicAdd(&out.n_touched[s_id[tid]], (int)(wd & 0x0fffffffu));
     }
     if (inside) {
         const float b0 = v.bg[0], b1 = v.bg[1], b2 = v.bg[2];
@@ -679,6 +619,10 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 }  // namespace
 
+int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, hipStream_t s);
+int dqo_launch_bin_emit(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
+                        int64_t capacity, hipStream_t s);
+
 int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s) {
     const DqoView v = dqo_make_view(p, in);
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
@@ -690,7 +634,10 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;
         DQO_LAUNCH("preprocess_kernel", preprocess_kernel, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
-                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, img.tile_count, img.tile_flag, out->radii, out->n_touched);
+                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched);
+        // per-tile histogram, tiles_touched, gaussian-major slots (forward.cu:344-353 + the cub scan of rasterizer_impl.cu:303)
+        int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, s);
+        if (rc) return rc;
     }
     return DQO_OK;
 }
@@ -703,8 +650,8 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     const int T = v.gx * v.gy;
     DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, (int64_t)ctx->inst_capacity);
     if (p->P > 0) {
-        DQO_LAUNCH("emit_kernel", emit_kernel, dim3((p->P + 255) / 256), dim3(256), s, p->P, v.gx, in->tile_mask, g, img.tile_cursor, bin,
-                           (int64_t)ctx->inst_capacity);
+        int rc = dqo_launch_bin_emit(p->P, v.gx, in->tile_mask, g, img, bin, (int64_t)ctx->inst_capacity, s);
+        if (rc) return rc;
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(T), dim3(SORT_THREADS), s, img, bin);
     }
     DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(T), dim3(BLEND_THREADS), s, v, g, img, bin, *out);
