@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--cfg", type=int, default=3)
     ap.add_argument("--P", type=int, default=None)
     ap.add_argument("--sync-mode", default="lazy", choices=("lazy", "exact"))
+    ap.add_argument("--path", default="fused", choices=("fused", "dropin"),
+                    help="fused: dqo_harness.FusedMapper (activation / loss / Adam kernels of row f2 around the op); "
+                         "dropin: autograd through the drop-in op + torch.optim.Adam, exactly what unchanged DQO-MAP code runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-P", type=int, default=100_000)
@@ -97,6 +100,20 @@ def make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, 
     return step
 
 
+def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf):
+    from dqo_harness.fused_mapping import FusedMapper
+    fm = FusedMapper(scene, settings, device)
+    mask_u8 = render_mask.to(torch.uint8).contiguous()
+
+    def step():
+        out = fm.step(gt_color, gt_depth, mask_u8)
+        loss_buf.buf[:3].copy_(fm.loss[:3])
+        loss_buf.reduce()  # ONE packed all-reduce per iteration (no-op at world size 1)
+        return {"radii": out[8]}
+
+    return step
+
+
 def cpu_baseline(args, cam, scene, P_sample):
     """Single-thread CPU oracle (kind 'port': the reference has no CPU renderer) on a bounded sample of the
     same workload: ONE forward + backward at the same image size with the first P_sample Gaussians of the scene."""
@@ -139,7 +156,9 @@ def main():
     opt = mapping.make_optimizer(params)
     from dqo_harness.sharding import PackedAllReduce
     loss_buf = PackedAllReduce([("total", 1), ("color", 1), ("depth", 1)], device)
-    step = make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world)
+    step_dropin = make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world)
+    step_fused = make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf)
+    step = step_fused if args.path == "fused" else step_dropin
 
     def sync_all():
         if world > 1:
@@ -160,6 +179,24 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+
+    loss_now = [round(float(x) / world, 6) for x in loss_buf.buf.tolist()[:3]]
+    # the other path, timed the same way (single GPU only), so both numbers come from one run
+    alt = None
+    if world == 1:
+        other = step_dropin if args.path == "fused" else step_fused
+        for _ in range(max(2, args.warmup // 2)):
+            other()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            other()
+        torch.cuda.synchronize()
+        dt_alt = time.perf_counter() - t1
+        if args.sync_mode == "lazy":
+            dgr._verify_pending(block=True)
+        alt = {"path": "dropin" if args.path == "fused" else "fused", "value": round(args.steps / dt_alt, 3), "unit": "iter/s",
+               "ms_per_step": round(dt_alt / args.steps * 1e3, 4)}
 
     # workload statistics of the last iteration (reported next to every timing)
     n_vis = int((out["radii"] > 0).sum().item())
@@ -195,7 +232,8 @@ def main():
         # algorithmic bytes per launch: what the kernel must move at minimum
         alg = {
             "preprocess_kernel": 236 * n_vis + 12 * (P - n_vis) + 4 * P,             # read params of visible, xyz of culled; radii
-            "bin_emit_kernel": 12 * n_inst, "bin_count_kernel": 16 * n_inst,                                              # key + slot per instance
+            "bin_emit_kernel": 12 * n_inst, "bin_count_kernel": 16 * n_inst,
+            "adam_kernel": 236 * 7 * P, "loss_grad_kernel": 52 * HWa, "loss_reduce_kernel": 36 * HWa,                                              # key + slot per instance
             "tile_sort_kernel": 12 * n_inst + 8 * n_inst,                            # read key+slot, write id+slot
             "blend_forward_kernel": 28 * n_inst + 36 * HWa,                          # id + xy + conic/opacity gather; 9 output planes
             "blend_backward_kernel": 40 * n_inst + 16 * HWa,                         # + rgb gather; dL_dcolor + dL_ddepth
@@ -219,10 +257,12 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg{args.cfg}: surfel room, {P} Gaussians/GPU, {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, "
-                                   "SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 depth L1), raster fwd+bwd + fused Adam (6 groups)",
+                                   "SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 depth L1), raster fwd+bwd + Adam (6 groups); path=" + args.path,
                        "shards": world, "sync_mode": args.sync_mode, **stats},
-            "loss": [round(float(x) / world, 6) for x in loss_buf.buf.tolist()[:3]],
+            "loss": loss_now, "path": args.path,
         }
+        if alt is not None:
+            line["other_path"] = alt
         if roofline is not None:
             line["roofline"] = roofline
         if cpu is not None:

@@ -48,7 +48,17 @@ class DqoProfileEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("total_ms", ctypes.c_double), ("calls", ctypes.c_uint32)]
 
 
-EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_rast_geom_bytes", "dqo_rast_image_bytes", "dqo_rast_binning_bytes",
+class DqoAdamStep(ctypes.Structure):
+    _fields_ = ([("P", c_i32), ("M", c_i32), ("step", c_i32), ("beta1", c_f), ("beta2", c_f), ("eps", c_f), ("lr_xyz", c_f),
+                 ("lr_f_dc", c_f), ("lr_f_rest", c_f), ("lr_opacity", c_f), ("lr_scaling", c_f), ("lr_rotation", c_f)] +
+                [(n, c_vp) for n in ("xyz", "shs", "opacity_raw", "scaling_raw", "rotation_raw", "g_means3D", "g_sh", "g_opacity",
+                                     "g_scales", "g_rotations", "m_xyz", "m_shs", "m_opacity", "m_scaling", "m_rotation", "v_xyz",
+                                     "v_shs", "v_opacity", "v_scaling", "v_rotation")])
+
+
+EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
+           "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_adam_step", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
+           "dqo_rast_binning_bytes",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
            "dqo_rast_forward", "dqo_rast_backward", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
            "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam")
@@ -60,6 +70,9 @@ def lib():
     """Load libdqoraster.so (built by `make -C dqo-map_amd/csrc` / __graft_entry__.build()).  Fails loudly when absent."""
     global _lib
     if _lib is None:
+        # torch first: it loads its bundled HIP runtime; libdqoraster.so then binds to that same copy (same SONAME).  The
+        # other order puts two ROCr instances in one process and the second one sees "no ROCm-capable device".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()). "
                                "There is no CPU fallback for this operator.")
@@ -84,6 +97,11 @@ def lib():
         L.dqo_knn3.argtypes = [c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
         L.dqo_quadric_iou_fwd_bwd.argtypes = [c_i32] + [c_vp] * 12
         L.dqo_quadric_adam.argtypes = [c_i32, c_i32] + [c_vp] * 9
+        L.dqo_map_activate.argtypes = [c_i32] + [c_vp] * 7
+        L.dqo_map_loss_workspace_bytes.restype = ctypes.c_size_t
+        L.dqo_map_loss_workspace_bytes.argtypes = []
+        L.dqo_map_loss_fwd_bwd.argtypes = [c_i32, c_i32] + [c_vp] * 6 + [c_f, c_f, c_f] + [c_vp] * 4 + [ctypes.c_size_t, c_vp]
+        L.dqo_map_adam_step.argtypes = [P(DqoAdamStep), c_vp]
         L.dqo_profile_enable.argtypes = [ctypes.c_int]
         L.dqo_profile_collect.argtypes = [P(DqoProfileEntry), ctypes.c_int, ctypes.c_int]
         if L.dqo_abi_version() != 1:

@@ -23,6 +23,14 @@ int dqo_launch_quadric_iou(int B, const float* axes, const float* R, const float
 int dqo_launch_quadric_adam(int n_obj, int n_iters, const int32_t* view_offset, const float* P34_views, const float* obs_views,
                             const int32_t* view_schedule, float* axes, float* R, float* center, float* loss_hist, hipStream_t s);
 
+int dqo_launch_map_activate(int P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
+                            float* scales, float* rotations, hipStream_t s);
+size_t dqo_map_loss_ws_bytes(void);
+int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, const int32_t* depth_index, const float* gt_color,
+                        const float* gt_depth, const uint8_t* render_mask, float color_weight, float depth_weight, float add_depth_thres,
+                        float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
+int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
+
 // ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -------------------------------
 #include <map>
 #include <string>
@@ -223,6 +231,42 @@ DQO_API int dqo_quadric_iou_fwd_bwd(int32_t B, const float* axes, const float* R
     if (B == 0) return DQO_OK;
     DQO_CHECK_ARG(axes && R && center && P34 && obs && bbox && loss && valid && g_axes && g_R && g_center, "null pointer");
     return dqo_launch_quadric_iou(B, axes, R, center, P34, obs, bbox, loss, valid, g_axes, g_R, g_center, (hipStream_t)stream);
+}
+
+DQO_API int dqo_map_activate(int32_t P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
+                             float* scales, float* rotations, void* stream) {
+    DQO_CHECK_ARG(P >= 0, "bad P");
+    if (P == 0) return DQO_OK;
+    DQO_CHECK_ARG(opacity_raw && scaling_raw && rotation_raw && opacity && scales && rotations, "null pointer");
+    return dqo_launch_map_activate(P, opacity_raw, scaling_raw, rotation_raw, opacity, scales, rotations, (hipStream_t)stream);
+}
+
+DQO_API size_t dqo_map_loss_workspace_bytes(void) { return dqo_map_loss_ws_bytes(); }
+
+DQO_API int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const float* depth, const int32_t* depth_index,
+                                 const float* gt_color, const float* gt_depth, const uint8_t* render_mask, float color_weight,
+                                 float depth_weight, float add_depth_thres, float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    DQO_CHECK_ARG(W > 0 && H > 0, "bad image size");
+    DQO_CHECK_ARG(color && depth && depth_index && gt_color && gt_depth && loss_out && dL_dcolor && dL_ddepth, "null pointer");
+    if (ws == nullptr || ws_bytes < dqo_map_loss_ws_bytes()) {
+        dqo_set_error("loss workspace too small (%zu < %zu)", ws_bytes, dqo_map_loss_ws_bytes());
+        return DQO_ERR_WORKSPACE;
+    }
+    return dqo_launch_map_loss(W, H, color, depth, depth_index, gt_color, gt_depth, render_mask, color_weight, depth_weight,
+                               add_depth_thres, loss_out, dL_dcolor, dL_ddepth, ws, (hipStream_t)stream);
+}
+
+DQO_API int dqo_map_adam_step(const DqoAdamStep* st, void* stream) {
+    DQO_CHECK_ARG(st, "null step");
+    DQO_CHECK_ARG(st->P >= 0 && st->M >= 1 && st->step >= 1, "bad P / M / step");
+    if (st->P == 0) return DQO_OK;
+    DQO_CHECK_ARG(st->xyz && st->shs && st->opacity_raw && st->scaling_raw && st->rotation_raw, "null parameter");
+    DQO_CHECK_ARG(st->g_means3D && st->g_sh && st->g_opacity && st->g_scales && st->g_rotations, "null gradient");
+    DQO_CHECK_ARG(st->m_xyz && st->m_shs && st->m_opacity && st->m_scaling && st->m_rotation && st->v_xyz && st->v_shs &&
+                      st->v_opacity && st->v_scaling && st->v_rotation,
+                  "null optimiser state");
+    return dqo_launch_map_adam(st, (hipStream_t)stream);
 }
 
 DQO_API int dqo_quadric_adam(int32_t n_obj, int32_t n_iters, const int32_t* view_offset, const float* P34_views, const float* obs_views,

@@ -1,0 +1,104 @@
+"""Fused mapping iteration: the same arithmetic as
+
+    out = render(settings, params.activated()); loss = mapping_loss(out, gt, mask); loss.backward(); adam.step()
+
+(dqo_harness/mapping.py, i.e. SLAM/multiprocess/mapper.py:531-605 + 836-875 + gaussian_pointcloud.py:331-378), but without
+the autograd graph and the ~110 eager launches per iteration: activation kernel -> rasteriser forward -> fused masked-loss
+forward+backward -> rasteriser backward -> fused (activation-Jacobian + Adam) kernel.  The rasteriser is called through the
+same operator code (`_RasterizeGaussians.forward / .backward`), so it is the same C-ABI path the drop-in op uses.
+
+Only the masked-loss case is fused (SSIM needs an 11x11 convolution and is skipped by the reference when a render mask is
+given, B14); without a mask use the autograd path of dqo_harness/mapping.py.  GPU only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+import _dqo_native as N
+import diff_gaussian_rasterization_depth as dgr
+from dqo_harness import mapping
+
+
+class _Ctx:
+    """Stand-in for the autograd ctx when the op's static forward/backward are driven directly."""
+
+    def save_for_backward(self, *a):
+        self.saved_tensors = a
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+class FusedMapper:
+    def __init__(self, scene, settings, device, lrs=None, betas=(0.9, 0.999), eps=1e-15, color_weight=mapping.COLOR_WEIGHT,
+                 depth_weight=mapping.DEPTH_WEIGHT, add_depth_thres=0.1):
+        t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=device)
+        self.device = device
+        self.settings = settings
+        self.xyz = t(scene["xyz"])
+        self.shs = t(scene["shs"])  # [P, M, 3]; coefficient 0 is f_dc, the rest f_rest (no torch.cat per iteration)
+        op = t(scene["opacity"]).clamp(1e-4, 1 - 1e-4)
+        self.opacity_raw = torch.log(op / (1 - op))
+        self.scaling_raw = torch.log(t(scene["scales"]))
+        self.rotation_raw = t(scene["rotations"]).clone()
+        self.P, self.M = self.xyz.shape[0], self.shs.shape[1]
+        self.lrs = dict(mapping.LRS if lrs is None else lrs)
+        self.betas, self.eps = betas, eps
+        self.color_weight, self.depth_weight, self.add_depth_thres = color_weight, depth_weight, add_depth_thres
+        self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in self._params().items()}
+        self.step_count = 0
+        P = self.P
+        f = dict(dtype=torch.float32, device=device)
+        self.opacity = torch.empty((P, 1), **f)
+        self.scales = torch.empty((P, 3), **f)
+        self.rotations = torch.empty((P, 4), **f)
+        H, W = settings.image_height, settings.image_width
+        self.dL_dcolor = torch.empty((3, H, W), **f)
+        self.dL_ddepth = torch.empty((1, H, W), **f)
+        self.loss = torch.zeros(4, **f)
+        lib = N.lib()
+        self.loss_ws = torch.empty((lib.dqo_map_loss_workspace_bytes(),), dtype=torch.uint8, device=device)
+        self._empty = torch.Tensor([])
+        self.tile_mask = torch.ones(((H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=device)
+
+    def _params(self):
+        return dict(xyz=self.xyz, shs=self.shs, opacity=self.opacity_raw, scaling=self.scaling_raw, rotation=self.rotation_raw)
+
+    @torch.no_grad()
+    def step(self, gt_color, gt_depth, render_mask, tile_mask=None):
+        """One mapping iteration; returns the op's 9-tuple (views of this iteration's outputs) — losses are in self.loss."""
+        lib = N.lib()
+        P, M = self.P, self.M
+        with torch.cuda.device(self.device):
+            stream = N.current_stream()
+            N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
+                                         N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), stream))
+            ctx = _Ctx()
+            out = dgr._RasterizeGaussians.forward(ctx, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations,
+                                                  self._empty, self.tile_mask if tile_mask is None else tile_mask, self.settings)
+            color, depth, hit_depth = out[0], out[1], out[3]
+            H, W = color.shape[1], color.shape[2]
+            mask_u8 = None if render_mask is None else render_mask
+            if mask_u8 is not None and mask_u8.dtype != torch.uint8:
+                mask_u8 = mask_u8.to(torch.uint8)
+            N.check(lib.dqo_map_loss_fwd_bwd(W, H, N.ptr(color), N.ptr(depth), N.ptr(hit_depth), N.ptr(gt_color), N.ptr(gt_depth),
+                                             N.ptr(mask_u8), self.color_weight, self.depth_weight, self.add_depth_thres,
+                                             N.ptr(self.loss), N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws),
+                                             self.loss_ws.numel(), stream))
+            grads = dgr._RasterizeGaussians.backward(ctx, self.dL_dcolor, self.dL_ddepth, None, None, None, None, None, None, None)
+            g_means3D, g_sh, _, g_opacity, g_scales, g_rot = grads[0], grads[1], grads[2], grads[3], grads[4], grads[5]
+            self.step_count += 1
+            st = N.DqoAdamStep(P=P, M=M, step=self.step_count, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                               lr_xyz=self.lrs["xyz"], lr_f_dc=self.lrs["f_dc"], lr_f_rest=self.lrs["f_rest"],
+                               lr_opacity=self.lrs["opacity"], lr_scaling=self.lrs["scaling"], lr_rotation=self.lrs["rotation"],
+                               xyz=N.ptr(self.xyz), shs=N.ptr(self.shs), opacity_raw=N.ptr(self.opacity_raw),
+                               scaling_raw=N.ptr(self.scaling_raw), rotation_raw=N.ptr(self.rotation_raw), g_means3D=N.ptr(g_means3D),
+                               g_sh=N.ptr(g_sh), g_opacity=N.ptr(g_opacity), g_scales=N.ptr(g_scales), g_rotations=N.ptr(g_rot),
+                               m_xyz=N.ptr(self.state["xyz"][0]), m_shs=N.ptr(self.state["shs"][0]),
+                               m_opacity=N.ptr(self.state["opacity"][0]), m_scaling=N.ptr(self.state["scaling"][0]),
+                               m_rotation=N.ptr(self.state["rotation"][0]), v_xyz=N.ptr(self.state["xyz"][1]),
+                               v_shs=N.ptr(self.state["shs"][1]), v_opacity=N.ptr(self.state["opacity"][1]),
+                               v_scaling=N.ptr(self.state["scaling"][1]), v_rotation=N.ptr(self.state["rotation"][1]))
+            N.check(lib.dqo_map_adam_step(ctypes.byref(st), stream))
+        return out

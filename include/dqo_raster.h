@@ -182,6 +182,36 @@ int dqo_quadric_adam(int32_t n_obj, int32_t n_iters, const int32_t* view_offset,
                      const float* obs_views, const int32_t* view_schedule, float* axes, float* R, float* center,
                      float* loss_hist, void* hipStream);
 
+/* ---- fused helpers around the rasteriser for one mapping iteration (optional) ------------------
+ * They replace eager torch op sequences of the reference's callers, not a CUDA binding:
+ *   dqo_map_activate      <- SLAM/gaussian_pointcloud.py:732-733, 746-747 (sigmoid / exp / F.normalize)
+ *   dqo_map_loss_fwd_bwd  <- SLAM/multiprocess/mapper.py:836-875 with a render mask (masked L1 colour + masked depth L1; SSIM
+ *                            is skipped in that case, B14) and its autograd backward
+ *   dqo_map_adam_step     <- autograd through the activations + torch.optim.Adam(eps=1e-15) over the six parameter groups
+ *                            (SLAM/gaussian_pointcloud.py:331-378, mapper.py:548) */
+int dqo_map_activate(int32_t P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
+                     float* scales, float* rotations, void* hipStream);
+
+size_t dqo_map_loss_workspace_bytes(void);
+/* color [3,H,W], depth [1,H,W], depth_index int32 [1,H,W] (the op's hit_depth), render_mask uint8 [H,W] or NULL (= all).
+ * loss_out[4] = {total, colour, depth, 0}; writes dL_dcolor [3,H,W] and dL_ddepth [1,H,W] of `total`. */
+int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const float* depth, const int32_t* depth_index,
+                         const float* gt_color, const float* gt_depth, const uint8_t* render_mask, float color_weight,
+                         float depth_weight, float add_depth_thres, float* loss_out, float* dL_dcolor, float* dL_ddepth,
+                         void* workspace, size_t workspace_bytes, void* hipStream);
+
+typedef struct DqoAdamStep {
+    int32_t P, M;      /* Gaussians, SH coefficients per Gaussian (f_dc = coefficient 0, f_rest = the others) */
+    int32_t step;      /* 1-based Adam step count */
+    float beta1, beta2, eps;
+    float lr_xyz, lr_f_dc, lr_f_rest, lr_opacity, lr_scaling, lr_rotation;
+    float *xyz, *shs, *opacity_raw, *scaling_raw, *rotation_raw;            /* raw parameters, updated in place */
+    const float *g_means3D, *g_sh, *g_opacity, *g_scales, *g_rotations;      /* dqo_rast_backward outputs (w.r.t. activated) */
+    float *m_xyz, *m_shs, *m_opacity, *m_scaling, *m_rotation;               /* exp_avg, same shapes as the parameters */
+    float *v_xyz, *v_shs, *v_opacity, *v_scaling, *v_rotation;               /* exp_avg_sq */
+} DqoAdamStep;
+int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
+
 #ifdef __cplusplus
 }
 #endif

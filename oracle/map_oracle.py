@@ -1,0 +1,53 @@
+"""ORACLE (test infrastructure only) for the fused mapping-step helpers: numpy restatement of
+
+  * the masked loss of /root/reference/SLAM/multiprocess/mapper.py:836-875 (render_mask given => no SSIM term, B14;
+    normal_weight = 0) and its gradient w.r.t. the rendered colour / depth,
+  * the activations of SLAM/gaussian_pointcloud.py:732-733, 746-747 and their Jacobians,
+  * one torch.optim.Adam step (mapper.py:548: Adam(lr=0 default, eps=1e-15); groups gaussian_pointcloud.py:338-370).
+
+PARITY STATUS: pinned — the reference's own implementation of these pieces IS torch (eager ops + torch.optim.Adam), which runs
+on CPU here: tests/test_oracle_map.py checks this restatement against torch autograd + torch.optim.Adam on the same inputs.
+"""
+import numpy as np
+
+
+def masked_loss(color, depth, depth_index, gt_color, gt_depth, render_mask, color_weight=0.8, depth_weight=1.0, add_depth_thres=0.1):
+    """Returns (total, color_loss, depth_loss, dL_dcolor[3,H,W], dL_ddepth[1,H,W]) in float64."""
+    color, depth, gt_color, gt_depth = (np.asarray(a, np.float64) for a in (color, depth, gt_color, gt_depth))
+    m = np.ones(depth.shape[1:], bool) if render_mask is None else np.asarray(render_mask).astype(bool)
+    n_col = max(int(m.sum()), 1)
+    d = color - gt_color
+    color_loss = np.abs(d)[:, m].sum() / (3.0 * n_col)                       # l1_loss(image[mask], gt[mask]) (mapper.py:847)
+    err = depth - gt_depth
+    valid = (np.asarray(depth_index) != -1) & (gt_depth > 0) & (err < add_depth_thres) & m[None]   # mapper.py:850-856
+    n_dep = max(int(valid.sum()), 1)
+    depth_loss = np.abs(err[valid]).sum() / n_dep
+    total = depth_weight * depth_loss + color_weight * color_loss
+    dL_dcolor = np.sign(d) * m[None] * (color_weight / (3.0 * n_col))
+    dL_ddepth = np.sign(err) * valid * (depth_weight / n_dep)
+    return total, color_loss, depth_loss, dL_dcolor, dL_ddepth
+
+
+def activate(opacity_raw, scaling_raw, rotation_raw):
+    q = np.asarray(rotation_raw, np.float64)
+    n = np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)
+    return 1.0 / (1.0 + np.exp(-np.asarray(opacity_raw, np.float64))), np.exp(np.asarray(scaling_raw, np.float64)), q / n
+
+
+def raw_grads(opacity_raw, scaling_raw, rotation_raw, g_opacity, g_scales, g_rot):
+    """Chain rule through sigmoid / exp / F.normalize."""
+    sg = 1.0 / (1.0 + np.exp(-np.asarray(opacity_raw, np.float64)))
+    q = np.asarray(rotation_raw, np.float64)
+    n = np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)
+    y = q / n
+    g = np.asarray(g_rot, np.float64)
+    return (np.asarray(g_opacity, np.float64) * sg * (1 - sg), np.asarray(g_scales, np.float64) * np.exp(np.asarray(scaling_raw, np.float64)),
+            (g - y * (y * g).sum(1, keepdims=True)) / n)
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-15):
+    m = m + (g - m) * (1 - beta1)
+    v = v * beta2 + (1 - beta2) * g * g
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    p = p - (lr / bc1) * (m / (np.sqrt(v) / np.sqrt(bc2) + eps))
+    return p, m, v

@@ -1,0 +1,98 @@
+"""GPU parity on the rarely-taken paths: per-tile lists longer than the LDS sort capacity (in-place global sort), screen-filling
+splats (multi-window binning, whole-image tile rects), image sizes that are not multiples of 16, lazy-mode capacity overflow."""
+import numpy as np
+import pytest
+
+from dqo_harness import scenes
+import util_rast as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    import _dqo_native
+    _dqo_native.lib()
+    return torch
+
+
+def _dL(cam, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.normal(size=(3, cam.H, cam.W)).astype(np.float32), rng.normal(size=(1, cam.H, cam.W)).astype(np.float32)
+
+
+def _check(oracle, cam, sc, dL, **kw):
+    h, hg = U.run_hip(cam, sc, dL=dL, **kw)
+    o, r, og = U.run_oracle(oracle, cam, sc, dL=dL, **kw)
+    st = U.compare_forward(h, r)
+    _, _, og64 = U.run_oracle(oracle, cam, sc, dL=dL, dtype=np.float64, **kw)
+    gs = U.compare_grads(hg, og, og64)
+    return o, st, gs
+
+
+def test_long_tile_lists_global_sort(torch_cuda, oracle):
+    """> 4096 instances in one tile: the sort kernel's in-place global path; semi-transparent so the whole list is walked."""
+    cam = scenes.Camera(96, 64, 80.0, 80.0, 47.5, 31.5)
+    rng = np.random.default_rng(0)
+    P = 9000
+    sc = scenes.frustum_cloud(5, P, cam, zmin=1.0, zmax=4.0)
+    # squeeze all centres into a 20x20-pixel window around the image centre
+    pc = np.stack([rng.uniform(-0.12, 0.12, P), rng.uniform(-0.12, 0.12, P), rng.uniform(1.0, 4.0, P)], 1)
+    pc[:, :2] *= pc[:, 2:3]
+    sc["xyz"] = pc.astype(np.float32)
+    sc["opacity"] = rng.uniform(0.02, 0.08, (P, 1)).astype(np.float32)
+    o, st, gs = _check(oracle, cam, sc, _dL(cam))
+    rg = o.ctx("ranges")
+    assert (rg[:, 1] - rg[:, 0]).max() > 4096, "scene does not exercise the long-list path"
+    print("long lists:", (rg[:, 1] - rg[:, 0]).max(), st)
+
+
+def test_screen_filling_splats_multi_window(torch_cuda, oracle):
+    """64 huge, close splats (tile rect = whole image) among small ones: > 16384 candidate pairs in one binning chunk."""
+    cam = scenes.Camera(640, 352, 300.0, 300.0, 319.5, 175.5)
+    sc = scenes.frustum_cloud(7, 1500, cam, zmin=1.0, zmax=4.0)
+    rng = np.random.default_rng(1)
+    big = rng.choice(1024, 64, replace=False)  # all inside the first chunk of 1024 Gaussians
+    sc["scales"][big] = np.array([1.5, 1.5, 0.15], np.float32)
+    sc["xyz"][big, 2] = rng.uniform(0.6, 1.2, 64).astype(np.float32)
+    sc["opacity"][big] = 0.05
+    o, st, gs = _check(oracle, cam, sc, _dL(cam, 1))
+    T = ((cam.W + 15) // 16) * ((cam.H + 15) // 16)
+    tt = o.ctx("tiles_touched")[big]
+    assert (tt >= T * 0.9).sum() >= 16 and tt.sum() > 16384  # whole-image rects, more candidates than one binning window
+    print("giant splats:", st)
+
+
+@pytest.mark.parametrize("W,H", [(17, 9), (100, 75), (333, 47)])
+def test_odd_image_sizes(torch_cuda, oracle, W, H):
+    cam = scenes.Camera(W, H, 0.8 * W, 0.8 * W, W / 2 - 0.3, H / 2 + 0.2, scenes.rot_yx(3.0, -2.0), np.array([0.01, 0.02, 0.0]))
+    sc = scenes.frustum_cloud(W, 800, cam, zmin=0.8, zmax=3.0)
+    sc["scales"] = (sc["scales"] * 3).astype(np.float32)
+    _check(oracle, cam, sc, _dL(cam, 2))
+
+
+def test_lazy_mode_overflow_is_detected_and_recovers(torch_cuda, oracle):
+    import torch
+    import diff_gaussian_rasterization_depth as dgr
+    cam, sc = scenes.make_config(1, P=3000)
+    try:
+        dgr.set_sync_mode("lazy")
+        h1, _ = U.run_hip(cam, sc)  # first call of this shape measures N and sets the capacity hint
+        key = (0, 3000, cam.W, cam.H)
+        assert key in dgr._cap_hint
+        dgr._verify_pending(block=True)
+        dgr._cap_hint[key] = 64  # far too small on purpose
+        U.run_hip(cam, sc)
+        with pytest.raises(RuntimeError, match="only 64 fitted"):
+            dgr._verify_pending(block=True)
+        assert dgr._cap_hint[key] > 64  # capacity raised: the re-run is valid again
+        h3, _ = U.run_hip(cam, sc)
+        dgr._verify_pending(block=True)
+        for k in ("color", "depth", "hit_depth", "T_map"):
+            np.testing.assert_array_equal(h3[k], h1[k])
+    finally:
+        dgr.set_sync_mode("exact")
+    o, r, _ = U.run_oracle(oracle, cam, sc)
+    U.compare_forward(h3, r)

@@ -1,0 +1,66 @@
+"""Pins the numpy oracle of the fused mapping helpers against torch (CPU): the reference implements these pieces WITH torch
+eager ops and torch.optim.Adam, so torch itself is the reference here."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import map_oracle as mo
+
+
+def _data(seed=0, H=40, W=56):
+    rng = np.random.default_rng(seed)
+    color, gt_color = rng.uniform(0, 1, (3, H, W)), rng.uniform(0, 1, (3, H, W))
+    depth, gt_depth = rng.uniform(0.5, 3, (1, H, W)), rng.uniform(0.4, 3, (1, H, W))
+    gt_depth[0, :3] = 0  # invalid gt depth
+    idx = rng.integers(-1, 50, (1, H, W)).astype(np.int32)
+    mask = rng.uniform(size=(H, W)) < 0.7
+    color[0, 5, 5] = gt_color[0, 5, 5]  # exact zero residual: sign(0) = 0
+    return color, depth, idx, gt_color, gt_depth, mask
+
+
+def test_masked_loss_matches_torch_autograd():
+    color, depth, idx, gt_color, gt_depth, mask = _data()
+    tc = torch.tensor(color, dtype=torch.float64, requires_grad=True)
+    td = torch.tensor(depth, dtype=torch.float64, requires_grad=True)
+    m = torch.tensor(mask)
+    gc, gd, ti = torch.tensor(gt_color), torch.tensor(gt_depth), torch.tensor(idx)
+    # literal restatement of mapper.py:836-875 for the masked case
+    image, dep, dindex = tc.permute(1, 2, 0), td.permute(1, 2, 0), ti.permute(1, 2, 0)
+    color_loss = torch.abs(image[m] - gc.permute(1, 2, 0)[m]).mean()
+    depth_error = dep - gd.permute(1, 2, 0)
+    valid = (dindex != -1).squeeze() & (gd.permute(1, 2, 0) > 0).squeeze() & (depth_error < 0.1).squeeze() & m
+    depth_loss = torch.abs(depth_error[valid]).mean()
+    total = 1.0 * depth_loss + 0.8 * color_loss
+    total.backward()
+    t, cl, dl, dC, dD = mo.masked_loss(color, depth, idx, gt_color, gt_depth, mask)
+    np.testing.assert_allclose([t, cl, dl], [total.item(), color_loss.item(), depth_loss.item()], rtol=1e-12)
+    np.testing.assert_allclose(dC, tc.grad.numpy(), atol=1e-15)
+    np.testing.assert_allclose(dD, td.grad.numpy(), atol=1e-15)
+
+
+def test_activation_jacobians_and_adam_match_torch():
+    rng = np.random.default_rng(1)
+    P = 64
+    raw = dict(op=rng.normal(size=(P, 1)), sc=rng.normal(-4, 0.5, (P, 3)), rot=rng.normal(size=(P, 4)))
+    g = dict(op=rng.normal(size=(P, 1)), sc=rng.normal(size=(P, 3)), rot=rng.normal(size=(P, 4)))
+    t = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in raw.items()}
+    act = (torch.sigmoid(t["op"]), torch.exp(t["sc"]), F.normalize(t["rot"]))
+    (act[0] * torch.tensor(g["op"])).sum().backward()
+    (act[1] * torch.tensor(g["sc"])).sum().backward()
+    (act[2] * torch.tensor(g["rot"])).sum().backward()
+    a = mo.activate(raw["op"], raw["sc"], raw["rot"])
+    for x, y in zip(a, act):
+        np.testing.assert_allclose(x, y.detach().numpy(), rtol=1e-12)
+    rg = mo.raw_grads(raw["op"], raw["sc"], raw["rot"], g["op"], g["sc"], g["rot"])
+    for x, k in zip(rg, ("op", "sc", "rot")):
+        np.testing.assert_allclose(x, t[k].grad.numpy(), rtol=1e-10, atol=1e-14)
+    # three Adam steps vs torch.optim.Adam(eps=1e-15) with the reference's group lrs
+    p = torch.tensor(raw["sc"], dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([{"params": [p], "lr": 0.004}], lr=0.0, eps=1e-15)
+    pn, m, v = raw["sc"].copy(), np.zeros_like(raw["sc"]), np.zeros_like(raw["sc"])
+    for step in range(1, 4):
+        gr = rng.normal(size=(P, 3))
+        p.grad = torch.tensor(gr)
+        opt.step()
+        pn, m, v = mo.adam_step(pn, gr, m, v, 0.004, step)
+        np.testing.assert_allclose(pn, p.detach().numpy(), rtol=1e-12, atol=1e-15)
