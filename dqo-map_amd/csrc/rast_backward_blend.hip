@@ -29,6 +29,39 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Reduce-scatter butterfly over the wave for EIGHT values at once: afterwards every lane l holds the 64-lane total of
+// v[l & 7].  Each of the first three stages halves the number of live values per lane (the lane keeps the half selected by
+// one bit of its id and ships the other half to its partner), so the whole thing costs ~35 VALU instead of 8 x 11 for eight
+// independent reductions.  Partners: xor 1 / xor 2 = DPP quad_perm, xor 4 = row_shl:4 | row_shr:4 split by bank mask,
+// xor 8 = row_ror:8, xor 16 / 32 = ds_bpermute.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov_bank(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_reduce8(const float (&v)[8], int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        w[i] = keep + dpp_mov<0xB1>(send);  // partner lane ^ 1
+    }
+    float x[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const float keep = b1 ? w[2 * m + 1] : w[2 * m], send = b1 ? w[2 * m] : w[2 * m + 1];
+        x[m] = keep + dpp_mov<0x4E>(send);  // partner lane ^ 2
+    }
+    const float keep = b2 ? x[1] : x[0], send = b2 ? x[0] : x[1];
+    float t = dpp_mov_bank<0x104, 0x5>(0.f, send);  // row_shl:4 -> lanes with bit2 = 0 read lane + 4
+    t = dpp_mov_bank<0x114, 0xA>(t, send);          // row_shr:4 -> lanes with bit2 = 1 read lane - 4
+    float y = keep + t;                              // partner lane ^ 4
+    y += dpp_mov<0x128>(y);                          // row_ror:8  == lane ^ 8 inside a row of 16
+    y += __shfl_xor(y, 16);
+    y += __shfl_xor(y, 32);
+    return y;
+}
+
 __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
 #pragma clang fp contract(off)
     float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
@@ -53,6 +86,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     __shared__ uint32_t s_qmask[BWD_BATCH];
     __shared__ uint8_t s_list[4][BWD_BATCH];
     __shared__ float4 s_part[4][BWD_BATCH][4];  // [wave][entry][4 x float4] = 32 KB
+    float* const s_part_f = reinterpret_cast<float*>(&s_part[0][0][0]);
 
     const int tile = img.tile_order[blockIdx.x];
     const uint2 range = img.ranges[tile];
@@ -142,59 +176,54 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                 cs_nx = s_rgb[j_nx];
             }
             const int c = L - 1 - (b * BWD_BATCH + j);  // 0-based list position == the reference's `contributor` after its --
-            float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
-            bool did_color = false;
-            if (c < last_contrib) {
-                const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                if (power <= 0.0f) {
-                    const float G = dqo_gauss(power);
-                    const float alpha = fminf(0.99f, co.w * G);
-                    if (alpha >= 1.0f / 255.0f) {
-                        const float4 cs = cs_cur;
-                        did_color = true;
-                        const float inv_1ma = dqo_rcp(1.f - alpha);
-                        T = T * inv_1ma;
-                        const float dchannel_dcolor = alpha * T;
-                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                        lc0 = cs.x, lc1 = cs.y, lc2 = cs.z;
-                        float dL_dalpha = (cs.x - acc0) * dp0 + (cs.y - acc1) * dp1 + (cs.z - acc2) * dp2;
-                        r_c0 = dchannel_dcolor * dp0;
-                        r_c1 = dchannel_dcolor * dp1;
-                        r_c2 = dchannel_dcolor * dp2;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final * inv_1ma) * bgdot;  // end_T, not the running T (quirk B2)
-                        const float dL_dG = co.w * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                        const float dG_ddely = -gdy * co.z - gdx * co.y;
-                        r_mx = dL_dG * dG_ddelx * ddelx_dx;
-                        r_my = dL_dG * dG_ddely * ddely_dy;
-                        r_ka = -0.5f * gdx * dx * dL_dG;
-                        r_kb = -0.5f * gdx * dy * dL_dG;
-                        r_kc = -0.5f * gdy * dy * dL_dG;
-                        r_op = G * dL_dalpha;
-                    }
-                }
-            }
+            // ---- predicated per-pixel gradient terms (backward.cu:932-994); masked lanes contribute exact zeros ----
+            const float dx = xy.x - pixfx, dy = xy.y - pixfy;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            const float G = dqo_gauss(power);
+            const float alpha = fminf(0.99f, co.w * G);
+            const bool did_color = c < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;
+            const float4 cs = cs_cur;
+            const float inv_1ma = dqo_rcp(1.f - alpha);
+            const float Tn = T * inv_1ma;                      // T / (1 - alpha)
+            const float dchannel_dcolor = alpha * Tn;
+            const float a0n = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+            const float a1n = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+            const float a2n = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+            float dL_dalpha = ((cs.x - a0n) * dp0 + (cs.y - a1n) * dp1 + (cs.z - a2n) * dp2) * Tn;
+            dL_dalpha += (-T_final * inv_1ma) * bgdot;         // end_T, not the running T (quirk B2)
+            const float sel = did_color ? 1.f : 0.f;
+            const float dL_dG = sel * co.w * dL_dalpha;
+            const float Gs = did_color ? G : 0.f;  // masked lanes must contribute exact zeros even if G overflowed (power > 0)
+            const float gdx = Gs * dx, gdy = Gs * dy;
+            const float r_c0 = sel * dchannel_dcolor * dp0;
+            const float r_c1 = sel * dchannel_dcolor * dp1;
+            const float r_c2 = sel * dchannel_dcolor * dp2;
+            const float r_mx = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
+            const float r_my = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
+            const float r_ka = -0.5f * gdx * dx * dL_dG;
+            const float r_kb = -0.5f * gdx * dy * dL_dG;
+            const float r_kc = -0.5f * gdy * dy * dL_dG;
+            const float r_op = sel * Gs * dL_dalpha;
+            // state update only for lanes that really blended this entry
+            T = did_color ? Tn : T;
+            acc0 = did_color ? a0n : acc0;
+            acc1 = did_color ? a1n : acc1;
+            acc2 = did_color ? a2n : acc2;
+            lc0 = did_color ? cs.x : lc0;
+            lc1 = did_color ? cs.y : lc1;
+            lc2 = did_color ? cs.z : lc2;
+            last_alpha = did_color ? alpha : last_alpha;
             const bool is_hit = (hit_pos == c + 1);
             const bool any_color = __ballot(did_color) != 0ull;
             const bool any_hit = __ballot(is_hit) != 0ull;
             if (!any_color && !any_hit) continue;
-            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0, o3 = o0;
+            float* rec = &s_part_f[(wave * BWD_BATCH + j) * 16];  // this wave's private slot for entry j (zeroed per batch)
             if (any_color) {
-                o0.x = wave_sum(r_c0);
-                o0.y = wave_sum(r_c1);
-                o0.z = wave_sum(r_c2);
-                o0.w = wave_sum(r_mx);
-                o1.x = wave_sum(r_my);
-                o1.y = wave_sum(r_ka);
-                o1.z = wave_sum(r_kb);
-                o1.w = wave_sum(r_kc);
-                o2.x = wave_sum(r_op);
+                const float cv[8] = {r_c0, r_c1, r_c2, r_mx, r_my, r_ka, r_kb, r_kc};
+                const float tot = wave_reduce8(cv, lane);
+                const float top = wave_sum(r_op);
+                if (lane < 8) rec[lane] = tot;   // record floats 0..7: dcolor[3], dmean2D[2], dconic[3]
+                if (lane == 8) rec[8] = top;     // float 8: dopacity
             }
             if (any_hit) {
                 // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth)
@@ -260,19 +289,9 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                         h_m2 = ddep * view[10];
                     }
                 }
-                o2.y = wave_sum(h_m0);
-                o2.z = wave_sum(h_m1);
-                o2.w = wave_sum(h_m2);
-                o3.x = wave_sum(h_q0);
-                o3.y = wave_sum(h_q1);
-                o3.z = wave_sum(h_q2);
-                o3.w = wave_sum(h_q3);
-            }
-            if (lane == 0) {
-                s_part[wave][j][0] = o0;
-                s_part[wave][j][1] = o1;
-                s_part[wave][j][2] = o2;
-                s_part[wave][j][3] = o3;
+                const float hv[8] = {h_m0, h_m1, h_m2, h_q0, h_q1, h_q2, h_q3, 0.f};
+                const float toth = wave_reduce8(hv, lane);
+                if (lane < 7) rec[9 + lane] = toth;  // floats 9..15: dmean3D[3], drot[4]
             }
         }
         __syncthreads();

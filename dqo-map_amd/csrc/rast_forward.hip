@@ -515,55 +515,47 @@ __global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoV
                 xy = s_xy[j];
                 co = s_co[j];
             }
-            bool contributes_half = false, lane_live = false;
-            if (!done) {
-                const int j = j_cur;
-                const uint32_t contributor = (uint32_t)(i * BLEND_THREADS + j + 1);  // the reference's running counter
-                const float4 xy = xy_cur;
-                const float4 co = co_cur;
-                const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                if (power <= 0.0f) {
-                    const float alpha = fminf(0.99f, co.w * dqo_gauss(power));
-                    if (alpha >= 1.0f / 255.0f) {
-                        const float4 cs = s_rgb[j];
-                        if (!hit_gaussian && alpha >= v.opaque_thr) {
-                            // forward.cu:792-810
-                            const int id = s_id[j];
-                            const HitEval h = eval_hit(ray, g.normal_c[id]);
-                            hit_id = id;
-                            hit_pos = contributor;
-                            hit_depth_weight = alpha * T;
-                            const float angle_distance = fabsf(h.den);
-                            const float depth_distance = fabsf(h.hit_z - xy.z);
-                            depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy.z;
-                            hit_gaussian = true;
-                            lane_live = true;
-                        }
-                        const float test_T = T * (1.f - alpha);
-                        if (test_T < v.T_thr && hit_gaussian) {
-                            done = true;
-                        } else {
-                            if (test_T >= v.T_thr) {
-                                const float w = alpha * T;
-                                C0 += cs.x * w;
-                                C1 += cs.y * w;
-                                C2 += cs.z * w;
-                                if (w > color_weight_max) {
-                                    color_weight_max = w;
-                                    hit_color_id = s_id[j];
-                                    hit_color_weight = w;
-                                }
-                                contributes_half = test_T > 0.5f;
-                                lane_live = true;
-                                last_contributor = contributor;
-                                end_T = test_T;
-                            }
-                            T = test_T;
-                        }
-                    }
+            // ---- predicated (branch-free) per-pixel update: nested divergent ifs cost more scalar exec-mask traffic than
+            // the arithmetic they guard; the only real branches left are wave-uniform ----
+            const uint32_t contributor = (uint32_t)(i * BLEND_THREADS + j_cur + 1);  // the reference's running counter
+            const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
+            const float power = -0.5f * (co_cur.x * dx * dx + co_cur.z * dy * dy) - co_cur.y * dx * dy;
+            const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
+            const bool valid = !done && power <= 0.0f && alpha >= 1.0f / 255.0f;  // forward.cu:763-772
+            if (__ballot(valid) == 0) continue;  // no pixel of this quadrant is touched by the entry
+            const float4 cs = s_rgb[j_cur];
+            const bool newhit = valid && !hit_gaussian && alpha >= v.opaque_thr;
+            if (__ballot(newhit)) {
+                // forward.cu:792-810: first Gaussian with alpha >= opaque_threshold fixes this pixel's depth (once per pixel)
+                if (newhit) {
+                    const int id = s_id[j_cur];
+                    const HitEval h = eval_hit(ray, g.normal_c[id]);
+                    hit_id = id;
+                    hit_pos = contributor;
+                    hit_depth_weight = alpha * T;
+                    const float angle_distance = fabsf(h.den);
+                    const float depth_distance = fabsf(h.hit_z - xy_cur.z);
+                    depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
+                    hit_gaussian = true;
                 }
             }
+            const float test_T = T * (1.f - alpha);
+            const bool finish = valid && test_T < v.T_thr && hit_gaussian;   // forward.cu:813-817: done, T NOT updated
+            const bool blend = valid && !finish && test_T >= v.T_thr;         // forward.cu:818-840
+            const float w = blend ? alpha * T : 0.f;
+            C0 += cs.x * w;
+            C1 += cs.y * w;
+            C2 += cs.z * w;
+            const bool newmax = blend && w > color_weight_max;
+            color_weight_max = newmax ? w : color_weight_max;
+            hit_color_id = newmax ? s_id[j_cur] : hit_color_id;
+            hit_color_weight = newmax ? w : hit_color_weight;
+            last_contributor = blend ? contributor : last_contributor;
+            end_T = blend ? test_T : end_T;
+            T = (valid && !finish) ? test_T : T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
+            done = done || finish;
+            const bool contributes_half = blend && test_T > 0.5f;  // forward.cu:833-835 (B8)
+            const bool lane_live = blend || newhit;
             // one LDS atomic per (wave, entry): low 28 bits count the T' > 0.5 pairs, bit 28+wave marks the quadrant live
             const unsigned long long m = __ballot(contributes_half);
             const unsigned long long lv = __ballot(lane_live);

@@ -22,8 +22,8 @@ def _check(oracle, cam, sc, dL, **kw):
     """HIP vs fp32 oracle (forward, 1e-4) and vs fp64 oracle as truth for gradients (see util_rast.compare_grads)."""
     h, hg = U.run_hip(cam, sc, dL=dL, **kw)
     o, r, og = U.run_oracle(oracle, cam, sc, dL=dL, **kw)
-    st = U.compare_forward(h, r)
-    _, _, og64 = U.run_oracle(oracle, cam, sc, dL=dL, dtype=np.float64, **kw)
+    _, r64, og64 = U.run_oracle(oracle, cam, sc, dL=dL, dtype=np.float64, **kw)
+    st = U.compare_forward(h, r, r64)
     gs = U.compare_grads(hg, og, og64)
     print("fwd", st, "grads (rel-to-max, q99)", gs)
     return h, r, o

@@ -26,8 +26,8 @@ def _dL(cam, seed=0):
 def _check(oracle, cam, sc, dL, **kw):
     h, hg = U.run_hip(cam, sc, dL=dL, **kw)
     o, r, og = U.run_oracle(oracle, cam, sc, dL=dL, **kw)
-    st = U.compare_forward(h, r)
-    _, _, og64 = U.run_oracle(oracle, cam, sc, dL=dL, dtype=np.float64, **kw)
+    _, r64, og64 = U.run_oracle(oracle, cam, sc, dL=dL, dtype=np.float64, **kw)
+    st = U.compare_forward(h, r, r64)
     gs = U.compare_grads(hg, og, og64)
     return o, st, gs
 
