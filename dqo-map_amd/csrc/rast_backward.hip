@@ -32,9 +32,47 @@ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
 __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v, DqoGeomLayout g,
                                                                 const float* __restrict__ means3D, const float* __restrict__ scales,
                                                                 const float* __restrict__ rotations, const float* __restrict__ shs,
-                                                                const DqoGradRec* __restrict__ recs, DqoRastGrads gr) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= v.P) return;
+                                                                const DqoGradRec* __restrict__ recs, int64_t capacity,
+                                                                DqoRastGrads gr) {
+    // ---- fixed-order sum of every Gaussian's instance records, staged through LDS ----
+    // The slots of the 256 consecutive Gaussians of a block are one contiguous, idx-ordered range (rast_binning.hip hands out
+    // slots per 1024-chunk in index order), so the block streams that range with coalesced 16-byte loads and each thread
+    // picks its own records out of LDS: no per-thread serial gather chain through HBM, no wave waiting for its largest splat.
+    constexpr int GB_CHUNK = 256;
+    __shared__ float4 s_rec[GB_CHUNK * 4];
+    __shared__ uint32_t s_lohi[2];
+    const int tid = threadIdx.x;
+    const int idx0 = blockIdx.x * blockDim.x;
+    const int idx = idx0 + tid;
+    const bool in_range = idx < v.P;
+    uint32_t base = 0, cnt = 0;
+    if (in_range) base = g.slot_base[idx], cnt = g.tiles_touched[idx];
+    if (tid == 0) s_lohi[0] = base;
+    if (idx == min(v.P - 1, idx0 + (int)blockDim.x - 1)) s_lohi[1] = base + cnt;
+    __syncthreads();
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i] = 0.f;
+    {
+        const uint32_t lo = s_lohi[0];
+        const uint32_t hi = (uint32_t)min((int64_t)s_lohi[1], capacity);  // an overflowed (invalid) forward must not read out of bounds
+        const float4* r4 = reinterpret_cast<const float4*>(recs);
+        for (uint32_t c0 = lo; c0 < hi; c0 += GB_CHUNK) {
+            const uint32_t nrec = min((uint32_t)GB_CHUNK, hi - c0);
+            for (uint32_t e = tid; e < nrec * 4; e += blockDim.x) s_rec[e] = r4[(size_t)c0 * 4 + e];
+            __syncthreads();
+            const uint32_t k0 = max(base, c0), k1 = min(base + cnt, c0 + nrec);
+            for (uint32_t k = k0; k < k1; k++) {
+                const float4 r0 = s_rec[(k - c0) * 4], r1 = s_rec[(k - c0) * 4 + 1], r2 = s_rec[(k - c0) * 4 + 2], r3 = s_rec[(k - c0) * 4 + 3];
+                a[0] += r0.x, a[1] += r0.y, a[2] += r0.z, a[3] += r0.w;
+                a[4] += r1.x, a[5] += r1.y, a[6] += r1.z, a[7] += r1.w;
+                a[8] += r2.x, a[9] += r2.y, a[10] += r2.z, a[11] += r2.w;
+                a[12] += r3.x, a[13] += r3.y, a[14] += r3.z, a[15] += r3.w;
+            }
+            __syncthreads();
+        }
+    }
+    if (!in_range) return;
     const int M = v.M, D = v.D;
     float* dm = gr.dL_dmeans3D + 3 * (size_t)idx;
     float* dsh = gr.dL_dsh ? gr.dL_dsh + (size_t)idx * M * 3 : nullptr;
@@ -57,21 +95,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         for (int i = 0; i < 6; i++) dcov[i] = 0.f;
         dm2[0] = dm2[1] = dm2[2] = 0.f;
         return;
-    }
-    // ---- fixed-order sum of this Gaussian's instance records ----
-    float a[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) a[i] = 0.f;
-    {
-        const uint32_t base = g.slot_base[idx], cnt = g.tiles_touched[idx];
-        const float4* r4 = reinterpret_cast<const float4*>(recs + base);
-        for (uint32_t k = 0; k < cnt; k++) {
-            const float4 r0 = r4[4 * k], r1 = r4[4 * k + 1], r2 = r4[4 * k + 2], r3 = r4[4 * k + 3];
-            a[0] += r0.x, a[1] += r0.y, a[2] += r0.z, a[3] += r0.w;
-            a[4] += r1.x, a[5] += r1.y, a[6] += r1.z, a[7] += r1.w;
-            a[8] += r2.x, a[9] += r2.y, a[10] += r2.z, a[11] += r2.w;
-            a[12] += r3.x, a[13] += r3.y, a[14] += r3.z, a[15] += r3.w;
-        }
     }
     const float dcolr[3] = {a[0], a[1], a[2]};
     const float g2x = a[3], g2y = a[4];
@@ -309,6 +332,6 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, (int64_t)ctx->inst_capacity, s);
     if (rc) return rc;
     DQO_LAUNCH("gaussian_backward_kernel", gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), s, v, g, in->means3D, in->scales, in->rotations,
-                       in->shs, recs, *gr);
+                       in->shs, recs, (int64_t)ctx->inst_capacity, *gr);
     return DQO_OK;
 }
