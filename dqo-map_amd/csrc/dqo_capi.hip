@@ -30,6 +30,10 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         const float* gt_depth, const uint8_t* render_mask, float color_weight, float depth_weight, float add_depth_thres,
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
+int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, const float* depth_err, const float* normal_err,
+                                const int32_t* color_index, const int32_t* depth_index, float color_thr, float depth_thr,
+                                float normal_thr, int check_max, float* gs_color, float* gs_depth, float* gs_normal, float* rescale,
+                                int32_t* counters, hipStream_t s);
 
 // ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -------------------------------
 #include <map>
@@ -255,6 +259,18 @@ DQO_API int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const
     }
     return dqo_launch_map_loss(W, H, color, depth, depth_index, gt_color, gt_depth, render_mask, color_weight, depth_weight,
                                add_depth_thres, loss_out, dL_dcolor, dL_ddepth, ws, (hipStream_t)stream);
+}
+
+DQO_API int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const float* ce, const float* de, const float* ne,
+                                          const int32_t* ci, const int32_t* di, float color_thr, float depth_thr, float normal_thr,
+                                          int32_t check_max, float* gs_color, float* gs_depth, float* gs_normal, float* rescale,
+                                          int32_t* counters, void* stream) {
+    DQO_CHECK_ARG(H > 0 && W > 0 && P >= 0, "bad sizes");
+    if (P == 0) return DQO_OK;
+    DQO_CHECK_ARG(ce && de && ne && ci && di && gs_color && gs_depth && gs_normal && rescale, "null pointer");
+    DQO_CHECK_ARG(check_max || counters, "mean mode needs the counters scratch buffer");
+    return dqo_launch_accumulate_error(H, W, P, ce, de, ne, ci, di, color_thr, depth_thr, normal_thr, check_max, gs_color, gs_depth,
+                                       gs_normal, rescale, counters, (hipStream_t)stream);
 }
 
 DQO_API int dqo_map_adam_step(const DqoAdamStep* st, void* stream) {

@@ -1,0 +1,82 @@
+// Per-Gaussian error accumulation for gfx950 — replaces
+// /root/reference/submodules/cuda_utils/map_process.cu:33-245 (acuumulate_error_preprocessCUDA, accumulate_error_meanCUDA) and
+// cuda_utils.cu:17-62 (accumulate_gaussian_error): scatter the per-pixel colour / depth / normal errors onto the Gaussians
+// named by the rasteriser's hit-index maps (max or mean), and count per Gaussian how many pixels exceed the thresholds.
+//
+// The reference implements float atomicMax as a compare-and-swap loop.  The accumulators start at 0 and only values that
+// compare greater replace them, so only strictly positive floats ever win — and for positive floats the IEEE bit pattern
+// orders like the value: one hardware integer atomic max per pixel instead of a CAS loop, bit-identical result.
+#include "dqo_common.h"
+
+namespace {
+
+__device__ __forceinline__ void atomic_max_pos(float* addr, float val) {
+    if (val > 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(val));  // NaN and values <= 0 never beat the 0 init
+}
+
+__global__ __launch_bounds__(256) void accumulate_error_kernel(int HW, int P, const float* __restrict__ color_err,
+                                                               const float* __restrict__ depth_err, const float* __restrict__ normal_err,
+                                                               const int32_t* __restrict__ color_index, const int32_t* __restrict__ depth_index,
+                                                               float color_thr, float depth_thr, float normal_thr, int check_max,
+                                                               float* __restrict__ gs_color, float* __restrict__ gs_depth,
+                                                               float* __restrict__ gs_normal, float* __restrict__ rescale,
+                                                               int32_t* __restrict__ counters /* [3][P], mean mode only */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float ce = color_err[i], de = depth_err[i], ne = normal_err[i];
+    const int ci = color_index[i], di = depth_index[i];
+    if (ci >= 0 && ci < P) {
+        if (check_max) atomic_max_pos(&gs_color[ci], ce);
+        else {
+            atomicAdd(&gs_color[ci], ce);
+            atomicAdd(&counters[ci], 1);
+        }
+        if (ce > color_thr) atomicAdd(&rescale[ci], 1.0f);
+    }
+    if (di >= 0 && di < P) {
+        if (check_max) {
+            atomic_max_pos(&gs_depth[di], de);
+            atomic_max_pos(&gs_normal[di], ne);
+        } else {
+            atomicAdd(&gs_depth[di], de);
+            atomicAdd(&gs_normal[di], ne);
+            atomicAdd(&counters[P + di], 1);
+        }
+        if (de > depth_thr) atomicAdd(&rescale[di], 1.0f);
+        if (ne > normal_thr) atomicAdd(&rescale[di], 1.0f);
+    }
+}
+
+__global__ void error_mean_kernel(int P, const int32_t* __restrict__ counters, float* __restrict__ gs_color, float* __restrict__ gs_depth,
+                                  float* __restrict__ gs_normal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int cc = counters[i], dc = counters[P + i];
+    if (cc > 0) gs_color[i] = gs_color[i] / cc;
+    if (dc > 0) {
+        gs_depth[i] = gs_depth[i] / dc;
+        gs_normal[i] = gs_normal[i] / dc;  // normal_error_counter == depth_error_counter (map_process.cu:103-104)
+    }
+}
+
+}  // namespace
+
+int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, const float* depth_err, const float* normal_err,
+                                const int32_t* color_index, const int32_t* depth_index, float color_thr, float depth_thr,
+                                float normal_thr, int check_max, float* gs_color, float* gs_depth, float* gs_normal, float* rescale,
+                                int32_t* counters, hipStream_t s) {
+    const size_t nb = sizeof(float) * (size_t)P;
+    DQO_CHECK_HIP(hipMemsetAsync(gs_color, 0, nb, s));
+    DQO_CHECK_HIP(hipMemsetAsync(gs_depth, 0, nb, s));
+    DQO_CHECK_HIP(hipMemsetAsync(gs_normal, 0, nb, s));
+    DQO_CHECK_HIP(hipMemsetAsync(rescale, 0, nb, s));
+    if (!check_max) DQO_CHECK_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int32_t) * (size_t)P, s));
+    const int HW = H * W;
+    DQO_LAUNCH("accumulate_error_kernel", accumulate_error_kernel, dim3((HW + 255) / 256), dim3(256), s, HW, P, color_err, depth_err,
+               normal_err, color_index, depth_index, color_thr, depth_thr, normal_thr, check_max, gs_color, gs_depth, gs_normal, rescale,
+               counters);
+    if (!check_max) {
+        DQO_LAUNCH("error_mean_kernel", error_mean_kernel, dim3((P + 255) / 256), dim3(256), s, P, counters, gs_color, gs_depth, gs_normal);
+    }
+    return DQO_OK;
+}

@@ -200,6 +200,16 @@ int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const float* 
                          float depth_weight, float add_depth_thres, float* loss_out, float* dL_dcolor, float* dL_ddepth,
                          void* workspace, size_t workspace_bytes, void* hipStream);
 
+/* dqo_accumulate_gaussian_error <- cuda_utils._C.accumulate_gaussian_error (submodules/cuda_utils/ext.cpp, cuda_utils.cu:17-62,
+ * map_process.cu:33-245; caller SLAM/multiprocess/mapper.py:1034-1047).  Maps are [H*W]; outputs [P] are fully written
+ * (zero-initialised inside).  check_max != 0: per-Gaussian maximum of the errors (the mode DQO-MAP uses); 0: mean, which needs
+ * `counters` (int32 [2*P] scratch).  rescale_counter counts pixels whose error exceeds the thresholds. */
+int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const float* screen_color_error, const float* screen_depth_error,
+                                  const float* screen_normal_error, const int32_t* screen_color_index,
+                                  const int32_t* screen_depth_index, float color_threshold, float depth_threshold,
+                                  float normal_threshold, int32_t check_max, float* gs_color_error, float* gs_depth_error,
+                                  float* gs_normal_error, float* gs_rescale_counter, int32_t* counters, void* hipStream);
+
 typedef struct DqoAdamStep {
     int32_t P, M;      /* Gaussians, SH coefficients per Gaussian (f_dc = coefficient 0, f_rest = the others) */
     int32_t step;      /* 1-based Adam step count */

@@ -51,3 +51,33 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-15):
     bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
     p = p - (lr / bc1) * (m / (np.sqrt(v) / np.sqrt(bc2) + eps))
     return p, m, v
+
+
+def accumulate_gaussian_error(H, W, P, color_err, depth_err, normal_err, color_index, depth_index, color_thr, depth_thr, normal_thr,
+                              check_max=True):
+    """/root/reference/submodules/cuda_utils/map_process.cu:33-110 (+ :146-172 mean) restated with numpy scatter ops.
+    PARITY STATUS: unpinned by reference tests (CUDA source, no fixtures); max / count results are exact integer-like
+    operations (order-independent), the mean mode is compared with a tolerance."""
+    f = np.float32
+    ce, de, ne = (np.asarray(a, f).reshape(-1)[:H * W] for a in (color_err, depth_err, normal_err))
+    ci, di = (np.asarray(a, np.int64).reshape(-1)[:H * W] for a in (color_index, depth_index))
+    gc, gd, gn, rs = (np.zeros(P, f) for _ in range(4))
+    cm, dm = (ci >= 0) & (ci < P), (di >= 0) & (di < P)
+    if check_max:
+        # float atomicMax against a 0 initial value: NaN never wins (val > old is false)
+        np.maximum.at(gc, ci[cm & ~np.isnan(ce)], ce[cm & ~np.isnan(ce)])
+        np.maximum.at(gd, di[dm & ~np.isnan(de)], de[dm & ~np.isnan(de)])
+        np.maximum.at(gn, di[dm & ~np.isnan(ne)], ne[dm & ~np.isnan(ne)])
+    else:
+        s = [np.zeros(P, np.float64) for _ in range(3)]
+        np.add.at(s[0], ci[cm], ce[cm])
+        np.add.at(s[1], di[dm], de[dm])
+        np.add.at(s[2], di[dm], ne[dm])
+        cc, dc = np.bincount(ci[cm], minlength=P), np.bincount(di[dm], minlength=P)
+        gc = np.where(cc > 0, s[0] / np.maximum(cc, 1), s[0]).astype(f)
+        gd = np.where(dc > 0, s[1] / np.maximum(dc, 1), s[1]).astype(f)
+        gn = np.where(dc > 0, s[2] / np.maximum(dc, 1), s[2]).astype(f)
+    np.add.at(rs, ci[cm & (ce > color_thr)], 1)
+    np.add.at(rs, di[dm & (de > depth_thr)], 1)
+    np.add.at(rs, di[dm & (ne > normal_thr)], 1)
+    return gc.reshape(P, 1), gd.reshape(P, 1), gn.reshape(P, 1), rs.reshape(P, 1)

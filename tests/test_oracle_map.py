@@ -64,3 +64,20 @@ def test_activation_jacobians_and_adam_match_torch():
         opt.step()
         pn, m, v = mo.adam_step(pn, gr, m, v, 0.004, step)
         np.testing.assert_allclose(pn, p.detach().numpy(), rtol=1e-12, atol=1e-15)
+
+
+def test_accumulate_error_oracle_small_hand_case():
+    """map_process.cu:33-110 on a 2x3 image worked by hand."""
+    ce = np.array([[0.5, 0.1, -1.0], [0.3, 0.9, 0.2]], np.float32)
+    de = np.array([[0.05, 0.2, 0.0], [0.15, 0.01, 0.3]], np.float32)
+    ne = np.zeros((2, 3), np.float32)
+    ci = np.array([[0, 0, 1], [-1, 2, 2]], np.int32)
+    di = np.array([[1, 1, 1], [5, 0, -1]], np.int32)  # 5 is out of range for P = 3
+    gc, gd, gn, rs = mo.accumulate_gaussian_error(2, 3, 3, ce, de, ne, ci, di, 0.25, 0.1, 0.3, True)
+    np.testing.assert_allclose(gc[:, 0], [0.5, 0.0, 0.9])   # Gaussian 1 only saw a negative error: stays at the 0 init
+    np.testing.assert_allclose(gd[:, 0], [0.01, 0.2, 0.0])
+    np.testing.assert_allclose(rs[:, 0], [1 + 0, 0 + 1, 1])  # colour > .25: g0 (0.5), g2 (0.9); depth > .1: g1 (0.2)
+    gc, gd, gn, rs2 = mo.accumulate_gaussian_error(2, 3, 3, ce, de, ne, ci, di, 0.25, 0.1, 0.3, False)
+    np.testing.assert_allclose(gc[:, 0], [0.3, -1.0, 0.55], rtol=1e-6)
+    np.testing.assert_allclose(gd[:, 0], [0.01, (0.05 + 0.2 + 0.0) / 3, 0.0], rtol=1e-6)
+    np.testing.assert_array_equal(rs, rs2)
