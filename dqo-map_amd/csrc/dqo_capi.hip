@@ -112,7 +112,7 @@ DQO_API size_t dqo_rast_geom_bytes(int32_t P, int32_t W, int32_t H) {
 }
 DQO_API size_t dqo_rast_image_bytes(int32_t W, int32_t H) { return dqo_image_layout(nullptr, W, H).total; }
 DQO_API size_t dqo_rast_binning_bytes(int64_t cap) { return dqo_bin_layout(nullptr, cap < 0 ? 0 : cap).total; }
-DQO_API size_t dqo_rast_backward_workspace_bytes(int64_t cap) { return sizeof(DqoGradRec) * (size_t)(cap < 0 ? 0 : cap) + 256; }
+DQO_API size_t dqo_rast_backward_workspace_bytes(int64_t cap) { return dqo_bwd_ws_bytes(cap); }
 
 static int check_common(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx) {
     DQO_CHECK_ARG(p && in && ctx, "null params / inputs / ctx");

@@ -89,7 +89,8 @@ struct DqoImageLayout {
     uint32_t* tile_flag;    // [T] 1 = some Gaussian's reference rect covers the tile but all such instances were culled as dead
     uint32_t* tile_cursor;  // [T] emit cursor
     uint2* ranges;          // [T] [start, end) into the sorted list (rasterizer_impl.cu:120-142)
-    uint32_t* tile_walk;    // [T] entries the backward must walk = max over pixels of max(n_contrib, hit position)
+    uint32_t* walk4;        // [4T] per (tile, 8x8 quadrant): entries the backward must walk = max over the quadrant's pixels of
+                            //      max(n_contrib, hit position)
     uint32_t* tile_order;   // [T] tile ids, active tiles first (row-major), rasterizer_impl.cu:353-365
     float* final_T;         // [HW] end_T  (forward.cu:849)
     uint32_t* n_contrib;    // [HW] last contributor, 1-based (forward.cu:850)
@@ -111,7 +112,7 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
     L.tile_flag = (uint32_t*)take(4 * T);  // directly after tile_count: both are zeroed by one memset
     L.tile_cursor = (uint32_t*)take(4 * T);
     L.ranges = (uint2*)take(8 * T);
-    L.tile_walk = (uint32_t*)take(4 * T);
+    L.walk4 = (uint32_t*)take(16 * T);
     L.tile_order = (uint32_t*)take(4 * T);
     L.final_T = (float*)take(4 * HW);
     L.n_contrib = (uint32_t*)take(4 * HW);
@@ -126,7 +127,7 @@ struct DqoBinLayout {
     uint32_t* slots;      // [cap] unsorted gaussian-major slot of the instance
     uint32_t* point_list; // [cap] sorted gaussian ids   (binningState.point_list)
     uint32_t* slot_list;  // [cap] sorted slots (where the backward stores this instance's gradient record)
-    uint8_t* live;        // [cap] per sorted instance: 4-bit mask of the tile quadrants in which the forward acted on it
+    uint8_t* live_q;      // [4][cap] per (tile quadrant, sorted instance): 1 iff the forward acted on the instance in that quadrant
     size_t total;
 };
 
@@ -142,7 +143,7 @@ static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap) {
     L.slots = (uint32_t*)take(4 * (size_t)cap);
     L.point_list = (uint32_t*)take(4 * (size_t)cap);
     L.slot_list = (uint32_t*)take(4 * (size_t)cap);
-    L.live = (uint8_t*)take((size_t)cap);
+    L.live_q = (uint8_t*)take(4 * (size_t)cap);
     L.total = (size_t)(p - (char*)base);
     return L;
 }
@@ -158,6 +159,11 @@ struct __attribute__((aligned(16))) DqoGradRec {
     float drot[4];     // depth-hit gradient (backward.cu:1053-1056)
 };
 static_assert(sizeof(DqoGradRec) == 64, "record must be one 64-byte line");
+
+// backward workspace: [cap][4] partial records, one per (instance slot, tile quadrant), then [cap] validity words (byte q of
+// word `slot` = 1 iff partial record (slot, q) was written by this backward pass; zeroed by dqo_launch_backward).
+static inline size_t dqo_bwd_recs_bytes(int64_t cap) { return dqo_align_up(sizeof(DqoGradRec) * 4 * (size_t)(cap < 0 ? 0 : cap), 256); }
+static inline size_t dqo_bwd_ws_bytes(int64_t cap) { return dqo_bwd_recs_bytes(cap) + dqo_align_up(4 * (size_t)(cap < 0 ? 0 : cap), 256) + 256; }
 
 // Per-view constants.  Scalars travel by value (kernarg -> SGPRs); the matrices stay device pointers because the
 // reference API hands them over as device tensors (no host read, no sync) — kernels fetch them with scalar loads.

@@ -8,10 +8,11 @@
 // MI355X design: the reference issues ~10 scattered global float atomics per (pixel, Gaussian) pair plus 3-7 per hit
 // pixel.  On gfx950 global float atomics execute memory-side and a wave instruction whose 64 lanes hit 64 different rows
 // runs ~17x below the streaming rate (MI355X_MICROARCH.md, Global float atomics), so none are used here:
-//   * one wave64 owns a whole 16x16 tile (4 pixels per lane); every lane looks at the same list entry in the same
-//     trip, so the per-entry gradient is a register sum over the lane's 4 pixels followed by one DPP wave reduction;
-//   * the wave stores ONE 64-byte record per (tile, Gaussian) instance at the instance's gaussian-major slot;
-//   * gaussian_backward_kernel sums each Gaussian's contiguous records in a fixed order (bitwise reproducible) and
+//   * one wave64 owns one 8x8 quadrant of a 16x16 tile (1 pixel per lane); every lane looks at the same list entry in
+//     the same trip, so the per-entry gradient is one DPP/bpermute wave reduction (rast_backward_blend.hip);
+//   * the wave stores ONE 64-byte partial record per live (quadrant, instance) pair at the instance's gaussian-major
+//     slot (4 partial records per slot + a validity word);
+//   * gaussian_backward_kernel sums each Gaussian's valid partial records in a fixed order (bitwise reproducible) and
 //     finishes the chain rule (cov2D, projection, SH, cov3D) in the same pass.
 #include "dqo_common.h"
 #include "dqo_cull.h"
@@ -32,44 +33,81 @@ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
 __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v, DqoGeomLayout g,
                                                                 const float* __restrict__ means3D, const float* __restrict__ scales,
                                                                 const float* __restrict__ rotations, const float* __restrict__ shs,
-                                                                const DqoGradRec* __restrict__ recs, int64_t capacity,
+                                                                const DqoGradRec* __restrict__ recs,
+                                                                const uint32_t* __restrict__ valid, int64_t capacity,
                                                                 DqoRastGrads gr) {
-    // ---- fixed-order sum of every Gaussian's instance records, staged through LDS ----
-    // The slots of the 256 consecutive Gaussians of a block are one contiguous, idx-ordered range (rast_binning.hip hands out
-    // slots per 1024-chunk in index order), so the block streams that range with coalesced 16-byte loads and each thread
-    // picks its own records out of LDS: no per-thread serial gather chain through HBM, no wave waiting for its largest splat.
-    constexpr int GB_CHUNK = 256;
-    __shared__ float4 s_rec[GB_CHUNK * 4];
-    __shared__ uint32_t s_lohi[2];
+    // ---- fixed-order sum of every Gaussian's partial records, staged through LDS, one wave64 on its own ----
+    // Every instance slot owns four partial records (one per tile quadrant, written by blend_backward_kernel only for the
+    // quadrants in which the instance was live); the slot's validity word says which of them exist.  The slots of the 64
+    // consecutive Gaussians of a wave are one contiguous, idx-ordered range (rast_binning.hip hands out slots in index
+    // order), so the wave walks that range 64 slots at a time: it compacts the valid partial records into a list (wave
+    // prefix sum of the per-slot counts), gathers them with coalesced 16-byte loads (4 lanes per 64-byte record) into its
+    // private LDS region, and every lane adds its own Gaussian's records, which are contiguous in the compacted order.
+    // No per-lane serial gather chain through HBM, no block barrier.
+    constexpr int GB_SLOTS = 64;    // slots per trip = one per lane
+    constexpr int GB_BATCH = 128;   // partial records staged at once (8 KB per wave)
+    __shared__ float4 s_rec_all[4][GB_BATCH * 4];
+    __shared__ uint32_t s_list_all[4][GB_SLOTS * 4];
+    __shared__ uint32_t s_off_all[4][GB_SLOTS + 1];
     const int tid = threadIdx.x;
-    const int idx0 = blockIdx.x * blockDim.x;
-    const int idx = idx0 + tid;
+    const int wave = tid >> 6, lane = tid & 63;
+    float4* const s_rec = s_rec_all[wave];
+    uint32_t* const s_list = s_list_all[wave];
+    uint32_t* const s_off = s_off_all[wave];
+    const int idx = blockIdx.x * blockDim.x + tid;
     const bool in_range = idx < v.P;
     uint32_t base = 0, cnt = 0;
     if (in_range) base = g.slot_base[idx], cnt = g.tiles_touched[idx];
-    if (tid == 0) s_lohi[0] = base;
-    if (idx == min(v.P - 1, idx0 + (int)blockDim.x - 1)) s_lohi[1] = base + cnt;
-    __syncthreads();
     float a[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) a[i] = 0.f;
     {
-        const uint32_t lo = s_lohi[0];
-        const uint32_t hi = (uint32_t)min((int64_t)s_lohi[1], capacity);  // an overflowed (invalid) forward must not read out of bounds
+        uint32_t lo = cnt ? base : 0xffffffffu, hi = cnt ? base + cnt : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+        }
+        hi = (uint32_t)min((int64_t)hi, capacity);  // an overflowed (invalid) forward must not read out of bounds
         const float4* r4 = reinterpret_cast<const float4*>(recs);
-        for (uint32_t c0 = lo; c0 < hi; c0 += GB_CHUNK) {
-            const uint32_t nrec = min((uint32_t)GB_CHUNK, hi - c0);
-            for (uint32_t e = tid; e < nrec * 4; e += blockDim.x) s_rec[e] = r4[(size_t)c0 * 4 + e];
-            __syncthreads();
-            const uint32_t k0 = max(base, c0), k1 = min(base + cnt, c0 + nrec);
-            for (uint32_t k = k0; k < k1; k++) {
-                const float4 r0 = s_rec[(k - c0) * 4], r1 = s_rec[(k - c0) * 4 + 1], r2 = s_rec[(k - c0) * 4 + 2], r3 = s_rec[(k - c0) * 4 + 3];
-                a[0] += r0.x, a[1] += r0.y, a[2] += r0.z, a[3] += r0.w;
-                a[4] += r1.x, a[5] += r1.y, a[6] += r1.z, a[7] += r1.w;
-                a[8] += r2.x, a[9] += r2.y, a[10] += r2.z, a[11] += r2.w;
-                a[12] += r3.x, a[13] += r3.y, a[14] += r3.z, a[15] += r3.w;
+        for (uint32_t c0 = lo; c0 < hi; c0 += GB_SLOTS) {
+            const uint32_t slot = c0 + lane;
+            const uint32_t vw = slot < hi ? valid[slot] : 0u;
+            const uint32_t m = ((vw & 0xffu) ? 1u : 0u) | ((vw & 0xff00u) ? 2u : 0u) | ((vw & 0xff0000u) ? 4u : 0u) | ((vw & 0xff000000u) ? 8u : 0u);
+            const uint32_t pc = __popc(m);
+            uint32_t incl = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= off) incl += o;
             }
-            __syncthreads();
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+            uint32_t w = incl - pc;
+            s_off[lane] = w;
+            if (lane == 63) s_off[GB_SLOTS] = total;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++)
+                if (m & (1u << q)) s_list[w++] = slot * 4u + q;
+            __builtin_amdgcn_wave_barrier();
+            // this lane's Gaussian owns compacted positions [p0, p1) of this trip
+            const uint32_t k0 = max(base, c0), k1 = min(base + cnt, min(c0 + (uint32_t)GB_SLOTS, hi));
+            uint32_t p0 = 0, p1 = 0;
+            if (k0 < k1) p0 = s_off[k0 - c0], p1 = s_off[k1 - c0];
+            for (uint32_t b0 = 0; b0 < total; b0 += GB_BATCH) {
+                const uint32_t nb = min((uint32_t)GB_BATCH, total - b0);
+                for (uint32_t e = lane; e < nb * 4; e += 64) s_rec[e] = r4[(size_t)s_list[b0 + (e >> 2)] * 4 + (e & 3u)];
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t j0 = max(p0, b0), j1 = min(p1, b0 + nb);
+                for (uint32_t j = j0; j < j1; j++) {
+                    const float4* p = &s_rec[(j - b0) * 4];
+                    const float4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+                    a[0] += r0.x, a[1] += r0.y, a[2] += r0.z, a[3] += r0.w;
+                    a[4] += r1.x, a[5] += r1.y, a[6] += r1.z, a[7] += r1.w;
+                    a[8] += r2.x, a[9] += r2.y, a[10] += r2.z, a[11] += r2.w;
+                    a[12] += r3.x, a[13] += r3.y, a[14] += r3.z, a[15] += r3.w;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     if (!in_range) return;
@@ -316,7 +354,7 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, int64_t capacity, hipStream_t s);
+                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, hipStream_t s);
 
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                         const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* gr, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -328,10 +366,13 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity);
     const int T = v.gx * v.gy;
+    const int64_t cap = (int64_t)ctx->inst_capacity;
     DqoGradRec* recs = (DqoGradRec*)ws;
-    int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, (int64_t)ctx->inst_capacity, s);
+    uint8_t* valid = (uint8_t*)ws + dqo_bwd_recs_bytes(cap);
+    if (cap > 0) DQO_CHECK_HIP(hipMemsetAsync(valid, 0, 4 * (size_t)cap, s));
+    int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap, s);
     if (rc) return rc;
-    DQO_LAUNCH("gaussian_backward_kernel", gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), s, v, g, in->means3D, in->scales, in->rotations,
-                       in->shs, recs, (int64_t)ctx->inst_capacity, *gr);
+    DQO_LAUNCH("gaussian_backward_kernel", gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), s, v, g, in->means3D, in->scales,
+               in->rotations, in->shs, recs, reinterpret_cast<const uint32_t*>(valid), cap, *gr);
     return DQO_OK;
 }

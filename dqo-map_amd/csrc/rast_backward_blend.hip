@@ -1,14 +1,17 @@
 // Backward blend kernel (K7) for gfx950 — replaces /root/reference/submodules/diff-gaussian-rasterizer-depth/
 // cuda_rasterizer/backward.cu:808-1066 (renderCUDA_flat) and :100-148 (propagateRotationGrad).
 //
-// Structure: one 16x16 tile per 256-thread block = four wave64, each wave owns one 8x8 pixel quadrant (1 pixel per lane).
-// The tile's list is walked back to front in batches of 128 entries staged in LDS as 16-byte records together with a 4-bit
-// quadrant mask (dqo_cull.h): a wave skips — wave-uniformly, for the price of one LDS read — every entry that cannot reach
-// its quadrant, and every entry behind the last position any of its 64 pixels needs.  For the entries it does process, each
-// lane evaluates its pixel, the nine colour-path sums (and the seven depth-hit sums when a lane's depth was fixed by this
-// entry) are reduced across the wave with DPP, and lane 0 parks them in the wave's own LDS slot.  After the batch the four
-// slots of every entry are added in a fixed order and stored as ONE 64-byte record at the instance's gaussian-major slot.
-// No global float atomics (the reference: ~10 per (pixel, Gaussian) pair + 3-7 per hit pixel), bitwise reproducible.
+// Structure: ONE wave64 per (tile, 8x8 quadrant) — four single-wave workgroups per 16x16 tile, no __syncthreads, no global
+// float atomics (the reference: ~10 per (pixel, Gaussian) pair + 3-7 per hit pixel).  The wave walks its tile's list back to
+// front in chunks of 64 positions but only over the entries the forward marked live for this quadrant (live bytes = exactly
+// the (pixel, entry) pairs the reference's backward has work for): the live ones of a chunk are compacted with one ballot,
+// their 16-byte records gathered into wave-private LDS, and processed with the next entry prefetched from LDS; the next
+// chunk's live bytes are loaded while the current chunk is processed.  Per live entry every lane evaluates its pixel with
+// predicated (branch-free) arithmetic; the eight colour-path sums go through a reduce-scatter butterfly (DPP quad_perm /
+// row_shl|shr / row_ror + two ds_bpermute), the ninth through a plain DPP reduction, the seven depth-hit sums through a
+// second butterfly when some pixel's depth was fixed by this entry; lanes 0..15 then store the 64-byte partial record of
+// this (quadrant, instance) pair at recs[slot * 4 + quadrant] and lane 16 marks it valid.  gaussian_backward_kernel adds a
+// Gaussian's valid partial records in a fixed order: bitwise reproducible.
 #include "dqo_common.h"
 #include "dqo_cull.h"
 
@@ -69,37 +72,35 @@ __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx
     return make_float3(rx * n, ry * n, rz * n);
 }
 
-constexpr int BWD_THREADS = 256;
-constexpr int BWD_BATCH = 128;
+constexpr int BWD_THREADS = 64;
 
 __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                      DqoBinLayout bin, const float* __restrict__ scales,
                                                                      const float* __restrict__ rotations,
                                                                      const float* __restrict__ dL_dpixels,
                                                                      const float* __restrict__ dL_ddepths,
-                                                                     DqoGradRec* __restrict__ recs, int64_t capacity) {
-    __shared__ float4 s_co[BWD_BATCH];
-    __shared__ float4 s_xy[BWD_BATCH];
-    __shared__ float4 s_rgb[BWD_BATCH];
-    __shared__ int s_id[BWD_BATCH];
-    __shared__ uint32_t s_slot[BWD_BATCH];
-    __shared__ uint32_t s_qmask[BWD_BATCH];
-    __shared__ uint8_t s_list[4][BWD_BATCH];
-    __shared__ float4 s_part[4][BWD_BATCH][4];  // [wave][entry][4 x float4] = 32 KB
-    float* const s_part_f = reinterpret_cast<float*>(&s_part[0][0][0]);
+                                                                     float* __restrict__ recs, uint8_t* __restrict__ valid,
+                                                                     int64_t capacity) {
+    __shared__ float4 s_co[BWD_THREADS];
+    __shared__ float4 s_xy[BWD_THREADS];
+    __shared__ float4 s_rgb[BWD_THREADS];
+    __shared__ int s_id[BWD_THREADS];
+    __shared__ uint32_t s_slot[BWD_THREADS];
+    __shared__ int s_pos[BWD_THREADS];
 
-    const int tile = img.tile_order[blockIdx.x];
+    const int tile = img.tile_order[blockIdx.x >> 2];
+    const int quad = blockIdx.x & 3;
     const uint2 range = img.ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n == 0) return;
-    const int L = min((int)img.tile_walk[tile], n);
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int L = min((int)img.walk4[tile * 4 + quad], n);  // list positions [0, L) matter to this quadrant
+    if (L == 0) return;
+    const int lane = threadIdx.x;
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
     const size_t HW = (size_t)v.W * v.H;
 
-    const uint32_t px = tile_x * DQO_TILE + (wave & 1) * 8 + (lane & 7);
-    const uint32_t py = tile_y * DQO_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + (lane & 7);
+    const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + (lane >> 3);
     const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
     const size_t pid = (size_t)v.W * py + px;
     const float pixfx = (float)px, pixfy = (float)py;
@@ -114,83 +115,55 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
     const float ddelx_dx = 0.5f * v.W, ddely_dy = 0.5f * v.H;
-    // entries at list positions >= wave_need are of no interest to any pixel of this wave
-    int wave_need = max(last_contrib, hit_pos);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wave_need = max(wave_need, __shfl_xor(wave_need, off));
+    const uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;
 
-    // entries [L, n) were never reached by any pixel of the tile: zero records
-    for (int e = L * 4 + tid; e < n * 4; e += BWD_THREADS) {
-        const uint32_t slot = bin.slot_list[range.x + (e >> 2)];
-        if ((int64_t)slot < capacity) reinterpret_cast<float4*>(recs + slot)[e & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
-    const int rounds = (L + BWD_BATCH - 1) / BWD_BATCH;
-    for (int b = 0; b < rounds; b++) {
-        __syncthreads();  // previous batch fully consumed (records written) before LDS is reused
-        // batch b covers list positions L-1-b*128 ... descending; thread t < 128 stages position L-1-(b*128+t)
-        if (tid < BWD_BATCH) {
-            const int pos = L - 1 - (b * BWD_BATCH + tid);
-            if (pos >= 0) {
-                const int id = (int)bin.point_list[range.x + pos];
-                const float4 co = g.conic_opacity[id];
-                const float4 xy = g.xy_depth[id];
-                s_id[tid] = id;
-                s_slot[tid] = bin.slot_list[range.x + pos];
-                s_co[tid] = co;
-                s_xy[tid] = xy;
-                s_rgb[tid] = g.rgb_smax[id];
-                // exact live mask recorded by the forward: quadrants in which some pixel blended this entry or took it
-                // as its depth hit — precisely the (pixel, entry) pairs the reference's backward does work for
-                s_qmask[tid] = (uint32_t)bin.live[range.x + pos];
-            }
-        }
+    const int chunks = (L + BWD_THREADS - 1) / BWD_THREADS;
+    // chunk c covers list positions L-1-c*64 ... descending; lane l looks at position L-1-(c*64+l): lane order == walk order
+    uint8_t lv_nx = (L - 1 - lane >= 0) ? live[L - 1 - lane] : (uint8_t)0;
+    for (int c = 0; c < chunks; c++) {
+        const int pos = L - 1 - (c * BWD_THREADS + lane);
+        const bool is_live = lv_nx != 0;
         {
-            float4* pz = &s_part[0][0][0];
-#pragma unroll
-            for (int k = 0; k < (4 * BWD_BATCH * 4) / BWD_THREADS; k++) pz[k * BWD_THREADS + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int pn = pos - BWD_THREADS;
+            lv_nx = pn >= 0 ? live[pn] : (uint8_t)0;  // next chunk's live bytes, in flight while this chunk is processed
         }
-        __syncthreads();
-        const int batch = min(BWD_BATCH, L - b * BWD_BATCH);
-        // per-wave compaction: entries of this batch that are live in this wave's quadrant (forward's live mask) and not
-        // behind everything this wave's pixels ever looked at, in walk order
-        int cnt = 0;
-#pragma unroll
-        for (int base = 0; base < BWD_BATCH; base += 64) {
-            const int jj = base + lane;
-            const bool lv = jj < batch && ((s_qmask[jj] >> wave) & 1u) && (L - 1 - (b * BWD_BATCH + jj) < wave_need);
-            const unsigned long long mm = __ballot(lv);
-            if (lv) s_list[wave][cnt + (int)__popcll(mm & ((1ull << lane) - 1ull))] = (uint8_t)jj;
-            cnt += (int)__popcll(mm);
+        const unsigned long long lm = __ballot(is_live);
+        const int cnt = (int)__popcll(lm);
+        if (cnt == 0) continue;
+        const int myk = (int)__popcll(lm & ((1ull << lane) - 1ull));
+        if (is_live) {
+            // only live entries are gathered at all
+            const int id = (int)bin.point_list[range.x + pos];
+            s_id[myk] = id;
+            s_pos[myk] = pos;
+            s_slot[myk] = bin.slot_list[range.x + pos];
+            s_co[myk] = g.conic_opacity[id];
+            s_xy[myk] = g.xy_depth[id];
+            s_rgb[myk] = g.rgb_smax[id];
         }
-        // software-pipelined walk: next entry's records are fetched from LDS while the current one is processed
-        int j_nx = cnt > 0 ? (int)s_list[wave][0] : 0;
-        float4 co_nx = s_co[j_nx], xy_nx = s_xy[j_nx], cs_nx = s_rgb[j_nx];
+        float4 co_nx = s_co[0], xy_nx = s_xy[0], cs_nx = s_rgb[0];
         for (int k = 0; k < cnt; k++) {
-            const int j = j_nx;
-            const float4 co = co_nx, xy = xy_nx, cs_cur = cs_nx;
+            const float4 co = co_nx, xy = xy_nx, cs = cs_nx;
             if (k + 1 < cnt) {
-                j_nx = (int)s_list[wave][k + 1];
-                co_nx = s_co[j_nx];
-                xy_nx = s_xy[j_nx];
-                cs_nx = s_rgb[j_nx];
+                co_nx = s_co[k + 1];
+                xy_nx = s_xy[k + 1];
+                cs_nx = s_rgb[k + 1];
             }
-            const int c = L - 1 - (b * BWD_BATCH + j);  // 0-based list position == the reference's `contributor` after its --
+            const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
             // ---- predicated per-pixel gradient terms (backward.cu:932-994); masked lanes contribute exact zeros ----
             const float dx = xy.x - pixfx, dy = xy.y - pixfy;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             const float G = dqo_gauss(power);
             const float alpha = fminf(0.99f, co.w * G);
-            const bool did_color = c < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;
-            const float4 cs = cs_cur;
+            const bool did_color = c0 < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;
             const float inv_1ma = dqo_rcp(1.f - alpha);
-            const float Tn = T * inv_1ma;                      // T / (1 - alpha)
+            const float Tn = T * inv_1ma;  // T / (1 - alpha)
             const float dchannel_dcolor = alpha * Tn;
             const float a0n = last_alpha * lc0 + (1.f - last_alpha) * acc0;
             const float a1n = last_alpha * lc1 + (1.f - last_alpha) * acc1;
             const float a2n = last_alpha * lc2 + (1.f - last_alpha) * acc2;
             float dL_dalpha = ((cs.x - a0n) * dp0 + (cs.y - a1n) * dp1 + (cs.z - a2n) * dp2) * Tn;
-            dL_dalpha += (-T_final * inv_1ma) * bgdot;         // end_T, not the running T (quirk B2)
+            dL_dalpha += (-T_final * inv_1ma) * bgdot;  // end_T, not the running T (quirk B2)
             const float sel = did_color ? 1.f : 0.f;
             const float dL_dG = sel * co.w * dL_dalpha;
             const float Gs = did_color ? G : 0.f;  // masked lanes must contribute exact zeros even if G overflowed (power > 0)
@@ -213,24 +186,19 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
             lc1 = did_color ? cs.y : lc1;
             lc2 = did_color ? cs.z : lc2;
             last_alpha = did_color ? alpha : last_alpha;
-            const bool is_hit = (hit_pos == c + 1);
-            const bool any_color = __ballot(did_color) != 0ull;
+
+            const bool is_hit = (hit_pos == c0 + 1);
             const bool any_hit = __ballot(is_hit) != 0ull;
-            if (!any_color && !any_hit) continue;
-            float* rec = &s_part_f[(wave * BWD_BATCH + j) * 16];  // this wave's private slot for entry j (zeroed per batch)
-            if (any_color) {
-                const float cv[8] = {r_c0, r_c1, r_c2, r_mx, r_my, r_ka, r_kb, r_kc};
-                const float tot = wave_reduce8(cv, lane);
-                const float top = wave_sum(r_op);
-                if (lane < 8) rec[lane] = tot;   // record floats 0..7: dcolor[3], dmean2D[2], dconic[3]
-                if (lane == 8) rec[8] = top;     // float 8: dopacity
-            }
+            const float cv[8] = {r_c0, r_c1, r_c2, r_mx, r_my, r_ka, r_kb, r_kc};
+            const float tot = wave_reduce8(cv, lane);  // lane l: wave total of cv[l & 7]   -> record floats 0..7
+            const float top = wave_sum(r_op);           //                                    -> record float 8 (dopacity)
+            float toth = 0.f;                           // lane 9 + i: total of hit value i  -> record floats 9..15
             if (any_hit) {
                 // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth)
                 float h_m0 = 0.f, h_m1 = 0.f, h_m2 = 0.f, h_q0 = 0.f, h_q1 = 0.f, h_q2 = 0.f, h_q3 = 0.f;
                 if (is_hit) {
 #pragma clang fp contract(off)
-                    const int id = s_id[j];
+                    const int id = s_id[k];
                     const float4 n_np = g.normal_c[id];
                     const float4 pc = g.point_c[id];
                     const float sx = scales[3 * id], sy = scales[3 * id + 1], sz = scales[3 * id + 2];
@@ -289,20 +257,16 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                         h_m2 = ddep * view[10];
                     }
                 }
-                const float hv[8] = {h_m0, h_m1, h_m2, h_q0, h_q1, h_q2, h_q3, 0.f};
-                const float toth = wave_reduce8(hv, lane);
-                if (lane < 7) rec[9 + lane] = toth;  // floats 9..15: dmean3D[3], drot[4]
+                // rotated by one so that lane 9 + i receives hit value i (lane l gets the total of hv[l & 7])
+                const float hv[8] = {0.f, h_m0, h_m1, h_m2, h_q0, h_q1, h_q2, h_q3};
+                toth = wave_reduce8(hv, lane);
             }
-        }
-        __syncthreads();
-        // fixed-order sum of the four quadrant partials, one 64-byte record per instance (4 lanes per record)
-        for (int e = tid; e < batch * 4; e += BWD_THREADS) {
-            const int j = e >> 2, k = e & 3;
-            const float4 a = s_part[0][j][k], b4 = s_part[1][j][k], c4 = s_part[2][j][k], d4 = s_part[3][j][k];
-            const float4 r = make_float4(((a.x + b4.x) + c4.x) + d4.x, ((a.y + b4.y) + c4.y) + d4.y, ((a.z + b4.z) + c4.z) + d4.z,
-                                         ((a.w + b4.w) + c4.w) + d4.w);
-            const uint32_t slot = s_slot[j];
-            if ((int64_t)slot < capacity) reinterpret_cast<float4*>(recs + slot)[k] = r;
+            // lanes 0..15 hold the 16 floats of the record: one 64-byte store per live (quadrant, instance) pair
+            const uint32_t slot = s_slot[k];
+            if ((int64_t)slot < capacity) {
+                if (lane < 16) recs[((size_t)slot * 4 + quad) * 16 + lane] = lane < 8 ? tot : (lane == 8 ? top : toth);
+                if (lane == 16) valid[(size_t)slot * 4 + quad] = (uint8_t)1;
+            }
         }
     }
 }
@@ -311,8 +275,8 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, int64_t capacity, hipStream_t s) {
-    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(T), dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
-               dL_dcolor, dL_ddepth, recs, capacity);
+                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, hipStream_t s) {
+    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(T * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
+               dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity);
     return DQO_OK;
 }

@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_ITEMS = 4;
+constexpr int BIN_ITEMS = 1;
 constexpr int BIN_CHUNK = BIN_THREADS * BIN_ITEMS;  // Gaussians per block
 constexpr int BIN_WINDOW = 16384;                   // candidate pairs whose live bits fit the LDS bit array at once
 

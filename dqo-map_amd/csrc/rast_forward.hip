@@ -254,7 +254,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
             const uint32_t cs = (uint32_t)min((int64_t)start, capacity), ce = (uint32_t)min((int64_t)start + c, capacity);
             img.ranges[t] = make_uint2(c ? cs : 0u, c ? ce : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
             img.tile_cursor[t] = start;
-            img.tile_walk[t] = 0;
             if (a) img.tile_order[apos] = (uint32_t)t;
         }
         __syncthreads();
@@ -404,232 +403,6 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(DqoImageLayout 
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// K6: forward blend.  One 16x16 tile per 256-thread block = 4 waves, each wave an 8x8 pixel quadrant so that whole
-// waves drop out of an entry (ballot) when the splat misses their quadrant.  Per-entry data is staged in LDS as
-// three 16-byte records and read back as broadcasts.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int BLEND_THREADS = 256;
-
-__device__ __forceinline__ float3 pixel_ray(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
-#pragma clang fp contract(off)
-    // ndc2ray, forward.cu:92-100
-    float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
-    const float n = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
-    return make_float3(rx * n, ry * n, rz * n);
-}
-
-// Ray / surfel-plane intersection of forward.cu:784-791 with its literal mixed precision: float numerator and
-// denominator, `+ 1e-8` and the division in double.
-struct HitEval {
-    float t, den, hit_z;
-};
-__device__ __forceinline__ HitEval eval_hit(const float3 ray, const float4 n_np) {
-#pragma clang fp contract(off)
-    HitEval h;
-    h.den = ray.x * n_np.x + ray.y * n_np.y + ray.z * n_np.z;
-    h.t = (float)((double)n_np.w / ((double)h.den + 1e-8));
-    h.hit_z = h.t * ray.z;
-    return h;
-}
-
-__global__ __launch_bounds__(BLEND_THREADS) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
-                                                                      DqoBinLayout bin, DqoRastOutputs out) {
-    __shared__ float4 s_co[BLEND_THREADS];
-    __shared__ float4 s_xy[BLEND_THREADS];
-    __shared__ float4 s_rgb[BLEND_THREADS];
-    __shared__ int s_id[BLEND_THREADS];
-    __shared__ int s_cnt[BLEND_THREADS];
-    __shared__ uint32_t s_qmask[BLEND_THREADS];
-    __shared__ uint8_t s_list[4][BLEND_THREADS];
-    __shared__ uint32_t s_walk;
-
-    const int tile = img.tile_order[blockIdx.x];
-    const int tile_x = tile % v.gx, tile_y = tile / v.gx;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const uint32_t px = tile_x * DQO_TILE + (wave & 1) * 8 + (lane & 7);
-    const uint32_t py = tile_y * DQO_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
-    const size_t HW = (size_t)v.W * v.H;
-    const size_t pix_id = (size_t)v.W * py + px;
-    const uint2 range = img.ranges[tile];
-    const int n = (int)(range.y - range.x);
-
-    if (n == 0) {
-        // masked or empty tile: the reference's torch::full initial values (rasterize_points.cu:79-89).  A tile that is
-        // active in the reference but whose instances were all culled as dead is rendered with an empty list instead:
-        // colour = bg, ids = -1 (forward.cu:724-725, 852-860).
-        const bool rendered = img.tile_flag[tile] != 0u;
-        if (inside) {
-            out.out_color[pix_id] = rendered ? v.bg[0] : 0.f;
-            out.out_color[HW + pix_id] = rendered ? v.bg[1] : 0.f;
-            out.out_color[2 * HW + pix_id] = rendered ? v.bg[2] : 0.f;
-            out.out_depth[pix_id] = 0.f;
-            out.out_hit_depth[pix_id] = rendered ? -1 : 0;
-            out.out_hit_color[pix_id] = rendered ? -1 : 0;
-            out.out_hit_color_weight[pix_id] = 0.f;
-            out.out_hit_depth_weight[pix_id] = 0.f;
-            out.out_T[pix_id] = 1.f;
-            img.final_T[pix_id] = 1.f;
-            img.n_contrib[pix_id] = 0;
-            img.hit_pos[pix_id] = 0;
-        }
-        return;
-    }
-
-    const float pixfx = (float)px, pixfy = (float)py;
-    const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
-    bool done = !inside;
-    float T = 1.0f, end_T = 1.0f;
-    uint32_t last_contributor = 0, hit_pos = 0;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    float depth_ = 0.f;
-    bool hit_gaussian = false;
-    int hit_id = -1, hit_color_id = -1;
-    float color_weight_max = -1.f, hit_color_weight = 0.f, hit_depth_weight = 0.f;
-
-    s_cnt[tid] = 0;
-    int flushed_upto = 0;  // index of the batch currently held in LDS
-    if (tid == 0) s_walk = 0;
-    const int rounds = (n + BLEND_THREADS - 1) / BLEND_THREADS;
-    int toDo = n;
-    for (int i = 0; i < rounds; i++, toDo -= BLEND_THREADS) {
-        // also orders the previous round's LDS reads before this round's staging writes
-        if (__syncthreads_and(done)) break;
-        // flush the previous batch: n_touched counts (forward.cu:833-835: one count per pair with T' > 0.5) and the
-        // 4-bit live mask (which quadrants had a lane this entry acted on) that lets the backward skip dead pairs
-        if (i > 0) {
-            const uint32_t wd = (uint32_t)s_cnt[tid];
-            const int prev = (i - 1) * BLEND_THREADS + tid;
-            if (prev < n) bin.live[range.x + prev] = (uint8_t)(wd >> 28);
-            if (wd & 0x0fffffffu) atomicAdd(&out.n_touched[s_id[tid]], (int)(wd & 0x0fffffffu));
-            s_cnt[tid] = 0;
-        }
-        flushed_upto = i;
-        __syncthreads();
-        const int progress = i * BLEND_THREADS + tid;
-        if (progress < n) {
-            const int id = (int)bin.point_list[range.x + progress];
-            const float4 co = g.conic_opacity[id];
-            const float4 xy = g.xy_depth[id];
-            s_id[tid] = id;
-            s_co[tid] = co;
-            s_xy[tid] = xy;
-            s_rgb[tid] = g.rgb_smax[id];
-            // which of the four 8x8 quadrants (= waves) the splat can reach at all (dqo_cull.h)
-            const float qthr = dqo_q_threshold(co.w);
-            uint32_t qm = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float x0 = (float)(tile_x * DQO_TILE + (q & 1) * 8), y0 = (float)(tile_y * DQO_TILE + (q >> 1) * 8);
-                qm |= dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, qthr, x0, y0, x0 + 7.f, y0 + 7.f) ? (1u << q) : 0u;
-            }
-            s_qmask[tid] = qm;
-        }
-        __syncthreads();
-        const int batch = min(BLEND_THREADS, toDo);
-        // per-wave compaction: the entries of this batch that can reach this wave's quadrant, in list order
-        int cnt = 0;
-#pragma unroll
-        for (int base = 0; base < BLEND_THREADS; base += 64) {
-            const int jj = base + lane;
-            const bool lv = jj < batch && ((s_qmask[jj] >> wave) & 1u);
-            const unsigned long long mm = __ballot(lv);
-            if (lv) s_list[wave][cnt + (int)__popcll(mm & ((1ull << lane) - 1ull))] = (uint8_t)jj;
-            cnt += (int)__popcll(mm);
-        }
-        // software-pipelined walk: the next entry's records are fetched from LDS while the current one is blended
-        int j = cnt > 0 ? (int)s_list[wave][0] : 0;
-        float4 xy = s_xy[j], co = s_co[j];
-        for (int k = 0; k < cnt; k++) {
-            if (__ballot(!done) == 0) break;  // whole wave finished
-            const int j_cur = j;
-            const float4 xy_cur = xy, co_cur = co;
-            if (k + 1 < cnt) {
-                j = (int)s_list[wave][k + 1];
-                xy = s_xy[j];
-                co = s_co[j];
-            }
-            // ---- predicated (branch-free) per-pixel update: nested divergent ifs cost more scalar exec-mask traffic than
-            // the arithmetic they guard; the only real branches left are wave-uniform ----
-            const uint32_t contributor = (uint32_t)(i * BLEND_THREADS + j_cur + 1);  // the reference's running counter
-            const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
-            const float power = -0.5f * (co_cur.x * dx * dx + co_cur.z * dy * dy) - co_cur.y * dx * dy;
-            const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
-            const bool valid = !done && power <= 0.0f && alpha >= 1.0f / 255.0f;  // forward.cu:763-772
-            if (__ballot(valid) == 0) continue;  // no pixel of this quadrant is touched by the entry
-            const float4 cs = s_rgb[j_cur];
-            const bool newhit = valid && !hit_gaussian && alpha >= v.opaque_thr;
-            if (__ballot(newhit)) {
-                // forward.cu:792-810: first Gaussian with alpha >= opaque_threshold fixes this pixel's depth (once per pixel)
-                if (newhit) {
-                    const int id = s_id[j_cur];
-                    const HitEval h = eval_hit(ray, g.normal_c[id]);
-                    hit_id = id;
-                    hit_pos = contributor;
-                    hit_depth_weight = alpha * T;
-                    const float angle_distance = fabsf(h.den);
-                    const float depth_distance = fabsf(h.hit_z - xy_cur.z);
-                    depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
-                    hit_gaussian = true;
-                }
-            }
-            const float test_T = T * (1.f - alpha);
-            const bool finish = valid && test_T < v.T_thr && hit_gaussian;   // forward.cu:813-817: done, T NOT updated
-            const bool blend = valid && !finish && test_T >= v.T_thr;         // forward.cu:818-840
-            const float w = blend ? alpha * T : 0.f;
-            C0 += cs.x * w;
-            C1 += cs.y * w;
-            C2 += cs.z * w;
-            const bool newmax = blend && w > color_weight_max;
-            color_weight_max = newmax ? w : color_weight_max;
-            hit_color_id = newmax ? s_id[j_cur] : hit_color_id;
-            hit_color_weight = newmax ? w : hit_color_weight;
-            last_contributor = blend ? contributor : last_contributor;
-            end_T = blend ? test_T : end_T;
-            T = (valid && !finish) ? test_T : T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
-            done = done || finish;
-            const bool contributes_half = blend && test_T > 0.5f;  // forward.cu:833-835 (B8)
-            const bool lane_live = blend || newhit;
-            // one LDS atomic per (wave, entry): low 28 bits count the T' > 0.5 pairs, bit 28+wave marks the quadrant live
-            const unsigned long long m = __ballot(contributes_half);
-            const unsigned long long lv = __ballot(lane_live);
-            if (lv && lane == 0) atomicAdd(&s_cnt[j_cur], (int)((uint32_t)__popcll(m) | (1u << (28 + wave))));
-        }
-    }
-    __syncthreads();
-    {
-        // the last batch that was staged (index flushed_upto) has not been flushed yet
-        const uint32_t wd = (uint32_t)s_cnt[tid];
-        const int prev = flushed_upto * BLEND_THREADS + tid;
-        if (prev < n) bin.live[range.x + prev] = (uint8_t)(wd >> 28);
-        if (wd & 0x0fffffffu) atomicAdd(&out.n_touched[s_id[tid]], (int)(wd & 0x0fffffffu));
-    }
-    if (inside) {
-        const float b0 = v.bg[0], b1 = v.bg[1], b2 = v.bg[2];
-        img.final_T[pix_id] = end_T;
-        img.n_contrib[pix_id] = last_contributor;
-        img.hit_pos[pix_id] = hit_pos;
-        out.out_color[pix_id] = C0 + T * b0;  // running T, not end_T (quirk B2, forward.cu:852)
-        out.out_color[HW + pix_id] = C1 + T * b1;
-        out.out_color[2 * HW + pix_id] = C2 + T * b2;
-        out.out_depth[pix_id] = depth_;
-        out.out_hit_depth[pix_id] = hit_id;
-        out.out_hit_color[pix_id] = hit_color_id;
-        out.out_hit_color_weight[pix_id] = hit_color_weight;
-        out.out_hit_depth_weight[pix_id] = hit_depth_weight;
-        out.out_T[pix_id] = end_T;
-    }
-    // entries the backward has to walk for this tile
-    uint32_t w = inside ? max(last_contributor, hit_pos) : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) w = max(w, (uint32_t)__shfl_xor((int)w, off));
-    if (lane == 0) atomicMax(&s_walk, w);
-    __syncthreads();
-    if (tid == 0) img.tile_walk[tile] = s_walk;
-}
-
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view,
                                     const float* __restrict__ proj, uint8_t* __restrict__ present) {
 #pragma clang fp contract(off)
@@ -647,6 +420,8 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 }  // namespace
 
+int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
+                             const DqoRastOutputs& out, int T, int64_t capacity, hipStream_t s);
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, hipStream_t s);
 int dqo_launch_bin_emit(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                         int64_t capacity, hipStream_t s);
@@ -682,8 +457,7 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
         if (rc) return rc;
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(T), dim3(SORT_THREADS), s, img, bin);
     }
-    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(T), dim3(BLEND_THREADS), s, v, g, img, bin, *out);
-    return DQO_OK;
+    return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, s);
 }
 
 int dqo_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s) {

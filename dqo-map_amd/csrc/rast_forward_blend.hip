@@ -1,0 +1,224 @@
+// Forward blend kernel (K6) for gfx950 — replaces /root/reference/submodules/diff-gaussian-rasterizer-depth/
+// cuda_rasterizer/forward.cu:636-866 (renderCUDA_withMask) with its helpers :54-100.
+//
+// Structure: ONE wave64 per (tile, 8x8 quadrant) — four single-wave workgroups per 16x16 tile, no __syncthreads anywhere.
+// The wave streams its tile's depth-sorted list in chunks of 64 positions (one per lane: coalesced id load + two 16-byte
+// record gathers), tests each entry's footprint against its own quadrant (dqo_cull.h), compacts the survivors into a
+// wave-private LDS buffer with one ballot, and blends them front to back with the next entry's record prefetched from LDS.
+// The next chunk's global loads are issued before the current chunk is blended, so the gather latency hides behind compute.
+// A wave stops as soon as its own 64 pixels are finished (the reference keeps a whole 256-thread block alive until its
+// last pixel is done, and so did the previous 4-wave version of this kernel, paying a block barrier per batch).
+//
+// Per (quadrant, list position) the wave records a live byte: 1 iff some pixel of the quadrant blended the entry or took it
+// as its depth hit.  Those are exactly the (pixel, entry) pairs the backward has work for; the backward walks live entries
+// only.  The per-Gaussian surfel normal / camera-space point are read from the preprocess tables (forward.cu:779-791 rebuilds
+// them from the quaternion for every (pixel, Gaussian) pair).
+#include "dqo_common.h"
+#include "dqo_cull.h"
+
+namespace {
+
+__device__ __forceinline__ float3 pixel_ray(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
+#pragma clang fp contract(off)
+    // ndc2ray, forward.cu:92-100
+    float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
+    const float n = 1.0f / sqrtf(rx * rx + ry * ry + rz * rz);
+    return make_float3(rx * n, ry * n, rz * n);
+}
+
+// Ray / surfel-plane intersection of forward.cu:784-791 with its literal mixed precision: float numerator and
+// denominator, `+ 1e-8` and the division in double.
+struct HitEval {
+    float t, den, hit_z;
+};
+__device__ __forceinline__ HitEval eval_hit(const float3 ray, const float4 n_np) {
+#pragma clang fp contract(off)
+    HitEval h;
+    h.den = ray.x * n_np.x + ray.y * n_np.y + ray.z * n_np.z;
+    h.t = (float)((double)n_np.w / ((double)h.den + 1e-8));
+    h.hit_z = h.t * ray.z;
+    return h;
+}
+
+constexpr int FWD_THREADS = 64;
+
+__global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+                                                                    DqoBinLayout bin, DqoRastOutputs out, int64_t capacity) {
+    __shared__ float4 s_co[FWD_THREADS];
+    __shared__ float4 s_xy[FWD_THREADS];
+    __shared__ float4 s_rgb[FWD_THREADS];
+    __shared__ int s_id[FWD_THREADS];
+    __shared__ int s_pos[FWD_THREADS];
+
+    const int tile = img.tile_order[blockIdx.x >> 2];
+    const int quad = blockIdx.x & 3;
+    const int tile_x = tile % v.gx, tile_y = tile / v.gx;
+    const int lane = threadIdx.x;
+    const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + (lane & 7);
+    const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + (lane >> 3);
+    const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
+    const size_t HW = (size_t)v.W * v.H;
+    const size_t pix_id = (size_t)v.W * py + px;
+    const uint2 range = img.ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    if (n == 0) {
+        // masked or empty tile: the reference's torch::full initial values (rasterize_points.cu:79-89).  A tile that is
+        // active in the reference but whose instances were all culled as dead is rendered with an empty list instead:
+        // colour = bg, ids = -1 (forward.cu:724-725, 852-860).
+        const bool rendered = img.tile_flag[tile] != 0u;
+        if (inside) {
+            out.out_color[pix_id] = rendered ? v.bg[0] : 0.f;
+            out.out_color[HW + pix_id] = rendered ? v.bg[1] : 0.f;
+            out.out_color[2 * HW + pix_id] = rendered ? v.bg[2] : 0.f;
+            out.out_depth[pix_id] = 0.f;
+            out.out_hit_depth[pix_id] = rendered ? -1 : 0;
+            out.out_hit_color[pix_id] = rendered ? -1 : 0;
+            out.out_hit_color_weight[pix_id] = 0.f;
+            out.out_hit_depth_weight[pix_id] = 0.f;
+            out.out_T[pix_id] = 1.f;
+            img.final_T[pix_id] = 1.f;
+            img.n_contrib[pix_id] = 0;
+            img.hit_pos[pix_id] = 0;
+        }
+        if (lane == 0) img.walk4[tile * 4 + quad] = 0;
+        return;
+    }
+
+    const float qx0 = (float)(tile_x * DQO_TILE + (quad & 1) * 8), qy0 = (float)(tile_y * DQO_TILE + (quad >> 1) * 8);
+    const float pixfx = (float)px, pixfy = (float)py;
+    const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
+    bool done = !inside;
+    float T = 1.0f, end_T = 1.0f;
+    uint32_t last_contributor = 0, hit_pos = 0;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    float depth_ = 0.f;
+    bool hit_gaussian = false;
+    int hit_id = -1, hit_color_id = -1;
+    float color_weight_max = -1.f, hit_color_weight = 0.f, hit_depth_weight = 0.f;
+    uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;  // this quadrant's live bytes of this tile's segment
+
+    const int chunks = (n + FWD_THREADS - 1) / FWD_THREADS;
+    // prologue: loads of chunk 0
+    int id_nx = 0;
+    float4 co_nx = make_float4(0.f, 0.f, 0.f, 0.f), xy_nx = co_nx;
+    if (lane < n) {
+        id_nx = (int)bin.point_list[range.x + lane];
+        co_nx = g.conic_opacity[id_nx];
+        xy_nx = g.xy_depth[id_nx];
+    }
+    for (int c = 0; c < chunks; c++) {
+        if (__ballot(!done) == 0) break;  // this quadrant is finished: entries further back are never looked at
+        const int pos = c * FWD_THREADS + lane;
+        const int id = id_nx;
+        const float4 co = co_nx, xy = xy_nx;
+        // issue the next chunk's loads now; they complete while this chunk is blended
+        {
+            const int pn = pos + FWD_THREADS;
+            if (pn < n) {
+                id_nx = (int)bin.point_list[range.x + pn];
+                co_nx = g.conic_opacity[id_nx];
+                xy_nx = g.xy_depth[id_nx];
+            }
+        }
+        // which entries of this chunk can reach this quadrant at all (conservative, dqo_cull.h); compact them into LDS
+        const bool reach = pos < n && dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, dqo_q_threshold(co.w), qx0, qy0, qx0 + 7.f, qy0 + 7.f);
+        const unsigned long long rm = __ballot(reach);
+        const int cnt = (int)__popcll(rm);
+        const int myk = (int)__popcll(rm & ((1ull << lane) - 1ull));
+        if (reach) {
+            s_co[myk] = co;
+            s_xy[myk] = xy;
+            s_rgb[myk] = g.rgb_smax[id];
+            s_id[myk] = id;
+            s_pos[myk] = pos;
+        }
+        unsigned long long live_bits = 0ull;  // bit k: compacted entry k was blended / became a hit for some pixel
+        if (cnt > 0) {
+            float4 xy_c = s_xy[0], co_c = s_co[0];
+            for (int k = 0; k < cnt; k++) {
+                if (__ballot(!done) == 0) break;
+                const float4 xy_cur = xy_c, co_cur = co_c;
+                if (k + 1 < cnt) {
+                    xy_c = s_xy[k + 1];
+                    co_c = s_co[k + 1];
+                }
+                // ---- predicated per-pixel update (forward.cu:750-842); the only branches left are wave-uniform ----
+                const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
+                const float power = -0.5f * (co_cur.x * dx * dx + co_cur.z * dy * dy) - co_cur.y * dx * dy;
+                const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
+                const bool valid = !done && power <= 0.0f && alpha >= 1.0f / 255.0f;  // forward.cu:763-772
+                if (__ballot(valid) == 0) continue;
+                const uint32_t contributor = (uint32_t)(s_pos[k] + 1);  // the reference's running counter = list position + 1
+                const float4 cs = s_rgb[k];
+                const int gid = s_id[k];
+                const bool newhit = valid && !hit_gaussian && alpha >= v.opaque_thr;
+                if (__ballot(newhit)) {
+                    // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
+                    if (newhit) {
+                        const HitEval h = eval_hit(ray, g.normal_c[gid]);
+                        hit_id = gid;
+                        hit_pos = contributor;
+                        hit_depth_weight = alpha * T;
+                        const float angle_distance = fabsf(h.den);
+                        const float depth_distance = fabsf(h.hit_z - xy_cur.z);
+                        depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
+                        hit_gaussian = true;
+                    }
+                }
+                const float test_T = T * (1.f - alpha);
+                const bool finish = valid && test_T < v.T_thr && hit_gaussian;  // forward.cu:813-817: done, T NOT updated
+                const bool blend = valid && !finish && test_T >= v.T_thr;        // forward.cu:818-840
+                const float w = blend ? alpha * T : 0.f;
+                C0 += cs.x * w;
+                C1 += cs.y * w;
+                C2 += cs.z * w;
+                const bool newmax = blend && w > color_weight_max;
+                color_weight_max = newmax ? w : color_weight_max;
+                hit_color_id = newmax ? gid : hit_color_id;
+                hit_color_weight = newmax ? w : hit_color_weight;
+                last_contributor = blend ? contributor : last_contributor;
+                end_T = blend ? test_T : end_T;
+                T = (valid && !finish) ? test_T : T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
+                done = done || finish;
+                const unsigned long long lv = __ballot(blend || newhit);
+                if (lv) {
+                    live_bits |= 1ull << k;
+                    // forward.cu:833-835 (B8): one count per (pixel, Gaussian) pair with T' > 0.5
+                    const int half = (int)__popcll(__ballot(blend && test_T > 0.5f));
+                    if (half && lane == 0) atomicAdd(&out.n_touched[gid], half);
+                }
+            }
+        }
+        // live byte of every list position of this chunk (coalesced 64-byte store)
+        if (pos < n) live[pos] = (reach && ((live_bits >> myk) & 1ull)) ? (uint8_t)1 : (uint8_t)0;
+    }
+    if (inside) {
+        const float b0 = v.bg[0], b1 = v.bg[1], b2 = v.bg[2];
+        img.final_T[pix_id] = end_T;
+        img.n_contrib[pix_id] = last_contributor;
+        img.hit_pos[pix_id] = hit_pos;
+        out.out_color[pix_id] = C0 + T * b0;  // running T, not end_T (quirk B2, forward.cu:852)
+        out.out_color[HW + pix_id] = C1 + T * b1;
+        out.out_color[2 * HW + pix_id] = C2 + T * b2;
+        out.out_depth[pix_id] = depth_;
+        out.out_hit_depth[pix_id] = hit_id;
+        out.out_hit_color[pix_id] = hit_color_id;
+        out.out_hit_color_weight[pix_id] = hit_color_weight;
+        out.out_hit_depth_weight[pix_id] = hit_depth_weight;
+        out.out_T[pix_id] = end_T;
+    }
+    // list positions the backward has to walk for this quadrant
+    int w = inside ? (int)max(last_contributor, hit_pos) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w = max(w, __shfl_xor(w, off));
+    if (lane == 0) img.walk4[tile * 4 + quad] = (uint32_t)w;
+}
+
+}  // namespace
+
+int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
+                             const DqoRastOutputs& out, int T, int64_t capacity, hipStream_t s) {
+    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(T * 4), dim3(FWD_THREADS), s, v, g, img, bin, out, capacity);
+    return DQO_OK;
+}
