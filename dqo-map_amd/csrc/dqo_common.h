@@ -50,7 +50,7 @@ struct DqoGeomLayout {
     float4* xy_depth;        // [P] (pix.x, pix.y, depth = p_view.z, bits(radius))  forward.cu:339-341
     float4* rgb_smax;        // [P] (r, g, b, max(scale)*scale_mod)                 forward.cu:333-335, 73
     float4* normal_c;        // [P] (n_c.xyz, n_c . p_c)   surfel normal in camera space, hoisted out of the blend loop
-    float4* point_c;         // [P] (p_c.xyz, unused)      forward.cu:782-783
+    float4* point_c;         // [P] (p_c.xyz, max raw scale)   forward.cu:782-783, backward.cu:1009
     uint32_t* rect;          // [P] packed tile rect: minx | miny<<8 | maxx<<16 | maxy<<24 (tile grid <= 255x255) — else rect16
     uint2* rect16;           // [P] (minx | maxx<<16, miny | maxy<<16)
     uint32_t* tiles_touched; // [P]
@@ -94,7 +94,8 @@ struct DqoImageLayout {
     uint32_t* tile_order;   // [T] tile ids, active tiles first (row-major), rasterizer_impl.cu:353-365
     float* final_T;         // [HW] end_T  (forward.cu:849)
     uint32_t* n_contrib;    // [HW] last contributor, 1-based (forward.cu:850)
-    uint32_t* hit_pos;      // [HW] 1-based list position of the Gaussian that fixed the depth, 0 if none
+    uint32_t* hit_pos;      // [HW] bits 0..30: 1-based list position of the Gaussian that fixed the depth, 0 if none;
+                            //      bit 31: the backward's ray/plane-depth branch applies to it (backward.cu:1016)
     size_t total;
 };
 
@@ -155,8 +156,12 @@ struct __attribute__((aligned(16))) DqoGradRec {
     float dmean2D[2];  // dL/d pixel-space mean (already scaled by W/2, H/2)
     float dconic[3];   // dL/d conic (xx, xy, yy)
     float dopacity;
-    float dmean3D[3];  // depth-hit gradient (backward.cu:1034-1036, 1061-1063)
-    float drot[4];     // depth-hit gradient (backward.cu:1053-1056)
+    // depth-hit sums over the pixels whose depth this instance fixed (backward.cu:997-1065); the per-Gaussian factors of
+    // that gradient (normal, camera-space point, view matrix, quaternion Jacobian) are applied once per Gaussian by
+    // gaussian_backward_kernel:  hit[0] = sum dL/ddepth over pixels in the centre-depth branch,  hit[1] = sum of
+    // u = dL/ddepth * ray.z / (n.ray) over pixels in the ray/plane branch,  hit[2..4] = sum of u * ray / (n.ray)
+    float hit[5];
+    float pad[2];
 };
 static_assert(sizeof(DqoGradRec) == 64, "record must be one 64-byte line");
 

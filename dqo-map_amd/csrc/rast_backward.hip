@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     const float dcolr[3] = {a[0], a[1], a[2]};
     const float g2x = a[3], g2y = a[4];
     const float dcx = a[5], dcy = a[6], dcz = a[7];
-    float mean_g[3] = {a[9], a[10], a[11]};
-    float rot_g[4] = {a[12], a[13], a[14], a[15]};
+    float mean_g[3] = {0.f, 0.f, 0.f};
+    float rot_g[4] = {0.f, 0.f, 0.f, 0.f};
     gr.dL_dopacity[idx] = a[8];
     dcol[0] = dcolr[0], dcol[1] = dcolr[1], dcol[2] = dcolr[2];
     dm2[0] = g2x, dm2[1] = g2y, dm2[2] = 0.f;
@@ -158,6 +158,48 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     Rm[0][0] = 1. - 2. * (y * y + z * z), Rm[0][1] = 2. * (x * y - r * z), Rm[0][2] = 2. * (x * z + r * y);
     Rm[1][0] = 2. * (x * y + r * z), Rm[1][1] = 1. - 2. * (x * x + z * z), Rm[1][2] = 2. * (y * z - r * x);
     Rm[2][0] = 2. * (x * z - r * y), Rm[2][1] = 2. * (y * z + r * x), Rm[2][2] = 1. - 2. * (x * x + y * y);
+    // ---- depth-hit gradient (backward.cu:997-1065 + propagateRotationGrad :100-148) ----
+    // The blend kernel delivered the pixel sums hit[0..4] (DqoGradRec); everything that is constant per Gaussian — surfel
+    // normal n_c, camera-space point p_c, view matrix, d(normal)/d(quaternion) — is applied here, once, in fp64:
+    //   dL/dmean3D = hit1 * V^T n_c + hit0 * V^T e_z,   dL/dn_c = p_c * hit1 - (n_c . p_c) * hit[2..4],   dL/dq = (dn_w/dq)^T V^T dL/dn_c
+    if (a[9] != 0.f || a[10] != 0.f || a[11] != 0.f || a[12] != 0.f || a[13] != 0.f) {
+        const float4 n_np = g.normal_c[idx];
+        const float4 pc = g.point_c[idx];
+        const real h0 = a[9], h1 = a[10], h2x = a[11], h2y = a[12], h2z = a[13];
+        const real nx = n_np.x, ny = n_np.y, nz = n_np.z;
+        const real np = nx * pc.x + ny * pc.y + nz * pc.z;
+        mean_g[0] = (float)(h1 * (nx * view[0] + ny * view[1] + nz * view[2]) + h0 * view[2]);
+        mean_g[1] = (float)(h1 * (nx * view[4] + ny * view[5] + nz * view[6]) + h0 * view[6]);
+        mean_g[2] = (float)(h1 * (nx * view[8] + ny * view[9] + nz * view[10]) + h0 * view[10]);
+        const real n1c = pc.x * h1 - np * h2x, n2c = pc.y * h1 - np * h2y, n3c = pc.z * h1 - np * h2z;
+        const real n1w = n1c * view[0] + n2c * view[1] + n3c * view[2];
+        const real n2w = n1c * view[4] + n2c * view[5] + n3c * view[6];
+        const real n3w = n1c * view[8] + n2c * view[9] + n3c * view[10];
+        // the surfel normal is column `axis` of R(q), axis = the smallest raw scale (forward.cu:54-74)
+        const int axis = (sx <= sy && sx <= sz) ? 0 : ((sy <= sx && sy <= sz) ? 1 : 2);
+        const real q0 = r, q1 = x, q2 = y, q3 = z;
+        real d0[3], d1[3], d2[3], d3[3];
+        if (axis == 0) {
+            d0[0] = 0, d0[1] = 2 * q3, d0[2] = -2 * q2;
+            d1[0] = 0, d1[1] = 2 * q2, d1[2] = 2 * q3;
+            d2[0] = -4 * q2, d2[1] = 2 * q1, d2[2] = -2 * q0;
+            d3[0] = -4 * q3, d3[1] = 2 * q0, d3[2] = 2 * q1;
+        } else if (axis == 1) {
+            d0[0] = -2 * q3, d0[1] = 0, d0[2] = 2 * q1;
+            d1[0] = 2 * q2, d1[1] = -4 * q1, d1[2] = 2 * q0;
+            d2[0] = 2 * q1, d2[1] = 0, d2[2] = 2 * q3;
+            d3[0] = -2 * q0, d3[1] = -4 * q3, d3[2] = 2 * q2;
+        } else {
+            d0[0] = 2 * q2, d0[1] = -2 * q1, d0[2] = 0;
+            d1[0] = 2 * q3, d1[1] = -2 * q0, d1[2] = -4 * q1;
+            d2[0] = 2 * q0, d2[1] = 2 * q3, d2[2] = -4 * q2;
+            d3[0] = 2 * q1, d3[1] = 2 * q2, d3[2] = 0;
+        }
+        rot_g[0] = (float)(n1w * d0[0] + n2w * d0[1] + n3w * d0[2]);
+        rot_g[1] = (float)(n1w * d1[0] + n2w * d1[1] + n3w * d1[2]);
+        rot_g[2] = (float)(n1w * d2[0] + n2w * d2[1] + n3w * d2[2]);
+        rot_g[3] = (float)(n1w * d3[0] + n2w * d3[1] + n3w * d3[2]);
+    }
     const real s[3] = {(real)v.scale_mod * sx, (real)v.scale_mod * sy, (real)v.scale_mod * sz};
     real Mm[3][3];
 #pragma unroll

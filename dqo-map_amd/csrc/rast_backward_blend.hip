@@ -107,13 +107,18 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     const float T_final = inside ? img.final_T[pid] : 0.f;
     float T = T_final;
     const int last_contrib = inside ? (int)img.n_contrib[pid] : 0;
-    const int hit_pos = inside ? (int)img.hit_pos[pid] : 0;
+    const uint32_t hit_word = inside ? img.hit_pos[pid] : 0u;
+    const int hit_pos = (int)(hit_word & 0x7fffffffu);
+    const bool hit_plane = (hit_word >> 31) != 0u;  // the forward decided backward.cu:1016's branch for this pixel
     const float dp0 = inside ? dL_dpixels[pid] : 0.f;
     const float dp1 = inside ? dL_dpixels[HW + pid] : 0.f;
     const float dp2 = inside ? dL_dpixels[2 * HW + pid] : 0.f;
     const float ddep = inside ? dL_ddepths[pid] : 0.f;
     const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+    const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
+    // colour blended behind the current entry (the reference's accum_rec after folding in last_alpha / last_color,
+    // backward.cu:957-962, evaluated one step earlier: same operands, same rounding)
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f;
     const float ddelx_dx = 0.5f * v.W, ddely_dy = 0.5f * v.H;
     const uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;
 
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
             const int pn = pos - BWD_THREADS;
             lv_nx = pn >= 0 ? live[pn] : (uint8_t)0;  // next chunk's live bytes, in flight while this chunk is processed
         }
-        const unsigned long long lm = __ballot(is_live);
+        const unsigned long long lm = __builtin_amdgcn_ballot_w64(is_live);
         const int cnt = (int)__popcll(lm);
         if (cnt == 0) continue;
         const int myk = (int)__popcll(lm & ((1ull << lane) - 1ull));
@@ -150,115 +155,63 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                 cs_nx = s_rgb[k + 1];
             }
             const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
-            // ---- predicated per-pixel gradient terms (backward.cu:932-994); masked lanes contribute exact zeros ----
+            // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
+            // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T and
+            // 0 * c + 1 * S = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
             const float dx = xy.x - pixfx, dy = xy.y - pixfy;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            const float G = dqo_gauss(power);
-            const float alpha = fminf(0.99f, co.w * G);
-            const bool did_color = c0 < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;
+            const float Gx = dqo_gauss(power);
+            const float alpha_x = fminf(0.99f, co.w * Gx);
+            const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f;
+            const float alpha = did_color ? alpha_x : 0.f;
+            const float G = did_color ? Gx : 0.f;
             const float inv_1ma = dqo_rcp(1.f - alpha);
-            const float Tn = T * inv_1ma;  // T / (1 - alpha)
-            const float dchannel_dcolor = alpha * Tn;
-            const float a0n = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-            const float a1n = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-            const float a2n = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-            float dL_dalpha = ((cs.x - a0n) * dp0 + (cs.y - a1n) * dp1 + (cs.z - a2n) * dp2) * Tn;
+            T = T * inv_1ma;  // T / (1 - alpha), backward.cu:948
+            float dL_dalpha = ((cs.x - S0) * dp0 + (cs.y - S1) * dp1 + (cs.z - S2) * dp2) * T;
             dL_dalpha += (-T_final * inv_1ma) * bgdot;  // end_T, not the running T (quirk B2)
-            const float sel = did_color ? 1.f : 0.f;
-            const float dL_dG = sel * co.w * dL_dalpha;
-            const float Gs = did_color ? G : 0.f;  // masked lanes must contribute exact zeros even if G overflowed (power > 0)
-            const float gdx = Gs * dx, gdy = Gs * dy;
-            const float r_c0 = sel * dchannel_dcolor * dp0;
-            const float r_c1 = sel * dchannel_dcolor * dp1;
-            const float r_c2 = sel * dchannel_dcolor * dp2;
+            const float dchannel_dcolor = alpha * T;
+            S0 = alpha * cs.x + (1.f - alpha) * S0;
+            S1 = alpha * cs.y + (1.f - alpha) * S1;
+            S2 = alpha * cs.z + (1.f - alpha) * S2;
+            const float dL_dG = co.w * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float r_c0 = dchannel_dcolor * dp0;
+            const float r_c1 = dchannel_dcolor * dp1;
+            const float r_c2 = dchannel_dcolor * dp2;
             const float r_mx = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
             const float r_my = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
             const float r_ka = -0.5f * gdx * dx * dL_dG;
             const float r_kb = -0.5f * gdx * dy * dL_dG;
             const float r_kc = -0.5f * gdy * dy * dL_dG;
-            const float r_op = sel * Gs * dL_dalpha;
-            // state update only for lanes that really blended this entry
-            T = did_color ? Tn : T;
-            acc0 = did_color ? a0n : acc0;
-            acc1 = did_color ? a1n : acc1;
-            acc2 = did_color ? a2n : acc2;
-            lc0 = did_color ? cs.x : lc0;
-            lc1 = did_color ? cs.y : lc1;
-            lc2 = did_color ? cs.z : lc2;
-            last_alpha = did_color ? alpha : last_alpha;
+            const float r_op = G * dL_dalpha;
 
             const bool is_hit = (hit_pos == c0 + 1);
-            const bool any_hit = __ballot(is_hit) != 0ull;
+            const bool any_hit = __builtin_amdgcn_ballot_w64(is_hit) != 0ull;
             const float cv[8] = {r_c0, r_c1, r_c2, r_mx, r_my, r_ka, r_kb, r_kc};
             const float tot = wave_reduce8(cv, lane);  // lane l: wave total of cv[l & 7]   -> record floats 0..7
             const float top = wave_sum(r_op);           //                                    -> record float 8 (dopacity)
-            float toth = 0.f;                           // lane 9 + i: total of hit value i  -> record floats 9..15
+            float toth = 0.f;                           // lane 9 + i: total of hit sum i    -> record floats 9..13
             if (any_hit) {
-                // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth)
-                float h_m0 = 0.f, h_m1 = 0.f, h_m2 = 0.f, h_q0 = 0.f, h_q1 = 0.f, h_q2 = 0.f, h_q3 = 0.f;
-                if (is_hit) {
+                // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth).
+                // Only the pixel-dependent factors are summed here; see DqoGradRec::hit.
+                const float4 n_np = g.normal_c[s_id[k]];
+                float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+                {
 #pragma clang fp contract(off)
-                    const int id = s_id[k];
-                    const float4 n_np = g.normal_c[id];
-                    const float4 pc = g.point_c[id];
-                    const float sx = scales[3 * id], sy = scales[3 * id + 1], sz = scales[3 * id + 2];
-                    const float4 qt = reinterpret_cast<const float4*>(rotations)[id];
-                    const float scale_max = fmaxf(fmaxf(sx, sy), sz);  // raw scales, quirk B6 (backward.cu:1009)
-                    const int axis = (sx <= sy && sx <= sz) ? 0 : ((sy <= sx && sy <= sz) ? 1 : 2);
-                    const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
                     const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
-                    // hit_point.z exactly as the forward computed it (forward.cu:784-786)
-                    const float den_f = ray.x * n_np.x + ray.y * n_np.y + ray.z * n_np.z;
-                    const float t = (float)((double)n_np.w / ((double)den_f + 1e-8));
-                    const float hit_z = t * ray.z;
-                    const float angle_distance = fabsf(nr_f);
-                    const float depth_distance = fabsf(hit_z - pc.z);
-                    const float* view = v.view;
-                    if (depth_distance <= v.depth_thr * scale_max && angle_distance >= v.normal_thr) {
-                        const float nr = (float)((double)nr_f + 1e-8);
-                        const float inv_nr = 1.f / nr, inv_nr2 = inv_nr * inv_nr;
-                        const float np = n_np.x * pc.x + n_np.y * pc.y + n_np.z * pc.z;
-                        const float dpx = ray.z * n_np.x * inv_nr, dpy = ray.z * n_np.y * inv_nr, dpz = ray.z * n_np.z * inv_nr;
-                        h_m0 = ddep * (dpx * view[0] + dpy * view[1] + dpz * view[2]);
-                        h_m1 = ddep * (dpx * view[4] + dpy * view[5] + dpz * view[6]);
-                        h_m2 = ddep * (dpx * view[8] + dpy * view[9] + dpz * view[10]);
-                        const float n1c = ray.z * (nr * pc.x - np * ray.x) * inv_nr2;
-                        const float n2c = ray.z * (nr * pc.y - np * ray.y) * inv_nr2;
-                        const float n3c = ray.z * (nr * pc.z - np * ray.z) * inv_nr2;
-                        const float n1w = n1c * view[0] + n2c * view[1] + n3c * view[2];
-                        const float n2w = n1c * view[4] + n2c * view[5] + n3c * view[6];
-                        const float n3w = n1c * view[8] + n2c * view[9] + n3c * view[10];
-                        // propagateRotationGrad, backward.cu:100-148: d(column `axis` of R(q)) / dq
-                        const float q0 = qt.x, q1 = qt.y, q2 = qt.z, q3 = qt.w;
-                        float d0[3], d1[3], d2[3], d3[3];
-                        if (axis == 0) {
-                            d0[0] = 0, d0[1] = 2 * q3, d0[2] = -2 * q2;
-                            d1[0] = 0, d1[1] = 2 * q2, d1[2] = 2 * q3;
-                            d2[0] = -4 * q2, d2[1] = 2 * q1, d2[2] = -2 * q0;
-                            d3[0] = -4 * q3, d3[1] = 2 * q0, d3[2] = 2 * q1;
-                        } else if (axis == 1) {
-                            d0[0] = -2 * q3, d0[1] = 0, d0[2] = 2 * q1;
-                            d1[0] = 2 * q2, d1[1] = -4 * q1, d1[2] = 2 * q0;
-                            d2[0] = 2 * q1, d2[1] = 0, d2[2] = 2 * q3;
-                            d3[0] = -2 * q0, d3[1] = -4 * q3, d3[2] = 2 * q2;
-                        } else {
-                            d0[0] = 2 * q2, d0[1] = -2 * q1, d0[2] = 0;
-                            d1[0] = 2 * q3, d1[1] = -2 * q0, d1[2] = -4 * q1;
-                            d2[0] = 2 * q0, d2[1] = 2 * q3, d2[2] = -4 * q2;
-                            d3[0] = 2 * q1, d3[1] = 2 * q2, d3[2] = 0;
-                        }
-                        h_q0 = ddep * (n1w * d0[0] + n2w * d0[1] + n3w * d0[2]);
-                        h_q1 = ddep * (n1w * d1[0] + n2w * d1[1] + n3w * d1[2]);
-                        h_q2 = ddep * (n1w * d2[0] + n2w * d2[1] + n3w * d2[2]);
-                        h_q3 = ddep * (n1w * d3[0] + n2w * d3[1] + n3w * d3[2]);
-                    } else {
-                        h_m0 = ddep * view[2];
-                        h_m1 = ddep * view[6];
-                        h_m2 = ddep * view[10];
-                    }
+                    const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
+                    const float inv_nr = 1.f / nr;
+                    const float u = ddep * ray.z * inv_nr;
+                    const float w = u * inv_nr;
+                    const bool plane = is_hit && hit_plane;
+                    h0 = (is_hit && !hit_plane) ? ddep : 0.f;
+                    h1 = plane ? u : 0.f;
+                    h2 = plane ? w * ray.x : 0.f;
+                    h3 = plane ? w * ray.y : 0.f;
+                    h4 = plane ? w * ray.z : 0.f;
                 }
-                // rotated by one so that lane 9 + i receives hit value i (lane l gets the total of hv[l & 7])
-                const float hv[8] = {0.f, h_m0, h_m1, h_m2, h_q0, h_q1, h_q2, h_q3};
+                // rotated by one so that lane 9 + i receives hit sum i (lane l gets the total of hv[l & 7])
+                const float hv[8] = {0.f, h0, h1, h2, h3, h4, 0.f, 0.f};
                 toth = wave_reduce8(hv, lane);
             }
             // lanes 0..15 hold the 16 floats of the record: one 64-byte store per live (quadrant, instance) pair

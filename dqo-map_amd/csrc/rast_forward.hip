@@ -202,7 +202,8 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
             g.xy_depth[idx] = make_float4(pixx, pixy, tvz, __int_as_float(ir));
             g.rgb_smax[idx] = make_float4(rgb[0], rgb[1], rgb[2], smax);
             g.normal_c[idx] = make_float4(ncx, ncy, ncz, npc);
-            g.point_c[idx] = make_float4(tvx, tvy, tvz, 0.f);
+            // .w = max of the RAW scales: the backward's depth test uses it without scale_modifier (backward.cu:1009, quirk B6)
+            g.point_c[idx] = make_float4(tvx, tvy, tvz, maxis == 0 ? sx : (maxis == 1 ? sy : sz));
             g.clamped[idx] = (uint8_t)clampbits;
         } while (false);
         radii_out[idx] = radius;

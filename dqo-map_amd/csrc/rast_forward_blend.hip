@@ -107,8 +107,8 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         co_nx = g.conic_opacity[id_nx];
         xy_nx = g.xy_depth[id_nx];
     }
-    for (int c = 0; c < chunks; c++) {
-        if (__ballot(!done) == 0) break;  // this quadrant is finished: entries further back are never looked at
+    bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;  // wave-uniform
+    for (int c = 0; c < chunks && !all_done; c++) {  // a finished quadrant never looks at the entries further back
         const int pos = c * FWD_THREADS + lane;
         const int id = id_nx;
         const float4 co = co_nx, xy = xy_nx;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         }
         // which entries of this chunk can reach this quadrant at all (conservative, dqo_cull.h); compact them into LDS
         const bool reach = pos < n && dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, dqo_q_threshold(co.w), qx0, qy0, qx0 + 7.f, qy0 + 7.f);
-        const unsigned long long rm = __ballot(reach);
+        const unsigned long long rm = __builtin_amdgcn_ballot_w64(reach);
         const int cnt = (int)__popcll(rm);
         const int myk = (int)__popcll(rm & ((1ull << lane) - 1ull));
         if (reach) {
@@ -133,11 +133,12 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
             s_id[myk] = id;
             s_pos[myk] = pos;
         }
-        unsigned long long live_bits = 0ull;  // bit k: compacted entry k was blended / became a hit for some pixel
+        // lane k keeps the per-entry results of compacted entry k: was it live for this quadrant, and how many of the
+        // quadrant's pixels saw it with T' > 0.5 (n_touched, forward.cu:833-835, quirk B8)
+        int live_k = 0, half_k = 0;
         if (cnt > 0) {
             float4 xy_c = s_xy[0], co_c = s_co[0];
-            for (int k = 0; k < cnt; k++) {
-                if (__ballot(!done) == 0) break;
+            for (int k = 0; k < cnt && !all_done; k++) {
                 const float4 xy_cur = xy_c, co_cur = co_c;
                 if (k + 1 < cnt) {
                     xy_c = s_xy[k + 1];
@@ -148,50 +149,57 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                 const float power = -0.5f * (co_cur.x * dx * dx + co_cur.z * dy * dy) - co_cur.y * dx * dy;
                 const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
                 const bool valid = !done && power <= 0.0f && alpha >= 1.0f / 255.0f;  // forward.cu:763-772
-                if (__ballot(valid) == 0) continue;
-                const uint32_t contributor = (uint32_t)(s_pos[k] + 1);  // the reference's running counter = list position + 1
-                const float4 cs = s_rgb[k];
-                const int gid = s_id[k];
-                const bool newhit = valid && !hit_gaussian && alpha >= v.opaque_thr;
-                if (__ballot(newhit)) {
-                    // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
-                    if (newhit) {
-                        const HitEval h = eval_hit(ray, g.normal_c[gid]);
-                        hit_id = gid;
-                        hit_pos = contributor;
-                        hit_depth_weight = alpha * T;
-                        const float angle_distance = fabsf(h.den);
-                        const float depth_distance = fabsf(h.hit_z - xy_cur.z);
-                        depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
-                        hit_gaussian = true;
+                if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+                    const uint32_t contributor = (uint32_t)(s_pos[k] + 1);  // the reference's running counter = list position + 1
+                    const float4 cs = s_rgb[k];
+                    const int gid = s_id[k];
+                    const bool newhit = valid && !hit_gaussian && alpha >= v.opaque_thr;
+                    if (__builtin_amdgcn_ballot_w64(newhit) != 0ull) {
+                        // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
+                        const float4 n_np = g.normal_c[gid];
+                        const float raw_smax = g.point_c[gid].w;
+                        if (newhit) {
+                            const HitEval h = eval_hit(ray, n_np);
+                            hit_id = gid;
+                            hit_depth_weight = alpha * T;
+                            const float angle_distance = fabsf(h.den);
+                            const float depth_distance = fabsf(h.hit_z - xy_cur.z);
+                            depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
+                            // the backward repeats the test with the raw scales (backward.cu:1009-1016): decide it here once
+                            const bool plane_b = depth_distance <= v.depth_thr * raw_smax && angle_distance >= v.normal_thr;
+                            hit_pos = contributor | (plane_b ? 0x80000000u : 0u);
+                            hit_gaussian = true;
+                        }
                     }
-                }
-                const float test_T = T * (1.f - alpha);
-                const bool finish = valid && test_T < v.T_thr && hit_gaussian;  // forward.cu:813-817: done, T NOT updated
-                const bool blend = valid && !finish && test_T >= v.T_thr;        // forward.cu:818-840
-                const float w = blend ? alpha * T : 0.f;
-                C0 += cs.x * w;
-                C1 += cs.y * w;
-                C2 += cs.z * w;
-                const bool newmax = blend && w > color_weight_max;
-                color_weight_max = newmax ? w : color_weight_max;
-                hit_color_id = newmax ? gid : hit_color_id;
-                hit_color_weight = newmax ? w : hit_color_weight;
-                last_contributor = blend ? contributor : last_contributor;
-                end_T = blend ? test_T : end_T;
-                T = (valid && !finish) ? test_T : T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
-                done = done || finish;
-                const unsigned long long lv = __ballot(blend || newhit);
-                if (lv) {
-                    live_bits |= 1ull << k;
-                    // forward.cu:833-835 (B8): one count per (pixel, Gaussian) pair with T' > 0.5
-                    const int half = (int)__popcll(__ballot(blend && test_T > 0.5f));
-                    if (half && lane == 0) atomicAdd(&out.n_touched[gid], half);
+                    const float test_T = T * (1.f - alpha);
+                    const bool below = test_T < v.T_thr;
+                    const bool finish = valid && below && hit_gaussian;  // forward.cu:813-817: done, T NOT updated
+                    const bool blend = valid && !below;                  // forward.cu:818-840
+                    const float w = blend ? alpha * T : 0.f;
+                    C0 += cs.x * w;
+                    C1 += cs.y * w;
+                    C2 += cs.z * w;
+                    const bool newmax = blend && w > color_weight_max;
+                    color_weight_max = newmax ? w : color_weight_max;
+                    hit_color_id = newmax ? gid : hit_color_id;
+                    hit_color_weight = newmax ? w : hit_color_weight;
+                    last_contributor = blend ? contributor : last_contributor;
+                    end_T = blend ? test_T : end_T;
+                    T = (valid && !finish) ? test_T : T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
+                    done = done || finish;
+                    const bool is_live = __builtin_amdgcn_ballot_w64(blend || newhit) != 0ull;
+                    const int half = (int)__popcll(__builtin_amdgcn_ballot_w64(blend && test_T > 0.5f));
+                    live_k = lane == k ? (is_live ? 1 : 0) : live_k;
+                    half_k = lane == k ? half : half_k;
+                    if (__builtin_amdgcn_ballot_w64(finish) != 0ull) all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
                 }
             }
         }
+        // one scattered integer atomic per touched Gaussian of this chunk
+        if (half_k > 0) atomicAdd(&out.n_touched[s_id[lane]], half_k);
         // live byte of every list position of this chunk (coalesced 64-byte store)
-        if (pos < n) live[pos] = (reach && ((live_bits >> myk) & 1ull)) ? (uint8_t)1 : (uint8_t)0;
+        const int lv = __shfl(live_k, myk);
+        if (pos < n) live[pos] = (reach && lv) ? (uint8_t)1 : (uint8_t)0;
     }
     if (inside) {
         const float b0 = v.bg[0], b1 = v.bg[1], b2 = v.bg[2];
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         out.out_T[pix_id] = end_T;
     }
     // list positions the backward has to walk for this quadrant
-    int w = inside ? (int)max(last_contributor, hit_pos) : 0;
+    int w = inside ? (int)max(last_contributor, hit_pos & 0x7fffffffu) : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) w = max(w, __shfl_xor(w, off));
     if (lane == 0) img.walk4[tile * 4 + quad] = (uint32_t)w;
