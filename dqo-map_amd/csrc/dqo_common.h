@@ -7,6 +7,11 @@
 
 #define DQO_TILE 16  // reference BLOCK_X = BLOCK_Y = 16 (cuda_rasterizer/config.h:15-16); part of the op's semantics
 #define DQO_WAVE 64
+// The per-tile atomic counters (histogram, emit cursors) are spread one per DQO_TSTRIDE words: device-scope atomics execute
+// memory-side on MI355X, and counters sharing a line / channel serialise there.
+#ifndef DQO_TSTRIDE
+#define DQO_TSTRIDE 64
+#endif
 
 // ---- error plumbing -------------------------------------------------------------------------------------------
 void dqo_set_error(const char* fmt, ...);
@@ -109,9 +114,9 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
         p += dqo_align_up(bytes, 256);
         return r;
     };
-    L.tile_count = (uint32_t*)take(4 * T);
+    L.tile_count = (uint32_t*)take(4 * T * DQO_TSTRIDE);
     L.tile_flag = (uint32_t*)take(4 * T);  // directly after tile_count: both are zeroed by one memset
-    L.tile_cursor = (uint32_t*)take(4 * T);
+    L.tile_cursor = (uint32_t*)take(4 * T * DQO_TSTRIDE);
     L.ranges = (uint2*)take(8 * T);
     L.walk4 = (uint32_t*)take(16 * T);
     L.tile_order = (uint32_t*)take(4 * T);

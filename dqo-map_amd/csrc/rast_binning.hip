@@ -122,7 +122,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(int P, int gx, const i
                                                   (float)(y * DQO_TILE + DQO_TILE - 1));
             if (live) {
                 atomicOr(&s_bits[(w - win) >> 5], 1u << ((w - win) & 31));
-                if (!EMIT) atomicAdd(&tile_count[t], 1u);
+                if (!EMIT) atomicAdd(&tile_count[(size_t)t * DQO_TSTRIDE], 1u);
             } else if (!EMIT && tile_flag[t] == 0u) {
                 // active in the reference (its list holds this dead entry): render the tile, do not leave the initial fills
                 tile_flag[t] = 1u;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(int P, int gx, const i
                 const int t = y * gx + x;
                 const uint32_t first = max(s_off[gi], win);
                 const uint32_t rank = s_prev[gi] + popcount_range(s_bits, first - win, w - win);
-                const uint32_t pos = atomicAdd(&tile_cursor[t], 1u);
+                const uint32_t pos = atomicAdd(&tile_cursor[(size_t)t * DQO_TSTRIDE], 1u);
                 if ((int64_t)pos < capacity) {
                     bin.keys[pos] = ((uint64_t)__float_as_uint(g.xy_depth[idx].z) << 32) | (uint32_t)idx;
                     bin.slots[pos] = g.slot_base[idx] + rank;

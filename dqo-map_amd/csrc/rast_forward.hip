@@ -235,7 +235,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
     uint32_t local_max = 0;
     for (int base = 0; base < T; base += SCAN_THREADS) {
         const int t = base + tid;
-        const uint32_t c = t < T ? img.tile_count[t] : 0u;
+        const uint32_t c = t < T ? img.tile_count[(size_t)t * DQO_TSTRIDE] : 0u;
         const uint32_t a = c ? 1u : 0u;
         local_max = max(local_max, c);
         uint32_t incl = c, incl_a = a;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
             // clamp to capacity so later kernels never index past the binning buffer (overflow is flagged below)
             const uint32_t cs = (uint32_t)min((int64_t)start, capacity), ce = (uint32_t)min((int64_t)start + c, capacity);
             img.ranges[t] = make_uint2(c ? cs : 0u, c ? ce : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
-            img.tile_cursor[t] = start;
+            img.tile_cursor[(size_t)t * DQO_TSTRIDE] = start;
             if (a) img.tile_order[apos] = (uint32_t)t;
         }
         __syncthreads();
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
     const uint32_t n_act = s_carry_act;
     for (int base = 0; base < T; base += SCAN_THREADS) {
         const int t = base + tid;
-        const uint32_t c = t < T ? img.tile_count[t] : 1u;
+        const uint32_t c = t < T ? img.tile_count[(size_t)t * DQO_TSTRIDE] : 1u;
         const uint32_t a = c ? 0u : 1u;
         uint32_t incl_a = a;
 #pragma unroll
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         for (int i = tid; i < LPT_BUCKETS; i += SCAN_THREADS) s_bucket[i] = 0;
         __syncthreads();
         for (int t = tid; t < T; t += SCAN_THREADS) {
-            const uint32_t c = img.tile_count[t];
+            const uint32_t c = img.tile_count[(size_t)t * DQO_TSTRIDE];
             if (c) atomicAdd(&s_bucket[LPT_BUCKETS - 1 - (c >> shift)], 1u);
         }
         __syncthreads();
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         }
         __syncthreads();
         for (int t = tid; t < T; t += SCAN_THREADS) {
-            const uint32_t c = img.tile_count[t];
+            const uint32_t c = img.tile_count[(size_t)t * DQO_TSTRIDE];
             if (c) img.tile_order[atomicAdd(&s_bucket[LPT_BUCKETS - 1 - (c >> shift)], 1u)] = (uint32_t)t;
         }
     }

@@ -95,8 +95,8 @@ def test_binning_exact(torch_cuda, oracle):
     # binning layout: keys u64[cap] | slots u32[cap] | point_list u32[cap] | slot_list u32[cap], each 256-B aligned
     off_pl = al(8 * Nn) + al(4 * Nn)
     pl = binning[off_pl:off_pl + 4 * Nn].view(torch.int32).cpu().numpy().astype(np.uint32)
-    # image layout: tile_count | tile_flag | tile_cursor | ranges ...
-    off_rg = 3 * al(4 * T)
+    # image layout: tile_count (one counter per 64 words) | tile_flag | tile_cursor (same stride) | ranges ...  (dqo_common.h)
+    off_rg = 2 * al(4 * T * 64) + al(4 * T)
     rg = img[off_rg:off_rg + 8 * T].view(torch.int32).cpu().numpy().reshape(T, 2).astype(np.uint32)
     np.testing.assert_array_equal(out[8].cpu().numpy(), r["radii"])
     # Per tile the HIP list is the oracle's (= reference's) list with the dead entries removed, in the same order:
