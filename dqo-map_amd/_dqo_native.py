@@ -41,7 +41,8 @@ class DqoRastGrads(ctypes.Structure):
 
 class DqoRastHeader(ctypes.Structure):
     _fields_ = [("num_rendered", ctypes.c_uint32), ("num_tiles", ctypes.c_uint32), ("overflow", ctypes.c_uint32),
-                ("max_tile_count", ctypes.c_uint32), ("num_visible", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 3)]
+                ("max_tile_count", ctypes.c_uint32), ("num_visible", ctypes.c_uint32), ("num_candidates", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 2)]
 
 
 class DqoProfileEntry(ctypes.Structure):

@@ -168,6 +168,7 @@ DQO_API int dqo_rast_read_header(const DqoRastCtx* ctx, DqoRastHeader* host_out,
     // after `prepare` only the counters are valid; `render` fills the header proper
     host_out->num_rendered = counters[0];
     host_out->num_visible = counters[1];
+    host_out->num_candidates = counters[3];
     return host_out->overflow ? DQO_ERR_OVERFLOW : DQO_OK;
 }
 

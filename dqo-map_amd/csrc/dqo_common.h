@@ -134,6 +134,8 @@ struct DqoBinLayout {
     uint32_t* point_list; // [cap] sorted gaussian ids   (binningState.point_list)
     uint32_t* slot_list;  // [cap] sorted slots (where the backward stores this instance's gradient record)
     uint8_t* live_q;      // [4][cap] per (tile quadrant, sorted instance): 1 iff the forward acted on the instance in that quadrant
+    uint2* slot_info;     // [cap] per gaussian-major slot: (tile, rank inside the tile's segment), bin_count -> bin_place
+    uint32_t* slot_gid;   // [cap] per gaussian-major slot: Gaussian id
     size_t total;
 };
 
@@ -150,6 +152,8 @@ static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap) {
     L.point_list = (uint32_t*)take(4 * (size_t)cap);
     L.slot_list = (uint32_t*)take(4 * (size_t)cap);
     L.live_q = (uint8_t*)take(4 * (size_t)cap);
+    L.slot_info = (uint2*)take(8 * (size_t)cap);
+    L.slot_gid = (uint32_t*)take(4 * (size_t)cap);
     L.total = (size_t)(p - (char*)base);
     return L;
 }

@@ -1,38 +1,33 @@
-// Tile binning for gfx950: per-tile instance counts and the instance emit, both as a load-balanced expansion over the
-// candidate (Gaussian, tile) pairs.  Replaces the per-Gaussian tile loops of
+// Tile binning for gfx950: which (Gaussian, tile) pairs become list entries, and where.  Replaces the per-Gaussian tile
+// loops of
 //   /root/reference/submodules/diff-gaussian-rasterizer-depth/cuda_rasterizer/forward.cu:344-353 (tiles_touched) and
-//   cuda_rasterizer/rasterizer_impl.cu:70-115 (duplicateWithKeys),
+//   cuda_rasterizer/rasterizer_impl.cu:70-115 (duplicateWithKeys) + the cub scan of :303,
 // where one thread walks its Gaussian's whole tile rect: a wave then runs as long as its largest splat and every
-// iteration waits for its own atomic.  Here a block owns a chunk of 1024 consecutive Gaussians, scans their rect areas in
-// LDS and hands out ONE candidate pair per thread-iteration (binary search in the scanned offsets), so lanes are evenly
-// loaded and all their atomics are independent and in flight together.
+// iteration waits for its own atomic.
 //
-// The live / dead decision per candidate is the output-invariant footprint test of dqo_cull.h; it is evaluated with the
-// same inputs and IEEE-only arithmetic in both kernels, so count and emit agree bit for bit.  A Gaussian's k-th live tile
-// (rect order) gets gaussian-major slot slot_base + k: fixed order => the backward's per-Gaussian sum is reproducible.
+// bin_count_kernel: a block owns 256 consecutive Gaussians, scans their rect areas in LDS and hands out ONE candidate
+//   (Gaussian, tile) pair per thread-iteration (binary search in the scanned offsets), so lanes are evenly loaded.  Each
+//   candidate takes the output-invariant footprint test of dqo_cull.h ONCE; the survivors are numbered per Gaussian (rect
+//   order -> gaussian-major slot = slot_base + k: a fixed order, so the backward's per-Gaussian sum is reproducible) and
+//   take their rank inside their tile from the tile histogram's atomic counter.  (tile, rank, Gaussian) goes into the
+//   slot-indexed info table.
+// tile_scan_kernel (rast_forward.hip) turns the histogram into the tiles' list ranges.
+// bin_place_kernel: one thread per slot, no atomics, no decoding: position = range start + rank; writes the sort key and
+//   the slot payload.
+//
+// Device-scope atomics execute memory-side on MI355X; the counters are spread one per 256 bytes (DQO_TSTRIDE) and every
+// thread keeps up to four of them in flight.
 #include "dqo_common.h"
 #include "dqo_cull.h"
 
 namespace {
 
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_ITEMS = 1;
-constexpr int BIN_CHUNK = BIN_THREADS * BIN_ITEMS;  // Gaussians per block
-constexpr int BIN_WINDOW = 16384;                   // candidate pairs whose live bits fit the LDS bit array at once
+constexpr int BIN_CHUNK = BIN_THREADS;  // Gaussians per block, one per thread
+constexpr int BIN_WINDOW = 16384;       // candidate pairs whose live bits fit the LDS bit array at once
+constexpr int BIN_FLIGHT = 4;           // returning atomics in flight per thread
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-struct RectD {
-    int minx, maxx, miny, maxy;
-};
-__device__ __forceinline__ RectD unpack_rect(uint2 r) {
-    RectD d;
-    d.minx = r.x & 0xffff;
-    d.maxx = r.x >> 16;
-    d.miny = r.y & 0xffff;
-    d.maxy = r.y >> 16;
-    return d;
-}
 
 // number of set bits of bits[] in the bit range [a, b)
 __device__ __forceinline__ uint32_t popcount_range(const uint32_t* bits, uint32_t a, uint32_t b) {
@@ -45,175 +40,205 @@ __device__ __forceinline__ uint32_t popcount_range(const uint32_t* bits, uint32_
     return n;
 }
 
-// EMIT = false: count pass (tile histogram, tiles_touched, slot_base, tile_flag).
-// EMIT = true : emit pass (keys + slots into the tile segments through the per-tile cursors).
-template <bool EMIT>
-__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
-                                                          uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
-                                                          uint32_t* __restrict__ tile_cursor, DqoBinLayout bin, int64_t capacity) {
+// block-wide exclusive scan of one value per thread; returns the exclusive prefix, *total = block sum.  Two barriers.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t lane, uint32_t wave, uint32_t* total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += o;
+    }
+    __syncthreads();  // s_wave free for reuse
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BIN_THREADS / 64; w++) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) wbase += t;
+        tot += t;
+    }
+    *total = tot;
+    return wbase + incl - v;
+}
+
+struct Cand {
+    int gi, tile;
+};
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
+                                                                uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
+                                                                DqoBinLayout bin, int64_t capacity) {
     __shared__ uint32_t s_off[BIN_CHUNK + 1];  // exclusive prefix of the rect areas
-    __shared__ uint32_t s_prev[BIN_CHUNK];     // live candidates of each Gaussian in earlier windows
+    __shared__ uint2 s_rect[BIN_CHUNK];        // packed tile rects
+    __shared__ float4 s_con[BIN_CHUNK];        // conic + opacity
+    __shared__ float4 s_xyq[BIN_CHUNK];        // (pix.x, pix.y, q threshold, depth bits)
+    __shared__ uint32_t s_cnt[BIN_CHUNK];      // live candidates of each Gaussian
+    __shared__ uint32_t s_prev[BIN_CHUNK];     // ... of them in earlier windows (placement sweep)
+    __shared__ uint32_t s_gb[BIN_CHUNK];       // exclusive prefix of s_cnt
     __shared__ uint32_t s_bits[BIN_WINDOW / 32];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id(), wave = tid >> 6;
     const int chunk0 = blockIdx.x * BIN_CHUNK;
+    const int my_idx = chunk0 + tid;
 
-    // ---- rect areas of this block's Gaussians, thread-major (thread t owns items 4t..4t+3), exclusive scan in LDS ----
-    uint32_t area[BIN_ITEMS], mine = 0;
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) {
-        const int idx = chunk0 + tid * BIN_ITEMS + it;
-        uint32_t a = 0;
-        if (idx < P) {
-            const RectD r = unpack_rect(g.rect16[idx]);
-            a = (uint32_t)((r.maxx - r.minx) * (r.maxy - r.miny));
-        }
-        area[it] = a;
-        mine += a;
-    }
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= (uint32_t)off) incl += o;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < wave; w++) wbase += s_wave[w];
+    // ---- this thread's Gaussian: rect area (0 = culled by K1) and the inputs of the footprint test, parked in LDS ----
+    uint32_t area = 0;
     {
-        uint32_t run = wbase + incl - mine;
-#pragma unroll
-        for (int it = 0; it < BIN_ITEMS; it++) {
-            s_off[tid * BIN_ITEMS + it] = run;
-            s_prev[tid * BIN_ITEMS + it] = 0;
-            run += area[it];
+        uint2 rc = make_uint2(0u, 0u);
+        if (my_idx < P) {
+            rc = g.rect16[my_idx];
+            area = ((rc.x >> 16) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.y & 0xffffu));
         }
-        if (tid == BIN_THREADS - 1) s_off[BIN_CHUNK] = run;
+        s_rect[tid] = rc;
+        if (area) {
+            const float4 co = g.conic_opacity[my_idx];
+            const float4 xy = g.xy_depth[my_idx];
+            s_con[tid] = co;
+            s_xyq[tid] = make_float4(xy.x, xy.y, dqo_q_threshold(co.w), 0.f);
+        }
+        s_cnt[tid] = 0;
+        s_prev[tid] = 0;
     }
+    uint32_t total;
+    const uint32_t my_off = block_exclusive_scan(area, s_wave, lane, wave, &total);
+    s_off[tid] = my_off;
+    if (tid == BIN_THREADS - 1) s_off[BIN_CHUNK] = total;
     __syncthreads();
-    const uint32_t total = s_off[BIN_CHUNK];
+    if (total == 0) {  // nothing visible in this chunk
+        if (my_idx < P) g.tiles_touched[my_idx] = 0, g.slot_base[my_idx] = 0;
+        return;
+    }
 
-    for (uint32_t win = 0; win < total; win += BIN_WINDOW) {
-        const uint32_t wend = min(total, win + (uint32_t)BIN_WINDOW);
+    // candidate w of the block -> (Gaussian, tile)
+    auto decode = [&](uint32_t w) {
+        int lo = 0, hi = BIN_CHUNK;  // largest gi with s_off[gi] <= w
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= w) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t r = w - s_off[lo];
+        const uint2 rc = s_rect[lo];
+        const uint32_t minx = rc.x & 0xffffu, rw = (rc.x >> 16) - minx, miny = rc.y & 0xffffu;
+        const uint32_t ry = r / rw, rx = r - ry * rw;
+        Cand c;
+        c.gi = lo;
+        c.tile = (int)((miny + ry) * (uint32_t)gx + minx + rx);
+        return c;
+    };
+    // footprint test of every candidate of the window [win, wend) -> s_bits (and tile_flag for the dead ones)
+    auto cull_window = [&](uint32_t win, uint32_t wend, bool flag_dead) {
         for (int i = tid; i < BIN_WINDOW / 32; i += BIN_THREADS) s_bits[i] = 0;
         __syncthreads();
-        // ---- phase B: one candidate pair per thread-iteration: decode, mask + footprint test, count ----
         for (uint32_t w = win + tid; w < wend; w += BIN_THREADS) {
-            int lo = 0, hi = BIN_CHUNK;  // largest gi with s_off[gi] <= w
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_off[mid] <= w) lo = mid;
-                else hi = mid;
-            }
-            const int gi = lo, idx = chunk0 + gi;
-            const uint32_t r = w - s_off[gi];
-            const RectD rc = unpack_rect(g.rect16[idx]);
-            const int rw = rc.maxx - rc.minx;
-            const int x = rc.minx + (int)(r % (uint32_t)rw), y = rc.miny + (int)(r / (uint32_t)rw);
-            const int t = y * gx + x;
-            if (tile_mask != nullptr && !tile_mask[t]) continue;
-            const float4 xyd = g.xy_depth[idx];
-            const float4 co = g.conic_opacity[idx];
-            const bool live = dqo_splat_hits_rect(xyd.x, xyd.y, co.x, co.y, co.z, dqo_q_threshold(co.w), (float)(x * DQO_TILE),
-                                                  (float)(y * DQO_TILE), (float)(x * DQO_TILE + DQO_TILE - 1),
-                                                  (float)(y * DQO_TILE + DQO_TILE - 1));
+            const Cand c = decode(w);
+            if (tile_mask != nullptr && !tile_mask[c.tile]) continue;
+            const float4 co = s_con[c.gi], xyq = s_xyq[c.gi];
+            const int x = c.tile % gx, y = c.tile / gx;
+            const bool live = dqo_splat_hits_rect(xyq.x, xyq.y, co.x, co.y, co.z, xyq.z, (float)(x * DQO_TILE), (float)(y * DQO_TILE),
+                                                  (float)(x * DQO_TILE + DQO_TILE - 1), (float)(y * DQO_TILE + DQO_TILE - 1));
             if (live) {
                 atomicOr(&s_bits[(w - win) >> 5], 1u << ((w - win) & 31));
-                if (!EMIT) atomicAdd(&tile_count[(size_t)t * DQO_TSTRIDE], 1u);
-            } else if (!EMIT && tile_flag[t] == 0u) {
+            } else if (flag_dead && tile_flag[c.tile] == 0u) {
                 // active in the reference (its list holds this dead entry): render the tile, do not leave the initial fills
-                tile_flag[t] = 1u;
+                tile_flag[c.tile] = 1u;
             }
         }
         __syncthreads();
-        if (EMIT) {
-            // ---- phase C: live candidates take a position in their tile segment; slot = slot_base + rank within the Gaussian ----
-            for (uint32_t w = win + tid; w < wend; w += BIN_THREADS) {
-                if (!((s_bits[(w - win) >> 5] >> ((w - win) & 31)) & 1u)) continue;
-                int lo = 0, hi = BIN_CHUNK;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_off[mid] <= w) lo = mid;
-                    else hi = mid;
-                }
-                const int gi = lo, idx = chunk0 + gi;
-                const uint32_t r = w - s_off[gi];
-                const RectD rc = unpack_rect(g.rect16[idx]);
-                const int rw = rc.maxx - rc.minx;
-                const int x = rc.minx + (int)(r % (uint32_t)rw), y = rc.miny + (int)(r / (uint32_t)rw);
-                const int t = y * gx + x;
-                const uint32_t first = max(s_off[gi], win);
-                const uint32_t rank = s_prev[gi] + popcount_range(s_bits, first - win, w - win);
-                const uint32_t pos = atomicAdd(&tile_cursor[(size_t)t * DQO_TSTRIDE], 1u);
-                if ((int64_t)pos < capacity) {
-                    bin.keys[pos] = ((uint64_t)__float_as_uint(g.xy_depth[idx].z) << 32) | (uint32_t)idx;
-                    bin.slots[pos] = g.slot_base[idx] + rank;
-                }
-            }
-        }
-        __syncthreads();  // phase C still reads s_prev
-        // ---- phase D: carry each Gaussian's live count of this window ----
-        for (int gi = tid; gi < BIN_CHUNK; gi += BIN_THREADS) {
-            const uint32_t a = max(s_off[gi], win), b = min(s_off[gi + 1], wend);
-            if (a < b) s_prev[gi] += popcount_range(s_bits, a - win, b - win);
-        }
-        __syncthreads();
-    }
-    if (EMIT) return;
+    };
+    // per-Gaussian live count of the window, added to acc[]
+    auto carry_window = [&](uint32_t win, uint32_t wend, uint32_t* acc) {
+        const uint32_t a = max(my_off, win), b = min(my_off + area, wend);
+        if (a < b) acc[tid] += popcount_range(s_bits, a - win, b - win);
+    };
 
+    // ---- sweep 1: live candidates per Gaussian ----
+    const bool one_window = total <= (uint32_t)BIN_WINDOW;
+    for (uint32_t win = 0; win < total; win += BIN_WINDOW) {
+        const uint32_t wend = min(total, win + (uint32_t)BIN_WINDOW);
+        cull_window(win, wend, true);
+        carry_window(win, wend, s_cnt);
+        if (!one_window) __syncthreads();  // s_bits is rebuilt by the next window
+    }
     // ---- tiles_touched + gaussian-major slot allocation: block scan of the live counts, one atomic per block ----
-    uint32_t cnt[BIN_ITEMS], my2 = 0;
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) {
-        cnt[it] = s_prev[tid * BIN_ITEMS + it];
-        my2 += cnt[it];
-    }
-    uint32_t inc2 = my2;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(inc2, off);
-        if (lane >= (uint32_t)off) inc2 += o;
-    }
+    const uint32_t my_cnt = s_cnt[tid];
+    uint32_t block_live;
+    const uint32_t my_gb = block_exclusive_scan(my_cnt, s_wave, lane, wave, &block_live);
+    s_gb[tid] = my_gb;
+    if (tid == 0) s_base = block_live ? atomicAdd(&g.counters[0], block_live) : 0u;
     __syncthreads();
-    if (lane == 63) s_wave[wave] = inc2;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < BIN_THREADS / 64; w++) {
-            const uint32_t t = s_wave[w];
-            s_wave[w] = tot;
-            tot += t;
+    const uint32_t base = s_base;
+    if (my_idx < P) {
+        g.tiles_touched[my_idx] = my_cnt;
+        g.slot_base[my_idx] = base + my_gb;
+    }
+    if (block_live == 0) return;
+
+    // ---- sweep 2: every live candidate takes its rank in its tile and records (tile, rank, Gaussian) at its slot ----
+    for (uint32_t win = 0; win < total; win += BIN_WINDOW) {
+        const uint32_t wend = min(total, win + (uint32_t)BIN_WINDOW);
+        if (!one_window) cull_window(win, wend, false);  // (a single window's bits are still in LDS)
+        for (uint32_t w0 = win + tid; w0 < wend; w0 += BIN_THREADS * BIN_FLIGHT) {
+            uint32_t slot[BIN_FLIGHT], rank[BIN_FLIGHT];
+            int tile[BIN_FLIGHT], gid[BIN_FLIGHT];
+            bool ok[BIN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < BIN_FLIGHT; u++) {
+                const uint32_t w = w0 + u * BIN_THREADS;
+                ok[u] = w < wend && ((s_bits[(w - win) >> 5] >> ((w - win) & 31)) & 1u);
+                if (ok[u]) {
+                    const Cand c = decode(w);
+                    const uint32_t first = max(s_off[c.gi], win);
+                    slot[u] = base + s_gb[c.gi] + s_prev[c.gi] + popcount_range(s_bits, first - win, w - win);
+                    tile[u] = c.tile;
+                    gid[u] = chunk0 + c.gi;
+                    rank[u] = atomicAdd(&tile_count[(size_t)c.tile * DQO_TSTRIDE], 1u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BIN_FLIGHT; u++) {
+                if (ok[u] && (int64_t)slot[u] < capacity) {
+                    bin.slot_info[slot[u]] = make_uint2((uint32_t)tile[u], rank[u]);
+                    bin.slot_gid[slot[u]] = (uint32_t)gid[u];
+                }
+            }
         }
-        s_base = tot ? atomicAdd(&g.counters[0], tot) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_base + s_wave[wave] + (inc2 - my2);
-#pragma unroll
-    for (int it = 0; it < BIN_ITEMS; it++) {
-        const int idx = chunk0 + tid * BIN_ITEMS + it;
-        if (idx < P) {
-            g.tiles_touched[idx] = cnt[it];
-            g.slot_base[idx] = base;
+        if (!one_window) {
+            __syncthreads();  // the loop above still reads s_prev and s_bits
+            carry_window(win, wend, s_prev);
+            __syncthreads();
         }
-        base += cnt[it];
     }
+}
+
+// One thread per instance slot: list position = start of its tile's range + its rank there.
+__global__ __launch_bounds__(256) void bin_place_kernel(DqoGeomLayout g, DqoImageLayout img, DqoBinLayout bin, int64_t capacity) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = min((int64_t)g.counters[0], capacity);
+    if (slot >= n) return;
+    const uint2 info = bin.slot_info[slot];
+    const uint32_t gid = bin.slot_gid[slot];
+    const uint2 range = img.ranges[info.x];
+    const uint32_t pos = range.x + info.y;
+    if (pos >= range.y) return;  // only when the forward overflowed its capacity (ranges are emptied then)
+    bin.keys[pos] = ((uint64_t)__float_as_uint(g.xy_depth[gid].z) << 32) | gid;
+    bin.slots[pos] = (uint32_t)slot;
 }
 
 }  // namespace
 
-int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, hipStream_t s) {
-    DqoBinLayout none = {};
-    DQO_LAUNCH("bin_count_kernel", bin_kernel<false>, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
-               img.tile_count, img.tile_flag, img.tile_cursor, none, (int64_t)0);
+int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
+                         int64_t capacity, hipStream_t s) {
+    DQO_LAUNCH("bin_count_kernel", bin_count_kernel, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
+               img.tile_count, img.tile_flag, bin, capacity);
     return DQO_OK;
 }
 
-int dqo_launch_bin_emit(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                        int64_t capacity, hipStream_t s) {
-    DQO_LAUNCH("bin_emit_kernel", bin_kernel<true>, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
-               img.tile_count, img.tile_flag, img.tile_cursor, bin, capacity);
+int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s) {
+    if (capacity <= 0) return DQO_OK;
+    DQO_LAUNCH("bin_place_kernel", bin_place_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), s, g, img, bin, capacity);
     return DQO_OK;
 }

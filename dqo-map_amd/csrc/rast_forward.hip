@@ -72,10 +72,11 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
 #pragma unroll
     for (int i = 0; i < 16; i++) view[i] = v.view[i], proj[i] = v.proj[i];
     const float cam0 = v.campos[0], cam1 = v.campos[1], cam2 = v.campos[2];
-    if (tid == 0) s_visible = 0;
+    __shared__ uint32_t s_cand;
+    if (tid == 0) s_visible = 0, s_cand = 0;
     __syncthreads();
 
-    uint32_t nvis = 0;
+    uint32_t nvis = 0, ncand = 0;
 #pragma unroll 1
     for (int it = 0; it < K1_ITEMS; it++) {
         const int idx = blockIdx.x * (K1_THREADS * K1_ITEMS) + it * K1_THREADS + tid;
@@ -210,11 +211,15 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
         n_touched_out[idx] = 0;
         g.rect16[idx] = make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16));
         nvis += radius > 0 ? 1u : 0u;
+        ncand += (uint32_t)((rmaxx - rminx) * (rmaxy - rminy));
     }
-    // visible count for the header (statistics only)
+    // visible count (statistics) and the number of (Gaussian, tile) pairs in the tile rects — the reference's num_rendered
+    // (rasterizer_impl.cu:303-309) and an upper bound of the instances the binning keeps
     if (nvis) atomicAdd(&s_visible, nvis);
+    if (ncand) atomicAdd(&s_cand, ncand);
     __syncthreads();
     if (tid == 0 && s_visible) atomicAdd(&g.counters[1], s_visible);
+    if (tid == 0 && s_cand) atomicAdd(&g.counters[3], s_cand);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
     const uint32_t lane = lane_id(), wave = tid >> 6;
     if (tid == 0) s_carry = 0, s_carry_act = 0, s_max = 0;
     __syncthreads();
+    const bool overflow = (int64_t)g.counters[0] > capacity;  // instance total of bin_count_kernel
     uint32_t local_max = 0;
     for (int base = 0; base < T; base += SCAN_THREADS) {
         const int t = base + tid;
@@ -251,10 +257,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         const uint32_t start = s_carry + wbase + incl - c;
         const uint32_t apos = s_carry_act + wbase_a + incl_a - a;
         if (t < T) {
-            // clamp to capacity so later kernels never index past the binning buffer (overflow is flagged below)
-            const uint32_t cs = (uint32_t)min((int64_t)start, capacity), ce = (uint32_t)min((int64_t)start + c, capacity);
-            img.ranges[t] = make_uint2(c ? cs : 0u, c ? ce : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
-            img.tile_cursor[(size_t)t * DQO_TSTRIDE] = start;
+            // More instances than the binning buffer holds: the slot tables are incomplete, so every list is emptied (the
+            // frame is invalid and flagged as such in the header; nothing indexes past a buffer).
+            const bool keep = c != 0u && !overflow;
+            img.ranges[t] = make_uint2(keep ? start : 0u, keep ? start + c : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
             if (a) img.tile_order[apos] = (uint32_t)t;
         }
         __syncthreads();
@@ -329,7 +335,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         h.overflow = ((int64_t)s_carry > capacity) ? 1u : 0u;
         h.max_tile_count = s_max;
         h.num_visible = g.counters[1];
-        h.reserved[0] = h.reserved[1] = h.reserved[2] = 0;
+        h.num_candidates = g.counters[3];
+        h.reserved[0] = h.reserved[1] = 0;
         *g.header = h;
     }
 }
@@ -423,9 +430,9 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                              const DqoRastOutputs& out, int T, int64_t capacity, hipStream_t s);
-int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, hipStream_t s);
-int dqo_launch_bin_emit(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                        int64_t capacity, hipStream_t s);
+int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
+                         int64_t capacity, hipStream_t s);
+int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
 
 int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s) {
     const DqoView v = dqo_make_view(p, in);
@@ -439,9 +446,6 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
         const int grid = (p->P + per_block - 1) / per_block;
         DQO_LAUNCH("preprocess_kernel", preprocess_kernel, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
                            in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched);
-        // per-tile histogram, tiles_touched, gaussian-major slots (forward.cu:344-353 + the cub scan of rasterizer_impl.cu:303)
-        int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, s);
-        if (rc) return rc;
     }
     return DQO_OK;
 }
@@ -452,9 +456,15 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity);
     const int T = v.gx * v.gy;
-    DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, (int64_t)ctx->inst_capacity);
+    const int64_t cap = (int64_t)ctx->inst_capacity;
     if (p->P > 0) {
-        int rc = dqo_launch_bin_emit(p->P, v.gx, in->tile_mask, g, img, bin, (int64_t)ctx->inst_capacity, s);
+        // footprint test, per-tile histogram + ranks, tiles_touched, gaussian-major slots (forward.cu:344-353, rasterizer_impl.cu:303)
+        int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap, s);
+        if (rc) return rc;
+    }
+    DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, cap);
+    if (p->P > 0) {
+        int rc = dqo_launch_bin_place(g, img, bin, cap, s);
         if (rc) return rc;
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(T), dim3(SORT_THREADS), s, img, bin);
     }

@@ -145,7 +145,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             if _sync_mode == "exact":
                 hdr = N.DqoRastHeader()
                 N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))  # the one D2H read
-                num_rendered = int(hdr.num_rendered)
+                # (Gaussian, tile) pairs in the tile rects: the reference's num_rendered, and an upper bound of the instances
+                # the binning keeps after its footprint test — a capacity that always fits
+                num_rendered = int(hdr.num_candidates)
                 cap = max(num_rendered, 1)
                 _last["num_rendered"], _last["num_visible"] = num_rendered, int(hdr.num_visible)
             else:
@@ -154,7 +156,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if cap is None:  # first call for this shape: measure once
                     hdr = N.DqoRastHeader()
                     N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))
-                    cap = _cap_hint[key] = int(hdr.num_rendered * 1.25) + 4096
+                    cap = _cap_hint[key] = int(hdr.num_candidates) + 4096  # later calls shrink it to 1.25 x the measured N
                 num_rendered = -1
             binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
             cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap

@@ -116,12 +116,14 @@ typedef struct DqoRastGrads {
 
 /* Host-visible copy of the device header kept at the start of ctx.geom. */
 typedef struct DqoRastHeader {
-    uint32_t num_rendered;   /* N: (Gaussian, tile) instances */
+    uint32_t num_rendered;   /* N: (Gaussian, tile) instances kept in the tile lists (valid after stage 2) */
     uint32_t num_tiles;      /* active (non-empty, unmasked) tiles */
     uint32_t overflow;       /* non-zero: N exceeded inst_capacity, results of this forward are invalid */
     uint32_t max_tile_count; /* longest per-tile list */
     uint32_t num_visible;    /* Gaussians with radius > 0 */
-    uint32_t reserved[3];
+    uint32_t num_candidates; /* (Gaussian, tile) pairs inside the tile rects = the reference's num_rendered
+                                (rasterizer_impl.cu:303-309); an upper bound of N, valid after stage 1 */
+    uint32_t reserved[2];
 } DqoRastHeader;
 
 int dqo_abi_version(void);
@@ -143,13 +145,14 @@ size_t dqo_rast_image_bytes(int32_t W, int32_t H);
 size_t dqo_rast_binning_bytes(int64_t inst_capacity);
 size_t dqo_rast_backward_workspace_bytes(int64_t inst_capacity);
 
-/* Stage 1 (per-Gaussian preprocess + per-tile counts + offsets).  Needs ctx.geom and ctx.image; leaves N in the
- * device header.  rasterizer_impl.cu:272-307 (K1, K2). */
+/* Stage 1 (per-Gaussian preprocess).  Needs ctx.geom and ctx.image; leaves num_candidates (>= N) in the device
+ * header: the capacity a caller that wants a guaranteed fit allocates.  rasterizer_impl.cu:272-307 (K1, K2). */
 int dqo_rast_forward_prepare(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
 /* D2H read of the header (the ONLY synchronising call; replaces the reference's cudaMemcpy at rasterizer_impl.cu:307). */
 int dqo_rast_read_header(const DqoRastCtx*, DqoRastHeader* host_out, void* hipStream);
-/* Stage 2 (instance emit, per-tile sort, blend).  Needs ctx.binning with inst_capacity >= N, otherwise the device
- * header's overflow flag is raised and no instance is written out of bounds.  rasterizer_impl.cu:309-440 (K3-K6). */
+/* Stage 2 (footprint test + tile binning, per-tile sort, blend).  Needs ctx.binning with inst_capacity >= N, otherwise
+ * the device header's overflow flag is raised, nothing is written out of bounds and the outputs are invalid.
+ * rasterizer_impl.cu:309-440 (K3-K6). */
 int dqo_rast_forward_render(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
 /* Both stages back to back, no host synchronisation (caller guarantees / later checks capacity). */
 int dqo_rast_forward(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
