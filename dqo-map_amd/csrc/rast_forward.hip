@@ -228,6 +228,7 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 1024;
 constexpr int LPT_BUCKETS = 256;
+constexpr int SCAN_CACHE = 8192;
 
 __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImageLayout img, DqoGeomLayout g, int64_t capacity) {
     __shared__ uint32_t s_part[SCAN_THREADS / 64];
@@ -238,10 +239,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
     if (tid == 0) s_carry = 0, s_carry_act = 0, s_max = 0;
     __syncthreads();
     const bool overflow = (int64_t)g.counters[0] > capacity;  // instance total of bin_count_kernel
+    // the padded histogram is read from HBM once; the four passes below work on an LDS copy (images up to ~2M pixels)
+    __shared__ uint32_t s_tc[SCAN_CACHE];
+    const bool cached = T <= SCAN_CACHE;
+    if (cached) {
+        for (int t = tid; t < T; t += SCAN_THREADS) s_tc[t] = img.tile_count[(size_t)t * DQO_TSTRIDE];
+        __syncthreads();
+    }
+    auto tcount = [&](int t) { return cached ? s_tc[t] : img.tile_count[(size_t)t * DQO_TSTRIDE]; };
     uint32_t local_max = 0;
     for (int base = 0; base < T; base += SCAN_THREADS) {
         const int t = base + tid;
-        const uint32_t c = t < T ? img.tile_count[(size_t)t * DQO_TSTRIDE] : 0u;
+        const uint32_t c = t < T ? tcount(t) : 0u;
         const uint32_t a = c ? 1u : 0u;
         local_max = max(local_max, c);
         uint32_t incl = c, incl_a = a;
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
     const uint32_t n_act = s_carry_act;
     for (int base = 0; base < T; base += SCAN_THREADS) {
         const int t = base + tid;
-        const uint32_t c = t < T ? img.tile_count[(size_t)t * DQO_TSTRIDE] : 1u;
+        const uint32_t c = t < T ? tcount(t) : 1u;
         const uint32_t a = c ? 0u : 1u;
         uint32_t incl_a = a;
 #pragma unroll
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         for (int i = tid; i < LPT_BUCKETS; i += SCAN_THREADS) s_bucket[i] = 0;
         __syncthreads();
         for (int t = tid; t < T; t += SCAN_THREADS) {
-            const uint32_t c = img.tile_count[(size_t)t * DQO_TSTRIDE];
+            const uint32_t c = tcount(t);
             if (c) atomicAdd(&s_bucket[LPT_BUCKETS - 1 - (c >> shift)], 1u);
         }
         __syncthreads();
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         }
         __syncthreads();
         for (int t = tid; t < T; t += SCAN_THREADS) {
-            const uint32_t c = img.tile_count[(size_t)t * DQO_TSTRIDE];
+            const uint32_t c = tcount(t);
             if (c) img.tile_order[atomicAdd(&s_bucket[LPT_BUCKETS - 1 - (c >> shift)], 1u)] = (uint32_t)t;
         }
     }
@@ -342,13 +351,109 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Per-tile sort of (depth, id) keys with the slot as payload.  Ascending-comparator bitonic network (works for any n
-// without padding: elements past n behave as +inf and never move).  Lists up to SORT_LDS_CAP entries are sorted in
-// LDS; longer ones in place in global memory by the same block (rare: correctness path, not a fast path).
+// Per-tile sort of (depth, id) keys with the slot as payload (replaces the device-wide cub radix sort of
+// rasterizer_impl.cu:316-330; ties in depth fall back to the Gaussian id = the reference's stable order).
+//   tile_sort_wave_kernel : lists up to 1024 entries (in practice all of them): ONE WAVE per tile, four tiles per block,
+//       the whole list in registers (E = 2..16 elements per lane, blocked layout).  Bitonic network: the steps with
+//       distance < E are compare-exchanges between a lane's own registers, the others exchange with lane ^ (distance / E)
+//       through ds_bpermute.  No LDS round trips, no barriers: the sort is latency-bound (a few hundred thousand keys in
+//       all), so the serial chain per tile is what counts.
+//   tile_sort_kernel : longer lists, one block per tile; in LDS up to SORT_LDS_CAP entries, beyond that in place in
+//       global memory (correctness path, not a fast path).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_LDS_CAP = 4096;
+constexpr int SORT_LDS_CAP = 2048;
+constexpr int SORTW_CAP = 1024;
 
+template <int E>
+__device__ __forceinline__ void wave_bitonic(uint64_t (&key)[E], uint32_t (&val)[E], int lane) {
+    // k and the cross-lane distances stay run-time loop variables: only the register pairings of the in-lane steps are
+    // unrolled, which keeps the kernel's five instantiations inside the instruction cache.
+#pragma unroll 1
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j >= E; j >>= 1) {
+            // partner element lives in lane ^ d, same register
+            const int d = j / E;
+            const bool up = ((lane * E) & k) == 0;  // ascending sub-sequence (k >= 2E here, so the bit is a lane bit)
+            const bool keep_min = (((lane & d) == 0) == up);
+            // all of the step's exchanges are issued before any result is used; the selects are branch-free
+            uint64_t ok[E];
+            uint32_t ov[E];
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)key[r], d);
+                const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(key[r] >> 32), d);
+                ov[r] = (uint32_t)__shfl_xor((int)val[r], d);
+                ok[r] = ((uint64_t)ohi << 32) | olo;
+            }
+#pragma unroll
+            for (int r = 0; r < E; r++) {
+                const bool take = (ok[r] < key[r]) == keep_min;  // keys are distinct (padding carries identical payloads)
+                key[r] = take ? ok[r] : key[r];
+                val[r] = take ? ov[r] : val[r];
+            }
+        }
+#pragma unroll
+        for (int j = E >> 1; j > 0; j >>= 1) {
+            if (j < k) {
+                // both elements in this lane's registers r and r | j
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if ((r & j) == 0) {
+                        const int p = r | j;
+                        const bool up = (((lane * E + r) & k) == 0);
+                        const bool sw = (key[r] > key[p]) == up;
+                        const uint64_t kr = key[r], kp = key[p];
+                        const uint32_t vr = val[r], vp = val[p];
+                        key[r] = sw ? kp : kr;
+                        key[p] = sw ? kr : kp;
+                        val[r] = sw ? vp : vr;
+                        val[p] = sw ? vr : vp;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(const DqoBinLayout& bin, uint32_t base, int n, int lane) {
+    uint64_t key[E];
+    uint32_t val[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int i = lane * E + r;
+        key[r] = i < n ? bin.keys[base + i] : ~0ull;  // padding sorts behind every real key (depth bits of a finite float)
+        val[r] = i < n ? bin.slots[base + i] : 0u;
+    }
+    wave_bitonic<E>(key, val, lane);
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int i = lane * E + r;
+        if (i < n) {
+            bin.point_list[base + i] = (uint32_t)key[r];
+            bin.slot_list[base + i] = val[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ti = blockIdx.x * (SORT_THREADS / 64) + wave;
+    if (ti >= T) return;
+    const int tile = img.tile_order[ti];
+    const uint2 rg = img.ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= 0 || n > SORTW_CAP) return;
+    if (n <= 64) wave_sort_tile<1>(bin, rg.x, n, lane);
+    else if (n <= 128) wave_sort_tile<2>(bin, rg.x, n, lane);
+    else if (n <= 256) wave_sort_tile<4>(bin, rg.x, n, lane);
+    else if (n <= 512) wave_sort_tile<8>(bin, rg.x, n, lane);
+    else wave_sort_tile<16>(bin, rg.x, n, lane);
+}
+
+// in-place global version for lists longer than SORT_LDS_CAP, LDS version below that
 template <typename KeyPtr, typename ValPtr>
 __device__ __forceinline__ void bitonic_any(KeyPtr keys, ValPtr vals, int n, int tid) {
     int n2 = 1;
@@ -367,7 +472,7 @@ __device__ __forceinline__ void bitonic_any(KeyPtr keys, ValPtr vals, int n, int
                     i = 2 * j * (t / j) + (t % j);
                     p = i + j;
                 }
-                if (p < n) {
+                if (p < n) {  // ascending-comparator network: elements past n behave as +inf and never move
                     const uint64_t a = keys[i], b = keys[p];
                     if (a > b) {
                         keys[i] = b;
@@ -390,7 +495,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(DqoImageLayout 
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
     const int tid = threadIdx.x;
-    if (n <= 0) return;
+    if (n <= SORTW_CAP) return;  // tile_sort_wave_kernel's
     uint64_t* gk = bin.keys + rg.x;
     uint32_t* gv = bin.slots + rg.x;
     if (n <= SORT_LDS_CAP) {
@@ -466,6 +571,7 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     if (p->P > 0) {
         int rc = dqo_launch_bin_place(g, img, bin, cap, s);
         if (rc) return rc;
+        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3((T + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64)), dim3(SORT_THREADS), s, T, img, bin);
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(T), dim3(SORT_THREADS), s, img, bin);
     }
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, s);

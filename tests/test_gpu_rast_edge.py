@@ -32,11 +32,12 @@ def _check(oracle, cam, sc, dL, **kw):
     return o, st, gs
 
 
-def test_long_tile_lists_global_sort(torch_cuda, oracle):
-    """> 4096 instances in one tile: the sort kernel's in-place global path; semi-transparent so the whole list is walked."""
+@pytest.mark.parametrize("P,longer_than", [(2800, 1024), (9000, 4096)])
+def test_long_tile_lists_global_sort(torch_cuda, oracle, P, longer_than):
+    """Lists beyond the one-wave register sort (> 1024: block sort in LDS) and beyond the LDS capacity (> 4096 instances in one
+    tile: the sort kernel's in-place global path); semi-transparent so the whole list is walked."""
     cam = scenes.Camera(96, 64, 80.0, 80.0, 47.5, 31.5)
     rng = np.random.default_rng(0)
-    P = 9000
     sc = scenes.frustum_cloud(5, P, cam, zmin=1.0, zmax=4.0)
     # squeeze all centres into a 20x20-pixel window around the image centre
     pc = np.stack([rng.uniform(-0.12, 0.12, P), rng.uniform(-0.12, 0.12, P), rng.uniform(1.0, 4.0, P)], 1)
@@ -45,7 +46,7 @@ def test_long_tile_lists_global_sort(torch_cuda, oracle):
     sc["opacity"] = rng.uniform(0.02, 0.08, (P, 1)).astype(np.float32)
     o, st, gs = _check(oracle, cam, sc, _dL(cam))
     rg = o.ctx("ranges")
-    assert (rg[:, 1] - rg[:, 0]).max() > 4096, "scene does not exercise the long-list path"
+    assert (rg[:, 1] - rg[:, 0]).max() > longer_than, "scene does not exercise the long-list path"
     print("long lists:", (rg[:, 1] - rg[:, 0]).max(), st)
 
 

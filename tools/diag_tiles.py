@@ -24,22 +24,23 @@ off=0
 def take(nbytes, dt):
     global off
     t=img[off:off+nbytes].view(dt).cpu().numpy(); off+=al(nbytes); return t
-tile_count=take(4*T, torch.int32); tflag=take(4*T, torch.int32); cursor=take(4*T, torch.int32); ranges=take(8*T, torch.int32).reshape(T,2); walk=take(4*T, torch.int32); order=take(4*T, torch.int32)
-final_T=take(4*HW, torch.float32); ncon=take(4*HW, torch.int32); hitpos=take(4*HW, torch.int32)
+tile_count=take(4*T*64, torch.int32)[::64]; tflag=take(4*T, torch.int32); cursor=take(4*T*64, torch.int32); ranges=take(8*T, torch.int32).reshape(T,2); walk4=take(16*T, torch.int32).reshape(T,4); order=take(4*T, torch.int32)
+final_T=take(4*HW, torch.float32); ncon=take(4*HW, torch.int32); hitpos=take(4*HW, torch.int32) & 0x7fffffff
 n=ranges[:,1]-ranges[:,0]
 q=lambda x:[int(np.quantile(x,p)) for p in (0.5,0.9,0.99,1.0)]
-print('N',c.num_rendered,'tiles',T,'n: mean',n.mean(),'q50/90/99/max',q(n))
-print('walk L: mean',walk.mean(),'q',q(walk),' sum(L)/sum(n)=',walk.sum()/n.sum())
+print('candidates',c.num_rendered,'instances',int(n.sum()),'tiles',T,'n: mean',n.mean(),'q50/90/99/max',q(n))
+for lim in (64,128,256,512,1024,2048): print('tiles with n >',lim,':',int((n>lim).sum()),' instances in them', int(n[n>lim].sum()))
+walk=walk4.max(1)
+print('walk L per quadrant: mean',walk4.mean(),'q',q(walk4.ravel()),' sum(L4)/(4 sum n)=',walk4.sum()/(4*n.sum()))
 print('n_contrib per pixel: mean',ncon.mean(),'q',q(ncon),' hit_pos mean',hitpos.mean(),'q',q(hitpos), 'frac no-hit', (hitpos==0).mean())
-# per-tile: fraction of pixels whose walk exceeds half the tile's L
-need=np.maximum(ncon,hitpos).reshape(H,W)
-gx=(W+15)//16
-fr=[]
-for t in np.argsort(-walk)[:10]:
-    ty,tx=divmod(int(t),gx); blk=need[ty*16:(ty+1)*16, tx*16:(tx+1)*16]
-    print('tile',t,'n',n[t],'L',walk[t],'px need q50/q90/max',q(blk.ravel())[:2], blk.max(), 'active px at L/2', int((blk>walk[t]/2).sum()))
-# work estimates
-print('sum over tiles of L (wave-entries bwd):', walk.sum(), ' max L', walk.max())
-pix_need=need.astype(np.int64).sum()
-print('sum over pixels of need:', pix_need, ' => avg lanes busy per wave-entry:', pix_need/ (walk.astype(np.int64).sum()*256+1)*256, 'of 256')
+# live (quadrant, instance) pairs
+binning=c.saved[9]; cap=c.inst_capacity
+offb=al(8*cap)+al(4*cap)+al(4*cap)+al(4*cap)
+lq=binning[offb:offb+4*cap].cpu().numpy().reshape(4,cap)
+live=0
+for t in range(T):
+    for qd in range(4):
+        L=walk4[t,qd]
+        if L: live+=int(lq[qd, ranges[t,0]:ranges[t,0]+L].sum())
+print('live (quadrant, instance) pairs walked by the backward:', live, ' per instance', live/max(1,n.sum()))
 vis=(out[8]>0).sum().item(); print('visible',vis)
