@@ -61,6 +61,7 @@ struct DqoGeomLayout {
     uint32_t* tiles_touched; // [P]
     uint32_t* slot_base;     // [P] first gaussian-major instance slot of this Gaussian
     uint8_t* clamped;        // [P] bit0..2 = SH colour channel clamped at 0 (forward.cu:151-153)
+    float4* grad_sum;        // [P][4] backward only: summed gradient record (DqoGradRec) of each Gaussian with instances
     size_t total;
 };
 
@@ -84,6 +85,7 @@ static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
     L.tiles_touched = (uint32_t*)take(sizeof(uint32_t) * P);
     L.slot_base = (uint32_t*)take(sizeof(uint32_t) * P);
     L.clamped = (uint8_t*)take(P);
+    L.grad_sum = (float4*)take(sizeof(float4) * 4 * P);
     L.total = (size_t)(p - (char*)base);
     return L;
 }

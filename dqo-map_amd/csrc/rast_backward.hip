@@ -20,6 +20,71 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
+// Fixed-order sum of every Gaussian's gradient records: sums[idx] = sum over the Gaussian's instance slots (ascending) of
+// the sum over the slot's valid per-quadrant partial records (quadrant order) — bitwise reproducible.
+// A block owns 256 consecutive Gaussians; their slots are one contiguous, idx-ordered range (rast_binning.hip hands out
+// slots in index order).  Per chunk of 256 slots, thread t merges slot c0 + t (validity word, then up to four 64-byte
+// partial records, all loads in flight together) into LDS, and each Gaussian's thread then adds its own contiguous records
+// out of LDS.  Kept apart from gaussian_backward_kernel on purpose: this part is a sparse gather whose latency is hidden by
+// occupancy (few registers, 16 KB LDS), which the register-heavy fp64 chain rule kernel cannot provide.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void record_sum_kernel(int P, DqoGeomLayout g, const float4* __restrict__ partial,
+                                                         const uint32_t* __restrict__ valid, float4* __restrict__ sums,
+                                                         int64_t capacity) {
+    constexpr int GB_CHUNK = 256;
+    __shared__ float4 s_rec[GB_CHUNK * 4];
+    __shared__ uint32_t s_lohi[2];
+    const int tid = threadIdx.x;
+    const int idx = blockIdx.x * blockDim.x + tid;
+    uint32_t base = 0, cnt = 0;
+    if (idx < P) base = g.slot_base[idx], cnt = g.tiles_touched[idx];
+    if (tid == 0) s_lohi[0] = 0xffffffffu, s_lohi[1] = 0u;
+    __syncthreads();
+    if (cnt) {
+        atomicMin(&s_lohi[0], base);
+        atomicMax(&s_lohi[1], base + cnt);
+    }
+    __syncthreads();
+    const uint32_t lo = s_lohi[0];
+    const uint32_t hi = (uint32_t)min((int64_t)s_lohi[1], capacity);  // an overflowed (invalid) forward must not read out of bounds
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    const float4 z = a0;
+    for (uint32_t c0 = lo; c0 < hi; c0 += GB_CHUNK) {
+        const uint32_t slot = c0 + tid;
+        if (slot < hi) {
+            const uint32_t vw = valid[slot];
+            const float4* p = partial + (size_t)slot * 16;
+            float4 m0 = z, m1 = z, m2 = z, m3 = z;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if ((vw >> (8 * q)) & 0xffu) {
+                    const float4 r0 = p[4 * q], r1 = p[4 * q + 1], r2 = p[4 * q + 2], r3 = p[4 * q + 3];
+                    m0.x += r0.x, m0.y += r0.y, m0.z += r0.z, m0.w += r0.w;
+                    m1.x += r1.x, m1.y += r1.y, m1.z += r1.z, m1.w += r1.w;
+                    m2.x += r2.x, m2.y += r2.y, m2.z += r2.z, m2.w += r2.w;
+                    m3.x += r3.x, m3.y += r3.y, m3.z += r3.z, m3.w += r3.w;
+                }
+            }
+            s_rec[tid * 4] = m0, s_rec[tid * 4 + 1] = m1, s_rec[tid * 4 + 2] = m2, s_rec[tid * 4 + 3] = m3;
+        }
+        __syncthreads();
+        const uint32_t k0 = max(base, c0), k1 = min(base + cnt, min(c0 + (uint32_t)GB_CHUNK, hi));
+        for (uint32_t k = k0; k < k1; k++) {
+            const float4 r0 = s_rec[(k - c0) * 4], r1 = s_rec[(k - c0) * 4 + 1], r2 = s_rec[(k - c0) * 4 + 2], r3 = s_rec[(k - c0) * 4 + 3];
+            a0.x += r0.x, a0.y += r0.y, a0.z += r0.z, a0.w += r0.w;
+            a1.x += r1.x, a1.y += r1.y, a1.z += r1.z, a1.w += r1.w;
+            a2.x += r2.x, a2.y += r2.y, a2.z += r2.z, a2.w += r2.w;
+            a3.x += r3.x, a3.y += r3.y, a3.z += r3.z, a3.w += r3.w;
+        }
+        __syncthreads();
+    }
+    if (cnt) {
+        float4* o = sums + (size_t)idx * 4;
+        o[0] = a0, o[1] = a1, o[2] = a2, o[3] = a3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Per-Gaussian backward: sum the instance records, then K8 (cov2D) + K9 (projection, SH, cov3D) in one pass.
 // Writes every gradient element (zeros for culled Gaussians), so the caller's tensors can be torch.empty.
 // ------------------------------------------------------------------------------------------------------------------
@@ -33,82 +98,22 @@ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
 __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v, DqoGeomLayout g,
                                                                 const float* __restrict__ means3D, const float* __restrict__ scales,
                                                                 const float* __restrict__ rotations, const float* __restrict__ shs,
-                                                                const DqoGradRec* __restrict__ recs,
-                                                                const uint32_t* __restrict__ valid, int64_t capacity,
+                                                                const DqoGradRec* __restrict__ recs, int64_t capacity,
                                                                 DqoRastGrads gr) {
-    // ---- fixed-order sum of every Gaussian's partial records, staged through LDS, one wave64 on its own ----
-    // Every instance slot owns four partial records (one per tile quadrant, written by blend_backward_kernel only for the
-    // quadrants in which the instance was live); the slot's validity word says which of them exist.  The slots of the 64
-    // consecutive Gaussians of a wave are one contiguous, idx-ordered range (rast_binning.hip hands out slots in index
-    // order), so the wave walks that range 64 slots at a time: it compacts the valid partial records into a list (wave
-    // prefix sum of the per-slot counts), gathers them with coalesced 16-byte loads (4 lanes per 64-byte record) into its
-    // private LDS region, and every lane adds its own Gaussian's records, which are contiguous in the compacted order.
-    // No per-lane serial gather chain through HBM, no block barrier.
-    constexpr int GB_SLOTS = 64;    // slots per trip = one per lane
-    constexpr int GB_BATCH = 128;   // partial records staged at once (8 KB per wave)
-    __shared__ float4 s_rec_all[4][GB_BATCH * 4];
-    __shared__ uint32_t s_list_all[4][GB_SLOTS * 4];
-    __shared__ uint32_t s_off_all[4][GB_SLOTS + 1];
+    // record_sum_kernel left the summed gradient record of every Gaussian that owns instances
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    float4* const s_rec = s_rec_all[wave];
-    uint32_t* const s_list = s_list_all[wave];
-    uint32_t* const s_off = s_off_all[wave];
     const int idx = blockIdx.x * blockDim.x + tid;
     const bool in_range = idx < v.P;
-    uint32_t base = 0, cnt = 0;
-    if (in_range) base = g.slot_base[idx], cnt = g.tiles_touched[idx];
     float a[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) a[i] = 0.f;
-    {
-        uint32_t lo = cnt ? base : 0xffffffffu, hi = cnt ? base + cnt : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
-            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
-        }
-        hi = (uint32_t)min((int64_t)hi, capacity);  // an overflowed (invalid) forward must not read out of bounds
-        const float4* r4 = reinterpret_cast<const float4*>(recs);
-        for (uint32_t c0 = lo; c0 < hi; c0 += GB_SLOTS) {
-            const uint32_t slot = c0 + lane;
-            const uint32_t vw = slot < hi ? valid[slot] : 0u;
-            const uint32_t m = ((vw & 0xffu) ? 1u : 0u) | ((vw & 0xff00u) ? 2u : 0u) | ((vw & 0xff0000u) ? 4u : 0u) | ((vw & 0xff000000u) ? 8u : 0u);
-            const uint32_t pc = __popc(m);
-            uint32_t incl = pc;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= off) incl += o;
-            }
-            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-            uint32_t w = incl - pc;
-            s_off[lane] = w;
-            if (lane == 63) s_off[GB_SLOTS] = total;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++)
-                if (m & (1u << q)) s_list[w++] = slot * 4u + q;
-            __builtin_amdgcn_wave_barrier();
-            // this lane's Gaussian owns compacted positions [p0, p1) of this trip
-            const uint32_t k0 = max(base, c0), k1 = min(base + cnt, min(c0 + (uint32_t)GB_SLOTS, hi));
-            uint32_t p0 = 0, p1 = 0;
-            if (k0 < k1) p0 = s_off[k0 - c0], p1 = s_off[k1 - c0];
-            for (uint32_t b0 = 0; b0 < total; b0 += GB_BATCH) {
-                const uint32_t nb = min((uint32_t)GB_BATCH, total - b0);
-                for (uint32_t e = lane; e < nb * 4; e += 64) s_rec[e] = r4[(size_t)s_list[b0 + (e >> 2)] * 4 + (e & 3u)];
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t j0 = max(p0, b0), j1 = min(p1, b0 + nb);
-                for (uint32_t j = j0; j < j1; j++) {
-                    const float4* p = &s_rec[(j - b0) * 4];
-                    const float4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
-                    a[0] += r0.x, a[1] += r0.y, a[2] += r0.z, a[3] += r0.w;
-                    a[4] += r1.x, a[5] += r1.y, a[6] += r1.z, a[7] += r1.w;
-                    a[8] += r2.x, a[9] += r2.y, a[10] += r2.z, a[11] += r2.w;
-                    a[12] += r3.x, a[13] += r3.y, a[14] += r3.z, a[15] += r3.w;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+    if (in_range && g.tiles_touched[idx] != 0u) {
+        const float4* r = reinterpret_cast<const float4*>(recs) + (size_t)idx * 4;
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        a[0] = r0.x, a[1] = r0.y, a[2] = r0.z, a[3] = r0.w;
+        a[4] = r1.x, a[5] = r1.y, a[6] = r1.z, a[7] = r1.w;
+        a[8] = r2.x, a[9] = r2.y, a[10] = r2.z, a[11] = r2.w;
+        a[12] = r3.x, a[13] = r3.y, a[14] = r3.z, a[15] = r3.w;
     }
     if (!in_range) return;
     const int M = v.M, D = v.D;
@@ -414,7 +419,10 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     if (cap > 0) DQO_CHECK_HIP(hipMemsetAsync(valid, 0, 4 * (size_t)cap, s));
     int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap, s);
     if (rc) return rc;
+    DqoGradRec* sums = reinterpret_cast<DqoGradRec*>(g.grad_sum);  // [P], lives in the forward's geometry buffer
+    DQO_LAUNCH("record_sum_kernel", record_sum_kernel, dim3((p->P + 255) / 256), dim3(256), s, p->P, g, reinterpret_cast<const float4*>(recs),
+               reinterpret_cast<const uint32_t*>(valid), reinterpret_cast<float4*>(sums), cap);
     DQO_LAUNCH("gaussian_backward_kernel", gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), s, v, g, in->means3D, in->scales,
-               in->rotations, in->shs, recs, reinterpret_cast<const uint32_t*>(valid), cap, *gr);
+               in->rotations, in->shs, sums, cap, *gr);
     return DQO_OK;
 }
