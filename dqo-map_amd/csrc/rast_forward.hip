@@ -223,7 +223,7 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// One-block exclusive scan over the per-tile histogram: ranges, emit cursors, tile order, header.
+// One block: exclusive scan over the per-tile histogram (list ranges), launch order of the tiles, header.
 // Replaces cub::DeviceScan + identifyTileRanges + the host compaction loop (rasterizer_impl.cu:303, 338-365).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 1024;
@@ -232,115 +232,81 @@ constexpr int SCAN_CACHE = 8192;
 
 __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImageLayout img, DqoGeomLayout g, int64_t capacity) {
     __shared__ uint32_t s_part[SCAN_THREADS / 64];
-    __shared__ uint32_t s_part_act[SCAN_THREADS / 64];
-    __shared__ uint32_t s_carry, s_carry_act, s_max;
+    __shared__ uint32_t s_carry, s_max;
+    __shared__ uint32_t s_bucket[LPT_BUCKETS + 1];
+    __shared__ uint32_t s_tc[SCAN_CACHE];
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id(), wave = tid >> 6;
-    if (tid == 0) s_carry = 0, s_carry_act = 0, s_max = 0;
-    __syncthreads();
+    if (tid == 0) s_carry = 0, s_max = 0;
     const bool overflow = (int64_t)g.counters[0] > capacity;  // instance total of bin_count_kernel
-    // the padded histogram is read from HBM once; the four passes below work on an LDS copy (images up to ~2M pixels)
-    __shared__ uint32_t s_tc[SCAN_CACHE];
+    // the padded histogram is read from HBM once; the passes below work on an LDS copy (images up to ~2M pixels)
     const bool cached = T <= SCAN_CACHE;
-    if (cached) {
+    if (cached)
         for (int t = tid; t < T; t += SCAN_THREADS) s_tc[t] = img.tile_count[(size_t)t * DQO_TSTRIDE];
-        __syncthreads();
-    }
+    __syncthreads();
     auto tcount = [&](int t) { return cached ? s_tc[t] : img.tile_count[(size_t)t * DQO_TSTRIDE]; };
+
+    // ---- ranges: chunked block scan ----
     uint32_t local_max = 0;
     for (int base = 0; base < T; base += SCAN_THREADS) {
         const int t = base + tid;
         const uint32_t c = t < T ? tcount(t) : 0u;
-        const uint32_t a = c ? 1u : 0u;
         local_max = max(local_max, c);
-        uint32_t incl = c, incl_a = a;
+        uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off), oa = __shfl_up(incl_a, off);
-            if (lane >= (uint32_t)off) incl += o, incl_a += oa;
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += o;
         }
-        if (lane == 63) s_part[wave] = incl, s_part_act[wave] = incl_a;
+        if (lane == 63) s_part[wave] = incl;
         __syncthreads();
-        uint32_t wbase = 0, wbase_a = 0;
-        for (uint32_t w = 0; w < wave; w++) wbase += s_part[w], wbase_a += s_part_act[w];
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; w++) wbase += s_part[w];
         const uint32_t start = s_carry + wbase + incl - c;
-        const uint32_t apos = s_carry_act + wbase_a + incl_a - a;
         if (t < T) {
             // More instances than the binning buffer holds: the slot tables are incomplete, so every list is emptied (the
             // frame is invalid and flagged as such in the header; nothing indexes past a buffer).
             const bool keep = c != 0u && !overflow;
             img.ranges[t] = make_uint2(keep ? start : 0u, keep ? start + c : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
-            if (a) img.tile_order[apos] = (uint32_t)t;
         }
         __syncthreads();
-        if (tid == SCAN_THREADS - 1) s_carry = start + c, s_carry_act = apos + a;
-        __syncthreads();
+        if (tid == SCAN_THREADS - 1) s_carry = start + c;
     }
-    atomicMax(&s_max, local_max);
+    if (local_max) atomicMax(&s_max, local_max);
+    for (int i = tid; i <= LPT_BUCKETS; i += SCAN_THREADS) s_bucket[i] = 0;
     __syncthreads();
-    // inactive tiles after the active ones (they still get a block: it writes the reference's initial fills)
-    const uint32_t n_act = s_carry_act;
-    for (int base = 0; base < T; base += SCAN_THREADS) {
-        const int t = base + tid;
-        const uint32_t c = t < T ? tcount(t) : 1u;
-        const uint32_t a = c ? 0u : 1u;
-        uint32_t incl_a = a;
+    // ---- launch order of the blend kernels (tile_order): longest-processing-time-first.  Tiles are bucketed by list length
+    // (256 levels, descending; empty tiles — they still get blocks, which write the reference's initial fills — in a last
+    // bucket of their own) with an LDS counting sort.  Only the blockIdx -> tile mapping depends on it, no result does. ----
+    const uint32_t mx = s_max;
+    int shift = 0;
+    while ((mx >> shift) >= (uint32_t)LPT_BUCKETS) shift++;
+    auto bucket_of = [&](uint32_t c) { return c ? LPT_BUCKETS - 1 - (int)(c >> shift) : LPT_BUCKETS; };
+    for (int t = tid; t < T; t += SCAN_THREADS) atomicAdd(&s_bucket[bucket_of(tcount(t))], 1u);
+    __syncthreads();
+    const uint32_t n_empty = s_bucket[LPT_BUCKETS];
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the bucket sizes by one wave (4 buckets per lane, the empty-tile bucket last)
+        uint32_t v4[LPT_BUCKETS / 64], sum = 0;
+#pragma unroll
+        for (int k = 0; k < LPT_BUCKETS / 64; k++) v4[k] = s_bucket[tid * (LPT_BUCKETS / 64) + k], sum += v4[k];
+        uint32_t incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t oa = __shfl_up(incl_a, off);
-            if (lane >= (uint32_t)off) incl_a += oa;
+            const uint32_t o = __shfl_up(incl, off);
+            if (tid >= off) incl += o;
         }
-        __syncthreads();
-        if (lane == 63) s_part_act[wave] = incl_a;
-        if (tid == 0 && base == 0) s_carry_act = 0;
-        __syncthreads();
-        uint32_t wbase_a = 0;
-        for (uint32_t w = 0; w < wave; w++) wbase_a += s_part_act[w];
-        const uint32_t ipos = s_carry_act + wbase_a + incl_a - a;
-        if (t < T && a) img.tile_order[n_act + ipos] = (uint32_t)t;
-        __syncthreads();
-        if (tid == SCAN_THREADS - 1) s_carry_act = ipos + a;
-        __syncthreads();
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < LPT_BUCKETS / 64; k++) s_bucket[tid * (LPT_BUCKETS / 64) + k] = run, run += v4[k];
+        if (tid == 63) s_bucket[LPT_BUCKETS] = run;  // = number of non-empty tiles
     }
-    // ---- longest-processing-time-first launch order for the blend kernels: active tiles bucketed by list length (256
-    // levels, descending) with an LDS counting sort — 3 barriers instead of a full sort.  Only the blockIdx -> tile mapping
-    // changes: results do not depend on it. ----
-    if (n_act > 1) {
-        __shared__ uint32_t s_bucket[LPT_BUCKETS];
-        const uint32_t mx = s_max;
-        int shift = 0;
-        while ((mx >> shift) >= (uint32_t)LPT_BUCKETS) shift++;
-        for (int i = tid; i < LPT_BUCKETS; i += SCAN_THREADS) s_bucket[i] = 0;
-        __syncthreads();
-        for (int t = tid; t < T; t += SCAN_THREADS) {
-            const uint32_t c = tcount(t);
-            if (c) atomicAdd(&s_bucket[LPT_BUCKETS - 1 - (c >> shift)], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {  // exclusive scan of the 256 bucket sizes by one wave (4 buckets per lane)
-            uint32_t v4[LPT_BUCKETS / 64], sum = 0;
-#pragma unroll
-            for (int k = 0; k < LPT_BUCKETS / 64; k++) v4[k] = s_bucket[tid * (LPT_BUCKETS / 64) + k], sum += v4[k];
-            uint32_t incl = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off);
-                if (tid >= off) incl += o;
-            }
-            uint32_t run = incl - sum;
-#pragma unroll
-            for (int k = 0; k < LPT_BUCKETS / 64; k++) s_bucket[tid * (LPT_BUCKETS / 64) + k] = run, run += v4[k];
-        }
-        __syncthreads();
-        for (int t = tid; t < T; t += SCAN_THREADS) {
-            const uint32_t c = tcount(t);
-            if (c) img.tile_order[atomicAdd(&s_bucket[LPT_BUCKETS - 1 - (c >> shift)], 1u)] = (uint32_t)t;
-        }
-    }
+    __syncthreads();
+    for (int t = tid; t < T; t += SCAN_THREADS) img.tile_order[atomicAdd(&s_bucket[bucket_of(tcount(t))], 1u)] = (uint32_t)t;
     if (tid == 0) {
         DqoRastHeader h;
         h.num_rendered = s_carry;
-        h.num_tiles = n_act;
+        h.num_tiles = (uint32_t)T - n_empty;
         h.overflow = ((int64_t)s_carry > capacity) ? 1u : 0u;
         h.max_tile_count = s_max;
         h.num_visible = g.counters[1];
