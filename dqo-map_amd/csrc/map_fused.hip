@@ -137,6 +137,7 @@ struct AdamArgs {
     const float *g_xyz, *g_shs, *g_opacity, *g_scales, *g_rot;                    // gradients w.r.t. the ACTIVATED parameters
     float *m_xyz, *m_shs, *m_opacity, *m_scaling, *m_rotation;                    // exp_avg
     float *v_xyz, *v_shs, *v_opacity, *v_scaling, *v_rotation;                    // exp_avg_sq
+    float *act_opacity, *act_scales, *act_rotations;                              // optional: activations of the updated parameters
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float step_size) {
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         float ps = a.scaling_raw[i], ms = a.m_scaling[i], vs = a.v_scaling[i];
         adam1(ps, a.g_scales[i] * expf(ps), ms, vs, a, a.step_scaling);  // d exp(x)/dx = exp(x)
         a.scaling_raw[i] = ps, a.m_scaling[i] = ms, a.v_scaling[i] = vs;
+        if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
     }
     // SH coefficients [P,M,3]: coefficient 0 = f_dc (lr feature_lr), the rest = f_rest (feature_lr / 20)
     const int64_t nsh = (int64_t)P * a.M * 3;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         const float sg = 1.0f / (1.0f + expf(-p));
         adam1(p, a.g_opacity[i] * (sg * (1.f - sg)), m, v, a, a.step_opacity);
         a.opacity_raw[i] = p, a.m_opacity[i] = m, a.v_opacity[i] = v;
+        if (a.act_opacity) a.act_opacity[i] = 1.0f / (1.0f + expf(-p));
 
         float4 q = reinterpret_cast<float4*>(a.rotation_raw)[i];
         const float4 g = reinterpret_cast<const float4*>(a.g_rot)[i];
@@ -189,6 +192,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
         adam1(q.z, (g.z - yz * dot) / nrm, mq.z, vq.z, a, a.step_rotation);
         adam1(q.w, (g.w - yw * dot) / nrm, mq.w, vq.w, a, a.step_rotation);
         reinterpret_cast<float4*>(a.rotation_raw)[i] = q;
+        if (a.act_rotations) {
+            const float n2 = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+            reinterpret_cast<float4*>(a.act_rotations)[i] = make_float4(q.x / n2, q.y / n2, q.z / n2, q.w / n2);
+        }
         reinterpret_cast<float4*>(a.m_rotation)[i] = mq;
         reinterpret_cast<float4*>(a.v_rotation)[i] = vq;
     }
@@ -235,6 +242,7 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.g_xyz = st->g_means3D, a.g_shs = st->g_sh, a.g_opacity = st->g_opacity, a.g_scales = st->g_scales, a.g_rot = st->g_rotations;
     a.m_xyz = st->m_xyz, a.m_shs = st->m_shs, a.m_opacity = st->m_opacity, a.m_scaling = st->m_scaling, a.m_rotation = st->m_rotation;
     a.v_xyz = st->v_xyz, a.v_shs = st->v_shs, a.v_opacity = st->v_opacity, a.v_scaling = st->v_scaling, a.v_rotation = st->v_rotation;
+    a.act_opacity = st->act_opacity, a.act_scales = st->act_scales, a.act_rotations = st->act_rotations;
     const int64_t n = (int64_t)st->P * st->M * 3;
     const int grid = (int)min((int64_t)(256 * 16), (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
     DQO_LAUNCH("adam_kernel", adam_kernel, dim3(grid), dim3(256), s, a);

@@ -48,6 +48,7 @@ class FusedMapper:
         self.color_weight, self.depth_weight, self.add_depth_thres = color_weight, depth_weight, add_depth_thres
         self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in self._params().items()}
         self.step_count = 0
+        self._act_valid = False  # opacity / scales / rotations hold the activations of the current raw parameters
         P = self.P
         f = dict(dtype=torch.float32, device=device)
         self.opacity = torch.empty((P, 1), **f)
@@ -72,8 +73,9 @@ class FusedMapper:
         P, M = self.P, self.M
         with torch.cuda.device(self.device):
             stream = N.current_stream()
-            N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
-                                         N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), stream))
+            if not self._act_valid:  # later iterations get the activations from the previous Adam step
+                N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
+                                             N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), stream))
             ctx = _Ctx()
             out = dgr._RasterizeGaussians.forward(ctx, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations,
                                                   self._empty, self.tile_mask if tile_mask is None else tile_mask, self.settings)
@@ -99,6 +101,8 @@ class FusedMapper:
                                m_opacity=N.ptr(self.state["opacity"][0]), m_scaling=N.ptr(self.state["scaling"][0]),
                                m_rotation=N.ptr(self.state["rotation"][0]), v_xyz=N.ptr(self.state["xyz"][1]),
                                v_shs=N.ptr(self.state["shs"][1]), v_opacity=N.ptr(self.state["opacity"][1]),
-                               v_scaling=N.ptr(self.state["scaling"][1]), v_rotation=N.ptr(self.state["rotation"][1]))
+                               v_scaling=N.ptr(self.state["scaling"][1]), v_rotation=N.ptr(self.state["rotation"][1]),
+                               act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales), act_rotations=N.ptr(self.rotations))
             N.check(lib.dqo_map_adam_step(ctypes.byref(st), stream))
+            self._act_valid = True
         return out

@@ -222,6 +222,9 @@ typedef struct DqoAdamStep {
     const float *g_means3D, *g_sh, *g_opacity, *g_scales, *g_rotations;      /* dqo_rast_backward outputs (w.r.t. activated) */
     float *m_xyz, *m_shs, *m_opacity, *m_scaling, *m_rotation;               /* exp_avg, same shapes as the parameters */
     float *v_xyz, *v_shs, *v_opacity, *v_scaling, *v_rotation;               /* exp_avg_sq */
+    /* Optional (NULL = skip): the activated values of the UPDATED parameters, exactly what dqo_map_activate would
+     * compute from them — saves that launch in the next iteration. */
+    float *act_opacity, *act_scales, *act_rotations;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
 

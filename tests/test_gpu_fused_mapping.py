@@ -94,8 +94,13 @@ def test_activate_and_adam_kernels_vs_oracle(env):
                            rotation_raw=N.ptr(t["rot"]), g_means3D=N.ptr(tg["xyz"]), g_sh=N.ptr(tg["shs"]), g_opacity=N.ptr(tg["op"]),
                            g_scales=N.ptr(tg["sc"]), g_rotations=N.ptr(tg["rot"]), m_xyz=N.ptr(m["xyz"]), m_shs=N.ptr(m["shs"]),
                            m_opacity=N.ptr(m["op"]), m_scaling=N.ptr(m["sc"]), m_rotation=N.ptr(m["rot"]), v_xyz=N.ptr(v["xyz"]),
-                           v_shs=N.ptr(v["shs"]), v_opacity=N.ptr(v["op"]), v_scaling=N.ptr(v["sc"]), v_rotation=N.ptr(v["rot"]))
+                           v_shs=N.ptr(v["shs"]), v_opacity=N.ptr(v["op"]), v_scaling=N.ptr(v["sc"]), v_rotation=N.ptr(v["rot"]),
+                           act_opacity=N.ptr(opac), act_scales=N.ptr(scal), act_rotations=N.ptr(rots))
         N.check(lib.dqo_map_adam_step(ctypes.byref(st), N.current_stream()))
+        # the activations written by the Adam kernel are bit-identical to a separate activate launch on the updated values
+        o2, s2, r2 = torch.empty_like(opac), torch.empty_like(scal), torch.empty_like(rots)
+        N.check(lib.dqo_map_activate(P, N.ptr(t["op"]), N.ptr(t["sc"]), N.ptr(t["rot"]), N.ptr(o2), N.ptr(s2), N.ptr(r2), N.current_stream()))
+        assert torch.equal(o2, opac) and torch.equal(s2, scal) and torch.equal(r2, rots)
         rg_op, rg_sc, rg_rot = mo.raw_grads(op_["op"], op_["sc"], op_["rot"], g["op"], g["sc"], g["rot"])
         rawg = dict(xyz=g["xyz"].astype(np.float64), shs=g["shs"].astype(np.float64), op=rg_op, sc=rg_sc, rot=rg_rot)
         for k in raw:
