@@ -41,7 +41,7 @@ def parse():
                          "dropin: autograd through the drop-in op + torch.optim.Adam, exactly what unchanged DQO-MAP code runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-P", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-P", type=int, default=500_000)
     return ap.parse_args()
 
 
@@ -221,29 +221,33 @@ def main():
         stats["kernel_us"] = kernels
         dom = max(prof.items(), key=lambda kv: kv[1][0])
         dom_name, dom_ms = dom[0], dom[1][0] / max(dom[1][1], 1)
-        # instance count from a fresh exact forward
-        dgr.set_sync_mode("exact")
-        with torch.no_grad():
-            o2 = mapping.render(settings, params.activated())
-        dgr.set_sync_mode(args.sync_mode)
-        n_inst = dgr.last_num_rendered()
+        # workload counts of the current state from the device header of the last forward
+        hdr = dgr.last_header()
+        n_inst, n_cand = hdr["num_rendered"], hdr["num_candidates"]
         HWa = cam.W * cam.H
-        stats.update(N_instances=n_inst)
-        # algorithmic bytes per launch: what the kernel must move at minimum
+        stats.update(N_instances=n_inst, N_candidates=n_cand, max_tile_list=hdr["max_tile_count"])
+        # algorithmic bytes per launch (DESIGN.md "Kernels"): what the kernel must move at minimum, per unit
+        # (instance = (Gaussian, tile) list entry; Gaussian; pixel) x the units of this launch
         alg = {
-            "preprocess_kernel": 236 * n_vis + 12 * (P - n_vis) + 4 * P,             # read params of visible, xyz of culled; radii
-            "bin_emit_kernel": 12 * n_inst, "bin_count_kernel": 16 * n_inst,
-            "adam_kernel": 236 * 7 * P, "loss_grad_kernel": 52 * HWa, "loss_reduce_kernel": 36 * HWa,                                              # key + slot per instance
-            "tile_sort_kernel": 12 * n_inst + 8 * n_inst,                            # read key+slot, write id+slot
-            "blend_forward_kernel": 28 * n_inst + 36 * HWa,                          # id + xy + conic/opacity gather; 9 output planes
-            "blend_backward_kernel": 40 * n_inst + 16 * HWa,                         # + rgb gather; dL_dcolor + dL_ddepth
-            "gaussian_backward_kernel": 236 * 2 * n_vis,                             # re-read params, write grads
+            "preprocess_kernel": 236 * n_vis + 12 * (P - n_vis) + 8 * P + 88 * n_vis,   # params of visible, xyz of culled; radii, rect; 5 tables + rect
+            "bin_count_kernel": 40 * n_vis + 12 * n_inst,                                # rect + 2 tables per visible; (tile, rank, id) per instance
+            "bin_place_kernel": 24 * n_inst,                                             # info + id in, key + slot out
+            "tile_sort_wave_kernel": 20 * n_inst, "tile_sort_kernel": 20 * n_inst,       # key + slot in, id + slot out
+            "blend_forward_kernel": 40 * n_inst + 36 * HWa,                              # id + 2 records (+ rgb for survivors), live bytes; 9 output planes
+            "blend_backward_kernel": 120 * n_inst + 32 * HWa,                            # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
+            "record_sum_kernel": 68 * n_inst + 64 * n_vis,                               # gradient records in, one summed record per visible Gaussian out
+            "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * P,               # summed record, params, tables; all gradient rows written
+            "loss_reduce_kernel": 36 * HWa, "loss_grad_kernel": 52 * HWa,
+            "adam_kernel": 236 * 7 * P,                                                  # 59 floats x (param, grad, m, v in; param, m, v out)
         }
         bytes_dom = alg.get(dom_name, 0)
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, avg_launch_us=round(dom_ms * 1e3, 2),
-                        algorithmic_bytes=int(bytes_dom))
+                        algorithmic_bytes=int(bytes_dom),
+                        note="the blend kernels are VALU-issue bound, not HBM bound (profiles/README.md: SQ_INSTS_VALU x 4 cycles / "
+                             "(CUs x SIMDs) ~ kernel time); per-kernel GB/s of every kernel: config.kernel_gbs",
+                        kernel_gbs={k: round(alg[k] / (us * 1e-6) / 1e9, 1) for k, us in kernels.items() if k in alg and us > 0})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -138,6 +138,8 @@ struct DqoBinLayout {
     uint8_t* live_q;      // [4][cap] per (tile quadrant, sorted instance): 1 iff the forward acted on the instance in that quadrant
     uint2* slot_info;     // [cap] per gaussian-major slot: (tile, rank inside the tile's segment), bin_count -> bin_place
     uint32_t* slot_gid;   // [cap] per gaussian-major slot: Gaussian id
+    uint32_t* rec_valid;  // [cap] backward: byte q of word `slot` = 1 iff the partial gradient record (slot, quadrant q) was written;
+                          //       zeroed by bin_place_kernel (the forward), so the backward needs no memset
     size_t total;
 };
 
@@ -156,6 +158,7 @@ static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap) {
     L.live_q = (uint8_t*)take(4 * (size_t)cap);
     L.slot_info = (uint2*)take(8 * (size_t)cap);
     L.slot_gid = (uint32_t*)take(4 * (size_t)cap);
+    L.rec_valid = (uint32_t*)take(4 * (size_t)cap);
     L.total = (size_t)(p - (char*)base);
     return L;
 }
@@ -176,10 +179,10 @@ struct __attribute__((aligned(16))) DqoGradRec {
 };
 static_assert(sizeof(DqoGradRec) == 64, "record must be one 64-byte line");
 
-// backward workspace: [cap][4] partial records, one per (instance slot, tile quadrant), then [cap] validity words (byte q of
-// word `slot` = 1 iff partial record (slot, q) was written by this backward pass; zeroed by dqo_launch_backward).
+// backward workspace: [cap][4] partial gradient records, one per (instance slot, tile quadrant); which of them exist is
+// recorded in DqoBinLayout::rec_valid.
 static inline size_t dqo_bwd_recs_bytes(int64_t cap) { return dqo_align_up(sizeof(DqoGradRec) * 4 * (size_t)(cap < 0 ? 0 : cap), 256); }
-static inline size_t dqo_bwd_ws_bytes(int64_t cap) { return dqo_bwd_recs_bytes(cap) + dqo_align_up(4 * (size_t)(cap < 0 ? 0 : cap), 256) + 256; }
+static inline size_t dqo_bwd_ws_bytes(int64_t cap) { return dqo_bwd_recs_bytes(cap) + 256; }
 
 // Per-view constants.  Scalars travel by value (kernarg -> SGPRs); the matrices stay device pointers because the
 // reference API hands them over as device tensors (no host read, no sync) — kernels fetch them with scalar loads.

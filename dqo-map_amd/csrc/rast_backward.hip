@@ -415,8 +415,7 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     const int T = v.gx * v.gy;
     const int64_t cap = (int64_t)ctx->inst_capacity;
     DqoGradRec* recs = (DqoGradRec*)ws;
-    uint8_t* valid = (uint8_t*)ws + dqo_bwd_recs_bytes(cap);
-    if (cap > 0) DQO_CHECK_HIP(hipMemsetAsync(valid, 0, 4 * (size_t)cap, s));
+    uint8_t* valid = reinterpret_cast<uint8_t*>(bin.rec_valid);  // zeroed by the forward (bin_place_kernel)
     int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap, s);
     if (rc) return rc;
     DqoGradRec* sums = reinterpret_cast<DqoGradRec*>(g.grad_sum);  // [P], lives in the forward's geometry buffer

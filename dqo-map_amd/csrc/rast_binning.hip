@@ -223,9 +223,13 @@ __global__ __launch_bounds__(256) void bin_place_kernel(DqoGeomLayout g, DqoImag
     const uint32_t gid = bin.slot_gid[slot];
     const uint2 range = img.ranges[info.x];
     const uint32_t pos = range.x + info.y;
-    if (pos >= range.y) return;  // only when the forward overflowed its capacity (ranges are emptied then)
+    if (pos >= range.y) {  // only when the forward overflowed its capacity (ranges are emptied then)
+        bin.rec_valid[slot] = 0u;
+        return;
+    }
     bin.keys[pos] = ((uint64_t)__float_as_uint(g.xy_depth[gid].z) << 32) | gid;
     bin.slots[pos] = (uint32_t)slot;
+    bin.rec_valid[slot] = 0u;  // no partial gradient record of this slot exists yet (backward)
 }
 
 }  // namespace

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
                                                                 const float* __restrict__ colors_precomp,
                                                                 const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
                                                                 int32_t* __restrict__ radii_out,
-                                                                int32_t* __restrict__ n_touched_out) {
+                                                                int32_t* __restrict__ n_touched_out, uint32_t* __restrict__ zero_base,
+                                                                size_t zero_words) {
 #pragma clang fp contract(off)
     __shared__ uint32_t s_visible;
     const int tid = threadIdx.x;
@@ -74,6 +75,12 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
     const float cam0 = v.campos[0], cam1 = v.campos[1], cam2 = v.campos[2];
     __shared__ uint32_t s_cand;
     if (tid == 0) s_visible = 0, s_cand = 0;
+    // this launch also zeroes the tile histogram + tile flags for bin_count_kernel (one contiguous range, a slice per block)
+    {
+        const size_t per = (zero_words + gridDim.x - 1) / gridDim.x;
+        const size_t z0 = (size_t)blockIdx.x * per, z1 = min(zero_words, z0 + per);
+        for (size_t i = z0 + tid; i < z1; i += K1_THREADS) zero_base[i] = 0u;
+    }
     __syncthreads();
 
     uint32_t nvis = 0, ncand = 0;
@@ -511,12 +518,13 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     const int T = v.gx * v.gy;
     DQO_CHECK_HIP(hipMemsetAsync(g.header, 0, 512, s));  // header + counters
-    DQO_CHECK_HIP(hipMemsetAsync(img.tile_count, 0, (size_t)((char*)(img.tile_flag + T) - (char*)img.tile_count), s));
+    const size_t zero_words = (size_t)((img.tile_flag + T) - img.tile_count);  // histogram (padded) + flags
+    if (p->P <= 0) DQO_CHECK_HIP(hipMemsetAsync(img.tile_count, 0, 4 * zero_words, s));
     if (p->P > 0) {
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;
         DQO_LAUNCH("preprocess_kernel", preprocess_kernel, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
-                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched);
+                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words);
     }
     return DQO_OK;
 }

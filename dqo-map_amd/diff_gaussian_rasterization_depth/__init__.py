@@ -28,7 +28,17 @@ import _dqo_native as N
 _sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy": reuse / grow the previous capacity, no sync
 _cap_hint = {}
 _pending = []          # lazy mode: (event, pinned header tensor, key) of forwards not yet verified
-_last = {"num_rendered": None, "num_visible": None}
+_last = {"num_rendered": None, "num_visible": None, "geom": None}
+
+
+def last_header():
+    """Device header of the most recent forward (one small D2H read, synchronises): dict with num_rendered = instances kept in
+    the tile lists, num_candidates = the reference's num_rendered, num_tiles, max_tile_count, num_visible, overflow."""
+    g = _last["geom"]
+    if g is None:
+        return None
+    h = g[:32].view(torch.int32).cpu().tolist()
+    return dict(num_rendered=h[0], num_tiles=h[1], overflow=h[2], max_tile_count=h[3], num_visible=h[4], num_candidates=h[5])
 
 
 def last_num_rendered():
@@ -168,6 +178,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record()
                 _pending.append((ev, host, key, cap))
+        _last["geom"] = geomBuffer
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.inst_capacity = cap
