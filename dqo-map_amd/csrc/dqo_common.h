@@ -167,9 +167,12 @@ static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap) {
 // Gaussian in a fixed order by the per-Gaussian backward kernel: bitwise reproducible, no float atomics.
 struct __attribute__((aligned(16))) DqoGradRec {
     float dcolor[3];   // dL/d rgb
-    float dmean2D[2];  // dL/d pixel-space mean (already scaled by W/2, H/2)
-    float dconic[3];   // dL/d conic (xx, xy, yy)
-    float dopacity;
+    // pixel moments of q = G * dL/dalpha over the pixels that blended the instance; the opacity / conic / viewport factors that
+    // turn them into dL/d(2D mean), dL/d(conic), dL/d(opacity) (backward.cu:964-994) are per-Gaussian constants and are
+    // applied by gaussian_backward_kernel
+    float m1[2];       // sum q dx, sum q dy
+    float m2[3];       // sum q dx^2, sum q dx dy, sum q dy^2
+    float m0;          // sum q
     // depth-hit sums over the pixels whose depth this instance fixed (backward.cu:997-1065); the per-Gaussian factors of
     // that gradient (normal, camera-space point, view matrix, quaternion Jacobian) are applied once per Gaussian by
     // gaussian_backward_kernel:  hit[0] = sum dL/ddepth over pixels in the centre-depth branch,  hit[1] = sum of

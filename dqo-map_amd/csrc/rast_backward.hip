@@ -140,8 +140,12 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         return;
     }
     const float dcolr[3] = {a[0], a[1], a[2]};
-    const float g2x = a[3], g2y = a[4];
-    const float dcx = a[5], dcy = a[6], dcz = a[7];
+    // pixel moments of q = G * dL/dalpha summed by the blend kernel (DqoGradRec) -> gradients w.r.t. the 2D mean, the conic and
+    // the opacity (backward.cu:964-994): the per-Gaussian constants are applied here, once
+    const float4 cop = g.conic_opacity[idx];
+    const float g2x = -cop.w * (cop.x * a[3] + cop.y * a[4]) * (0.5f * v.W);
+    const float g2y = -cop.w * (cop.z * a[4] + cop.y * a[3]) * (0.5f * v.H);
+    const float dcx = -0.5f * cop.w * a[5], dcy = -0.5f * cop.w * a[6], dcz = -0.5f * cop.w * a[7];
     float mean_g[3] = {0.f, 0.f, 0.f};
     float rot_g[4] = {0.f, 0.f, 0.f, 0.f};
     gr.dL_dopacity[idx] = a[8];

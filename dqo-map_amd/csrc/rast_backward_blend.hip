@@ -119,7 +119,6 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     // colour blended behind the current entry (the reference's accum_rec after folding in last_alpha / last_color,
     // backward.cu:957-962, evaluated one step earlier: same operands, same rounding)
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
-    const float ddelx_dx = 0.5f * v.W, ddely_dy = 0.5f * v.H;
     const uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;
 
     const int chunks = (L + BWD_THREADS - 1) / BWD_THREADS;
@@ -173,17 +172,19 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
             S0 = alpha * cs.x + (1.f - alpha) * S0;
             S1 = alpha * cs.y + (1.f - alpha) * S1;
             S2 = alpha * cs.z + (1.f - alpha) * S2;
-            const float dL_dG = co.w * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
+            // Everything downstream of dL/dalpha * G is linear in per-Gaussian constants (opacity, conic, W/2, H/2): the
+            // wave only sums the pixel moments of q = G * dL/dalpha — q, q dx, q dy, q dx^2, q dx dy, q dy^2 — and
+            // gaussian_backward_kernel applies those constants once per Gaussian (backward.cu:964-994 does it per pair).
+            const float q = G * dL_dalpha;
+            const float qx = q * dx, qy = q * dy;
             const float r_c0 = dchannel_dcolor * dp0;
             const float r_c1 = dchannel_dcolor * dp1;
             const float r_c2 = dchannel_dcolor * dp2;
-            const float r_mx = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
-            const float r_my = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
-            const float r_ka = -0.5f * gdx * dx * dL_dG;
-            const float r_kb = -0.5f * gdx * dy * dL_dG;
-            const float r_kc = -0.5f * gdy * dy * dL_dG;
-            const float r_op = G * dL_dalpha;
+            const float r_mx = qx, r_my = qy;
+            const float r_ka = qx * dx;
+            const float r_kb = qx * dy;
+            const float r_kc = qy * dy;
+            const float r_op = q;
 
             const bool is_hit = (hit_pos == c0 + 1);
             const bool any_hit = __builtin_amdgcn_ballot_w64(is_hit) != 0ull;
