@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float a[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) a[i] = 0.f;
+    float4 cop = make_float4(0.f, 0.f, 0.f, 0.f);  // (conic, opacity) of the forward
     if (in_range && g.tiles_touched[idx] != 0u) {
+        cop = g.conic_opacity[idx];
         const float4* r = reinterpret_cast<const float4*>(recs) + (size_t)idx * 4;
         const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
         a[0] = r0.x, a[1] = r0.y, a[2] = r0.z, a[3] = r0.w;
@@ -142,7 +144,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     const float dcolr[3] = {a[0], a[1], a[2]};
     // pixel moments of q = G * dL/dalpha summed by the blend kernel (DqoGradRec) -> gradients w.r.t. the 2D mean, the conic and
     // the opacity (backward.cu:964-994): the per-Gaussian constants are applied here, once
-    const float4 cop = g.conic_opacity[idx];
     const float g2x = -cop.w * (cop.x * a[3] + cop.y * a[4]) * (0.5f * v.W);
     const float g2y = -cop.w * (cop.z * a[4] + cop.y * a[3]) * (0.5f * v.H);
     const float dcx = -0.5f * cop.w * a[5], dcy = -0.5f * cop.w * a[6], dcz = -0.5f * cop.w * a[7];

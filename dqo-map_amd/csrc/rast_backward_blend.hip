@@ -195,7 +195,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
             if (any_hit) {
                 // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth).
                 // Only the pixel-dependent factors are summed here; see DqoGradRec::hit.
-                const float4 n_np = g.normal_c[s_id[k]];
+                const float4 n_np = g.normal_c[__builtin_amdgcn_readfirstlane(s_id[k])];
                 float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
                 {
 #pragma clang fp contract(off)
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                 toth = wave_reduce8(hv, lane);
             }
             // lanes 0..15 hold the 16 floats of the record: one 64-byte store per live (quadrant, instance) pair
-            const uint32_t slot = s_slot[k];
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[k]);  // wave-uniform: scalar address arithmetic
             if ((int64_t)slot < capacity) {
                 if (lane < 16) recs[((size_t)slot * 4 + quad) * 16 + lane] = lane < 8 ? tot : (lane == 8 ? top : toth);
                 if (lane == 16) valid[(size_t)slot * 4 + quad] = (uint8_t)1;

@@ -187,9 +187,11 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                     end_T = blend ? test_T : end_T;
                     T = (valid && !finish) ? test_T : T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
                     done = done || finish;
-                    const bool is_live = __builtin_amdgcn_ballot_w64(blend || newhit) != 0ull;
+                    // live for the backward: some pixel of the quadrant saw the entry with alpha >= 1/255 while unfinished — a
+                    // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
+                    // below T_threshold), so the backward never misses a pair it has work for
                     const int half = (int)__popcll(__builtin_amdgcn_ballot_w64(blend && test_T > 0.5f));
-                    live_k = lane == k ? (is_live ? 1 : 0) : live_k;
+                    live_k = lane == k ? 1 : live_k;
                     half_k = lane == k ? half : half_k;
                     if (__builtin_amdgcn_ballot_w64(finish) != 0ull) all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
                 }
