@@ -57,12 +57,16 @@ __global__ __launch_bounds__(256) void record_sum_kernel(int P, DqoGeomLayout g,
             float4 m0 = z, m1 = z, m2 = z, m3 = z;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if ((vw >> (8 * q)) & 0xffu) {
+                const uint32_t bq = (vw >> (8 * q)) & 0xffu;  // 1: floats 0..8 written, 3: depth-hit floats 9..13 as well
+                if (bq) {
                     const float4 r0 = p[4 * q], r1 = p[4 * q + 1], r2 = p[4 * q + 2], r3 = p[4 * q + 3];
                     m0.x += r0.x, m0.y += r0.y, m0.z += r0.z, m0.w += r0.w;
                     m1.x += r1.x, m1.y += r1.y, m1.z += r1.z, m1.w += r1.w;
-                    m2.x += r2.x, m2.y += r2.y, m2.z += r2.z, m2.w += r2.w;
-                    m3.x += r3.x, m3.y += r3.y, m3.z += r3.z, m3.w += r3.w;
+                    m2.x += r2.x;
+                    if (bq & 2u) {
+                        m2.y += r2.y, m2.z += r2.z, m2.w += r2.w;
+                        m3.x += r3.x, m3.y += r3.y;
+                    }
                 }
             }
             s_rec[tid * 4] = m0, s_rec[tid * 4 + 1] = m1, s_rec[tid * 4 + 2] = m2, s_rec[tid * 4 + 3] = m3;

@@ -65,6 +65,58 @@ __device__ __forceinline__ float wave_reduce8(const float (&v)[8], int lane) {
     return y;
 }
 
+// Reduce-scatter butterfly for SIXTY-FOUR values at once: afterwards lane l holds the 64-lane total of v[l].  Stage order
+// = cheapest exchanges first, while the value count per lane is still high:
+//   lane ^ 32, lane ^ 16 : v_permlane32_swap / v_permlane16_swap (gfx950) — the swap itself routes the two halves, so a pair
+//                          costs one swap + one add, no select
+//   lane ^ 8,  lane ^ 4  : DPP row_ror:8 / row_shl:4 | row_shr:4, the two lane classes are whole DPP banks (bank_mask)
+//   lane ^ 2,  lane ^ 1  : DPP quad_perm with explicit selects
+// 141 VALU for 64 sums (2.2 per sum; eight separate DPP reductions of one value each would cost ~11 per sum).
+typedef unsigned dqo_uint2v __attribute__((ext_vector_type(2)));
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_pick(float old, float v) {  // lanes of the enabled banks read v through CTRL, the others keep old
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_reduce64(const float (&v)[64], int lane) {
+    float a[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {  // lanes 0..31 end up with the sum of v[i], lanes 32..63 with that of v[i + 32]
+        const dqo_uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+        a[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    float b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {  // rows 0, 2 (lane bit 4 clear): a[i];  rows 1, 3: a[i + 16]
+        const dqo_uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 16]), false, false);
+        b[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {  // lane bit 3 = DPP banks 2, 3 of every row; partner = row_ror:8
+        const float mine = dpp_pick<0xE4, 0xC>(b[i], b[i + 8]);          // quad_perm [0,1,2,3] = identity: banks 2,3 take b[i+8]
+        float other = dpp_pick<0x128, 0x3>(0.f, b[i]);                    // banks 0,1 read the partner's b[i]
+        other = dpp_pick<0x128, 0xC>(other, b[i + 8]);                    // banks 2,3 read the partner's b[i+8]
+        c[i] = mine + other;
+    }
+    float d[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // lane bit 2 = odd DPP banks; partner = lane + 4 (row_shl:4) / lane - 4 (row_shr:4)
+        const float mine = dpp_pick<0xE4, 0xA>(c[i], c[i + 4]);
+        float other = dpp_pick<0x104, 0x5>(0.f, c[i]);
+        other = dpp_pick<0x114, 0xA>(other, c[i + 4]);
+        d[i] = mine + other;
+    }
+    const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    float e[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float keep = b1 ? d[i + 2] : d[i], send = b1 ? d[i] : d[i + 2];
+        e[i] = keep + dpp_mov<0x4E>(send);  // partner lane ^ 2
+    }
+    const float keep = b0 ? e[1] : e[0], send = b0 ? e[0] : e[1];
+    return keep + dpp_mov<0xB1>(send);  // partner lane ^ 1
+}
+
 __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
 #pragma clang fp contract(off)
     float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
@@ -73,6 +125,7 @@ __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx
 }
 
 constexpr int BWD_THREADS = 64;
+constexpr int BWD_NB = 7;  // live entries per reduction batch: 7 x 9 = 63 of the butterfly's 64 values
 
 __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                      DqoBinLayout bin, const float* __restrict__ scales,
@@ -119,6 +172,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     // colour blended behind the current entry (the reference's accum_rec after folding in last_alpha / last_color,
     // backward.cu:957-962, evaluated one step earlier: same operands, same rounding)
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
+    const int lane_b = lane / 9, lane_f = lane - 9 * lane_b;  // this lane's (entry of the batch, record float) after the butterfly
     const uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;
 
     const int chunks = (L + BWD_THREADS - 1) / BWD_THREADS;
@@ -145,81 +199,93 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
             s_xy[myk] = g.xy_depth[id];
             s_rgb[myk] = g.rgb_smax[id];
         }
-        float4 co_nx = s_co[0], xy_nx = s_xy[0], cs_nx = s_rgb[0];
-        for (int k = 0; k < cnt; k++) {
-            const float4 co = co_nx, xy = xy_nx, cs = cs_nx;
-            if (k + 1 < cnt) {
-                co_nx = s_co[k + 1];
-                xy_nx = s_xy[k + 1];
-                cs_nx = s_rgb[k + 1];
-            }
-            const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
-            // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
-            // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T and
-            // 0 * c + 1 * S = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
-            const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            const float Gx = dqo_gauss(power);
-            const float alpha_x = fminf(0.99f, co.w * Gx);
-            const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f;
-            const float alpha = did_color ? alpha_x : 0.f;
-            const float G = did_color ? Gx : 0.f;
-            const float inv_1ma = dqo_rcp(1.f - alpha);
-            T = T * inv_1ma;  // T / (1 - alpha), backward.cu:948
-            float dL_dalpha = ((cs.x - S0) * dp0 + (cs.y - S1) * dp1 + (cs.z - S2) * dp2) * T;
-            dL_dalpha += (-T_final * inv_1ma) * bgdot;  // end_T, not the running T (quirk B2)
-            const float dchannel_dcolor = alpha * T;
-            S0 = alpha * cs.x + (1.f - alpha) * S0;
-            S1 = alpha * cs.y + (1.f - alpha) * S1;
-            S2 = alpha * cs.z + (1.f - alpha) * S2;
-            // Everything downstream of dL/dalpha * G is linear in per-Gaussian constants (opacity, conic, W/2, H/2): the
-            // wave only sums the pixel moments of q = G * dL/dalpha — q, q dx, q dy, q dx^2, q dx dy, q dy^2 — and
-            // gaussian_backward_kernel applies those constants once per Gaussian (backward.cu:964-994 does it per pair).
-            const float q = G * dL_dalpha;
-            const float qx = q * dx, qy = q * dy;
-            const float r_c0 = dchannel_dcolor * dp0;
-            const float r_c1 = dchannel_dcolor * dp1;
-            const float r_c2 = dchannel_dcolor * dp2;
-            const float r_mx = qx, r_my = qy;
-            const float r_ka = qx * dx;
-            const float r_kb = qx * dy;
-            const float r_kc = qy * dy;
-            const float r_op = q;
+        // The live entries of the chunk are processed BWD_NB at a time: their 9 colour-path sums each (63 values) go through
+        // ONE 64-value reduce-scatter butterfly, after which lane l = 9 b + f holds float f of entry b's record.
+        for (int k0 = 0; k0 < cnt; k0 += BWD_NB) {
+            float v64[64];
+            v64[63] = 0.f;
+            uint32_t hitmask = 0u;  // entries of this batch that also carry depth-hit sums (wave-uniform)
+#pragma unroll
+            for (int b = 0; b < BWD_NB; b++) {
+                const int k = k0 + b;
+                float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
+                if (k < cnt) {  // wave-uniform
+                    const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
+                    const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
+                    // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
+                    // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
+                    // and 0 * c + 1 * S = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
+                    const float dx = xy.x - pixfx, dy = xy.y - pixfy;
+                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    const float Gx = dqo_gauss(power);
+                    const float alpha_x = fminf(0.99f, co.w * Gx);
+                    const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f;
+                    const float alpha = did_color ? alpha_x : 0.f;
+                    const float G = did_color ? Gx : 0.f;
+                    const float inv_1ma = dqo_rcp(1.f - alpha);
+                    T = T * inv_1ma;  // T / (1 - alpha), backward.cu:948
+                    float dL_dalpha = ((cs.x - S0) * dp0 + (cs.y - S1) * dp1 + (cs.z - S2) * dp2) * T;
+                    dL_dalpha += (-T_final * inv_1ma) * bgdot;  // end_T, not the running T (quirk B2)
+                    const float dchannel_dcolor = alpha * T;
+                    S0 = alpha * cs.x + (1.f - alpha) * S0;
+                    S1 = alpha * cs.y + (1.f - alpha) * S1;
+                    S2 = alpha * cs.z + (1.f - alpha) * S2;
+                    // Everything downstream of dL/dalpha * G is linear in per-Gaussian constants (opacity, conic, W/2, H/2):
+                    // the wave only sums the pixel moments of q = G * dL/dalpha — q, q dx, q dy, q dx^2, q dx dy, q dy^2 — and
+                    // gaussian_backward_kernel applies those constants once per Gaussian (backward.cu:964-994 does it per pair).
+                    const float q = G * dL_dalpha;
+                    const float qx = q * dx, qy = q * dy;
+                    r_c0 = dchannel_dcolor * dp0;
+                    r_c1 = dchannel_dcolor * dp1;
+                    r_c2 = dchannel_dcolor * dp2;
+                    r_mx = qx, r_my = qy;
+                    r_ka = qx * dx;
+                    r_kb = qx * dy;
+                    r_kc = qy * dy;
+                    r_op = q;
 
-            const bool is_hit = (hit_pos == c0 + 1);
-            const bool any_hit = __builtin_amdgcn_ballot_w64(is_hit) != 0ull;
-            const float cv[8] = {r_c0, r_c1, r_c2, r_mx, r_my, r_ka, r_kb, r_kc};
-            const float tot = wave_reduce8(cv, lane);  // lane l: wave total of cv[l & 7]   -> record floats 0..7
-            const float top = wave_sum(r_op);           //                                    -> record float 8 (dopacity)
-            float toth = 0.f;                           // lane 9 + i: total of hit sum i    -> record floats 9..13
-            if (any_hit) {
-                // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its depth).
-                // Only the pixel-dependent factors are summed here; see DqoGradRec::hit.
-                const float4 n_np = g.normal_c[__builtin_amdgcn_readfirstlane(s_id[k])];
-                float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
-                {
+                    const bool is_hit = (hit_pos == c0 + 1);
+                    if (__builtin_amdgcn_ballot_w64(is_hit) != 0ull) {
+                        // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its
+                        // depth).  Only the pixel-dependent factors are summed here; see DqoGradRec::hit.
+                        const float4 n_np = g.normal_c[__builtin_amdgcn_readfirstlane(s_id[k])];
+                        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+                        {
 #pragma clang fp contract(off)
-                    const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
-                    const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
-                    const float inv_nr = 1.f / nr;
-                    const float u = ddep * ray.z * inv_nr;
-                    const float w = u * inv_nr;
-                    const bool plane = is_hit && hit_plane;
-                    h0 = (is_hit && !hit_plane) ? ddep : 0.f;
-                    h1 = plane ? u : 0.f;
-                    h2 = plane ? w * ray.x : 0.f;
-                    h3 = plane ? w * ray.y : 0.f;
-                    h4 = plane ? w * ray.z : 0.f;
+                            const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
+                            const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
+                            const float inv_nr = 1.f / nr;
+                            const float u = ddep * ray.z * inv_nr;
+                            const float w = u * inv_nr;
+                            const bool plane = is_hit && hit_plane;
+                            h0 = (is_hit && !hit_plane) ? ddep : 0.f;
+                            h1 = plane ? u : 0.f;
+                            h2 = plane ? w * ray.x : 0.f;
+                            h3 = plane ? w * ray.y : 0.f;
+                            h4 = plane ? w * ray.z : 0.f;
+                        }
+                        // rotated by one so that lane 9 + i receives hit sum i (lane l gets the total of hv[l & 7])
+                        const float hv[8] = {0.f, h0, h1, h2, h3, h4, 0.f, 0.f};
+                        const float toth = wave_reduce8(hv, lane);
+                        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[k]);
+                        if (lane >= 9 && lane < 14 && (int64_t)slot < capacity) recs[((size_t)slot * 4 + quad) * 16 + lane] = toth;
+                        hitmask |= 1u << b;
+                    }
                 }
-                // rotated by one so that lane 9 + i receives hit sum i (lane l gets the total of hv[l & 7])
-                const float hv[8] = {0.f, h0, h1, h2, h3, h4, 0.f, 0.f};
-                toth = wave_reduce8(hv, lane);
+                v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
+                v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;
             }
-            // lanes 0..15 hold the 16 floats of the record: one 64-byte store per live (quadrant, instance) pair
-            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[k]);  // wave-uniform: scalar address arithmetic
-            if ((int64_t)slot < capacity) {
-                if (lane < 16) recs[((size_t)slot * 4 + quad) * 16 + lane] = lane < 8 ? tot : (lane == 8 ? top : toth);
-                if (lane == 16) valid[(size_t)slot * 4 + quad] = (uint8_t)1;
+            const float tot = wave_reduce64(v64, lane);
+            // lane 9 b + f stores float f (0..8) of entry b's 64-byte partial record; lanes 0..6 mark the records valid
+            // (1 = colour-path floats, 3 = depth-hit floats 9..13 present as well)
+            const int kb = k0 + lane_b;
+            if (lane < 9 * BWD_NB && kb < cnt) {
+                const uint32_t slot = s_slot[kb];
+                if ((int64_t)slot < capacity) recs[((size_t)slot * 4 + quad) * 16 + lane_f] = tot;
+            }
+            if (lane < BWD_NB && k0 + lane < cnt) {
+                const uint32_t slot = s_slot[k0 + lane];
+                if ((int64_t)slot < capacity) valid[(size_t)slot * 4 + quad] = ((hitmask >> lane) & 1u) ? (uint8_t)3 : (uint8_t)1;
             }
         }
     }
