@@ -160,15 +160,17 @@ DQO_API int dqo_rast_forward_prepare(const DqoRastParams* p, const DqoRastInputs
 
 DQO_API int dqo_rast_read_header(const DqoRastCtx* ctx, DqoRastHeader* host_out, void* stream) {
     DQO_CHECK_ARG(ctx && ctx->geom && host_out, "null ctx / out");
-    uint32_t buf[128];
+    static thread_local uint32_t buf[128 + 64 * DQO_SPREAD];  // header | counters | spread statistics counters
     DQO_CHECK_HIP(hipMemcpyAsync(buf, ctx->geom, sizeof(buf), hipMemcpyDeviceToHost, (hipStream_t)stream));
     DQO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     memcpy(host_out, buf, sizeof(DqoRastHeader));
     const uint32_t* counters = buf + 64;  // second 256-byte slot of the geom buffer
     // after `prepare` only the counters are valid; `render` fills the header proper
     host_out->num_rendered = counters[0];
-    host_out->num_visible = counters[1];
-    host_out->num_candidates = counters[3];
+    uint32_t nv = 0, nc = 0;
+    for (int j = 0; j < DQO_SPREAD; j++) nv += buf[128 + 64 * j], nc += buf[128 + 64 * j + 1];
+    host_out->num_visible = nv;
+    host_out->num_candidates = nc;
     return host_out->overflow ? DQO_ERR_OVERFLOW : DQO_OK;
 }
 

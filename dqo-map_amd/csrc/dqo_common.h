@@ -7,6 +7,7 @@
 
 #define DQO_TILE 16  // reference BLOCK_X = BLOCK_Y = 16 (cuda_rasterizer/config.h:15-16); part of the op's semantics
 #define DQO_WAVE 64
+#define DQO_SPREAD 64  // lines the per-block statistics atomics of K1 are spread over
 // The per-tile atomic counters (histogram, emit cursors) are spread one per DQO_TSTRIDE words: device-scope atomics execute
 // memory-side on MI355X, and counters sharing a line / channel serialise there.
 #ifndef DQO_TSTRIDE
@@ -50,7 +51,9 @@ void dqo_profile_after(hipStream_t s);
 // geom buffer: header + per-Gaussian SoA tables, every table 256-B aligned.
 struct DqoGeomLayout {
     DqoRastHeader* header;   // 256 B reserved
-    uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator), [1] visible count, [2] max tile count
+    uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator)
+    uint32_t* spread;        // [DQO_SPREAD][64] statistics counters spread over DQO_SPREAD lines (same-address atomics serialise
+                             //       memory-side): word 0 = visible Gaussians, word 1 = (Gaussian, tile) pairs in the tile rects
     float4* conic_opacity;   // [P] (conic.x, conic.y, conic.z, opacity)           forward.cu:343
     float4* xy_depth;        // [P] (pix.x, pix.y, depth = p_view.z, bits(radius))  forward.cu:339-341
     float4* rgb_smax;        // [P] (r, g, b, max(scale)*scale_mod)                 forward.cu:333-335, 73
@@ -75,6 +78,7 @@ static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
     };
     L.header = (DqoRastHeader*)take(256);
     L.counters = (uint32_t*)take(256);
+    L.spread = (uint32_t*)take(256 * DQO_SPREAD);
     L.conic_opacity = (float4*)take(sizeof(float4) * P);
     L.xy_depth = (float4*)take(sizeof(float4) * P);
     L.rgb_smax = (float4*)take(sizeof(float4) * P);

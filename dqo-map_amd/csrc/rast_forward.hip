@@ -29,7 +29,7 @@ struct PreOut {
 };
 
 constexpr int K1_THREADS = 256;
-constexpr int K1_ITEMS = 4;
+constexpr int K1_ITEMS = 1;
 
 __device__ __forceinline__ void quat_to_R(const float4 q, float Rm[3][3]) {
 #pragma clang fp contract(off)
@@ -55,7 +55,7 @@ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315
 __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
 
-__global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v, const float* __restrict__ means3D,
+__global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView v, const float* __restrict__ means3D,
                                                                 const float* __restrict__ scales,
                                                                 const float* __restrict__ rotations,
                                                                 const float* __restrict__ opacities,
@@ -225,8 +225,9 @@ __global__ __launch_bounds__(K1_THREADS) void preprocess_kernel(const DqoView v,
     if (nvis) atomicAdd(&s_visible, nvis);
     if (ncand) atomicAdd(&s_cand, ncand);
     __syncthreads();
-    if (tid == 0 && s_visible) atomicAdd(&g.counters[1], s_visible);
-    if (tid == 0 && s_cand) atomicAdd(&g.counters[3], s_cand);
+    uint32_t* const my_line = g.spread + (size_t)(blockIdx.x % DQO_SPREAD) * 64;
+    if (tid == 0 && s_visible) atomicAdd(&my_line[0], s_visible);
+    if (tid == 0 && s_cand) atomicAdd(&my_line[1], s_cand);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -241,10 +242,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
     __shared__ uint32_t s_part[SCAN_THREADS / 64];
     __shared__ uint32_t s_carry, s_max;
     __shared__ uint32_t s_bucket[LPT_BUCKETS + 1];
+    __shared__ uint32_t s_stat[2];
     __shared__ uint32_t s_tc[SCAN_CACHE];
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id(), wave = tid >> 6;
     if (tid == 0) s_carry = 0, s_max = 0;
+    if (tid < 64) {  // totals of K1's spread statistics counters
+        uint32_t nv = 0, nc = 0;
+        for (int j = tid; j < DQO_SPREAD; j += 64) nv += g.spread[(size_t)j * 64], nc += g.spread[(size_t)j * 64 + 1];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor((int)nv, off), nc += __shfl_xor((int)nc, off);
+        if (tid == 0) s_stat[0] = nv, s_stat[1] = nc;
+    }
     const bool overflow = (int64_t)g.counters[0] > capacity;  // instance total of bin_count_kernel
     // the padded histogram is read from HBM once; the passes below work on an LDS copy (images up to ~2M pixels)
     const bool cached = T <= SCAN_CACHE;
@@ -316,8 +325,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         h.num_tiles = (uint32_t)T - n_empty;
         h.overflow = ((int64_t)s_carry > capacity) ? 1u : 0u;
         h.max_tile_count = s_max;
-        h.num_visible = g.counters[1];
-        h.num_candidates = g.counters[3];
+        h.num_visible = s_stat[0];
+        h.num_candidates = s_stat[1];
         h.reserved[0] = h.reserved[1] = 0;
         *g.header = h;
     }
@@ -517,7 +526,7 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     const int T = v.gx * v.gy;
-    DQO_CHECK_HIP(hipMemsetAsync(g.header, 0, 512, s));  // header + counters
+    DQO_CHECK_HIP(hipMemsetAsync(g.header, 0, 512 + 256 * DQO_SPREAD, s));  // header + counters + spread statistics counters
     const size_t zero_words = (size_t)((img.tile_flag + T) - img.tile_count);  // histogram (padded) + flags
     if (p->P <= 0) DQO_CHECK_HIP(hipMemsetAsync(img.tile_count, 0, 4 * zero_words, s));
     if (p->P > 0) {
