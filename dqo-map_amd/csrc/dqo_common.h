@@ -102,7 +102,7 @@ struct DqoImageLayout {
     uint2* ranges;          // [T] [start, end) into the sorted list (rasterizer_impl.cu:120-142)
     uint32_t* walk4;        // [4T] per (tile, 8x8 quadrant): entries the backward must walk = max over the quadrant's pixels of
                             //      max(n_contrib, hit position)
-    uint32_t* tile_order;   // [T] tile ids, active tiles first (row-major), rasterizer_impl.cu:353-365
+    uint32_t* tile_order;   // [8][ceil(T/8)] tile ids per XCD group (block b serves group b % 8), longest list first; ~0 = unused
     float* final_T;         // [HW] end_T  (forward.cu:849)
     uint32_t* n_contrib;    // [HW] last contributor, 1-based (forward.cu:850)
     uint32_t* hit_pos;      // [HW] bits 0..30: 1-based list position of the Gaussian that fixed the depth, 0 if none;
@@ -125,7 +125,7 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
     L.tile_cursor = (uint32_t*)take(4 * T * DQO_TSTRIDE);
     L.ranges = (uint2*)take(8 * T);
     L.walk4 = (uint32_t*)take(16 * T);
-    L.tile_order = (uint32_t*)take(4 * T);
+    L.tile_order = (uint32_t*)take(4 * 8 * ((T + 7) / 8));
     L.final_T = (float*)take(4 * HW);
     L.n_contrib = (uint32_t*)take(4 * HW);
     L.hit_pos = (uint32_t*)take(4 * HW);

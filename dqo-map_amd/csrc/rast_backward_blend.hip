@@ -141,8 +141,12 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     __shared__ uint32_t s_slot[BWD_THREADS];
     __shared__ int s_pos[BWD_THREADS];
 
-    const int tile = img.tile_order[blockIdx.x >> 2];
-    const int quad = blockIdx.x & 3;
+    // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
+    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
+    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
+    if (tile_u == 0xffffffffu) return;  // unused slot
+    const int tile = (int)tile_u;
+    const int quad = jg & 3;
     const uint2 range = img.ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n == 0) return;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
                               DqoGradRec* recs, uint8_t* valid, int64_t capacity, hipStream_t s) {
-    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(T * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
+    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
                dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity);
     return DQO_OK;
 }

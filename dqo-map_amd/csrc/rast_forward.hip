@@ -241,9 +241,11 @@ constexpr int SCAN_CACHE = 8192;
 __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImageLayout img, DqoGeomLayout g, int64_t capacity) {
     __shared__ uint32_t s_part[SCAN_THREADS / 64];
     __shared__ uint32_t s_carry, s_max;
-    __shared__ uint32_t s_bucket[LPT_BUCKETS + 1];
+    __shared__ uint32_t s_bucket[8 * (LPT_BUCKETS + 1)];
+    __shared__ uint32_t s_seg_start[8], s_seg_len[8], s_free_pre[8], s_over_pre[8], s_n_empty;
     __shared__ uint32_t s_stat[2];
     __shared__ uint32_t s_tc[SCAN_CACHE];
+    __shared__ uint32_t s_st[SCAN_CACHE];  // exclusive prefix of the list lengths
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id(), wave = tid >> 6;
     if (tid == 0) s_carry = 0, s_max = 0;
@@ -284,41 +286,97 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
             // frame is invalid and flagged as such in the header; nothing indexes past a buffer).
             const bool keep = c != 0u && !overflow;
             img.ranges[t] = make_uint2(keep ? start : 0u, keep ? start + c : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
+            if (cached) s_st[t] = start;
+            else img.tile_cursor[(size_t)t * DQO_TSTRIDE] = start;
         }
         __syncthreads();
         if (tid == SCAN_THREADS - 1) s_carry = start + c;
     }
     if (local_max) atomicMax(&s_max, local_max);
-    for (int i = tid; i <= LPT_BUCKETS; i += SCAN_THREADS) s_bucket[i] = 0;
+    // ---- launch order of the per-tile kernels (tile_order): XCD-affine and longest-processing-time-first ----
+    // Blocks b and b + 8 share an XCD and its 4 MB L2 (MI355X_MICROARCH.md, workgroup dispatch).  The tiles are cut, in
+    // row-major order, into 8 bands of equal total list length (equal blend work); band x goes to the blocks with
+    // b % 8 == x, so the Gaussian records an XCD gathers belong to one image band (~1/8 of the visible Gaussians: fits its L2)
+    // instead of the whole frame.  Inside a band: descending list length (256 levels, LDS counting sort; empty tiles — they
+    // still get blocks, which write the reference's initial fills — last).  tile_order is [8][T8]; a band with more than T8
+    // tiles hands its smallest ones to the free slots of shorter bands.  Only the block -> tile mapping depends on any of
+    // this, no result does.
+    constexpr int NSEG = 8, SEGB = LPT_BUCKETS + 1;
+    const int T8 = (T + NSEG - 1) / NSEG;
+    for (int i = tid; i < NSEG * SEGB; i += SCAN_THREADS) s_bucket[i] = 0;
+    for (int i = tid; i < NSEG * T8; i += SCAN_THREADS) img.tile_order[i] = 0xffffffffu;
     __syncthreads();
-    // ---- launch order of the blend kernels (tile_order): longest-processing-time-first.  Tiles are bucketed by list length
-    // (256 levels, descending; empty tiles — they still get blocks, which write the reference's initial fills — in a last
-    // bucket of their own) with an LDS counting sort.  Only the blockIdx -> tile mapping depends on it, no result does. ----
-    const uint32_t mx = s_max;
+    const uint32_t mx = s_max, total = s_carry;
     int shift = 0;
     while ((mx >> shift) >= (uint32_t)LPT_BUCKETS) shift++;
-    auto bucket_of = [&](uint32_t c) { return c ? LPT_BUCKETS - 1 - (int)(c >> shift) : LPT_BUCKETS; };
-    for (int t = tid; t < T; t += SCAN_THREADS) atomicAdd(&s_bucket[bucket_of(tcount(t))], 1u);
+    auto key_of = [&](int t) {
+        const uint32_t c = tcount(t);
+        // band from the exclusive prefix of the list lengths; row-major position for frames without instances
+        const uint64_t pos = total ? (uint64_t)(cached ? s_st[t] : img.tile_cursor[(size_t)t * DQO_TSTRIDE]) : (uint64_t)t;
+        const uint64_t den = total ? (uint64_t)total : (uint64_t)T;
+        const int seg = (int)min((uint64_t)(NSEG - 1), pos * NSEG / den);
+        return seg * SEGB + (c ? LPT_BUCKETS - 1 - (int)(c >> shift) : LPT_BUCKETS);
+    };
+    for (int t = tid; t < T; t += SCAN_THREADS) atomicAdd(&s_bucket[key_of(t)], 1u);
     __syncthreads();
-    const uint32_t n_empty = s_bucket[LPT_BUCKETS];
-    __syncthreads();
-    if (tid < 64) {  // exclusive scan of the bucket sizes by one wave (4 buckets per lane, the empty-tile bucket last)
-        uint32_t v4[LPT_BUCKETS / 64], sum = 0;
+    {  // exclusive scan of the NSEG * SEGB bucket sizes by the whole block (3 consecutive buckets per thread)
+        constexpr int PER = (NSEG * SEGB + SCAN_THREADS - 1) / SCAN_THREADS;
+        uint32_t cnt[PER], sum = 0;
 #pragma unroll
-        for (int k = 0; k < LPT_BUCKETS / 64; k++) v4[k] = s_bucket[tid * (LPT_BUCKETS / 64) + k], sum += v4[k];
+        for (int k = 0; k < PER; k++) {
+            const int i = tid * PER + k;
+            cnt[k] = i < NSEG * SEGB ? s_bucket[i] : 0u;
+            sum += cnt[k];
+        }
         uint32_t incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off);
-            if (tid >= off) incl += o;
+            if (lane >= (uint32_t)off) incl += o;
         }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
         uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wave; w++) run += s_part[w];
 #pragma unroll
-        for (int k = 0; k < LPT_BUCKETS / 64; k++) s_bucket[tid * (LPT_BUCKETS / 64) + k] = run, run += v4[k];
-        if (tid == 63) s_bucket[LPT_BUCKETS] = run;  // = number of non-empty tiles
+        for (int k = 0; k < PER; k++) {
+            const int i = tid * PER + k;
+            if (i < NSEG * SEGB) s_bucket[i] = run;
+            run += cnt[k];
+        }
     }
     __syncthreads();
-    for (int t = tid; t < T; t += SCAN_THREADS) img.tile_order[atomicAdd(&s_bucket[bucket_of(tcount(t))], 1u)] = (uint32_t)t;
+    if (tid == 0) {  // band starts / lengths, empty-tile count, free-slot and overflow prefixes
+        uint32_t n_empty = 0, fre = 0, ovf = 0;
+        for (int x = 0; x < NSEG; x++) {
+            const uint32_t st = s_bucket[x * SEGB], en = x + 1 < NSEG ? s_bucket[(x + 1) * SEGB] : (uint32_t)T;
+            const uint32_t emp_start = s_bucket[x * SEGB + LPT_BUCKETS];
+            n_empty += en - emp_start;
+            s_seg_start[x] = st;
+            s_seg_len[x] = en - st;
+            s_free_pre[x] = fre;
+            s_over_pre[x] = ovf;
+            fre += (en - st) < (uint32_t)T8 ? (uint32_t)T8 - (en - st) : 0u;
+            ovf += (en - st) > (uint32_t)T8 ? (en - st) - (uint32_t)T8 : 0u;
+        }
+        s_n_empty = n_empty;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += SCAN_THREADS) {
+        const int key = key_of(t), seg = key / SEGB;
+        const uint32_t r = atomicAdd(&s_bucket[key], 1u) - s_seg_start[seg];  // rank inside the band, longest lists first
+        uint32_t slot;
+        if (r < (uint32_t)T8) {
+            slot = (uint32_t)seg * T8 + r;
+        } else {  // the band is longer than T8: its o-th surplus tile takes the o-th free slot of the shorter bands
+            const uint32_t o = s_over_pre[seg] + (r - (uint32_t)T8);
+            int y = 0;
+            while (y + 1 < NSEG && s_free_pre[y + 1] <= o) y++;
+            slot = (uint32_t)y * T8 + s_seg_len[y] + (o - s_free_pre[y]);
+        }
+        img.tile_order[slot] = (uint32_t)t;
+    }
+    const uint32_t n_empty = s_n_empty;
     if (tid == 0) {
         DqoRastHeader h;
         h.num_rendered = s_carry;
@@ -423,8 +481,9 @@ __device__ __forceinline__ void wave_sort_tile(const DqoBinLayout& bin, uint32_t
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ti = blockIdx.x * (SORT_THREADS / 64) + wave;
-    if (ti >= T) return;
-    const int tile = img.tile_order[ti];
+    if (ti >= 8 * ((T + 7) / 8)) return;
+    const uint32_t tile = img.tile_order[ti];  // [8][T8] slots, unused ones hold ~0
+    if (tile == 0xffffffffu) return;
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
     if (n <= 0 || n > SORTW_CAP) return;
@@ -473,7 +532,8 @@ __device__ __forceinline__ void bitonic_any(KeyPtr keys, ValPtr vals, int n, int
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(DqoImageLayout img, DqoBinLayout bin) {
     __shared__ uint64_t s_keys[SORT_LDS_CAP];
     __shared__ uint32_t s_vals[SORT_LDS_CAP];
-    const int tile = img.tile_order[blockIdx.x];
+    const uint32_t tile = img.tile_order[blockIdx.x];  // [8][T8] slots, unused ones hold ~0
+    if (tile == 0xffffffffu) return;
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
     const int tid = threadIdx.x;
@@ -554,8 +614,9 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     if (p->P > 0) {
         int rc = dqo_launch_bin_place(g, img, bin, cap, s);
         if (rc) return rc;
-        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3((T + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64)), dim3(SORT_THREADS), s, T, img, bin);
-        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(T), dim3(SORT_THREADS), s, img, bin);
+        const int slots = 8 * ((T + 7) / 8);  // tile_order is [8][T8]
+        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3((slots + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64)), dim3(SORT_THREADS), s, T, img, bin);
+        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(slots), dim3(SORT_THREADS), s, img, bin);
     }
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, s);
 }

@@ -50,8 +50,12 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
     __shared__ int s_id[FWD_THREADS];
     __shared__ int s_pos[FWD_THREADS];
 
-    const int tile = img.tile_order[blockIdx.x >> 2];
-    const int quad = blockIdx.x & 3;
+    // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
+    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
+    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
+    if (tile_u == 0xffffffffu) return;  // unused slot
+    const int tile = (int)tile_u;
+    const int quad = jg & 3;
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
     const int lane = threadIdx.x;
     const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + (lane & 7);
@@ -229,6 +233,6 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                              const DqoRastOutputs& out, int T, int64_t capacity, hipStream_t s) {
-    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(T * 4), dim3(FWD_THREADS), s, v, g, img, bin, out, capacity);
+    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out, capacity);
     return DQO_OK;
 }
