@@ -138,6 +138,8 @@ struct AdamArgs {
     float *m_xyz, *m_shs, *m_opacity, *m_scaling, *m_rotation;                    // exp_avg
     float *v_xyz, *v_shs, *v_opacity, *v_scaling, *v_rotation;                    // exp_avg_sq
     float *act_opacity, *act_scales, *act_rotations;                              // optional: activations of the updated parameters
+    const int32_t* radii;                                                         // optional: radii == 0 => the gradient row is zero and unread
+    uint64_t row_magic;                                                           // ceil(2^39 / (3 M)): division by the SH row length
 };
 
 // The moments and the gradients are touched exactly once per iteration (0.7 GB of the kernel's 0.83 GB): non-temporal loads /
@@ -166,33 +168,56 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     const int P = a.P;
     // xyz (identity activation) and scaling (exp): element-wise, [P,3]
     for (int64_t i = t0; i < 3LL * P; i += stride) {
+        const bool has_g = a.radii == nullptr || a.radii[(uint32_t)i / 3u] > 0;
         float p = a.xyz[i], m = ldnt(&a.m_xyz[i]), v = ldnt(&a.v_xyz[i]);
-        adam1(p, ldnt(&a.g_xyz[i]), m, v, a, a.step_xyz);
+        adam1(p, has_g ? ldnt(&a.g_xyz[i]) : 0.f, m, v, a, a.step_xyz);
         a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
         float ps = a.scaling_raw[i], ms = ldnt(&a.m_scaling[i]), vs = ldnt(&a.v_scaling[i]);
-        adam1(ps, ldnt(&a.g_scales[i]) * expf(ps), ms, vs, a, a.step_scaling);  // d exp(x)/dx = exp(x)
+        adam1(ps, (has_g ? ldnt(&a.g_scales[i]) : 0.f) * expf(ps), ms, vs, a, a.step_scaling);  // d exp(x)/dx = exp(x)
         a.scaling_raw[i] = ps, stnt(ms, &a.m_scaling[i]), stnt(vs, &a.v_scaling[i]);
         if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
     }
     // SH coefficients [P,M,3]: coefficient 0 = f_dc (lr feature_lr), the rest = f_rest (feature_lr / 20)
     const int64_t nsh = (int64_t)P * a.M * 3;
     const int row = a.M * 3;
-    for (int64_t i = t0; i < nsh; i += stride) {
-        const bool dc = (int)(i % row) < 3;
-        float p = a.shs[i], m = ldnt(&a.m_shs[i]), v = ldnt(&a.v_shs[i]);
-        adam1(p, ldnt(&a.g_shs[i]), m, v, a, dc ? a.step_dc : a.step_rest);
-        a.shs[i] = p, stnt(m, &a.m_shs[i]), stnt(v, &a.v_shs[i]);
+    // four elements per trip with every load issued before the first use: the row lookup (radii) and the gradient load that
+    // depends on it would otherwise put two memory latencies in series in each trip
+    for (int64_t i0 = t0; i0 < nsh; i0 += 4 * stride) {
+        float p[4], m[4], v[4], gq[4];
+        bool dc[4], ok[4], has_g[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = i0 + u * stride;
+            ok[u] = i < nsh;
+            const uint32_t ii = ok[u] ? (uint32_t)i : 0u;
+            const uint32_t gsn = (uint32_t)(((uint64_t)ii * a.row_magic) >> 39);  // ii / row, exact for ii < 2^31, row < 2^8
+            dc[u] = (ii - gsn * (uint32_t)row) < 3u;
+            has_g[u] = ok[u] && (a.radii == nullptr || a.radii[gsn] > 0);
+            p[u] = ok[u] ? a.shs[ii] : 0.f;
+            m[u] = ok[u] ? ldnt(&a.m_shs[ii]) : 0.f;
+            v[u] = ok[u] ? ldnt(&a.v_shs[ii]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) gq[u] = has_g[u] ? ldnt(&a.g_shs[i0 + u * stride]) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!ok[u]) continue;
+            const int64_t i = i0 + u * stride;
+            adam1(p[u], gq[u], m[u], v[u], a, dc[u] ? a.step_dc : a.step_rest);
+            a.shs[i] = p[u], stnt(m[u], &a.m_shs[i]), stnt(v[u], &a.v_shs[i]);
+        }
     }
     // opacity (sigmoid) [P] and rotation (normalize) [P,4]
     for (int64_t i = t0; i < P; i += stride) {
+        const bool has_g = a.radii == nullptr || a.radii[i] > 0;
         float p = a.opacity_raw[i], m = ldnt(&a.m_opacity[i]), v = ldnt(&a.v_opacity[i]);
         const float sg = 1.0f / (1.0f + expf(-p));
-        adam1(p, ldnt(&a.g_opacity[i]) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
+        adam1(p, (has_g ? ldnt(&a.g_opacity[i]) : 0.f) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
         a.opacity_raw[i] = p, stnt(m, &a.m_opacity[i]), stnt(v, &a.v_opacity[i]);
         if (a.act_opacity) a.act_opacity[i] = 1.0f / (1.0f + expf(-p));
 
         float4 q = reinterpret_cast<float4*>(a.rotation_raw)[i];
-        const float4 g = reinterpret_cast<const float4*>(a.g_rot)[i];
+        const float4 g = has_g ? reinterpret_cast<const float4*>(a.g_rot)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 mq = reinterpret_cast<float4*>(a.m_rotation)[i], vq = reinterpret_cast<float4*>(a.v_rotation)[i];
         // F.normalize backward: y = q / n, n = max(|q|, eps):  dq = (g - y (y . g)) / n
         const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
@@ -254,6 +279,10 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.m_xyz = st->m_xyz, a.m_shs = st->m_shs, a.m_opacity = st->m_opacity, a.m_scaling = st->m_scaling, a.m_rotation = st->m_rotation;
     a.v_xyz = st->v_xyz, a.v_shs = st->v_shs, a.v_opacity = st->v_opacity, a.v_scaling = st->v_scaling, a.v_rotation = st->v_rotation;
     a.act_opacity = st->act_opacity, a.act_scales = st->act_scales, a.act_rotations = st->act_rotations;
+    a.radii = st->radii;
+    DQO_CHECK_ARG(st->M >= 0 && st->M * 3 < 256, "M out of range");
+    a.row_magic = st->M > 0 ? ((1ull << 39) + (uint64_t)(3 * st->M) - 1) / (uint64_t)(3 * st->M) : 0ull;
+    DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");
     const int64_t n = (int64_t)st->P * st->M * 3;
     const int grid = (int)min((int64_t)(256 * 16), (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
     DQO_LAUNCH("adam_kernel", adam_kernel, dim3(grid), dim3(256), s, a);

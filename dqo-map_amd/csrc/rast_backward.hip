@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     const uint2 rc = g.rect16[idx];
     const bool visible = ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
     if (!visible) {
+        if (gr.skip_culled_rows) return;  // the consumer knows the row is zero from radii (DqoRastGrads)
         dm[0] = dm[1] = dm[2] = 0.f;
         if (dsh)
             for (int i = 0; i < 3 * M; i++) dsh[i] = 0.f;

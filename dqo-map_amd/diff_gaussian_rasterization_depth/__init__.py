@@ -229,7 +229,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                     inst_capacity=cap)
                 grads = N.DqoRastGrads(dL_dmeans3D=g_means3D.data_ptr(), dL_dsh=N.ptr(g_sh), dL_dcolors=g_colors.data_ptr(),
                                        dL_dopacity=g_opacity.data_ptr(), dL_dscales=g_scales.data_ptr(),
-                                       dL_drotations=g_rot.data_ptr(), dL_dcov3D=g_cov3D.data_ptr(), dL_dmeans2D=g_means2D.data_ptr())
+                                       dL_drotations=g_rot.data_ptr(), dL_dcov3D=g_cov3D.data_ptr(), dL_dmeans2D=g_means2D.data_ptr(),
+                                       skip_culled_rows=1 if getattr(ctx, "sparse_grad_rows", False) else 0)
                 N.check(lib.dqo_rast_backward(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(cctx),
                                               grad_out_color.data_ptr(), grad_out_depth.data_ptr(), hit_depth.data_ptr(),
                                               ctypes.byref(grads), ws.data_ptr(), ws.numel(), stream))

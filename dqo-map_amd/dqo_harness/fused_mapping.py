@@ -88,6 +88,7 @@ class FusedMapper:
                                              N.ptr(mask_u8), self.color_weight, self.depth_weight, self.add_depth_thres,
                                              N.ptr(self.loss), N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws),
                                              self.loss_ws.numel(), stream))
+            ctx.sparse_grad_rows = True  # gradient rows of culled Gaussians stay unwritten; the Adam kernel gets radii instead
             grads = dgr._RasterizeGaussians.backward(ctx, self.dL_dcolor, self.dL_ddepth, None, None, None, None, None, None, None)
             g_means3D, g_sh, _, g_opacity, g_scales, g_rot = grads[0], grads[1], grads[2], grads[3], grads[4], grads[5]
             self.step_count += 1
@@ -102,7 +103,8 @@ class FusedMapper:
                                m_rotation=N.ptr(self.state["rotation"][0]), v_xyz=N.ptr(self.state["xyz"][1]),
                                v_shs=N.ptr(self.state["shs"][1]), v_opacity=N.ptr(self.state["opacity"][1]),
                                v_scaling=N.ptr(self.state["scaling"][1]), v_rotation=N.ptr(self.state["rotation"][1]),
-                               act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales), act_rotations=N.ptr(self.rotations))
+                               act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales), act_rotations=N.ptr(self.rotations),
+                               radii=N.ptr(out[8]))
             N.check(lib.dqo_map_adam_step(ctypes.byref(st), stream))
             self._act_valid = True
         return out

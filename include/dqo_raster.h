@@ -112,6 +112,10 @@ typedef struct DqoRastGrads {
     float* dL_drotations; /* [P,4] */
     float* dL_dcov3D;     /* [P,6] */
     float* dL_dmeans2D;   /* [P,3] (x,y used; z = 0) */
+    /* 0 (the drop-in behaviour): every row is written, zeros for the Gaussians the forward culled (radii == 0).
+     * non-zero: those all-zero rows are left unwritten — for a consumer that looks at radii itself
+     * (dqo_map_adam_step with DqoAdamStep.radii) this saves writing and re-reading 236 B per culled Gaussian. */
+    int32_t skip_culled_rows;
 } DqoRastGrads;
 
 /* Host-visible copy of the device header kept at the start of ctx.geom. */
@@ -225,6 +229,10 @@ typedef struct DqoAdamStep {
     /* Optional (NULL = skip): the activated values of the UPDATED parameters, exactly what dqo_map_activate would
      * compute from them — saves that launch in the next iteration. */
     float *act_opacity, *act_scales, *act_rotations;
+    /* Optional (NULL = every gradient row is read): the forward's radii of this step.  Gradient rows of culled Gaussians
+     * (radii == 0) are taken as zero without being read (pair with DqoRastGrads.skip_culled_rows); their parameters and
+     * moments are still updated exactly as dense Adam does with a zero gradient. */
+    const int32_t* radii;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
 
