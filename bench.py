@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--path", default="fused", choices=("fused", "dropin"),
                     help="fused: dqo_harness.FusedMapper (activation / loss / Adam kernels of row f2 around the op); "
                          "dropin: autograd through the drop-in op + torch.optim.Adam, exactly what unchanged DQO-MAP code runs")
+    ap.add_argument("--no-graph", action="store_true", help="fused path: issue the kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-P", type=int, default=500_000)
@@ -100,18 +101,35 @@ def make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, 
     return step
 
 
-def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf):
+def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf, use_graph=True, world=1):
     from dqo_harness.fused_mapping import FusedMapper
     fm = FusedMapper(scene, settings, device)
     mask_u8 = render_mask.to(torch.uint8).contiguous()
 
-    def step():
+    def step_eager():
         out = fm.step(gt_color, gt_depth, mask_u8)
         loss_buf.buf[:3].copy_(fm.loss[:3])
         loss_buf.reduce()  # ONE packed all-reduce per iteration (no-op at world size 1)
         return {"radii": out[8]}
 
-    return step
+    if not use_graph:
+        return step_eager, step_eager
+    fm.capture(gt_color, gt_depth, mask_u8)  # the whole iteration as one hipGraph over persistent buffers
+
+    def step_graph():
+        out = fm.replay()
+        if world > 1:  # the per-iteration collective of the sharded path stays outside the graph
+            loss_buf.buf[:3].copy_(fm.loss[:3])
+            loss_buf.reduce()
+        return {"radii": out[8]}
+
+    def finish():
+        if fm.graph_overflowed():
+            raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
+        loss_buf.buf[:3].copy_(fm.loss[:3])
+
+    step_graph.finish = finish
+    return step_graph, step_eager
 
 
 def cpu_baseline(args, cam, scene, P_sample):
@@ -157,7 +175,8 @@ def main():
     from dqo_harness.sharding import PackedAllReduce
     loss_buf = PackedAllReduce([("total", 1), ("color", 1), ("depth", 1)], device)
     step_dropin = make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world)
-    step_fused = make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf)
+    step_fused, step_fused_eager = make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf,
+                                                   use_graph=not args.no_graph, world=world)
     step = step_fused if args.path == "fused" else step_dropin
 
     def sync_all():
@@ -173,6 +192,8 @@ def main():
         out = step()
     sync_all()
     dt = time.perf_counter() - t0
+    if hasattr(step, "finish"):
+        step.finish()  # graph path: overflow check + loss read-back, outside the timed region
     if args.sync_mode == "lazy":
         dgr._verify_pending(block=True)  # raises if any timed iteration overflowed its instance capacity
     if world > 1:
@@ -210,8 +231,9 @@ def main():
         N.profile_collect(reset=True)
         torch.cuda.synchronize()
         ksteps = min(args.steps, 20)
+        step_prof = step_fused_eager if args.path == "fused" else step_dropin  # HIP events cannot be recorded inside a graph replay
         for _ in range(ksteps):
-            step()
+            step_prof()
         torch.cuda.synchronize()
         prof = N.profile_collect(reset=True)
         N.profile_enable(False)
@@ -271,7 +293,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg{args.cfg}: surfel room, {P} Gaussians/GPU, {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, "
-                                   "SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 depth L1), raster fwd+bwd + Adam (6 groups); path=" + args.path,
+                                   "SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 depth L1), raster fwd+bwd + Adam (6 groups); path=" + args.path
+                                   + ("" if args.path != "fused" or args.no_graph else " (one hipGraph replay per iteration)"),
                        "shards": world, "sync_mode": args.sync_mode, **stats},
             "loss": loss_now, "path": args.path,
         }

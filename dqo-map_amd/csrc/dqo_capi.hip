@@ -278,7 +278,7 @@ DQO_API int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const
 
 DQO_API int dqo_map_adam_step(const DqoAdamStep* st, void* stream) {
     DQO_CHECK_ARG(st, "null step");
-    DQO_CHECK_ARG(st->P >= 0 && st->M >= 1 && st->step >= 1, "bad P / M / step");
+    DQO_CHECK_ARG(st->P >= 0 && st->M >= 1 && (st->step >= 1 || st->step_dev != nullptr), "bad P / M / step");
     if (st->P == 0) return DQO_OK;
     DQO_CHECK_ARG(st->xyz && st->shs && st->opacity_raw && st->scaling_raw && st->rotation_raw, "null parameter");
     DQO_CHECK_ARG(st->g_means3D && st->g_sh && st->g_opacity && st->g_scales && st->g_rotations, "null gradient");

@@ -140,6 +140,8 @@ struct AdamArgs {
     float *act_opacity, *act_scales, *act_rotations;                              // optional: activations of the updated parameters
     const int32_t* radii;                                                         // optional: radii == 0 => the gradient row is zero and unread
     uint64_t row_magic;                                                           // ceil(2^39 / (3 M)): division by the SH row length
+    const int32_t* step_dev;                                                      // optional: step count on the device (hipGraph replay)
+    float lr_xyz, lr_dc, lr_rest, lr_opacity, lr_scaling, lr_rotation;            // used with step_dev
 };
 
 // The moments and the gradients are touched exactly once per iteration (0.7 GB of the kernel's 0.83 GB): non-temporal loads /
@@ -162,7 +164,25 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
     p = p - step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
+__global__ void adam_advance_kernel(int32_t* step_dev) { *step_dev += 1; }
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a_in) {
+    AdamArgs a = a_in;
+    if (a.step_dev != nullptr) {
+        // bias corrections from the device-resident step count (double, like the host path / torch's python floats)
+        __shared__ float s_ss[7];
+        if (threadIdx.x == 0) {
+            const double t = (double)*a.step_dev;
+            const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+            s_ss[0] = (float)sqrt(bc2);
+            s_ss[1] = (float)((double)a.lr_xyz / bc1), s_ss[2] = (float)((double)a.lr_dc / bc1), s_ss[3] = (float)((double)a.lr_rest / bc1);
+            s_ss[4] = (float)((double)a.lr_opacity / bc1), s_ss[5] = (float)((double)a.lr_scaling / bc1);
+            s_ss[6] = (float)((double)a.lr_rotation / bc1);
+        }
+        __syncthreads();
+        a.bc2_sqrt = s_ss[0], a.step_xyz = s_ss[1], a.step_dc = s_ss[2], a.step_rest = s_ss[3], a.step_opacity = s_ss[4];
+        a.step_scaling = s_ss[5], a.step_rotation = s_ss[6];
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int P = a.P;
@@ -266,7 +286,8 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.P = st->P, a.M = st->M;
     a.beta1 = st->beta1, a.beta2 = st->beta2, a.eps = st->eps;
     // bias corrections in double like torch (python floats), then cast
-    const double bc1 = 1.0 - pow((double)st->beta1, (double)st->step), bc2 = 1.0 - pow((double)st->beta2, (double)st->step);
+    const double tstep = st->step >= 1 ? (double)st->step : 1.0;  // (ignored by the kernel when step_dev is given)
+    const double bc1 = 1.0 - pow((double)st->beta1, tstep), bc2 = 1.0 - pow((double)st->beta2, tstep);
     a.bc2_sqrt = (float)sqrt(bc2);
     a.step_xyz = (float)((double)st->lr_xyz / bc1);
     a.step_dc = (float)((double)st->lr_f_dc / bc1);
@@ -280,11 +301,15 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.v_xyz = st->v_xyz, a.v_shs = st->v_shs, a.v_opacity = st->v_opacity, a.v_scaling = st->v_scaling, a.v_rotation = st->v_rotation;
     a.act_opacity = st->act_opacity, a.act_scales = st->act_scales, a.act_rotations = st->act_rotations;
     a.radii = st->radii;
+    a.step_dev = st->step_dev;
+    a.lr_xyz = st->lr_xyz, a.lr_dc = st->lr_f_dc, a.lr_rest = st->lr_f_rest, a.lr_opacity = st->lr_opacity, a.lr_scaling = st->lr_scaling;
+    a.lr_rotation = st->lr_rotation;
     DQO_CHECK_ARG(st->M >= 0 && st->M * 3 < 256, "M out of range");
     a.row_magic = st->M > 0 ? ((1ull << 39) + (uint64_t)(3 * st->M) - 1) / (uint64_t)(3 * st->M) : 0ull;
     DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");
     const int64_t n = (int64_t)st->P * st->M * 3;
     const int grid = (int)min((int64_t)(256 * 16), (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
     DQO_LAUNCH("adam_kernel", adam_kernel, dim3(grid), dim3(256), s, a);
+    if (st->step_dev != nullptr) DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev);
     return DQO_OK;
 }

@@ -233,6 +233,10 @@ typedef struct DqoAdamStep {
      * (radii == 0) are taken as zero without being read (pair with DqoRastGrads.skip_culled_rows); their parameters and
      * moments are still updated exactly as dense Adam does with a zero gradient. */
     const int32_t* radii;
+    /* Optional (NULL = use `step`): device scalar holding the 1-based step count of THIS launch; the launch is followed
+     * by a one-thread kernel that increments it.  With it a whole mapping iteration has no host-side per-iteration
+     * argument and can be captured once in a hipGraph and replayed. */
+    int32_t* step_dev;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
 

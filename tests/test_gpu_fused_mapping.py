@@ -145,3 +145,35 @@ def test_fused_iteration_matches_autograd_path(env):
         lr = dict(xyz=0.001, shs=0.0005, opacity=1.0, scaling=0.004, rotation=0.001)[k]
         bad = np.abs(a - b) > 0.02 * 3 * lr + 1e-7
         assert bad.mean() < 2e-3, (k, bad.mean(), np.abs(a - b).max())
+
+
+def test_graph_replay_matches_eager_steps(env):
+    """capture() runs one iteration eagerly over the persistent buffers and records the next ones into a hipGraph (Adam step
+    count on the device): capture + 3 replays must leave the same parameters / moments as 4 eager step() calls."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, settings, dev)
+    for _ in range(4):
+        a.step(gt_color, gt_depth, mask)
+    b.capture(gt_color, gt_depth, mask)
+    for _ in range(3):
+        b.replay()
+    torch.cuda.synchronize()
+    assert not b.graph_overflowed()
+    assert a.step_count == b.step_count == 4
+    np.testing.assert_allclose(b.loss.cpu().numpy()[:3], a.loss.cpu().numpy()[:3], rtol=1e-5)
+    for k, pa in a._params().items():
+        pb = b._params()[k]
+        lr = dict(xyz=0.001, shs=0.0005, opacity=1.0, scaling=0.004, rotation=0.001)[k]
+        d = (pa - pb).abs()
+        # identical arithmetic except the bias corrections (host pow vs device pow): differences stay far below one Adam step
+        assert (d > 0.01 * lr + 1e-7).float().mean().item() < 1e-3, (k, d.max().item())
+        for i in (0, 1):
+            np.testing.assert_allclose(b.state[k][i].cpu().numpy(), a.state[k][i].cpu().numpy(), rtol=1e-3, atol=1e-9)
+    # an eager step between replays is allowed: the device-side step count is resynchronised
+    b.step(gt_color, gt_depth, mask)
+    b.replay()
+    torch.cuda.synchronize()
+    assert b.step_count == 6 and int(b._g.step_dev.item()) == 7
