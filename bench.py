@@ -66,6 +66,19 @@ def build_problem(args, rank, world, device):
     else:
         cam = scenes.replica_camera(cfgd["W"], cfgd["H"], cfgd["fx"], cfgd["fx"], cfgd["cx"], cfgd["cy"])
         scene = scenes.surfel_room(cfgd["seed"], P, n_objects=cfgd["n_objects"], rest_sigma=cfgd["rest_sigma"])
+    if os.environ.get("DQO_BENCH_MORTON"):  # experiment: storage order of the Gaussians = Morton order of their centres
+        q = scene["xyz"]
+        lo, hi = q.min(0), q.max(0)
+        u = np.clip(((q - lo) / (hi - lo + 1e-9) * 1023).astype(np.uint64), 0, 1023)
+        def spread(x):
+            x = (x | (x << 16)) & 0x030000FF
+            x = (x | (x << 8)) & 0x0300F00F
+            x = (x | (x << 4)) & 0x030C30C3
+            x = (x | (x << 2)) & 0x09249249
+            return x
+        code = spread(u[:, 0]) | (spread(u[:, 1]) << 1) | (spread(u[:, 2]) << 2)
+        perm = np.argsort(code, kind="stable")
+        scene = {k: (v[perm] if hasattr(v, "shape") and v.shape[:1] == (len(perm),) else v) for k, v in scene.items()}
     params = mapping.GaussianParams(scene, device)
     settings = mapping.make_settings(cam, device)
     # target = render of a perturbed copy, so the gradients are non-trivial
