@@ -127,7 +127,12 @@ def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, lo
 
     if not use_graph:
         return step_eager, step_eager
-    fm.capture(gt_color, gt_depth, mask_u8)  # the whole iteration as one hipGraph over persistent buffers
+    try:
+        fm.capture(gt_color, gt_depth, mask_u8)  # the whole iteration as one hipGraph over persistent buffers
+    except Exception as e:  # e.g. a runtime that refuses the capture: the eager path is the same arithmetic
+        print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the fused path eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        return step_eager, step_eager
 
     def step_graph():
         out = fm.replay()
@@ -171,9 +176,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl")  # RCCL on ROCm
+        torch.distributed.init_process_group(os.environ.get("DQO_BENCH_BACKEND", "nccl"))  # "nccl" is RCCL on ROCm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP rasteriser has no CPU path")
+    if os.environ.get("DQO_BENCH_BACKEND") == "gloo":  # code-path rehearsal of the N-rank run on fewer GPUs (not a measurement)
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -238,7 +245,7 @@ def main():
 
     roofline = None
     kernels = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:  # on every rank: the step function contains the per-iteration collective
         # per-kernel durations with HIP events on the launch stream, over the same step function
         N.profile_enable(True)
         N.profile_collect(reset=True)

@@ -171,6 +171,9 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     const float dp1 = inside ? dL_dpixels[HW + pid] : 0.f;
     const float dp2 = inside ? dL_dpixels[2 * HW + pid] : 0.f;
     const float ddep = inside ? dL_ddepths[pid] : 0.f;
+    // No incoming gradient on any pixel of the quadrant (outside the loss mask): every term of every record would be an exact
+    // zero, so nothing is written and the records stay invalid (= zero for the per-Gaussian sum).
+    if (__builtin_amdgcn_ballot_w64(dp0 != 0.f || dp1 != 0.f || dp2 != 0.f || ddep != 0.f) == 0ull) return;
     const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
     const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
     // colour blended behind the current entry (the reference's accum_rec after folding in last_alpha / last_color,

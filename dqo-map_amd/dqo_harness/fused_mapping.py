@@ -145,7 +145,8 @@ class FusedMapper:
             torch.cuda.current_stream().wait_stream(side)
             self.step_count += 1
             g.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g.graph):
+            # thread_local: other threads of the process (e.g. a collective library's watchdog) may keep issuing runtime calls
+            with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
                 self._static_iteration()
             g.expected_step = self.step_count + 1
         return self
