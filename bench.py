@@ -286,17 +286,19 @@ def main():
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # memory-side bytes per launch of the dominant kernel, from the separate rocprofv3 --pmc passes committed under profiles/
         # (tools/pmc_hbm.sh; counters cannot be collected from inside this process)
-        traffic = None
+        traffic, valu_frac = None, None
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as fh:
                 tk = json.load(fh)["kernels"].get(dom_name)
             if tk is not None and args.cfg == 3 and args.P is None:
                 traffic = int(tk["read_bytes"] + tk["write_bytes"])
+                if "valu_insts" in tk:  # VALU-issue occupancy of the dominant kernel: wave instructions / (CUs x clock x duration)
+                    valu_frac = tk["valu_insts"] / (256 * 2.4e9 * dom_ms * 1e-3)
         except OSError:
             pass
         roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, avg_launch_us=round(dom_ms * 1e3, 2),
-                        algorithmic_bytes=int(bytes_dom),
+                        algorithmic_bytes=int(bytes_dom), valu_issue_frac=None if valu_frac is None else round(valu_frac, 3),
                         note="the blend kernels are VALU-issue bound, not HBM bound (profiles/README.md: SQ_INSTS_VALU x 4 cycles / "
                              "(CUs x SIMDs) ~ kernel time); per-kernel GB/s of every kernel: config.kernel_gbs",
                         kernel_gbs={k: round(alg[k] / (us * 1e-6) / 1e9, 1) for k, us in kernels.items() if k in alg and us > 0})

@@ -92,14 +92,15 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
     const float qx0 = (float)(tile_x * DQO_TILE + (quad & 1) * 8), qy0 = (float)(tile_y * DQO_TILE + (quad >> 1) * 8);
     const float pixfx = (float)px, pixfy = (float)py;
     const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
-    bool done = !inside;
+    float gate = inside ? 1.f : 0.f;   // 0 = this pixel is finished (or outside the image)
+    float nohit = 1.f;                 // 0 = the pixel's depth has been fixed by an opaque hit
+    const float hit_thr = fmaxf(v.opaque_thr, 1.0f / 255.0f);
     float T = 1.0f, end_T = 1.0f;
     uint32_t last_contributor = 0, hit_pos = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float depth_ = 0.f;
-    bool hit_gaussian = false;
     int hit_id = -1, hit_color_id = -1;
-    float color_weight_max = -1.f, hit_color_weight = 0.f, hit_depth_weight = 0.f;
+    float color_weight_max = -1.f, hit_depth_weight = 0.f;
     uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;  // this quadrant's live bytes of this tile's segment
 
     const int chunks = (n + FWD_THREADS - 1) / FWD_THREADS;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         co_nx = g.conic_opacity[id_nx];
         xy_nx = g.xy_depth[id_nx];
     }
-    bool all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;  // wave-uniform
+    bool all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;  // wave-uniform
     for (int c = 0; c < chunks && !all_done; c++) {  // a finished quadrant never looks at the entries further back
         const int pos = c * FWD_THREADS + lane;
         const int id = id_nx;
@@ -148,16 +149,21 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                     xy_c = s_xy[k + 1];
                     co_c = s_co[k + 1];
                 }
-                // ---- predicated per-pixel update (forward.cu:750-842); the only branches left are wave-uniform ----
+                // ---- per-pixel update (forward.cu:750-842), arithmetic gating instead of per-lane control flow ----
+                // gate = 0 for a finished pixel, nohit = 0 once its depth is fixed: multiplying by them keeps the lane's
+                // predicates in VGPRs (a lane mask that lives across the loop costs scalar bookkeeping in every trip).  An
+                // entry that is not valid for a pixel acts on it with alpha = 0: T (1 - 0) = T, weight 0.
                 const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
                 const float power = -0.5f * (co_cur.x * dx * dx + co_cur.z * dy * dy) - co_cur.y * dx * dy;
                 const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
-                const bool valid = !done && power <= 0.0f && alpha >= 1.0f / 255.0f;  // forward.cu:763-772
+                const float a_g = power <= 0.0f ? alpha * gate : 0.f;
+                const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
                 if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
                     const uint32_t contributor = (uint32_t)(s_pos[k] + 1);  // the reference's running counter = list position + 1
                     const float4 cs = s_rgb[k];
                     const int gid = s_id[k];
-                    const bool newhit = valid && !hit_gaussian && alpha >= v.opaque_thr;
+                    const float a_v = valid ? alpha : 0.f;
+                    const bool newhit = a_v * nohit >= hit_thr;  // valid, no depth yet, alpha >= opaque_threshold
                     if (__builtin_amdgcn_ballot_w64(newhit) != 0ull) {
                         // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
                         const float4 n_np = g.normal_c[gid];
@@ -172,32 +178,31 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                             // the backward repeats the test with the raw scales (backward.cu:1009-1016): decide it here once
                             const bool plane_b = depth_distance <= v.depth_thr * raw_smax && angle_distance >= v.normal_thr;
                             hit_pos = contributor | (plane_b ? 0x80000000u : 0u);
-                            hit_gaussian = true;
+                            nohit = 0.f;
                         }
                     }
-                    const float test_T = T * (1.f - alpha);
+                    const float test_T = T * (1.f - a_v);  // == T when the entry is not valid for this pixel
                     const bool below = test_T < v.T_thr;
-                    const bool finish = valid && below && hit_gaussian;  // forward.cu:813-817: done, T NOT updated
-                    const bool blend = valid && !below;                  // forward.cu:818-840
-                    const float w = blend ? alpha * T : 0.f;
+                    const bool blend = valid && !below;                    // forward.cu:818-840
+                    const bool finish = valid && below && nohit == 0.f;    // forward.cu:813-817: done, T NOT updated
+                    const float w = below ? 0.f : a_v * T;                 // 0 unless blended
                     C0 += cs.x * w;
                     C1 += cs.y * w;
                     C2 += cs.z * w;
                     const bool newmax = blend && w > color_weight_max;
                     color_weight_max = newmax ? w : color_weight_max;
                     hit_color_id = newmax ? gid : hit_color_id;
-                    hit_color_weight = newmax ? w : hit_color_weight;
                     last_contributor = blend ? contributor : last_contributor;
                     end_T = blend ? test_T : end_T;
-                    T = (valid && !finish) ? test_T : T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
-                    done = done || finish;
+                    T = finish ? T : test_T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
+                    gate = finish ? 0.f : gate;
                     // live for the backward: some pixel of the quadrant saw the entry with alpha >= 1/255 while unfinished — a
                     // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
                     // below T_threshold), so the backward never misses a pair it has work for
                     const int half = (int)__popcll(__builtin_amdgcn_ballot_w64(blend && test_T > 0.5f));
                     live_k = lane == k ? 1 : live_k;
                     half_k = lane == k ? half : half_k;
-                    if (__builtin_amdgcn_ballot_w64(finish) != 0ull) all_done = __builtin_amdgcn_ballot_w64(!done) == 0ull;
+                    if (__builtin_amdgcn_ballot_w64(finish) != 0ull) all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;
                 }
             }
         }
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         out.out_depth[pix_id] = depth_;
         out.out_hit_depth[pix_id] = hit_id;
         out.out_hit_color[pix_id] = hit_color_id;
-        out.out_hit_color_weight[pix_id] = hit_color_weight;
+        out.out_hit_color_weight[pix_id] = fmaxf(color_weight_max, 0.f);  // the running maximum IS the recorded weight (0 if none)
         out.out_hit_depth_weight[pix_id] = hit_depth_weight;
         out.out_T[pix_id] = end_T;
     }
