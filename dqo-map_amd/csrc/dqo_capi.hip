@@ -30,6 +30,9 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         const float* gt_depth, const uint8_t* render_mask, float color_weight, float depth_weight, float add_depth_thres,
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
+int dqo_launch_tile_count(int W, int H, int mode, const uint8_t* mask_in, const float* T_map, uint8_t* mask_out, int32_t* tile_count,
+                          int32_t* total, hipStream_t s);
+int dqo_launch_tile_color_error(int W, int H, const float* render, const float* gt, float* err_px, float* tile_sum, hipStream_t s);
 int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, const float* depth_err, const float* normal_err,
                                 const int32_t* color_index, const int32_t* depth_index, float color_thr, float depth_thr,
                                 float normal_thr, int check_max, float* gs_color, float* gs_depth, float* gs_normal, float* rescale,
@@ -274,6 +277,23 @@ DQO_API int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const
     DQO_CHECK_ARG(check_max || counters, "mean mode needs the counters scratch buffer");
     return dqo_launch_accumulate_error(H, W, P, ce, de, ne, ci, di, color_thr, depth_thr, normal_thr, check_max, gs_color, gs_depth,
                                        gs_normal, rescale, counters, (hipStream_t)stream);
+}
+
+DQO_API int dqo_tile_count_mask(int32_t W, int32_t H, const uint8_t* pixel_mask, int32_t* tile_count, void* stream) {
+    DQO_CHECK_ARG(W > 0 && H > 0 && pixel_mask && tile_count, "bad size / null pointer");
+    return dqo_launch_tile_count(W, H, 0, pixel_mask, nullptr, nullptr, tile_count, nullptr, (hipStream_t)stream);
+}
+
+DQO_API int dqo_transmission_mask(int32_t W, int32_t H, const float* T_map, uint8_t* render_mask, int32_t* tile_count, int32_t* total,
+                                  void* stream) {
+    DQO_CHECK_ARG(W > 0 && H > 0 && T_map && tile_count, "bad size / null pointer");
+    return dqo_launch_tile_count(W, H, 1, nullptr, T_map, render_mask, tile_count, total, (hipStream_t)stream);
+}
+
+DQO_API int dqo_tile_color_error(int32_t W, int32_t H, const float* render, const float* gt, float* color_error, float* tile_sum,
+                                 void* stream) {
+    DQO_CHECK_ARG(W > 0 && H > 0 && render && gt && tile_sum, "bad size / null pointer");
+    return dqo_launch_tile_color_error(W, H, render, gt, color_error, tile_sum, (hipStream_t)stream);
 }
 
 DQO_API int dqo_map_adam_step(const DqoAdamStep* st, void* stream) {

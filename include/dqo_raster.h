@@ -217,6 +217,20 @@ int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const float* 
                                   float normal_threshold, int32_t check_max, float* gs_color_error, float* gs_depth_error,
                                   float* gs_normal_error, float* gs_rescale_counter, int32_t* counters, void* hipStream);
 
+/* Row f3 — tile-mask producers of the mapping loop (SLAM/utils.py:720-799, SLAM/multiprocess/mapper.py:930-988), 16x16 tiles
+ * with the reference's zero padding (a tile is always divided by 256).  All pointers are device pointers.
+ *   dqo_tile_count_mask:   tile_count[t] = number of non-zero pixels of a uint8 pixel mask in tile t
+ *                          (pixelmask2tilemask = count > 0; transmission2tilemask = count / 256 > ratio)
+ *   dqo_transmission_mask: render_mask = (T_map != 1) (written if non-NULL), tile_count as above, *total = its pixel count
+ *                          (evaluate_render_range: render_mask, tile_mask, render_ratio in one pass)
+ *   dqo_tile_color_error:  color_error = sum_c |render - gt|, zeroed where the rendered colour sums to 0 (written if
+ *                          non-NULL); tile_sum[t] = its sum over tile t (meanpool / colorerror2tilemask = tile_sum / 256) */
+int dqo_tile_count_mask(int32_t W, int32_t H, const uint8_t* pixel_mask, int32_t* tile_count, void* hipStream);
+int dqo_transmission_mask(int32_t W, int32_t H, const float* T_map, uint8_t* render_mask, int32_t* tile_count, int32_t* total,
+                          void* hipStream);
+int dqo_tile_color_error(int32_t W, int32_t H, const float* render, const float* gt, float* color_error, float* tile_sum,
+                         void* hipStream);
+
 typedef struct DqoAdamStep {
     int32_t P, M;      /* Gaussians, SH coefficients per Gaussian (f_dc = coefficient 0, f_rest = the others) */
     int32_t step;      /* 1-based Adam step count */

@@ -81,3 +81,52 @@ def accumulate_gaussian_error(H, W, P, color_err, depth_err, normal_err, color_i
     np.add.at(rs, di[dm & (de > depth_thr)], 1)
     np.add.at(rs, di[dm & (ne > normal_thr)], 1)
     return gc.reshape(P, 1), gd.reshape(P, 1), gn.reshape(P, 1), rs.reshape(P, 1)
+
+
+# ---------------------------------------------------------------- row f3: tile-mask producers ---------------------------
+def _pad_tiles(img, stride, value=0):
+    """F.pad(x, (0, pad_w, 0, pad_h), value) of SLAM/utils.py:721-724 and friends."""
+    h, w = img.shape[:2]
+    H, W = (h + stride - 1) // stride * stride, (w + stride - 1) // stride * stride
+    out = np.full((H, W), value, dtype=img.dtype)
+    out[:h, :w] = img
+    return out
+
+
+def pixelmask2tilemask(pixelmask, stride):
+    """SLAM/utils.py:731-743: max-pool of the zero-padded mask -> int32 [gy, gx]."""
+    p = _pad_tiles((np.asarray(pixelmask) != 0).astype(np.float32), stride)
+    gy, gx = p.shape[0] // stride, p.shape[1] // stride
+    return p.reshape(gy, stride, gx, stride).max((1, 3)).astype(np.int32)
+
+
+def meanpool(matrix, stride):
+    """SLAM/utils.py:720-729: avg_pool2d of the zero-padded image (count_include_pad: always / stride^2), float32."""
+    p = _pad_tiles(np.asarray(matrix, np.float32), stride)
+    gy, gx = p.shape[0] // stride, p.shape[1] // stride
+    return (p.reshape(gy, stride, gx, stride).astype(np.float64).sum((1, 3)) / (stride * stride)).astype(np.float32)
+
+
+def transmission2tilemask(pixelmask, stride, tile_mask_ratio=0.5):
+    """SLAM/utils.py:752-763."""
+    return (meanpool((np.asarray(pixelmask) != 0).astype(np.float32), stride) > np.float32(tile_mask_ratio)).astype(np.int32)
+
+
+def color_error_image(render, gt):
+    """mapper.py:949-956: sum over channels of |render - gt|, zero where the rendered colour sums to 0 (float32, torch order)."""
+    r, g = np.asarray(render, np.float32), np.asarray(gt, np.float32)
+    d = np.abs(r - g)
+    e = (d[0] + d[1]) + d[2]
+    e[((r[0] + r[1]) + r[2]) == 0] = 0
+    return e
+
+
+def colorerror2tilemask(color_error, stride, top_ratio=0.4):
+    """SLAM/utils.py:766-799.  Returns (mask int32 [gy, gx], pooled float32, k): ties at the k-th value make the reference's
+    torch.topk choice implementation-defined, so callers compare masks only away from that value."""
+    pooled = meanpool(color_error, stride)
+    k = int(pooled.size * top_ratio)
+    order = np.argsort(-pooled.reshape(-1), kind="stable")
+    mask = np.zeros(pooled.size, np.int32)
+    mask[order[:k]] = 1
+    return mask.reshape(pooled.shape), pooled, k
