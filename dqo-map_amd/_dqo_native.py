@@ -62,7 +62,8 @@ EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_profile_enable", "dqo_profi
            "dqo_rast_binning_bytes",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
            "dqo_rast_forward", "dqo_rast_backward", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
-           "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam", "dqo_tile_count_mask", "dqo_transmission_mask", "dqo_tile_color_error")
+           "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam", "dqo_tile_count_mask", "dqo_transmission_mask", "dqo_tile_color_error", "dqo_knn3_query_workspace_bytes",
+           "dqo_knn3_query")
 
 _lib = None
 
@@ -104,6 +105,9 @@ def lib():
         L.dqo_map_loss_fwd_bwd.argtypes = [c_i32, c_i32] + [c_vp] * 6 + [c_f, c_f, c_f] + [c_vp] * 4 + [ctypes.c_size_t, c_vp]
         L.dqo_map_adam_step.argtypes = [P(DqoAdamStep), c_vp]
         L.dqo_accumulate_gaussian_error.argtypes = [c_i32] * 3 + [c_vp] * 5 + [c_f] * 3 + [c_i32] + [c_vp] * 6
+        L.dqo_knn3_query_workspace_bytes.restype = ctypes.c_size_t
+        L.dqo_knn3_query_workspace_bytes.argtypes = [c_i32, c_i32]
+        L.dqo_knn3_query.argtypes = [c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
         L.dqo_tile_count_mask.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp]
         L.dqo_transmission_mask.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         L.dqo_tile_color_error.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]

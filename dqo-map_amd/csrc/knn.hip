@@ -251,13 +251,61 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(int P, const float4* __re
     }
 }
 
+// K = 3 nearest REFERENCE points of every QUERY point (row f3: Mapping.temp_points_filter, SLAM/multiprocess/mapper.py:
+// 1351-1380, which calls pytorch3d.ops.knn_points(temp_xyz, exist_xyz, K=3, norm=2): exact squared L2 distances, ascending).
+// Same structure as the self search above: the references are Morton-sorted and boxed, the queries are Morton-sorted too,
+// so the 64 queries of a wave are spatial neighbours and a box is scanned by the wave if ANY lane still needs it (broadcast
+// candidate loads).  First the wave scans the box closest to its first lane to get finite bounds, then every box that some
+// lane cannot exclude (box distance <= its current third-best).
+__global__ __launch_bounds__(256) void knn_query_scan_kernel(int Q, const float4* __restrict__ sorted_q, int R,
+                                                             const float4* __restrict__ sorted_r, const float* __restrict__ boxes,
+                                                             float* __restrict__ dist2, int32_t* __restrict__ idx3) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = qi < Q;
+    const float4 me = live ? sorted_q[qi] : sorted_q[Q - 1];
+    float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    int bidx[3] = {-1, -1, -1};
+    const int nb = (R + KNN_BOX - 1) / KNN_BOX;
+    // the box nearest to this wave's first query
+    int b0 = 0;
+    {
+        float dmin = FLT_MAX;
+        for (int b = 0; b < nb; b++) {
+            float bx[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) bx[a] = boxes[8 * b + a];
+            const float d = dist_box_point(bx, me);
+            if (d < dmin) dmin = d, b0 = b;
+        }
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+    }
+    for (int i = b0 * KNN_BOX; i < min(R, (b0 + 1) * KNN_BOX); i++) kbest(me, sorted_r[i], best, bidx);
+    for (int b = 0; b < nb; b++) {
+        if (b == b0) continue;
+        float bx[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) bx[a] = boxes[8 * b + a];
+        const bool need = live && !(dist_box_point(bx, me) > best[2]);
+        if (__ballot(need) == 0) continue;
+        const int lo = b * KNN_BOX, hi = min(R, (b + 1) * KNN_BOX);
+        for (int i = lo; i < hi; i++) {
+            const float4 c = sorted_r[i];  // wave-uniform address
+            if (need) kbest(me, c, best, bidx);
+        }
+    }
+    if (live) {
+        const uint32_t dst = __float_as_uint(me.w);
+#pragma unroll
+        for (int j = 0; j < 3; j++) dist2[dst * 3 + j] = best[j], idx3[dst * 3 + j] = bidx[j];
+    }
+}
+
 }  // namespace
 
 size_t dqo_knn3_ws_bytes(int P) { return knn_ws(nullptr, P).total; }
 
-int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void* ws, size_t ws_bytes, hipStream_t s) {
-    (void)ws_bytes;
-    KnnWs w = knn_ws(ws, P);
+// bounding box -> Morton keys -> sort -> gather into Morton order (-> boxes)
+static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, hipStream_t s) {
     const int P2 = next_pow2(P < SORT_RUN ? SORT_RUN : P);
     DQO_LAUNCH("bbox_kernel", bbox_kernel, dim3(1), dim3(1024), s, P, xyz, w.bbox);
     DQO_LAUNCH("morton_kernel", morton_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
@@ -270,8 +318,34 @@ int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void
         DQO_LAUNCH("bitonic_lds_kernel", bitonic_lds_kernel, dim3(runs), dim3(SORT_T), s, w.keys, k, 0);
     }
     DQO_LAUNCH("gather_sorted_kernel", gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), s, P, xyz, w.keys, w.sorted);
-    const int nb = (P + KNN_BOX - 1) / KNN_BOX;
-    DQO_LAUNCH("box_minmax_kernel", box_minmax_kernel, dim3(nb), dim3(256), s, P, w.sorted, w.boxes);
+    if (with_boxes) {
+        const int nb = (P + KNN_BOX - 1) / KNN_BOX;
+        DQO_LAUNCH("box_minmax_kernel", box_minmax_kernel, dim3(nb), dim3(256), s, P, w.sorted, w.boxes);
+    }
+    return DQO_OK;
+}
+
+int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void* ws, size_t ws_bytes, hipStream_t s) {
+    (void)ws_bytes;
+    KnnWs w = knn_ws(ws, P);
+    int rc = knn_build(P, xyz, w, true, s);
+    if (rc) return rc;
     DQO_LAUNCH("knn_scan_kernel", knn_scan_kernel, dim3((P + 255) / 256), dim3(256), s, P, w.sorted, w.boxes, mean_d2, idx3);
+    return DQO_OK;
+}
+
+size_t dqo_knn3_query_ws_bytes(int Q, int R) { return knn_ws(nullptr, Q).total + knn_ws(nullptr, R).total; }
+
+int dqo_launch_knn3_query(int Q, const float* q_xyz, int R, const float* r_xyz, float* dist2, int32_t* idx3, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
+    (void)ws_bytes;
+    KnnWs wr = knn_ws(ws, R);
+    KnnWs wq = knn_ws((char*)ws + wr.total, Q);
+    int rc = knn_build(R, r_xyz, wr, true, s);
+    if (rc) return rc;
+    rc = knn_build(Q, q_xyz, wq, false, s);
+    if (rc) return rc;
+    DQO_LAUNCH("knn_query_scan_kernel", knn_query_scan_kernel, dim3((Q + 255) / 256), dim3(256), s, Q, wq.sorted, R, wr.sorted, wr.boxes,
+               dist2, idx3);
     return DQO_OK;
 }

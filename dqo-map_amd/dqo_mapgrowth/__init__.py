@@ -1,0 +1,78 @@
+"""Map-growth geometry of DQO-MAP's mapper on MI355X (second half).
+
+    knn_points_k3        pytorch3d.ops.knn_points(p1[None], p2[None], K=3, norm=2) as the reference calls it
+                         (SLAM/multiprocess/mapper.py:1366-1372): exact squared distances, ascending, + indices into p2
+    bbox_filter          SLAM/utils.py:801-808
+    temp_points_filter_mask   the decision of Mapping.temp_points_filter (mapper.py:1351-1380): which new ("temp") points
+                         fall inside an existing unstable Gaussian (nearest-3 distance < 0.6 x its radius)
+    update_geometry_scales    the scale initialisation of GaussianPointCloud.update_geometry
+                         (SLAM/gaussian_pointcloud.py:519-570) on top of simple_knn's distCUDA2
+
+The nearest-neighbour search is libdqoraster.so's dqo_knn3_query (Morton-sorted, box-pruned, wave-uniform candidate loads —
+csrc/knn.hip); everything else is a handful of element-wise torch ops exactly as in the reference.  GPU only.
+"""
+import torch
+
+import _dqo_native as N
+from simple_knn._C import distCUDA2
+
+
+def knn_points_k3(p1, p2):
+    """(dists [Q, 3] squared L2 ascending, idx [Q, 3] int64 into p2).  Fewer than 3 references: FLT_MAX / -1 in the tail."""
+    N.require_gpu(p1, p2)
+    if not (p1.is_cuda and p2.is_cuda):
+        raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+    q = p1.float().contiguous()
+    r = p2.float().contiguous()
+    Q, R = q.shape[0], r.shape[0]
+    d = torch.empty((Q, 3), dtype=torch.float32, device=q.device)
+    i = torch.empty((Q, 3), dtype=torch.int32, device=q.device)
+    if Q == 0:
+        return d, i.long()
+    if R == 0:
+        raise RuntimeError("knn_points_k3: empty reference set")
+    lib = N.lib()
+    ws = torch.empty((lib.dqo_knn3_query_workspace_bytes(Q, R),), dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        N.check(lib.dqo_knn3_query(Q, N.ptr(q), R, N.ptr(r), N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(), N.current_stream()))
+    return d, i.long()
+
+
+def bbox_filter(local_xyz, total_xyz, padding=0.05):
+    """SLAM/utils.py:801-808: mask of the total_xyz points strictly inside the padded bounding box of local_xyz."""
+    local_min = local_xyz.min(dim=0)[0] - padding
+    local_max = local_xyz.max(dim=0)[0] + padding
+    return (total_xyz > local_min).all(dim=-1) & (total_xyz < local_max).all(dim=-1)
+
+
+def temp_points_filter_mask(temp_xyz, exist_xyz, exist_radius, topk=3):
+    """mapper.py:1351-1380: True for the temp points to delete.  Returns None where the reference returns early."""
+    if topk != 3:
+        raise ValueError("the kernel is built for K = 3, the only value the reference uses")
+    if torch.numel(exist_xyz) > 0 and torch.numel(temp_xyz) > 0:
+        inbbox = bbox_filter(temp_xyz, exist_xyz)
+        exist_xyz, exist_radius = exist_xyz[inbbox], exist_radius[inbbox]
+    if torch.numel(exist_xyz) == 0:
+        return None
+    nn_dist, nn_idx = knn_points_k3(temp_xyz, exist_xyz)
+    valid = nn_idx >= 0  # fewer than 3 existing points in the box
+    nn_dist = torch.sqrt(nn_dist)
+    corr_radius = exist_radius.reshape(-1)[nn_idx.clamp(min=0)] * 0.6
+    return ((nn_dist < corr_radius) & valid).any(dim=-1)
+
+
+def update_geometry_scales(xyz, radius, extra_xyz, extra_radius, min_radius, max_radius):
+    """gaussian_pointcloud.py:519-556: (scales [P], invalid_scale_mask [P]) for the P new points `xyz` among the
+    existing `extra_xyz`: root-mean-square gap to the 3 nearest neighbours' 3-sigma spheres, clipped."""
+    n = xyz.shape[0]
+    if torch.numel(extra_xyz) > 0:
+        inbbox = bbox_filter(xyz, extra_xyz)
+        extra_xyz, extra_radius = extra_xyz[inbbox], extra_radius[inbbox]
+    total_xyz = torch.cat([xyz, extra_xyz])
+    total_radius = torch.cat([radius, extra_radius]).reshape(-1)
+    _, knn_indices = distCUDA2(total_xyz.float().cuda())
+    knn_indices = knn_indices[:n].long()
+    d = [torch.norm(xyz - total_xyz[knn_indices[:, j]], p=2, dim=1) - 3 * total_radius[knn_indices[:, j]] for j in range(3)]
+    invalid = (d[0] < 0) | (d[1] < 0) | (d[2] < 0)
+    scales = torch.sqrt((d[0] ** 2 + d[1] ** 2 + d[2] ** 2) / 3)
+    return torch.clip(scales, min=min_radius, max=max_radius), invalid

@@ -176,6 +176,14 @@ size_t dqo_knn3_workspace_bytes(int32_t P);
 int dqo_knn3(int32_t P, const float* xyz, float* mean_d2, int32_t* idx3, void* workspace, size_t workspace_bytes,
              void* hipStream);
 
+/* Row f3: exact K = 3 nearest REFERENCE points of every QUERY point (Mapping.temp_points_filter, SLAM/multiprocess/mapper.py:
+ * 1351-1380 -> pytorch3d.ops.knn_points(K=3, norm=2)): dist2[Q,3] squared L2 distances ascending, idx3[Q,3] indices into the
+ * reference set (FLT_MAX / -1 when it has fewer than 3 points).  Ties between equally distant references are resolved
+ * arbitrarily. */
+size_t dqo_knn3_query_workspace_bytes(int32_t Q, int32_t R);
+int dqo_knn3_query(int32_t Q, const float* query_xyz, int32_t R, const float* ref_xyz, float* dist2, int32_t* idx3, void* workspace,
+                   size_t workspace_bytes, void* hipStream);
+
 /* Batched dual-quadric residual over B independent (object, view) pairs: loss = 1 - IoU(obs, bbox(ellipsoid, P34)),
  * with gradients.  valid[b] = 0 when loss == 1 (the reference skips that Adam step). */
 int dqo_quadric_iou_fwd_bwd(int32_t B, const float* axes, const float* R, const float* center, const float* P34,

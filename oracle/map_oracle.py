@@ -130,3 +130,37 @@ def colorerror2tilemask(color_error, stride, top_ratio=0.4):
     mask = np.zeros(pooled.size, np.int32)
     mask[order[:k]] = 1
     return mask.reshape(pooled.shape), pooled, k
+
+
+# ---------------------------------------------------------------- row f3: 3-NN with query != reference set -----------------
+def knn3_query(q, r, block=512, brute_limit=5e7):
+    """pytorch3d.ops.knn_points(q[None], r[None], K=3, norm=2) restated: exact squared L2 distances (float32, (dx^2 + dy^2) + dz^2
+    like the kernel) of the 3 nearest references, ascending, and their indices (ties: lower index first).  Brute force up to
+    brute_limit pairs; beyond that the 12 nearest candidates come from scipy's cKDTree (fp64) and are re-ranked with the same
+    fp32 arithmetic (fp32 rounding cannot promote a candidate from beyond the 12th place)."""
+    q, r = np.asarray(q, np.float32), np.asarray(r, np.float32)
+    Q, R = len(q), len(r)
+    k = min(3, R)
+    dist = np.full((Q, 3), np.finfo(np.float32).max, np.float32)
+    idx = np.full((Q, 3), -1, np.int64)
+
+    def d2_of(qq, cand):  # qq [n, 3], cand [n, m, 3]
+        d = qq[:, None, :] - cand
+        d = d * d
+        return (d[..., 0] + d[..., 1]) + d[..., 2]
+
+    if Q * R <= brute_limit or R <= 12:
+        for s in range(0, Q, block):
+            d2 = d2_of(q[s:s + block], r[None, :, :])
+            order = np.argsort(d2, axis=1, kind="stable")[:, :k]
+            idx[s:s + block, :k] = order
+            dist[s:s + block, :k] = np.take_along_axis(d2, order, 1)
+        return dist, idx
+    from scipy.spatial import cKDTree
+    _, cand = cKDTree(r.astype(np.float64)).query(q.astype(np.float64), k=12)
+    cand = np.sort(cand, axis=1)  # ascending index so that the stable sort breaks distance ties by lower index
+    d2 = d2_of(q, r[cand])
+    order = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    idx[:, :k] = np.take_along_axis(cand, order, 1)
+    dist[:, :k] = np.take_along_axis(d2, order, 1)
+    return dist, idx
