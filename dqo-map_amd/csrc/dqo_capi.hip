@@ -33,6 +33,10 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         const float* gt_depth, const uint8_t* render_mask, float color_weight, float depth_weight, float add_depth_thres,
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
+size_t dqo_icp_ws_bytes(void);
+int dqo_launch_icp(int H, int W, const float* vertex0, const float* vertex1, const float* normal0, const float* normal1, const float* pose10,
+                   float fx, float fy, float cx, float cy, float dist_thr, float normal_thr, float* JtJ, float* JtR, int32_t* valid_count,
+                   void* ws, hipStream_t s);
 int dqo_launch_tile_count(int W, int H, int mode, const uint8_t* mask_in, const float* T_map, uint8_t* mask_out, int32_t* tile_count,
                           int32_t* total, hipStream_t s);
 int dqo_launch_tile_color_error(int W, int H, const float* render, const float* gt, float* err_px, float* tile_sum, hipStream_t s);
@@ -312,6 +316,22 @@ DQO_API int dqo_tile_color_error(int32_t W, int32_t H, const float* render, cons
                                  void* stream) {
     DQO_CHECK_ARG(W > 0 && H > 0 && render && gt && tile_sum, "bad size / null pointer");
     return dqo_launch_tile_color_error(W, H, render, gt, color_error, tile_sum, (hipStream_t)stream);
+}
+
+DQO_API size_t dqo_icp_workspace_bytes(void) { return dqo_icp_ws_bytes(); }
+
+DQO_API int dqo_icp_normal_equations(int32_t H, int32_t W, const float* vertex0, const float* vertex1, const float* normal0,
+                                     const float* normal1, const float* pose10, float fx, float fy, float cx, float cy, float dist_thr,
+                                     float normal_thr, float* JtJ, float* JtR, int32_t* valid_count, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    DQO_CHECK_ARG(H > 1 && W > 1 && (int64_t)H * W < (int64_t)0x7fffffff / 3, "bad image size");
+    DQO_CHECK_ARG(vertex0 && vertex1 && normal0 && normal1 && pose10 && JtJ && JtR && valid_count, "null pointer");
+    if (ws == nullptr || ws_bytes < dqo_icp_ws_bytes()) {
+        dqo_set_error("icp workspace too small (%zu < %zu)", ws_bytes, dqo_icp_ws_bytes());
+        return DQO_ERR_WORKSPACE;
+    }
+    return dqo_launch_icp(H, W, vertex0, vertex1, normal0, normal1, pose10, fx, fy, cx, cy, dist_thr, normal_thr, JtJ, JtR, valid_count, ws,
+                          (hipStream_t)stream);
 }
 
 DQO_API int dqo_map_adam_step(const DqoAdamStep* st, void* stream) {

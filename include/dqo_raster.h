@@ -239,6 +239,16 @@ int dqo_transmission_mask(int32_t W, int32_t H, const float* T_map, uint8_t* ren
 int dqo_tile_color_error(int32_t W, int32_t H, const float* render, const float* gt, float* color_error, float* tile_sum,
                          void* hipStream);
 
+/* Row f4 — normal equations of one Gauss-Newton iteration of the point-to-plane ICP tracker (SLAM/icp.py:51-123:
+ * compute_residuals_jacobian + compute_jtj + compute_jtr).  vertex / normal maps are [H, W, 3] fp32, pose10 a row-major 4x4
+ * (maps frame-0 points into frame 1), normal_threshold the cosine.  Out: JtJ [6,6] (rotation block first), JtR [6],
+ * valid_count [1] = pixels that passed every test.  The 6x6 solve / se(3) update stay with the caller. */
+size_t dqo_icp_workspace_bytes(void);
+int dqo_icp_normal_equations(int32_t H, int32_t W, const float* vertex0, const float* vertex1, const float* normal0, const float* normal1,
+                             const float* pose10, float fx, float fy, float cx, float cy, float distance_threshold,
+                             float normal_threshold, float* JtJ, float* JtR, int32_t* valid_count, void* workspace,
+                             size_t workspace_bytes, void* hipStream);
+
 typedef struct DqoAdamStep {
     int32_t P, M;      /* Gaussians, SH coefficients per Gaussian (f_dc = coefficient 0, f_rest = the others) */
     int32_t step;      /* 1-based Adam step count */

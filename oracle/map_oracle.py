@@ -164,3 +164,37 @@ def knn3_query(q, r, block=512, brute_limit=5e7):
     idx[:, :k] = np.take_along_axis(cand, order, 1)
     dist[:, :k] = np.take_along_axis(d2, order, 1)
     return dist, idx
+
+
+# ---------------------------------------------------------------- row f4: ICP normal equations ------------------------------
+def icp_normal_equations(vertex0, vertex1, normal0, normal1, pose10, K, distance_threshold, normal_threshold):
+    """SLAM/icp.py:51-123 restated: per-pixel fp32 like the reference, sums in fp64.  Returns (JtJ [6,6], JtR [6], valid mask [H,W])."""
+    f = np.float32
+    v0, v1, n0, n1 = (np.asarray(a, f) for a in (vertex0, vertex1, normal0, normal1))
+    pose = np.asarray(pose10, f)
+    R, t = pose[:3, :3], pose[:3, 3]
+    H, W, _ = v0.shape
+    p = (v0.reshape(-1, 3) @ R.T).astype(f).reshape(H, W, 3) + t[None, None, :]
+    n = (n0.reshape(-1, 3) @ R.T).astype(f).reshape(H, W, 3)
+    fx, fy, cx, cy = f(K[0][0]), f(K[1][1]), f(K[0][2]), f(K[1][2])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = (p[..., 0] / p[..., 2]) * fx + cx
+        v = (p[..., 1] / p[..., 2]) * fy + cy
+        inview = (u > 0) & (u < W - 1) & (v > 0) & (v < H - 1)
+        # grid_sample(mode="nearest", padding_mode="border", align_corners=True) of warp_features (icp.py:131-149)
+        un, vn = u / f((W - 1) / 2) - f(1), v / f((H - 1) / 2) - f(1)
+        gx = np.clip(((un + f(1)) / f(2)) * f(W - 1), 0, W - 1)
+        gy = np.clip(((vn + f(1)) / f(2)) * f(H - 1), 0, H - 1)
+        xi = np.nan_to_num(np.rint(gx), nan=0.0).astype(np.int64).clip(0, W - 1)
+        yi = np.nan_to_num(np.rint(gy), nan=0.0).astype(np.int64).clip(0, H - 1)
+    q, m = v1[yi, xi], n1[yi, xi]
+    diff = p - q
+    ndm = (n * m).sum(-1) > f(normal_threshold)
+    res = (m * diff).sum(-1)
+    J = np.concatenate([np.cross(p, m), m], -1)  # J_rot = -(m^T [p]_x) = p x m
+    with np.errstate(invalid="ignore"):
+        occ = ~inview | (np.sqrt((diff * diff).sum(-1)) > f(distance_threshold))
+    valid = ~(occ | ~(v0[..., 2] > 0) | ~(q[..., 2] > 0) | ~ndm)
+    Jv = J[valid].astype(np.float64)
+    rv = res[valid].astype(np.float64)
+    return Jv.T @ Jv, Jv.T @ rv, valid
