@@ -191,6 +191,26 @@ static_assert(sizeof(DqoGradRec) == 64, "record must be one 64-byte line");
 static inline size_t dqo_bwd_recs_bytes(int64_t cap) { return dqo_align_up(sizeof(DqoGradRec) * 4 * (size_t)(cap < 0 ? 0 : cap), 256); }
 static inline size_t dqo_bwd_ws_bytes(int64_t cap) { return dqo_bwd_recs_bytes(cap) + 256; }
 
+// Block -> Gaussian assignment of the two kernels whose cost depends on WHICH Gaussians share a block (bin_count_kernel: same-
+// tile atomics; record_sum_kernel: slots per block).  A block of 256 threads owns 16 groups of 16 consecutive Gaussians taken
+// from 16 distant parts of the index range (a 16 x G/16 transpose of the group index), so a spatially coherent storage order
+// (an incrementally built map) is spread over the blocks the way a random order is, while every load still covers 16
+// consecutive records.  Both kernels use the same mapping: a block's Gaussians get one contiguous run of instance slots.
+// Returns >= P for the padding positions.
+__host__ __device__ static inline int dqo_spread_index(int logical, int P) {
+    const int G = (P + 15) >> 4;            // groups of 16
+    const int rows = (G + 15) >> 4;         // groups per region
+    const int L = logical >> 4;             // logical group
+    const int phys = (L & 15) * rows + (L >> 4);
+    return phys < G ? phys * 16 + (logical & 15) : P;
+}
+
+// number of 256-thread blocks that cover every logical position of dqo_spread_index
+static inline int dqo_spread_blocks(int P) {
+    const int G = (P + 15) >> 4, rows = (G + 15) >> 4;
+    return (rows * 16 * 16 + 255) / 256;
+}
+
 // Per-view constants.  Scalars travel by value (kernarg -> SGPRs); the matrices stay device pointers because the
 // reference API hands them over as device tensors (no host read, no sync) — kernels fetch them with scalar loads.
 struct DqoView {

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void record_sum_kernel(int P, DqoGeomLayout g,
     __shared__ float4 s_rec[GB_CHUNK * 4];
     __shared__ uint32_t s_lohi[2];
     const int tid = threadIdx.x;
-    const int idx = blockIdx.x * blockDim.x + tid;
+    const int idx = dqo_spread_index(blockIdx.x * blockDim.x + tid, P);  // same block -> Gaussian assignment as bin_count_kernel
     uint32_t base = 0, cnt = 0;
     if (idx < P) base = g.slot_base[idx], cnt = g.tiles_touched[idx];
     if (tid == 0) s_lohi[0] = 0xffffffffu, s_lohi[1] = 0u;
@@ -429,7 +429,7 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap, s);
     if (rc) return rc;
     DqoGradRec* sums = reinterpret_cast<DqoGradRec*>(g.grad_sum);  // [P], lives in the forward's geometry buffer
-    DQO_LAUNCH("record_sum_kernel", record_sum_kernel, dim3((p->P + 255) / 256), dim3(256), s, p->P, g, reinterpret_cast<const float4*>(recs),
+    DQO_LAUNCH("record_sum_kernel", record_sum_kernel, dim3(dqo_spread_blocks(p->P)), dim3(256), s, p->P, g, reinterpret_cast<const float4*>(recs),
                reinterpret_cast<const uint32_t*>(valid), reinterpret_cast<float4*>(sums), cap);
     DQO_LAUNCH("gaussian_backward_kernel", gaussian_backward_kernel, dim3((p->P + 255) / 256), dim3(256), s, v, g, in->means3D, in->scales,
                in->rotations, in->shs, sums, cap, *gr);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id(), wave = tid >> 6;
     const int chunk0 = blockIdx.x * BIN_CHUNK;
-    const int my_idx = chunk0 + tid;
+    const int my_idx = dqo_spread_index(chunk0 + tid, P);  // which Gaussian this thread owns (dqo_common.h)
 
     // ---- this thread's Gaussian: rect area (0 = culled by K1) and the inputs of the footprint test, parked in LDS ----
     uint32_t area = 0;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
                     const uint32_t first = max(s_off[c.gi], win);
                     slot[u] = base + s_gb[c.gi] + s_prev[c.gi] + popcount_range(s_bits, first - win, w - win);
                     tile[u] = c.tile;
-                    gid[u] = chunk0 + c.gi;
+                    gid[u] = dqo_spread_index(chunk0 + c.gi, P);
                     rank[u] = atomicAdd(&tile_count[(size_t)c.tile * DQO_TSTRIDE], 1u);
                 }
             }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void bin_place_kernel(DqoGeomLayout g, DqoImag
 
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                          int64_t capacity, hipStream_t s) {
-    DQO_LAUNCH("bin_count_kernel", bin_count_kernel, dim3((P + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
+    DQO_LAUNCH("bin_count_kernel", bin_count_kernel, dim3(dqo_spread_blocks(P)), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
                img.tile_count, img.tile_flag, bin, capacity);
     return DQO_OK;
 }
