@@ -278,9 +278,10 @@ def main():
             "blend_forward_kernel": 40 * n_inst + 36 * HWa,                              # id + 2 records (+ rgb for survivors), live bytes; 9 output planes
             "blend_backward_kernel": 120 * n_inst + 32 * HWa,                            # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
             "record_sum_kernel": 68 * n_inst + 64 * n_vis,                               # gradient records in, one summed record per visible Gaussian out
-            "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * P,               # summed record, params, tables; all gradient rows written
+            # summed record, params, tables in; gradient rows out (fused path: only the rows of visible Gaussians are written)
+            "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * (n_vis if args.path == "fused" else P),
             "loss_reduce_kernel": 36 * HWa, "loss_grad_kernel": 52 * HWa,
-            "adam_kernel": 236 * 7 * P,                                                  # 59 floats x (param, grad, m, v in; param, m, v out)
+            "adam_kernel": 236 * 6 * P + 236 * n_vis,   # 59 floats x (param, m, v in and out) + the gradient rows of visible Gaussians
         }
         bytes_dom = alg.get(dom_name, 0)
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
