@@ -3,14 +3,15 @@
 // Replaces (semantics, not structure) /root/reference/submodules/diff-gaussian-rasterizer-depth/
 //   cuda_rasterizer/forward.cu:238-354   preprocessCUDA            -> preprocess_kernel
 //   cuda_rasterizer/rasterizer_impl.cu:70-142, 303-365 (cub scan, duplicateWithKeys, cub radix sort,
-//   identifyTileRanges, host tile compaction with two D2H syncs)   -> tile_scan_kernel, emit_kernel, tile_sort_kernel
-//   cuda_rasterizer/forward.cu:636-866   renderCUDA_withMask       -> blend_forward_kernel
+//   identifyTileRanges, host tile compaction with two D2H syncs)   -> bin_count_kernel / bin_place_kernel (rast_binning.hip),
+//                                                                      tile_scan_kernel, tile_sort_wave_kernel, tile_sort_kernel
+//   cuda_rasterizer/forward.cu:636-866   renderCUDA_withMask       -> blend_forward_kernel (rast_forward_blend.hip)
 //
-// MI355X design: no host synchronisation anywhere; binning is a per-tile counting sort (atomic tile
-// histogram in K1 -> one-block scan -> cursor emit) followed by an LDS sort of each tile's (depth, id) keys, so an
-// instance crosses HBM once as an 8-byte key instead of 6 radix passes over 12-byte pairs; everything the blend loop
-// needs per Gaussian is precomputed once into 16-byte SoA records (the reference rebuilds the quaternion rotation and
-// four uncoalesced gathers per (pixel, Gaussian) pair, forward.cu:779-791).
+// MI355X design: no host synchronisation anywhere; binning is a per-tile counting sort (footprint test +
+// atomic tile histogram with ranks -> one-block scan -> atomic-free placement) followed by a register-resident sort of each
+// tile's (depth, id) keys by one wave, so an instance crosses HBM once as an 8-byte key instead of 6 radix passes over
+// 12-byte pairs; everything the blend loop needs per Gaussian is precomputed once into 16-byte SoA records (the reference
+// rebuilds the quaternion rotation and does four uncoalesced gathers per (pixel, Gaussian) pair, forward.cu:779-791).
 #include "dqo_common.h"
 #include "dqo_cull.h"
 
