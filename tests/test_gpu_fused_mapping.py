@@ -177,3 +177,23 @@ def test_graph_replay_matches_eager_steps(env):
     b.replay()
     torch.cuda.synchronize()
     assert b.step_count == 6 and int(b._g.step_dev.item()) == 7
+
+
+def test_graph_capacity_overflow_is_flagged(env):
+    """A captured graph has a fixed instance capacity; when the scene needs more, nothing is written out of bounds, the device
+    header says so and graph_overflowed() reports it (the frame's outputs are the initial fills)."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    fm = FusedMapper(scene, settings, dev)
+    before = {k: v.clone() for k, v in fm._params().items()}
+    fm.capture(gt_color, gt_depth, mask, capacity_margin=0.05)  # room for ~5 % of the candidate pairs only
+    fm.replay()
+    torch.cuda.synchronize()
+    assert fm.graph_overflowed()
+    for k, v in fm._params().items():
+        assert torch.isfinite(v).all(), k  # an invalid frame must not poison the parameters with NaN / inf
+    ok = FusedMapper(scene, settings, dev).capture(gt_color, gt_depth, mask)
+    ok.replay()
+    torch.cuda.synchronize()
+    assert not ok.graph_overflowed()
