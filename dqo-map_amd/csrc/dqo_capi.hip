@@ -65,16 +65,16 @@ hipEvent_t take_event() {
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 }  // namespace
 void dqo_profile_before(const char* name, hipStream_t s) {
     Pending p{name, take_event(), take_event()};
-    hipEventRecord(p.start, s);
+    (void)hipEventRecord(p.start, s);
     g_pending.push_back(p);
 }
-void dqo_profile_after(hipStream_t s) { hipEventRecord(g_pending.back().stop, s); }
+void dqo_profile_after(hipStream_t s) { (void)hipEventRecord(g_pending.back().stop, s); }
 
 extern "C" {
 

@@ -198,7 +198,6 @@ __global__ void quadric_adam_kernel(int n_obj, int n_iters, const int32_t* __res
     for (int i = 0; i < 9; i++) prm[6 + i] = R[9 * ob + i];
     for (int i = 0; i < 15; i++) mm[i] = 0.f, vv[i] = 0.f;
     const int v0 = view_offset[ob], nv = view_offset[ob + 1] - v0;
-    int step = 0;
     double pow1 = 1.0, pow2 = 1.0;  // beta1^step, beta2^step
     for (int it = 0; it < n_iters; it++) {
         int vi = view_schedule[ob * n_iters + it];
@@ -211,7 +210,6 @@ __global__ void quadric_adam_kernel(int n_obj, int n_iters, const int32_t* __res
         quadric_eval(prm, prm + 6, prm + 3, P, obx, o);
         if (loss_hist) loss_hist[ob * n_iters + it] = o.loss;
         if (!o.valid) continue;  // loss == 1: the reference raises and `continue`s before backward()/step()
-        step++;
         pow1 *= 0.9;
         pow2 *= 0.999;
         const double bc1 = 1.0 - pow1, bc2 = 1.0 - pow2;

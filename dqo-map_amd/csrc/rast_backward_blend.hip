@@ -37,6 +37,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // one bit of its id and ships the other half to its partner), so the whole thing costs ~35 VALU instead of 8 x 11 for eight
 // independent reductions.  Partners: xor 1 / xor 2 = DPP quad_perm, xor 4 = row_shl:4 | row_shr:4 split by bank mask,
 // xor 8 = row_ror:8, xor 16 / 32 = ds_bpermute.
+typedef unsigned dqo_uint2v __attribute__((ext_vector_type(2)));
 template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ float dpp_mov_bank(float old, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK_MASK, false));
@@ -60,9 +61,12 @@ __device__ __forceinline__ float wave_reduce8(const float (&v)[8], int lane) {
     t = dpp_mov_bank<0x114, 0xA>(t, send);          // row_shr:4 -> lanes with bit2 = 1 read lane - 4
     float y = keep + t;                              // partner lane ^ 4
     y += dpp_mov<0x128>(y);                          // row_ror:8  == lane ^ 8 inside a row of 16
-    y += __shfl_xor(y, 16);
-    y += __shfl_xor(y, 32);
-    return y;
+    // lane ^ 16 and lane ^ 32: a swap of a register with its own copy leaves (this half, partner half) in the two results —
+    // one VALU op instead of a ds_bpermute round trip through the LDS queue
+    const dqo_uint2v r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    y = __uint_as_float(r16.x) + __uint_as_float(r16.y);
+    const dqo_uint2v r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(r32.x) + __uint_as_float(r32.y);
 }
 
 // Reduce-scatter butterfly for SIXTY-FOUR values at once: afterwards lane l holds the 64-lane total of v[l].  Stage order
@@ -72,7 +76,6 @@ __device__ __forceinline__ float wave_reduce8(const float (&v)[8], int lane) {
 //   lane ^ 8,  lane ^ 4  : DPP row_ror:8 / row_shl:4 | row_shr:4, the two lane classes are whole DPP banks (bank_mask)
 //   lane ^ 2,  lane ^ 1  : DPP quad_perm with explicit selects
 // 141 VALU for 64 sums (2.2 per sum; eight separate DPP reductions of one value each would cost ~11 per sum).
-typedef unsigned dqo_uint2v __attribute__((ext_vector_type(2)));
 template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ float dpp_pick(float old, float v) {  // lanes of the enabled banks read v through CTRL, the others keep old
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK_MASK, false));
@@ -90,22 +93,29 @@ __device__ __forceinline__ float wave_reduce64(const float (&v)[64], int lane) {
         const dqo_uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 16]), false, false);
         b[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
     }
+    // lane bit 3 = DPP banks 2, 3 of every row, partner = row_ror:8: banks 0,1 take b[i] + partner's b[i], banks 2,3 take
+    // b[i + 8] + partner's b[i + 8] — two bank-masked v_add_f32_dpp writing the two halves of one register (the builtin only
+    // yields v_mov_dpp + select + add: 4 instructions).  Hand-written DPP: the leading s_nop covers the 2 wait states a DPP read
+    // needs after the VALU write of its source, which the compiler cannot see inside the asm.
     float c[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {  // lane bit 3 = DPP banks 2, 3 of every row; partner = row_ror:8
-        const float mine = dpp_pick<0xE4, 0xC>(b[i], b[i + 8]);          // quad_perm [0,1,2,3] = identity: banks 2,3 take b[i+8]
-        float other = dpp_pick<0x128, 0x3>(0.f, b[i]);                    // banks 0,1 read the partner's b[i]
-        other = dpp_pick<0x128, 0xC>(other, b[i + 8]);                    // banks 2,3 read the partner's b[i+8]
-        c[i] = mine + other;
-    }
+#define DQO_S3(i, j) "v_add_f32_dpp %[c" #i "], %[b" #i "], %[b" #i "] row_ror:8 row_mask:0xf bank_mask:0x3\n" \
+                     "v_add_f32_dpp %[c" #i "], %[b" #j "], %[b" #j "] row_ror:8 row_mask:0xf bank_mask:0xc\n"
+    asm volatile("s_nop 1\n" DQO_S3(0, 8) DQO_S3(1, 9) DQO_S3(2, 10) DQO_S3(3, 11) DQO_S3(4, 12) DQO_S3(5, 13) DQO_S3(6, 14) DQO_S3(7, 15)
+                 : [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [c4] "=&v"(c[4]), [c5] "=&v"(c[5]),
+                   [c6] "=&v"(c[6]), [c7] "=&v"(c[7])
+                 : [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6]),
+                   [b7] "v"(b[7]), [b8] "v"(b[8]), [b9] "v"(b[9]), [b10] "v"(b[10]), [b11] "v"(b[11]), [b12] "v"(b[12]),
+                   [b13] "v"(b[13]), [b14] "v"(b[14]), [b15] "v"(b[15]));
+#undef DQO_S3
+    // lane bit 2 = odd DPP banks; partner = lane + 4 (row_shl:4, even banks) / lane - 4 (row_shr:4, odd banks)
     float d[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {  // lane bit 2 = odd DPP banks; partner = lane + 4 (row_shl:4) / lane - 4 (row_shr:4)
-        const float mine = dpp_pick<0xE4, 0xA>(c[i], c[i + 4]);
-        float other = dpp_pick<0x104, 0x5>(0.f, c[i]);
-        other = dpp_pick<0x114, 0xA>(other, c[i + 4]);
-        d[i] = mine + other;
-    }
+#define DQO_S4(i, j) "v_add_f32_dpp %[d" #i "], %[c" #i "], %[c" #i "] row_shl:4 row_mask:0xf bank_mask:0x5\n" \
+                     "v_add_f32_dpp %[d" #i "], %[c" #j "], %[c" #j "] row_shr:4 row_mask:0xf bank_mask:0xa\n"
+    asm volatile("s_nop 1\n" DQO_S4(0, 4) DQO_S4(1, 5) DQO_S4(2, 6) DQO_S4(3, 7) "s_nop 1\n"
+                 : [d0] "=&v"(d[0]), [d1] "=&v"(d[1]), [d2] "=&v"(d[2]), [d3] "=&v"(d[3])
+                 : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]),
+                   [c7] "v"(c[7]));
+#undef DQO_S4
     const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
     float e[2];
 #pragma unroll
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
 #pragma clang fp contract(off)
                             const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
                             const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
-                            const float inv_nr = 1.f / nr;
+                            const float inv_nr = dqo_rcp(nr);  // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
                             const float u = ddep * ray.z * inv_nr;
                             const float w = u * inv_nr;
                             const bool plane = is_hit && hit_plane;

@@ -23,12 +23,6 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 // K1: per-Gaussian preprocess.  Bit-faithful to the oracle: IEEE ops only, no FMA contraction in this kernel (it is
 // bandwidth bound; contraction would only move discrete decisions such as ceil(radius) and the tile rect).
 // ------------------------------------------------------------------------------------------------------------------
-struct PreOut {
-    int radius;      // 0 = culled
-    uint32_t touch;  // unmasked tiles in rect
-    int rminx, rminy, rmaxx, rmaxy;
-};
-
 constexpr int K1_THREADS = 256;
 constexpr int K1_ITEMS = 1;
 
