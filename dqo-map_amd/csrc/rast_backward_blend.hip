@@ -150,6 +150,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     __shared__ int s_id[BWD_THREADS];
     __shared__ uint32_t s_slot[BWD_THREADS];
     __shared__ int s_pos[BWD_THREADS];
+    __shared__ float s_hit[BWD_THREADS * 5];
 
     // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
     const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
@@ -186,6 +187,64 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     if (__builtin_amdgcn_ballot_w64(dp0 != 0.f || dp1 != 0.f || dp2 != 0.f || ddep != 0.f) == 0ull) return;
     const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
     const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
+    // ---- depth-hit sums (backward.cu:997-1065): ONCE per pixel, outside the entry loop ----
+    // Every pixel has at most one entry that fixed its depth (hit_pos) and the gradient it sends to that Gaussian depends on
+    // nothing the walk below computes.  Only the pixel-dependent factors are summed here (DqoGradRec::hit).  Pixels of the
+    // quadrant that share the hit entry are added up through wave-private LDS: the lowest such lane (the leader) stores its own
+    // terms, the others ds_add_f32 theirs onto them — one instruction's lanes are served in a fixed order, and the table is
+    // private to the wave, so the sums are reproducible — and the leader writes floats 9..13 of the (quadrant, instance) record.
+    // The walk marks those records with validity 3 when it writes their colour part.
+    {
+        const bool has_hit = hit_pos > 0;  // implies inside
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(has_hit);
+        if (hm != 0ull) {
+            float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            uint32_t slot_h = 0xffffffffu;
+            if (has_hit) {
+#pragma clang fp contract(off)
+                const int gid = (int)bin.point_list[range.x + hit_pos - 1];
+                slot_h = bin.slot_list[range.x + hit_pos - 1];
+                const float4 n_np = g.normal_c[gid];
+                const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
+                const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
+                const float inv_nr = dqo_rcp(nr);               // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
+                const float u = ddep * ray.z * inv_nr;
+                const float w = u * inv_nr;
+                h[0] = hit_plane ? 0.f : ddep;  // the forward decided backward.cu:1016's branch for this pixel
+                h[1] = hit_plane ? u : 0.f;
+                h[2] = hit_plane ? w * ray.x : 0.f;
+                h[3] = hit_plane ? w * ray.y : 0.f;
+                h[4] = hit_plane ? w * ray.z : 0.f;
+            }
+            int leader = lane;  // lowest lane with the same hit entry
+            unsigned long long todo = hm;
+            while (todo != 0ull) {  // one trip per distinct hit entry of the quadrant (wave-uniform)
+                const int f = (int)__builtin_ctzll(todo);
+                const int key = __builtin_amdgcn_readlane(hit_pos, f);
+                const bool same = has_hit && hit_pos == key;
+                leader = same ? f : leader;
+                todo &= ~__builtin_amdgcn_ballot_w64(same);
+            }
+            const bool is_leader = has_hit && leader == lane;
+            if (is_leader) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) s_hit[lane * 5 + i] = h[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (has_hit && !is_leader) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) atomicAdd(&s_hit[leader * 5 + i], h[i]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (is_leader && (int64_t)slot_h < capacity) {
+                float* rec = recs + ((size_t)slot_h * 4 + quad) * 16 + 9;
+#pragma unroll
+                for (int i = 0; i < 5; i++) rec[i] = s_hit[lane * 5 + i];
+            }
+        }
+    }
     // colour blended behind the current entry (the reference's accum_rec after folding in last_alpha / last_color,
     // backward.cu:957-962, evaluated one step earlier: same operands, same rounding)
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
@@ -261,33 +320,8 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                     r_kc = qy * dy;
                     r_op = q;
 
-                    const bool is_hit = (hit_pos == c0 + 1);
-                    if (__builtin_amdgcn_ballot_w64(is_hit) != 0ull) {
-                        // hit-Gaussian depth gradient, backward.cu:997-1065 (once per pixel, for the entry that fixed its
-                        // depth).  Only the pixel-dependent factors are summed here; see DqoGradRec::hit.
-                        const float4 n_np = g.normal_c[__builtin_amdgcn_readfirstlane(s_id[k])];
-                        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
-                        {
-#pragma clang fp contract(off)
-                            const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
-                            const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
-                            const float inv_nr = dqo_rcp(nr);  // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
-                            const float u = ddep * ray.z * inv_nr;
-                            const float w = u * inv_nr;
-                            const bool plane = is_hit && hit_plane;
-                            h0 = (is_hit && !hit_plane) ? ddep : 0.f;
-                            h1 = plane ? u : 0.f;
-                            h2 = plane ? w * ray.x : 0.f;
-                            h3 = plane ? w * ray.y : 0.f;
-                            h4 = plane ? w * ray.z : 0.f;
-                        }
-                        // rotated by one so that lane 9 + i receives hit sum i (lane l gets the total of hv[l & 7])
-                        const float hv[8] = {0.f, h0, h1, h2, h3, h4, 0.f, 0.f};
-                        const float toth = wave_reduce8(hv, lane);
-                        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_slot[k]);
-                        if (lane >= 9 && lane < 14 && (int64_t)slot < capacity) recs[((size_t)slot * 4 + quad) * 16 + lane] = toth;
-                        hitmask |= 1u << b;
-                    }
+                    // the entry fixed some pixel's depth: its record also carries the depth-hit sums written before the loop
+                    if (__builtin_amdgcn_ballot_w64(hit_pos == c0 + 1) != 0ull) hitmask |= 1u << b;
                 }
                 v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
                 v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;
