@@ -49,6 +49,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
     __shared__ float4 s_rgb[FWD_THREADS];
     __shared__ int s_id[FWD_THREADS];
     __shared__ int s_pos[FWD_THREADS];
+    __shared__ int s_half[FWD_THREADS];
 
     // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
     const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
@@ -138,17 +139,12 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
             s_id[myk] = id;
             s_pos[myk] = pos;
         }
-        // lane k keeps the per-entry results of compacted entry k: was it live for this quadrant, and how many of the
-        // quadrant's pixels saw it with T' > 0.5 (n_touched, forward.cu:833-835, quirk B8)
-        int live_k = 0, half_k = 0;
+        // per-entry results of compacted entry k: was it live for this quadrant (bit k of live_m), and how many of the
+        // quadrant's pixels saw it with T' > 0.5 (s_half[k]; n_touched, forward.cu:833-835, quirk B8)
+        unsigned long long live_m = 0ull;  // compacted entries of this chunk that were live (wave-uniform)
         if (cnt > 0) {
-            float4 xy_c = s_xy[0], co_c = s_co[0];
             for (int k = 0; k < cnt && !all_done; k++) {
-                const float4 xy_cur = xy_c, co_cur = co_c;
-                if (k + 1 < cnt) {
-                    xy_c = s_xy[k + 1];
-                    co_c = s_co[k + 1];
-                }
+                const float4 xy_cur = s_xy[k], co_cur = s_co[k];
                 // ---- per-pixel update (forward.cu:750-842), arithmetic gating instead of per-lane control flow ----
                 // gate = 0 for a finished pixel, nohit = 0 once its depth is fixed: multiplying by them keeps the lane's
                 // predicates in VGPRs (a lane mask that lives across the loop costs scalar bookkeeping in every trip).  An
@@ -182,10 +178,9 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                         }
                     }
                     const float test_T = T * (1.f - a_v);  // == T when the entry is not valid for this pixel
-                    const bool below = test_T < v.T_thr;
-                    const bool blend = valid && !below;                    // forward.cu:818-840
-                    const bool finish = valid && below && nohit == 0.f;    // forward.cu:813-817: done, T NOT updated
-                    const float w = below ? 0.f : a_v * T;                 // 0 unless blended
+                    const bool blend = valid && !(test_T < v.T_thr);       // forward.cu:818-840
+                    const bool finish = valid && !blend && nohit == 0.f;   // forward.cu:813-817: done, T NOT updated
+                    const float w = blend ? a_v * T : 0.f;
                     C0 += cs.x * w;
                     C1 += cs.y * w;
                     C2 += cs.z * w;
@@ -198,19 +193,20 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                     gate = finish ? 0.f : gate;
                     // live for the backward: some pixel of the quadrant saw the entry with alpha >= 1/255 while unfinished — a
                     // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
-                    // below T_threshold), so the backward never misses a pair it has work for
-                    const int half = (int)__popcll(__builtin_amdgcn_ballot_w64(blend && test_T > 0.5f));
-                    live_k = lane == k ? 1 : live_k;
-                    half_k = lane == k ? half : half_k;
-                    if (__builtin_amdgcn_ballot_w64(finish) != 0ull) all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;
+                    // below T_threshold), so the backward never misses a pair it has work for.  The per-entry results are
+                    // wave-uniform: the live flag goes into a scalar mask, the n_touched count into LDS (uniform store).
+                    const float t_half = blend ? test_T : 0.f;
+                    s_half[k] = (int)__popcll(__builtin_amdgcn_ballot_w64(t_half > 0.5f));
+                    live_m |= 1ull << k;
+                    all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;
                 }
             }
         }
         // one scattered integer atomic per touched Gaussian of this chunk
+        const int half_k = ((live_m >> lane) & 1ull) ? s_half[lane] : 0;
         if (half_k > 0) atomicAdd(&out.n_touched[s_id[lane]], half_k);
         // live byte of every list position of this chunk (coalesced 64-byte store)
-        const int lv = __shfl(live_k, myk);
-        if (pos < n) live[pos] = (reach && lv) ? (uint8_t)1 : (uint8_t)0;
+        if (pos < n) live[pos] = (reach && ((live_m >> myk) & 1ull)) ? (uint8_t)1 : (uint8_t)0;
     }
     if (inside) {
         const float b0 = v.bg[0], b1 = v.bg[1], b2 = v.bg[2];
