@@ -211,8 +211,7 @@ DQO_API int dqo_rast_backward(const DqoRastParams* p, const DqoRastInputs* in, c
     DQO_CHECK_ARG(g, "null grads");
     if (p->P == 0) return DQO_OK;  // rasterize_points.cu:208
     DQO_CHECK_ARG(dL_dcolor && dL_ddepth, "null upstream gradients");
-    DQO_CHECK_ARG(g->dL_dmeans3D && g->dL_dcolors && g->dL_dopacity && g->dL_dscales && g->dL_drotations && g->dL_dcov3D && g->dL_dmeans2D,
-                  "null gradient output");
+    DQO_CHECK_ARG(g->dL_dmeans3D && g->dL_dopacity && g->dL_dscales && g->dL_drotations, "null gradient output");
     DQO_CHECK_ARG(p->M == 0 || g->dL_dsh, "null dL_dsh");
     DQO_CHECK_ARG(ctx->binning || ctx->inst_capacity == 0, "null binning buffer");
     if (ws_bytes < dqo_rast_backward_workspace_bytes(ctx->inst_capacity) || (ws == nullptr && ctx->inst_capacity > 0)) {

@@ -138,12 +138,13 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         dm[0] = dm[1] = dm[2] = 0.f;
         if (dsh)
             for (int i = 0; i < 3 * M; i++) dsh[i] = 0.f;
-        dcol[0] = dcol[1] = dcol[2] = 0.f;
+        if (gr.dL_dcolors) dcol[0] = dcol[1] = dcol[2] = 0.f;
         gr.dL_dopacity[idx] = 0.f;
         dsc[0] = dsc[1] = dsc[2] = 0.f;
         drot[0] = drot[1] = drot[2] = drot[3] = 0.f;
-        for (int i = 0; i < 6; i++) dcov[i] = 0.f;
-        dm2[0] = dm2[1] = dm2[2] = 0.f;
+        if (gr.dL_dcov3D)
+            for (int i = 0; i < 6; i++) dcov[i] = 0.f;
+        if (gr.dL_dmeans2D) dm2[0] = dm2[1] = dm2[2] = 0.f;
         return;
     }
     const float dcolr[3] = {a[0], a[1], a[2]};
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float mean_g[3] = {0.f, 0.f, 0.f};
     float rot_g[4] = {0.f, 0.f, 0.f, 0.f};
     gr.dL_dopacity[idx] = a[8];
-    dcol[0] = dcolr[0], dcol[1] = dcolr[1], dcol[2] = dcolr[2];
-    dm2[0] = g2x, dm2[1] = g2y, dm2[2] = 0.f;
+    if (gr.dL_dcolors) dcol[0] = dcolr[0], dcol[1] = dcolr[1], dcol[2] = dcolr[2];
+    if (gr.dL_dmeans2D) dm2[0] = g2x, dm2[1] = g2y, dm2[2] = 0.f;
 
     float view[16], proj[16];
 #pragma unroll
@@ -276,8 +277,10 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
 #pragma unroll
         for (int i = 0; i < 6; i++) dcv[i] = 0.;
     }
+    if (gr.dL_dcov3D) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) dcov[i] = (float)dcv[i];
+        for (int i = 0; i < 6; i++) dcov[i] = (float)dcv[i];
+    }
     real dT0[3], dT1[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {

@@ -102,9 +102,9 @@ class FusedMapper:
             g.img = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
             g.binning = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
             g.ws = torch.empty((lib.dqo_rast_backward_workspace_bytes(cap),), **u8)
-            g.grads = dict(means3D=torch.empty((P, 3), **f), sh=torch.empty((P, M, 3), **f), colors=torch.empty((P, 3), **f),
-                           opacity=torch.empty((P, 1), **f), scales=torch.empty((P, 3), **f), rot=torch.empty((P, 4), **f),
-                           cov3D=torch.empty((P, 6), **f), means2D=torch.empty((P, 3), **f))
+            # dL_dcolors / dL_dcov3D / dL_dmeans2D have no consumer in the mapping step: NULL = the backward does not store them
+            g.grads = dict(means3D=torch.empty((P, 3), **f), sh=torch.empty((P, M, 3), **f),
+                           opacity=torch.empty((P, 1), **f), scales=torch.empty((P, 3), **f), rot=torch.empty((P, 4), **f))
             g.step_dev = torch.full((1,), self.step_count + 1, **i32)
             g.params = dgr._params(st, P, M)
             g.inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, g.tile_mask)
@@ -116,10 +116,9 @@ class FusedMapper:
             g.cctx = N.DqoRastCtx(geom=g.geom.data_ptr(), geom_bytes=g.geom.numel(), binning=g.binning.data_ptr(),
                                   binning_bytes=g.binning.numel(), image=g.img.data_ptr(), image_bytes=g.img.numel(), inst_capacity=cap)
             gr = g.grads
-            g.cgrads = N.DqoRastGrads(dL_dmeans3D=gr["means3D"].data_ptr(), dL_dsh=gr["sh"].data_ptr(), dL_dcolors=gr["colors"].data_ptr(),
+            g.cgrads = N.DqoRastGrads(dL_dmeans3D=gr["means3D"].data_ptr(), dL_dsh=gr["sh"].data_ptr(), dL_dcolors=None,
                                       dL_dopacity=gr["opacity"].data_ptr(), dL_dscales=gr["scales"].data_ptr(),
-                                      dL_drotations=gr["rot"].data_ptr(), dL_dcov3D=gr["cov3D"].data_ptr(),
-                                      dL_dmeans2D=gr["means2D"].data_ptr(), skip_culled_rows=1)
+                                      dL_drotations=gr["rot"].data_ptr(), dL_dcov3D=None, dL_dmeans2D=None, skip_culled_rows=1)
             stt = self.state
             g.adam = N.DqoAdamStep(P=P, M=M, step=0, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, lr_xyz=self.lrs["xyz"],
                                    lr_f_dc=self.lrs["f_dc"], lr_f_rest=self.lrs["f_rest"], lr_opacity=self.lrs["opacity"],

@@ -102,16 +102,18 @@ typedef struct DqoRastCtx {
     int64_t inst_capacity; /* number of (Gaussian, tile) instances `binning` can hold */
 } DqoRastCtx;
 
-/* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206). */
+/* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206).  dL_dcolors, dL_dcov3D and
+ * dL_dmeans2D may be NULL when the caller has no use for them (the fused mapping step: no precomputed colours or covariances,
+ * no densification statistics) — three scattered partial-line stores per visible Gaussian less. */
 typedef struct DqoRastGrads {
     float* dL_dmeans3D;   /* [P,3] */
     float* dL_dsh;        /* [P,M,3] (NULL when M == 0) */
-    float* dL_dcolors;    /* [P,3] */
+    float* dL_dcolors;    /* [P,3] or NULL */
     float* dL_dopacity;   /* [P,1] */
     float* dL_dscales;    /* [P,3] */
     float* dL_drotations; /* [P,4] */
-    float* dL_dcov3D;     /* [P,6] */
-    float* dL_dmeans2D;   /* [P,3] (x,y used; z = 0) */
+    float* dL_dcov3D;     /* [P,6] or NULL */
+    float* dL_dmeans2D;   /* [P,3] (x,y used; z = 0) or NULL */
     /* 0 (the drop-in behaviour): every row is written, zeros for the Gaussians the forward culled (radii == 0).
      * non-zero: those all-zero rows are left unwritten — for a consumer that looks at radii itself
      * (dqo_map_adam_step with DqoAdamStep.radii) this saves writing and re-reading 236 B per culled Gaussian. */
