@@ -54,7 +54,7 @@ class DqoAdamStep(ctypes.Structure):
                  ("lr_f_dc", c_f), ("lr_f_rest", c_f), ("lr_opacity", c_f), ("lr_scaling", c_f), ("lr_rotation", c_f)] +
                 [(n, c_vp) for n in ("xyz", "shs", "opacity_raw", "scaling_raw", "rotation_raw", "g_means3D", "g_sh", "g_opacity",
                                      "g_scales", "g_rotations", "m_xyz", "m_shs", "m_opacity", "m_scaling", "m_rotation", "v_xyz",
-                                     "v_shs", "v_opacity", "v_scaling", "v_rotation", "act_opacity", "act_scales", "act_rotations", "radii", "step_dev")])
+                                     "v_shs", "v_opacity", "v_scaling", "v_rotation", "act_opacity", "act_scales", "act_rotations", "radii", "step_dev", "moment_live")])
 
 
 EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",

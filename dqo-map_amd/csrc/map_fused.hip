@@ -158,6 +158,9 @@ __device__ __forceinline__ void stnt(T v, T* p) {
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float step_size) {
     // torch.optim.Adam (single-/multi-tensor and fused paths share this math):
     //   m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g^2; p -= step_size * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+    // Separate IEEE operations (no FMA contraction): every instantiation of the kernel then produces the same bits, which the
+    // exact sparse mode's equivalence to the dense update is tested against.
+#pragma clang fp contract(off)
     m = m + (g - m) * (1.f - a.beta1);
     v = v * a.beta2 + (1.f - a.beta2) * g * g;
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
@@ -166,29 +169,59 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 
 __global__ void adam_advance_kernel(int32_t* step_dev) { *step_dev += 1; }
 
-__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a_in) {
+// One block per 256 consecutive Gaussians.  The block first lists the Gaussians it has to touch (LDS): all of them in dense mode;
+// in the exact sparse mode (DqoAdamStep.moment_live) those with a gradient row (radii > 0) or non-zero moments — the others are
+// fixed points of the update and their rows are neither read nor written.  It then runs one pass per parameter group over the
+// list; element e of a group with rows of `len` floats belongs to list row e / len, so the passes stay dense over the list
+// whatever its sparsity (no lane conditions on the loads), and a Gaussian's rows are read as whole contiguous pieces.
+constexpr int ADAM_THREADS = 256;
+
+template <bool SPARSE>
+__global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in, uint8_t* __restrict__ moment_live) {
     AdamArgs a = a_in;
-    if (a.step_dev != nullptr) {
+    __shared__ uint32_t s_rows[ADAM_THREADS];  // Gaussian index | has-gradient << 31
+    __shared__ int s_wave_n[ADAM_THREADS / 64];
+    __shared__ float s_ss[7];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.step_dev != nullptr && tid == 0) {
         // bias corrections from the device-resident step count (double, like the host path / torch's python floats)
-        __shared__ float s_ss[7];
-        if (threadIdx.x == 0) {
-            const double t = (double)*a.step_dev;
-            const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
-            s_ss[0] = (float)sqrt(bc2);
-            s_ss[1] = (float)((double)a.lr_xyz / bc1), s_ss[2] = (float)((double)a.lr_dc / bc1), s_ss[3] = (float)((double)a.lr_rest / bc1);
-            s_ss[4] = (float)((double)a.lr_opacity / bc1), s_ss[5] = (float)((double)a.lr_scaling / bc1);
-            s_ss[6] = (float)((double)a.lr_rotation / bc1);
-        }
-        __syncthreads();
+        const double t = (double)*a.step_dev;
+        const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+        s_ss[0] = (float)sqrt(bc2);
+        s_ss[1] = (float)((double)a.lr_xyz / bc1), s_ss[2] = (float)((double)a.lr_dc / bc1), s_ss[3] = (float)((double)a.lr_rest / bc1);
+        s_ss[4] = (float)((double)a.lr_opacity / bc1), s_ss[5] = (float)((double)a.lr_scaling / bc1);
+        s_ss[6] = (float)((double)a.lr_rotation / bc1);
+    }
+    const int idx = blockIdx.x * ADAM_THREADS + tid;
+    bool hg = false, act = false;
+    if (idx < a.P) {
+        hg = a.radii == nullptr || a.radii[idx] > 0;
+        act = !SPARSE || hg || moment_live[idx] != 0;
+        if (SPARSE && hg) moment_live[idx] = 1;  // only this thread ever looks at this byte
+    }
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+    if (lane == 0) s_wave_n[wave] = (int)__popcll(am);
+    __syncthreads();
+    if (a.step_dev != nullptr) {
         a.bc2_sqrt = s_ss[0], a.step_xyz = s_ss[1], a.step_dc = s_ss[2], a.step_rest = s_ss[3], a.step_opacity = s_ss[4];
         a.step_scaling = s_ss[5], a.step_rotation = s_ss[6];
     }
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int P = a.P;
+    int before = 0, n_rows = 0;
+#pragma unroll
+    for (int w = 0; w < ADAM_THREADS / 64; w++) {
+        const int c = s_wave_n[w];
+        before += w < wave ? c : 0;
+        n_rows += c;
+    }
+    if (act) s_rows[before + (int)__popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)idx | (hg ? 0x80000000u : 0u);
+    __syncthreads();
+    if (n_rows == 0) return;
+
     // xyz (identity activation) and scaling (exp): element-wise, [P,3]
-    for (int64_t i = t0; i < 3LL * P; i += stride) {
-        const bool has_g = a.radii == nullptr || a.radii[(uint32_t)i / 3u] > 0;
+    for (int e = tid; e < 3 * n_rows; e += ADAM_THREADS) {
+        const uint32_t k = (uint32_t)e / 3u, j = (uint32_t)e - 3u * k, r = s_rows[k];
+        const bool has_g = (r >> 31) != 0u;
+        const size_t i = (size_t)(r & 0x7fffffffu) * 3 + j;
         float p = a.xyz[i], m = ldnt(&a.m_xyz[i]), v = ldnt(&a.v_xyz[i]);
         adam1(p, has_g ? ldnt(&a.g_xyz[i]) : 0.f, m, v, a, a.step_xyz);
         a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
@@ -197,39 +230,43 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a_in) {
         a.scaling_raw[i] = ps, stnt(ms, &a.m_scaling[i]), stnt(vs, &a.v_scaling[i]);
         if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
     }
-    // SH coefficients [P,M,3]: coefficient 0 = f_dc (lr feature_lr), the rest = f_rest (feature_lr / 20)
-    const int64_t nsh = (int64_t)P * a.M * 3;
-    const int row = a.M * 3;
-    // four elements per trip with every load issued before the first use: the row lookup (radii) and the gradient load that
-    // depends on it would otherwise put two memory latencies in series in each trip
-    for (int64_t i0 = t0; i0 < nsh; i0 += 4 * stride) {
+    // SH coefficients [P,M,3]: coefficient 0 = f_dc (lr feature_lr), the rest = f_rest (feature_lr / 20).  Four elements per
+    // trip with every load issued before the first use; all loads unconditional on clamped addresses (a load under a lane
+    // condition makes the compiler drain every earlier load first).
+    const uint32_t row = (uint32_t)a.M * 3u;
+    const int nsh = n_rows * (int)row;
+    for (int e0 = tid; e0 < nsh; e0 += 4 * ADAM_THREADS) {
         float p[4], m[4], v[4], gq[4];
-        bool dc[4], ok[4], has_g[4];
+        uint32_t ei[4], fl[4];  // element index in the [P * M * 3] arrays; 1 = in range, 2 = has a gradient, 4 = f_dc
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int64_t i = i0 + u * stride;
-            ok[u] = i < nsh;
-            const uint32_t ii = ok[u] ? (uint32_t)i : 0u;
-            const uint32_t gsn = (uint32_t)(((uint64_t)ii * a.row_magic) >> 39);  // ii / row, exact for ii < 2^31, row < 2^8
-            dc[u] = (ii - gsn * (uint32_t)row) < 3u;
-            has_g[u] = ok[u] && (a.radii == nullptr || a.radii[gsn] > 0);
-            p[u] = ok[u] ? a.shs[ii] : 0.f;
-            m[u] = ok[u] ? ldnt(&a.m_shs[ii]) : 0.f;
-            v[u] = ok[u] ? ldnt(&a.v_shs[ii]) : 0.f;
+            const int e = e0 + u * ADAM_THREADS;
+            const bool in = e < nsh;
+            const uint32_t ee = in ? (uint32_t)e : 0u;
+            const uint32_t k = (uint32_t)(((uint64_t)ee * a.row_magic) >> 39);  // ee / row, exact for ee < 2^31, row < 2^8
+            const uint32_t j = ee - k * row, r = s_rows[k];
+            ei[u] = (r & 0x7fffffffu) * row + j;
+            fl[u] = in ? (1u | ((r >> 31) ? 2u : 0u) | (j < 3u ? 4u : 0u)) : 0u;
+            p[u] = a.shs[ei[u]];
+            m[u] = ldnt(&a.m_shs[ei[u]]);
+            v[u] = ldnt(&a.v_shs[ei[u]]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) gq[u] = has_g[u] ? ldnt(&a.g_shs[i0 + u * stride]) : 0.f;
+        for (int u = 0; u < 4; u++) {
+            const float gv = ldnt(&a.g_shs[(fl[u] & 2u) ? ei[u] : ei[0]]);  // (a row without a gradient may be unwritten memory)
+            gq[u] = (fl[u] & 2u) ? gv : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (!ok[u]) continue;
-            const int64_t i = i0 + u * stride;
-            adam1(p[u], gq[u], m[u], v[u], a, dc[u] ? a.step_dc : a.step_rest);
-            a.shs[i] = p[u], stnt(m[u], &a.m_shs[i]), stnt(v[u], &a.v_shs[i]);
+            if (!(fl[u] & 1u)) continue;
+            adam1(p[u], gq[u], m[u], v[u], a, (fl[u] & 4u) ? a.step_dc : a.step_rest);
+            a.shs[ei[u]] = p[u], stnt(m[u], &a.m_shs[ei[u]]), stnt(v[u], &a.v_shs[ei[u]]);
         }
     }
     // opacity (sigmoid) [P] and rotation (normalize) [P,4]
-    for (int64_t i = t0; i < P; i += stride) {
-        const bool has_g = a.radii == nullptr || a.radii[i] > 0;
+    if (tid < n_rows) {
+        const uint32_t r = s_rows[tid], i = r & 0x7fffffffu;
+        const bool has_g = (r >> 31) != 0u;
         float p = a.opacity_raw[i], m = ldnt(&a.m_opacity[i]), v = ldnt(&a.v_opacity[i]);
         const float sg = 1.0f / (1.0f + expf(-p));
         adam1(p, (has_g ? ldnt(&a.g_opacity[i]) : 0.f) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
@@ -309,7 +346,12 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");
     const int64_t n = (int64_t)st->P * st->M * 3;
     const int grid = (int)min((int64_t)(256 * 16), (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
-    DQO_LAUNCH("adam_kernel", adam_kernel, dim3(grid), dim3(256), s, a);
+    DQO_CHECK_ARG(st->moment_live == nullptr || st->radii != nullptr, "moment_live needs radii");
+    const int blocks = (st->P + ADAM_THREADS - 1) / ADAM_THREADS;
+    if (st->moment_live != nullptr)
+        DQO_LAUNCH("adam_kernel", adam_kernel<true>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+    else
+        DQO_LAUNCH("adam_kernel", adam_kernel<false>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
     if (st->step_dev != nullptr) DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev);
     return DQO_OK;
 }

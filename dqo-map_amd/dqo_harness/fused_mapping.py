@@ -36,7 +36,7 @@ class _Ctx:
 
 class FusedMapper:
     def __init__(self, scene, settings, device, lrs=None, betas=(0.9, 0.999), eps=1e-15, color_weight=mapping.COLOR_WEIGHT,
-                 depth_weight=mapping.DEPTH_WEIGHT, add_depth_thres=0.1):
+                 depth_weight=mapping.DEPTH_WEIGHT, add_depth_thres=0.1, sparse_moments=True):
         t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=device)
         self.device = device
         self.settings = settings
@@ -51,6 +51,8 @@ class FusedMapper:
         self.betas, self.eps = betas, eps
         self.color_weight, self.depth_weight, self.add_depth_thres = color_weight, depth_weight, add_depth_thres
         self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in self._params().items()}
+        # exact sparse Adam (DqoAdamStep.moment_live): 0 = the Gaussian's moments are still identically zero
+        self.moment_live = torch.zeros((self.xyz.shape[0],), dtype=torch.uint8, device=device) if sparse_moments else None
         self.step_count = 0
         self._act_valid = False  # opacity / scales / rotations hold the activations of the current raw parameters
         P = self.P
@@ -130,7 +132,8 @@ class FusedMapper:
                                    m_scaling=N.ptr(stt["scaling"][0]), m_rotation=N.ptr(stt["rotation"][0]), v_xyz=N.ptr(stt["xyz"][1]),
                                    v_shs=N.ptr(stt["shs"][1]), v_opacity=N.ptr(stt["opacity"][1]), v_scaling=N.ptr(stt["scaling"][1]),
                                    v_rotation=N.ptr(stt["rotation"][1]), act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales),
-                                   act_rotations=N.ptr(self.rotations), radii=o[8].data_ptr(), step_dev=g.step_dev.data_ptr())
+                                   act_rotations=N.ptr(self.rotations), radii=o[8].data_ptr(), step_dev=g.step_dev.data_ptr(),
+                                   moment_live=N.ptr(self.moment_live))
             if not self._act_valid:
                 stream = N.current_stream()
                 N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
@@ -228,7 +231,7 @@ class FusedMapper:
                                v_shs=N.ptr(self.state["shs"][1]), v_opacity=N.ptr(self.state["opacity"][1]),
                                v_scaling=N.ptr(self.state["scaling"][1]), v_rotation=N.ptr(self.state["rotation"][1]),
                                act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales), act_rotations=N.ptr(self.rotations),
-                               radii=N.ptr(out[8]))
+                               radii=N.ptr(out[8]), moment_live=N.ptr(self.moment_live))
             N.check(lib.dqo_map_adam_step(ctypes.byref(st), stream))
             self._act_valid = True
         return out

@@ -271,6 +271,11 @@ typedef struct DqoAdamStep {
      * by a one-thread kernel that increments it.  With it a whole mapping iteration has no host-side per-iteration
      * argument and can be captured once in a hipGraph and replayed. */
     int32_t* step_dev;
+    /* Optional (NULL = dense): one byte per Gaussian, 0 = both moment rows of the Gaussian are identically zero (the state of a
+     * freshly built optimiser, which the reference builds per mapping call, mapper.py:548).  Such a Gaussian with no gradient
+     * (radii == 0) is a fixed point of Adam — m, v stay 0 and p - step * 0 / (0 + eps) = p bit for bit — so its rows are neither
+     * read nor written; the first gradient sets its byte to 1.  Needs `radii`.  Results are identical to the dense update. */
+    uint8_t* moment_live;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
 

@@ -179,6 +179,31 @@ def test_graph_replay_matches_eager_steps(env):
     assert b.step_count == 6 and int(b._g.step_dev.item()) == 7
 
 
+def test_sparse_moments_are_bitwise_dense_adam(env):
+    """DqoAdamStep.moment_live: Gaussians whose moments are still all zero and that get no gradient are skipped — parameters,
+    moments and activations must come out bit for bit as from the dense update, also when the view (visible set) changes."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch, P=20000, cfg=3)  # cfg 3: 40 % of the map is in view
+    a = FusedMapper(scene, settings, dev, sparse_moments=True)
+    b = FusedMapper(scene, settings, dev, sparse_moments=False)
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    left = torch.zeros((gy, gx), dtype=torch.int32, device=dev)
+    left[:, : gx // 2] = 1  # tile mask: first only the left half is rendered (fewer Gaussians get gradients), then everything
+    for tm in (left, left, None, None):
+        a.step(gt_color, gt_depth, mask, tile_mask=tm)
+        b.step(gt_color, gt_depth, mask, tile_mask=tm)
+    torch.cuda.synchronize()
+    live = a.moment_live.cpu().numpy()
+    assert 0 < live.sum() < live.size  # some Gaussians were never in view: their rows were never touched
+    for k, pa in a._params().items():
+        assert torch.equal(pa, b._params()[k]), k
+        assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), k
+    assert torch.equal(a.opacity, b.opacity) and torch.equal(a.scales, b.scales) and torch.equal(a.rotations, b.rotations)
+    dormant = torch.from_numpy(live == 0).to(dev)
+    assert (a.state["xyz"][0][dormant] == 0).all() and (a.state["shs"][1][dormant] == 0).all()
+
+
 def test_graph_capacity_overflow_is_flagged(env):
     """A captured graph has a fixed instance capacity; when the scene needs more, nothing is written out of bounds, the device
     header says so and graph_overflowed() reports it (the frame's outputs are the initial fills)."""
