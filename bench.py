@@ -125,6 +125,7 @@ def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, lo
         loss_buf.reduce()  # ONE packed all-reduce per iteration (no-op at world size 1)
         return {"radii": out[8]}
 
+    step_eager.mapper = fm
     if not use_graph:
         return step_eager, step_eager
     try:
@@ -147,6 +148,7 @@ def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, lo
         loss_buf.buf[:3].copy_(fm.loss[:3])
 
     step_graph.finish = finish
+    step_graph.mapper = step_eager.mapper = fm
     return step_graph, step_eager
 
 
@@ -242,6 +244,12 @@ def main():
     # workload statistics of the last iteration (reported next to every timing)
     n_vis = int((out["radii"] > 0).sum().item())
     stats = dict(P=P, P_visible=n_vis)
+    fm_ = getattr(step_fused, "mapper", None)
+    if args.path == "fused" and fm_ is not None and fm_.moment_live is not None:
+        # exact sparse Adam (DqoAdamStep.moment_live): Gaussians with all-zero moments and no gradient are fixed points of the
+        # update and are skipped; bitwise equal to the dense update (tests/test_gpu_fused_mapping.py)
+        stats["adam"] = "exact-sparse"
+        stats["adam_rows_touched"] = int(fm_.moment_live.sum().item())
 
     roofline = None
     kernels = None
