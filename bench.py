@@ -289,7 +289,8 @@ def main():
             # summed record, params, tables in; gradient rows out (fused path: only the rows of visible Gaussians are written)
             "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * (n_vis if args.path == "fused" else P),
             "loss_reduce_kernel": 36 * HWa, "loss_grad_kernel": 52 * HWa,
-            "adam_kernel": 236 * 6 * P + 236 * n_vis,   # 59 floats x (param, m, v in and out) + the gradient rows of visible Gaussians
+            # 59 floats x (param, m, v in and out) of the Gaussians Adam touches (all of them in dense mode) + the gradient rows
+            "adam_kernel": 236 * 6 * stats.get("adam_rows_touched", P) + 236 * n_vis,
         }
         bytes_dom = alg.get(dom_name, 0)
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
