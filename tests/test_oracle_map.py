@@ -81,3 +81,26 @@ def test_accumulate_error_oracle_small_hand_case():
     np.testing.assert_allclose(gc[:, 0], [0.3, -1.0, 0.55], rtol=1e-6)
     np.testing.assert_allclose(gd[:, 0], [0.01, (0.05 + 0.2 + 0.0) / 3, 0.0], rtol=1e-6)
     np.testing.assert_array_equal(rs, rs2)
+
+
+def test_zero_moment_rows_without_gradient_are_fixed_points_of_adam():
+    """The property the exact sparse Adam (DqoAdamStep.moment_live) rests on, checked against torch.optim.Adam itself with the
+    reference's eps = 1e-15 (mapper.py:548): a row whose moments are zero and whose gradient is zero does not move by a single
+    bit, for any number of steps — so not touching it is the dense update."""
+    rng = np.random.default_rng(5)
+    p0 = rng.normal(size=(64, 3)).astype(np.float32)
+    p = torch.tensor(p0.copy(), requires_grad=True)
+    opt = torch.optim.Adam([p], lr=1e-3, eps=1e-15)
+    dormant = np.arange(64) % 3 != 0  # two thirds of the rows never get a gradient
+    for step in range(1, 6):
+        g = rng.normal(size=(64, 3)).astype(np.float32)
+        g[dormant] = 0.0
+        p.grad = torch.tensor(g)
+        opt.step()
+    st = opt.state[p]
+    assert np.array_equal(p.detach().numpy()[dormant], p0[dormant])
+    assert (st["exp_avg"].numpy()[dormant] == 0).all() and (st["exp_avg_sq"].numpy()[dormant] == 0).all()
+    assert not np.array_equal(p.detach().numpy()[~dormant], p0[~dormant])
+    # and the numpy restatement agrees: one dense step over a dormant row returns its inputs
+    q, m, v = mo.adam_step(p0[dormant].astype(np.float64), 0.0, 0.0, 0.0, 1e-3, 7)
+    assert np.array_equal(q, p0[dormant].astype(np.float64)) and np.all(m == 0) and np.all(v == 0)
