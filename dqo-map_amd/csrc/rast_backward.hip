@@ -54,12 +54,22 @@ __global__ __launch_bounds__(256) void record_sum_kernel(int P, DqoGeomLayout g,
         if (slot < hi) {
             const uint32_t vw = valid[slot];
             const float4* p = partial + (size_t)slot * 16;
+            // All sixteen loads are issued unconditionally and back to back: a load under a lane condition makes the compiler wait
+            // for every earlier load first, which would put the four quadrant records (and their validity word) in series.  The
+            // lanes of an invalid quadrant read one shared dummy record instead (one cached line per instruction, discarded).
+            float4 r[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4* src = ((vw >> (8 * q)) & 0xffu) ? p + 4 * q : partial;
+#pragma unroll
+                for (int i = 0; i < 4; i++) r[q][i] = src[i];
+            }
             float4 m0 = z, m1 = z, m2 = z, m3 = z;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t bq = (vw >> (8 * q)) & 0xffu;  // 1: floats 0..8 written, 3: depth-hit floats 9..13 as well
                 if (bq) {
-                    const float4 r0 = p[4 * q], r1 = p[4 * q + 1], r2 = p[4 * q + 2], r3 = p[4 * q + 3];
+                    const float4 r0 = r[q][0], r1 = r[q][1], r2 = r[q][2], r3 = r[q][3];
                     m0.x += r0.x, m0.y += r0.y, m0.z += r0.z, m0.w += r0.w;
                     m1.x += r1.x, m1.y += r1.y, m1.z += r1.z, m1.w += r1.w;
                     m2.x += r2.x;
