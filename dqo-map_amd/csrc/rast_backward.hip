@@ -9,11 +9,11 @@
 // pixel.  On gfx950 global float atomics execute memory-side and a wave instruction whose 64 lanes hit 64 different rows
 // runs ~17x below the streaming rate (MI355X_MICROARCH.md, Global float atomics), so none are used here:
 //   * one wave64 owns one 8x8 quadrant of a 16x16 tile (1 pixel per lane); every lane looks at the same list entry in
-//     the same trip, so the per-entry gradient is one DPP/bpermute wave reduction (rast_backward_blend.hip);
+//     the same trip, so the per-entry gradient is a wave reduction, shared by seven entries (rast_backward_blend.hip);
 //   * the wave stores ONE 64-byte partial record per live (quadrant, instance) pair at the instance's gaussian-major
 //     slot (4 partial records per slot + a validity word);
-//   * gaussian_backward_kernel sums each Gaussian's valid partial records in a fixed order (bitwise reproducible) and
-//     finishes the chain rule (cov2D, projection, SH, cov3D) in the same pass.
+//   * record_sum_kernel sums each Gaussian's valid partial records in a fixed order (bitwise reproducible);
+//   * gaussian_backward_kernel finishes the chain rule (cov2D, projection, SH, cov3D, depth-hit Jacobians) per Gaussian.
 #include "dqo_common.h"
 #include "dqo_cull.h"
 

@@ -2,16 +2,20 @@
 // cuda_rasterizer/backward.cu:808-1066 (renderCUDA_flat) and :100-148 (propagateRotationGrad).
 //
 // Structure: ONE wave64 per (tile, 8x8 quadrant) — four single-wave workgroups per 16x16 tile, no __syncthreads, no global
-// float atomics (the reference: ~10 per (pixel, Gaussian) pair + 3-7 per hit pixel).  The wave walks its tile's list back to
-// front in chunks of 64 positions but only over the entries the forward marked live for this quadrant (live bytes = exactly
-// the (pixel, entry) pairs the reference's backward has work for): the live ones of a chunk are compacted with one ballot,
-// their 16-byte records gathered into wave-private LDS, and processed with the next entry prefetched from LDS; the next
-// chunk's live bytes are loaded while the current chunk is processed.  Per live entry every lane evaluates its pixel with
-// predicated (branch-free) arithmetic; the eight colour-path sums go through a reduce-scatter butterfly (DPP quad_perm /
-// row_shl|shr / row_ror + two ds_bpermute), the ninth through a plain DPP reduction, the seven depth-hit sums through a
-// second butterfly when some pixel's depth was fixed by this entry; lanes 0..15 then store the 64-byte partial record of
-// this (quadrant, instance) pair at recs[slot * 4 + quadrant] and lane 16 marks it valid.  gaussian_backward_kernel adds a
-// Gaussian's valid partial records in a fixed order: bitwise reproducible.
+// float atomics (the reference: ~10 per (pixel, Gaussian) pair + 3-7 per hit pixel).
+//   * Depth-hit sums first, once per pixel: every pixel has at most one entry that fixed its depth; the pixels of the quadrant
+//     that share it are added up by their lowest lane through wave-private LDS and written as floats 9..13 of that
+//     (quadrant, instance) record.
+//   * The wave then walks its tile's list back to front in chunks of 64 positions, but only over the entries the forward marked
+//     live for this quadrant: the live ones of a chunk are compacted with one ballot and their 16-byte records gathered into
+//     wave-private LDS; the next chunk's live bytes are loaded while the current chunk is processed.
+//   * Per live entry every lane evaluates its pixel with predicated (branch-free) arithmetic and produces nine sums-to-be (three
+//     colour terms, six moments of q = G dL/dalpha).  Seven entries at a time, their 63 values go through ONE 64-value
+//     reduce-scatter butterfly (v_permlane32/16_swap, bank-masked v_add_f32_dpp, quad_perm), after which lane 9 b + f holds float
+//     f of entry b: those lanes store the 64-byte partial records at recs[slot * 4 + quadrant] and lanes 0..6 mark them valid
+//     (1 = colour-path floats, 3 = depth-hit floats as well).
+// record_sum_kernel adds a Gaussian's valid partial records in a fixed order: bitwise reproducible.  Instruction costs behind the
+// choices (swap = 8 cycles, DPP = 4-5, plain = 3-4): tools/ubench_valu.hip, profiles/r01_ubench_valu.txt.
 #include "dqo_common.h"
 #include "dqo_cull.h"
 
