@@ -4,14 +4,17 @@
 // Structure: ONE wave64 per (tile, 8x8 quadrant) — four single-wave workgroups per 16x16 tile, no __syncthreads anywhere.
 // The wave streams its tile's depth-sorted list in chunks of 64 positions (one per lane: coalesced id load + two 16-byte
 // record gathers), tests each entry's footprint against its own quadrant (dqo_cull.h), compacts the survivors into a
-// wave-private LDS buffer with one ballot, and blends them front to back with the next entry's record prefetched from LDS.
+// wave-private LDS buffer with one ballot, and blends them front to back (the entry record is read from LDS at the top of each
+// trip: at 7 waves per SIMD the other waves cover that latency, a register rotation for a software prefetch costs more).
 // The next chunk's global loads are issued before the current chunk is blended, so the gather latency hides behind compute.
+// The kernel is bound by VALU issue: predicates are kept as 0/1 floats where that saves a compare + select pair, and the
+// per-entry results that are wave-uniform (live flag, n_touched count) live in a scalar mask / one uniform LDS store.
 // A wave stops as soon as its own 64 pixels are finished (the reference keeps a whole 256-thread block alive until its
 // last pixel is done, and so did the previous 4-wave version of this kernel, paying a block barrier per batch).
 //
-// Per (quadrant, list position) the wave records a live byte: 1 iff some pixel of the quadrant blended the entry or took it
-// as its depth hit.  Those are exactly the (pixel, entry) pairs the backward has work for; the backward walks live entries
-// only.  The per-Gaussian surfel normal / camera-space point are read from the preprocess tables (forward.cu:779-791 rebuilds
+// Per (quadrant, list position) the wave records a live byte: 1 iff some unfinished pixel of the quadrant saw the entry with
+// alpha >= 1/255 — a superset of "blended it or took it as its depth hit", i.e. of the (pixel, entry) pairs the backward has
+// work for; the backward walks live entries only.  The per-Gaussian surfel normal / camera-space point are read from the preprocess tables (forward.cu:779-791 rebuilds
 // them from the quaternion for every (pixel, Gaussian) pair).
 #include "dqo_common.h"
 #include "dqo_cull.h"
