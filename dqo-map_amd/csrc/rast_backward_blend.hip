@@ -190,6 +190,8 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     // zero, so nothing is written and the records stay invalid (= zero for the per-Gaussian sum).
     if (__builtin_amdgcn_ballot_w64(dp0 != 0.f || dp1 != 0.f || dp2 != 0.f || ddep != 0.f) == 0ull) return;
     const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
+    const float bg_term = -T_final * bgdot;  // d(background term)/d(alpha) = bg_term / (1 - alpha): end_T, not the running T (quirk B2)
+    const int hit_c0 = hit_pos - 1;          // list position of the entry that fixed this pixel's depth (-1: none)
     const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
     // ---- depth-hit sums (backward.cu:997-1065): ONCE per pixel, outside the entry loop ----
     // Every pixel has at most one entry that fixed its depth (hit_pos) and the gradient it sends to that Gaussian depends on
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                     const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
                     // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
                     // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
-                    // and 0 * c + 1 * S = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
+                    // and S + 0 * (c - S) = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
                     const float dx = xy.x - pixfx, dy = xy.y - pixfy;
                     const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                     const float Gx = dqo_gauss(power);
@@ -304,12 +306,13 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                     const float G = did_color ? Gx : 0.f;
                     const float inv_1ma = dqo_rcp(1.f - alpha);
                     T = T * inv_1ma;  // T / (1 - alpha), backward.cu:948
-                    float dL_dalpha = ((cs.x - S0) * dp0 + (cs.y - S1) * dp1 + (cs.z - S2) * dp2) * T;
-                    dL_dalpha += (-T_final * inv_1ma) * bgdot;  // end_T, not the running T (quirk B2)
+                    const float e0 = cs.x - S0, e1 = cs.y - S1, e2 = cs.z - S2;
+                    float dL_dalpha = (e0 * dp0 + e1 * dp1 + e2 * dp2) * T;
+                    dL_dalpha += bg_term * inv_1ma;
                     const float dchannel_dcolor = alpha * T;
-                    S0 = alpha * cs.x + (1.f - alpha) * S0;
-                    S1 = alpha * cs.y + (1.f - alpha) * S1;
-                    S2 = alpha * cs.z + (1.f - alpha) * S2;
+                    S0 += alpha * e0;  // = alpha c + (1 - alpha) S: one fma on the difference that is needed anyway
+                    S1 += alpha * e1;
+                    S2 += alpha * e2;
                     // Everything downstream of dL/dalpha * G is linear in per-Gaussian constants (opacity, conic, W/2, H/2):
                     // the wave only sums the pixel moments of q = G * dL/dalpha — q, q dx, q dy, q dx^2, q dx dy, q dy^2 — and
                     // gaussian_backward_kernel applies those constants once per Gaussian (backward.cu:964-994 does it per pair).
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                     r_op = q;
 
                     // the entry fixed some pixel's depth: its record also carries the depth-hit sums written before the loop
-                    if (__builtin_amdgcn_ballot_w64(hit_pos == c0 + 1) != 0ull) hitmask |= 1u << b;
+                    if (__builtin_amdgcn_ballot_w64(hit_c0 == c0) != 0ull) hitmask |= 1u << b;
                 }
                 v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
                 v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
             s_xy[myk] = xy;
             s_rgb[myk] = g.rgb_smax[id];
             s_id[myk] = id;
-            s_pos[myk] = pos;
+            s_pos[myk] = pos + 1;  // the reference's running counter `contributor` = list position + 1
         }
         // per-entry results of compacted entry k: was it live for this quadrant (bit k of live_m), and how many of the
         // quadrant's pixels saw it with T' > 0.5 (s_half[k]; n_touched, forward.cu:833-835, quirk B8)
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                 const float a_g = power <= 0.0f ? alpha * gate : 0.f;
                 const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
                 if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                    const uint32_t contributor = (uint32_t)(s_pos[k] + 1);  // the reference's running counter = list position + 1
+                    const uint32_t contributor = (uint32_t)s_pos[k];
                     const float4 cs = s_rgb[k];
                     const int gid = s_id[k];
                     const float a_v = valid ? alpha : 0.f;
@@ -198,8 +198,12 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                     // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
                     // below T_threshold), so the backward never misses a pair it has work for.  The per-entry results are
                     // wave-uniform: the live flag goes into a scalar mask, the n_touched count into LDS (uniform store).
+                    // (the compare writes its lane mask straight into a scalar pair: through __builtin_amdgcn_ballot_w64 the
+                    // compiler materialises the predicate as 0/1 and compares it again)
                     const float t_half = blend ? test_T : 0.f;
-                    s_half[k] = (int)__popcll(__builtin_amdgcn_ballot_w64(t_half > 0.5f));
+                    unsigned long long half_m;
+                    asm volatile("v_cmp_lt_f32 %0, 0.5, %1" : "=s"(half_m) : "v"(t_half));
+                    s_half[k] = (int)__popcll(half_m);
                     live_m |= 1ull << k;
                     all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;
                 }
