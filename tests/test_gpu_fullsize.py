@@ -44,7 +44,8 @@ def test_cfg3_full_size_vs_oracle(torch_cuda, oracle, cfg3):
 
 
 def test_backward_is_bitwise_reproducible(torch_cuda, cfg3):
-    """No float atomics anywhere in the backward: two runs give identical bits (the reference's atomicAdd order varies, B10)."""
+    """No global float atomics in the backward (the only float adds that go through memory are wave-private LDS adds of one
+    instruction's lanes, served in a fixed order): two runs give identical bits (the reference's atomicAdd order varies, B10)."""
     cam, sc, dL = cfg3
     _, g1 = U.run_hip(cam, sc, dL=dL)
     _, g2 = U.run_hip(cam, sc, dL=dL)
