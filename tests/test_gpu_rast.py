@@ -166,7 +166,7 @@ def test_errors(torch_cuda):
 
 
 def test_backward_deterministic(torch_cuda):
-    """No float atomics in the backward: two runs are bitwise identical (the reference's is order-dependent, B10)."""
+    """No global float atomics in the backward: two runs are bitwise identical (the reference's is order-dependent, B10)."""
     cam, sc = scenes.make_config(1, P=5000)
     dL = _dL(cam, 6)
     _, g1 = U.run_hip(cam, sc, dL=dL)
