@@ -344,14 +344,14 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     DQO_CHECK_ARG(st->M >= 0 && st->M * 3 < 256, "M out of range");
     a.row_magic = st->M > 0 ? ((1ull << 39) + (uint64_t)(3 * st->M) - 1) / (uint64_t)(3 * st->M) : 0ull;
     DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");
-    const int64_t n = (int64_t)st->P * st->M * 3;
-    const int grid = (int)min((int64_t)(256 * 16), (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
     DQO_CHECK_ARG(st->moment_live == nullptr || st->radii != nullptr, "moment_live needs radii");
     const int blocks = (st->P + ADAM_THREADS - 1) / ADAM_THREADS;
-    if (st->moment_live != nullptr)
-        DQO_LAUNCH("adam_kernel", adam_kernel<true>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
-    else
-        DQO_LAUNCH("adam_kernel", adam_kernel<false>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+    if (blocks > 0) {  // (an empty map still advances the step count)
+        if (st->moment_live != nullptr)
+            DQO_LAUNCH("adam_kernel", adam_kernel<true>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+        else
+            DQO_LAUNCH("adam_kernel", adam_kernel<false>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+    }
     if (st->step_dev != nullptr) DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev);
     return DQO_OK;
 }
