@@ -137,15 +137,15 @@ def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, lo
 
     def step_graph():
         out = fm.replay()
-        if world > 1:  # the per-iteration collective of the sharded path stays outside the graph
-            loss_buf.buf[:3].copy_(fm.loss[:3])
-            loss_buf.reduce()
+        if world > 1:  # the per-iteration collective of the sharded path stays outside the graph and off its critical path
+            loss_buf.reduce_async(src=fm.loss[:3])
         return {"radii": out[8]}
 
     def finish():
         if fm.graph_overflowed():
             raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
-        loss_buf.buf[:3].copy_(fm.loss[:3])
+        if world == 1:
+            loss_buf.buf[:3].copy_(fm.loss[:3])
 
     step_graph.finish = finish
     step_graph.mapper = step_eager.mapper = fm
@@ -212,6 +212,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    loss_buf.finish()  # outstanding asynchronous all-reduces of the sharded path (inside the timed region)
     sync_all()
     dt = time.perf_counter() - t0
     if hasattr(step, "finish"):

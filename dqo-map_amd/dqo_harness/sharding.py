@@ -69,6 +69,48 @@ class PackedAllReduce:
             dist.all_reduce(self.buf, group=self.group)
         return self
 
+    # Nothing in the next iteration depends on the reduced values (loss scalars for the log), so the collective need not sit
+    # on the compute stream's critical path: reduce_async() snapshots the buffer into one of RING staging buffers and starts
+    # the all-reduce without making the caller's stream wait for it; the staging buffer is only waited for when its turn
+    # comes again (RING iterations later, long finished) or in finish(), which leaves the newest result in self.buf.
+    RING = 4
+
+    def reduce_async(self, src=None):
+        """Start the all-reduce of the current buffer contents (or of `src`, copied straight into the staging buffer: its
+        first src.numel() entries, the others zero) without waiting for it."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return self
+        if not hasattr(self, "_ring"):
+            self._ring = [torch.zeros_like(self.buf) for _ in range(self.RING)]
+            self._work = [None] * self.RING
+            self._turn = 0
+        i = self._turn % self.RING
+        if self._work[i] is not None:
+            self._work[i].wait()
+        if src is None:
+            self._ring[i].copy_(self.buf)
+        else:
+            self._ring[i][:src.numel()].copy_(src.reshape(-1))
+        self._work[i] = dist.all_reduce(self._ring[i], group=self.group, async_op=True)
+        self._last = i
+        self._turn += 1
+        return self
+
+    def finish(self):
+        """Wait for every outstanding reduce_async(); self.buf then holds the most recent reduced values."""
+        if getattr(self, "_work", None) is None:
+            return self
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        self._work = [None] * self.RING
+        if getattr(self, "_last", None) is not None:
+            self.buf.copy_(self._ring[self._last])
+            self._last = None
+        return self
+
     def get(self, name):
         off, n = self.offsets[name]
         return self.buf[off:off + n]

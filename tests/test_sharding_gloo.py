@@ -38,10 +38,20 @@ def _worker(rank, world, port, tmp):
     red.put("n_gauss", torch.tensor([float(len(mine["xyz"]))]))
     red.put("cam_grad", torch.arange(6, dtype=torch.float32) * (rank + 1))
     red.reduce()
+    # the asynchronous form (bench.py's sharded path): more rounds than staging buffers, the last one must survive finish()
+    ar = sharding.PackedAllReduce([("v", 2)], "cpu")
+    for it in range(2 * sharding.PackedAllReduce.RING + 1):
+        if it % 2:
+            ar.put("v", torch.tensor([float(it), float(rank + 1) * (it + 1)]))
+            ar.reduce_async()
+        else:  # straight from a source tensor
+            ar.reduce_async(src=torch.tensor([float(it), float(rank + 1) * (it + 1)]))
+    ar.finish()
     tm = sharding.tile_mask_from_pixel_mask(my_mask)
     np.savez(os.path.join(tmp, f"r{rank}.npz"), loss=red.get("loss_sum").numpy(), pixels=red.get("pixels").numpy(),
              n=red.get("n_gauss").numpy(), cam=red.get("cam_grad").numpy(), owned=np.array(sorted(my_objs)), tm=tm,
-             total=np.abs(img - gt)[pix_obj >= 0].sum(), npix=(pix_obj >= 0).sum(), mask_sum=my_mask.sum())
+             total=np.abs(img - gt)[pix_obj >= 0].sum(), npix=(pix_obj >= 0).sum(), mask_sum=my_mask.sum(),
+             async_v=ar.get("v").numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +66,9 @@ def test_object_shards_world2(tmp_path):
     np.testing.assert_allclose(r[0]["loss"][0], r[0]["total"], rtol=1e-5)
     assert int(r[0]["pixels"][0]) == int(r[0]["npix"]) and int(r[0]["n"][0]) == 20000
     np.testing.assert_allclose(r[0]["cam"], np.arange(6) * 3.0)
+    last = 2 * sharding.PackedAllReduce.RING  # reduce_async: both ranks hold the sum of the LAST round
+    for i in range(world):
+        np.testing.assert_allclose(r[i]["async_v"], [2.0 * last, 3.0 * (last + 1)])
     # partition: disjoint, complete
     owned = np.concatenate([r[0]["owned"], r[1]["owned"]])
     assert sorted(owned.tolist()) == list(range(8)) and len(set(owned.tolist())) == 8
