@@ -297,7 +297,7 @@ def main():
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # memory-side bytes per launch of the dominant kernel, from the separate rocprofv3 --pmc passes committed under profiles/
         # (tools/pmc_hbm.sh; counters cannot be collected from inside this process)
-        traffic, valu_frac = None, None
+        traffic, valu_frac, valu_busy = None, None, None
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as fh:
                 tk = json.load(fh)["kernels"].get(dom_name)
@@ -305,13 +305,17 @@ def main():
                 traffic = int(tk["read_bytes"] + tk["write_bytes"])
                 if "valu_insts" in tk:  # VALU-issue occupancy of the dominant kernel: wave instructions / (CUs x clock x duration)
                     valu_frac = tk["valu_insts"] / (256 * 2.4e9 * dom_ms * 1e-3)
+                if "valu_active_quadcycles" in tk:  # SQ_ACTIVE_INST_VALU (4-cycle units, summed over the chip) / all SIMD cycles
+                    valu_busy = tk["valu_active_quadcycles"] * 4 / (1024 * 2.4e9 * dom_ms * 1e-3)
         except OSError:
             pass
         roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, avg_launch_us=round(dom_ms * 1e3, 2),
                         algorithmic_bytes=int(bytes_dom), valu_issue_frac=None if valu_frac is None else round(valu_frac, 3),
-                        note="the blend kernels are VALU-issue bound, not HBM bound (profiles/README.md: SQ_INSTS_VALU x 4 cycles / "
-                             "(CUs x SIMDs) ~ kernel time); per-kernel GB/s of every kernel: config.kernel_gbs",
+                        valu_busy_frac=None if valu_busy is None else round(valu_busy, 3),
+                        note="the blend kernels are VALU bound, not HBM bound: valu_busy_frac = SQ_ACTIVE_INST_VALU over all SIMD cycles "
+                             "of the launch, valu_issue_frac = SQ_INSTS_VALU x 4 cycles over the same (profiles/README.md); per-kernel "
+                             "GB/s of every kernel: config.kernel_gbs",
                         kernel_gbs={k: round(alg[k] / (us * 1e-6) / 1e9, 1) for k, us in kernels.items() if k in alg and us > 0})
 
     cpu = None
