@@ -400,14 +400,12 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_LDS_CAP = 2048;
 constexpr int SORTW_CAP = 1024;
 
+// one merge phase of the bitonic network: the steps j = k/2 ... 1 for sub-sequences of length k
 template <int E>
-__device__ __forceinline__ void wave_bitonic(uint64_t (&key)[E], uint32_t (&val)[E], int lane) {
-    // k and the cross-lane distances stay run-time loop variables: only the register pairings of the in-lane steps are
-    // unrolled, which keeps the kernel's five instantiations inside the instruction cache.
+__device__ __forceinline__ void wave_bitonic_phase(uint64_t (&key)[E], uint32_t (&val)[E], int lane, int k) {
+    {
 #pragma unroll 1
-    for (int k = 2; k <= 64 * E; k <<= 1) {
-#pragma unroll 1
-        for (int j = k >> 1; j >= E; j >>= 1) {
+        for (int j = min(k >> 1, 32 * E); j >= E; j >>= 1) {
             // partner element lives in lane ^ d, same register
             const int d = j / E;
             const bool up = ((lane * E) & k) == 0;  // ascending sub-sequence (k >= 2E here, so the bit is a lane bit)
@@ -453,6 +451,14 @@ __device__ __forceinline__ void wave_bitonic(uint64_t (&key)[E], uint32_t (&val)
 }
 
 template <int E>
+__device__ __forceinline__ void wave_bitonic(uint64_t (&key)[E], uint32_t (&val)[E], int lane) {
+    // k and the cross-lane distances stay run-time loop variables: only the register pairings of the in-lane steps are
+    // unrolled, which keeps the kernel's instantiations inside the instruction cache.
+#pragma unroll 1
+    for (int k = 2; k <= 64 * E; k <<= 1) wave_bitonic_phase<E>(key, val, lane, k);
+}
+
+template <int E>
 __device__ __forceinline__ void wave_sort_tile(const DqoBinLayout& bin, uint32_t base, int n, int lane) {
     uint64_t key[E];
     uint32_t val[E];
@@ -473,20 +479,69 @@ __device__ __forceinline__ void wave_sort_tile(const DqoBinLayout& bin, uint32_t
     }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin) {
+// Lists of 513..1024 entries: TWO waves.  Each sorts one half of the list in registers (E = 8), the halves meet once in LDS —
+// element i of the lower run against element 511 - i of the upper run, the lower wave keeps the smaller, the upper wave the
+// larger: both halves are then bitonic — and every wave finishes with the nine merge steps of its own half.  The serial chain
+// of the longest lists (which is what the kernel's duration is) is that of a 512-element sort + one exchange + one merge
+// phase instead of a 1024-element sort.
+constexpr int SORTP_E = 8, SORTP_RUN = 64 * SORTP_E;
+__device__ __forceinline__ void pair_sort_tile(const DqoBinLayout& bin, uint32_t base, int n, int lane, int wave, uint64_t* s_key,
+                                               uint32_t* s_val) {
+    constexpr int E = SORTP_E;
+    uint64_t key[E];
+    uint32_t val[E];
+    const int run0 = wave * SORTP_RUN;
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int i = run0 + lane * E + r;
+        key[r] = i < n ? bin.keys[base + i] : ~0ull;  // padding sorts behind every real key
+        val[r] = i < n ? bin.slots[base + i] : 0u;
+    }
+    wave_bitonic<E>(key, val, lane);
+#pragma unroll
+    for (int r = 0; r < E; r++) s_key[run0 + lane * E + r] = key[r], s_val[run0 + lane * E + r] = val[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int o = (1 - wave) * SORTP_RUN + (SORTP_RUN - 1 - (lane * E + r));  // mirrored element of the other run
+        const uint64_t ok = s_key[o];
+        const uint32_t ov = s_val[o];
+        const bool take = (ok < key[r]) == (wave == 0);  // (equal keys only among the padding: identical payloads)
+        key[r] = take ? ok : key[r];
+        val[r] = take ? ov : val[r];
+    }
+    wave_bitonic_phase<E>(key, val, lane, 2 * SORTP_RUN);  // ascending merge of this wave's (bitonic) half
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int i = run0 + lane * E + r;
+        if (i < n) {
+            bin.point_list[base + i] = (uint32_t)key[r];
+            bin.slot_list[base + i] = val[r];
+        }
+    }
+}
+
+// one block (two waves) per tile slot; the second wave only works on lists longer than 512 entries
+constexpr int SORTW_THREADS = 128;
+__global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin) {
+    __shared__ uint64_t s_key[2 * SORTP_RUN];
+    __shared__ uint32_t s_val[2 * SORTP_RUN];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ti = blockIdx.x * (SORT_THREADS / 64) + wave;
-    if (ti >= 8 * ((T + 7) / 8)) return;
+    const int ti = blockIdx.x;
     const uint32_t tile = img.tile_order[ti];  // [8][T8] slots, unused ones hold ~0
     if (tile == 0xffffffffu) return;
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
     if (n <= 0 || n > SORTW_CAP) return;
+    if (n > SORTP_RUN) {
+        pair_sort_tile(bin, rg.x, n, lane, wave, s_key, s_val);
+        return;
+    }
+    if (wave != 0) return;
     if (n <= 64) wave_sort_tile<1>(bin, rg.x, n, lane);
     else if (n <= 128) wave_sort_tile<2>(bin, rg.x, n, lane);
     else if (n <= 256) wave_sort_tile<4>(bin, rg.x, n, lane);
-    else if (n <= 512) wave_sort_tile<8>(bin, rg.x, n, lane);
-    else wave_sort_tile<16>(bin, rg.x, n, lane);
+    else wave_sort_tile<8>(bin, rg.x, n, lane);
 }
 
 // in-place global version for lists longer than SORT_LDS_CAP, LDS version below that
@@ -610,7 +665,7 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
         int rc = dqo_launch_bin_place(g, img, bin, cap, s);
         if (rc) return rc;
         const int slots = 8 * ((T + 7) / 8);  // tile_order is [8][T8]
-        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3((slots + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64)), dim3(SORT_THREADS), s, T, img, bin);
+        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin);
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(slots), dim3(SORT_THREADS), s, img, bin);
     }
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, s);
