@@ -147,7 +147,14 @@ def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, lo
         if world == 1:
             loss_buf.buf[:3].copy_(fm.loss[:3])
 
+    def step_static():  # the graph's own calls issued eagerly: what the per-kernel profile pass times
+        out = fm.step_static()
+        loss_buf.buf[:3].copy_(fm.loss[:3])
+        loss_buf.reduce()
+        return {"radii": out[8]}
+
     step_graph.finish = finish
+    step_graph.static = step_static
     step_graph.mapper = step_eager.mapper = fm
     return step_graph, step_eager
 
@@ -260,7 +267,8 @@ def main():
         N.profile_collect(reset=True)
         torch.cuda.synchronize()
         ksteps = min(args.steps, 20)
-        step_prof = step_fused_eager if args.path == "fused" else step_dropin  # HIP events cannot be recorded inside a graph replay
+        # HIP events cannot be recorded inside a graph replay: the profile pass issues the graph's own calls eagerly
+        step_prof = getattr(step_fused, "static", step_fused_eager) if args.path == "fused" else step_dropin
         for _ in range(ksteps):
             step_prof()
         torch.cuda.synchronize()
@@ -273,7 +281,7 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][0])
         dom_name, dom_ms = dom[0], dom[1][0] / max(dom[1][1], 1)
         # workload counts of the current state from the device header of the last forward
-        hdr = dgr.last_header()
+        hdr = fm_.header() if (args.path == "fused" and fm_ is not None and getattr(fm_, "_g", None) is not None) else dgr.last_header()
         n_inst, n_cand = hdr["num_rendered"], hdr["num_candidates"]
         HWa = cam.W * cam.H
         stats.update(N_instances=n_inst, N_candidates=n_cand, max_tile_list=hdr["max_tile_count"])

@@ -31,7 +31,7 @@ class DqoRastOutputs(ctypes.Structure):
 
 class DqoRastCtx(ctypes.Structure):
     _fields_ = [("geom", c_vp), ("geom_bytes", ctypes.c_size_t), ("binning", c_vp), ("binning_bytes", ctypes.c_size_t),
-                ("image", c_vp), ("image_bytes", ctypes.c_size_t), ("inst_capacity", ctypes.c_int64)]
+                ("image", c_vp), ("image_bytes", ctypes.c_size_t), ("inst_capacity", ctypes.c_int64), ("tile_bucket_capacity", c_i32)]
 
 
 class DqoRastGrads(ctypes.Structure):
@@ -59,7 +59,7 @@ class DqoAdamStep(ctypes.Structure):
 
 EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
            "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_adam_step", "dqo_accumulate_gaussian_error", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
-           "dqo_rast_binning_bytes",
+           "dqo_rast_binning_bytes", "dqo_rast_binning_bytes_bucketed",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
            "dqo_rast_forward", "dqo_rast_backward", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
            "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam", "dqo_tile_count_mask", "dqo_transmission_mask", "dqo_tile_color_error", "dqo_knn3_query_workspace_bytes",
@@ -86,6 +86,8 @@ def lib():
         L.dqo_rast_geom_bytes.argtypes = [c_i32, c_i32, c_i32]
         L.dqo_rast_image_bytes.argtypes = [c_i32, c_i32]
         L.dqo_rast_binning_bytes.argtypes = [ctypes.c_int64]
+        L.dqo_rast_binning_bytes_bucketed.restype = ctypes.c_size_t
+        L.dqo_rast_binning_bytes_bucketed.argtypes = [ctypes.c_int64, c_i32, c_i32, c_i32]
         L.dqo_rast_backward_workspace_bytes.argtypes = [ctypes.c_int64]
         L.dqo_knn3_workspace_bytes.argtypes = [c_i32]
         P = ctypes.POINTER

@@ -121,7 +121,12 @@ DQO_API size_t dqo_rast_geom_bytes(int32_t P, int32_t W, int32_t H) {
     return dqo_geom_layout(nullptr, P < 0 ? 0 : P).total;
 }
 DQO_API size_t dqo_rast_image_bytes(int32_t W, int32_t H) { return dqo_image_layout(nullptr, W, H).total; }
-DQO_API size_t dqo_rast_binning_bytes(int64_t cap) { return dqo_bin_layout(nullptr, cap < 0 ? 0 : cap).total; }
+DQO_API size_t dqo_rast_binning_bytes(int64_t cap) { return dqo_bin_layout(nullptr, cap < 0 ? 0 : cap, cap < 0 ? 0 : cap, 0).total; }
+DQO_API size_t dqo_rast_binning_bytes_bucketed(int64_t cap, int32_t W, int32_t H, int32_t bucket) {
+    if (cap < 0) cap = 0;
+    if (bucket <= 0 || W <= 0 || H <= 0) return dqo_rast_binning_bytes(cap);
+    return dqo_bin_layout(nullptr, cap, dqo_list_cap(cap, W, H, bucket), bucket).total;
+}
 DQO_API size_t dqo_rast_backward_workspace_bytes(int64_t cap) { return dqo_bwd_ws_bytes(cap); }
 
 static int check_common(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx) {
@@ -191,8 +196,10 @@ DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs*
     if (rc) return rc;
     DQO_CHECK_ARG(ctx->inst_capacity >= 0 && ctx->inst_capacity < (int64_t)0xffffffffll, "bad inst_capacity");
     DQO_CHECK_ARG(ctx->inst_capacity == 0 || ctx->binning, "null binning buffer");
-    if (ctx->binning_bytes < dqo_rast_binning_bytes(ctx->inst_capacity)) {
-        dqo_set_error("binning buffer too small (%zu < %zu)", ctx->binning_bytes, dqo_rast_binning_bytes(ctx->inst_capacity));
+    DQO_CHECK_ARG(ctx->tile_bucket_capacity >= 0, "negative tile_bucket_capacity");
+    if (ctx->binning_bytes < dqo_rast_binning_bytes_bucketed(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity)) {
+        dqo_set_error("binning buffer too small (%zu < %zu)", ctx->binning_bytes,
+                      dqo_rast_binning_bytes_bucketed(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity));
         return DQO_ERR_WORKSPACE;
     }
     return dqo_launch_forward_render(p, in, out, ctx, (hipStream_t)stream);

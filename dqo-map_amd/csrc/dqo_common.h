@@ -141,23 +141,30 @@ struct DqoBinLayout {
     uint2* slot_info;     // [cap] per gaussian-major slot: (tile, rank inside the tile's segment), bin_count -> bin_place
     uint32_t* slot_gid;   // [cap] per gaussian-major slot: Gaussian id
     uint32_t* rec_valid;  // [cap] backward: byte q of word `slot` = 1 iff the partial gradient record (slot, quadrant q) was written;
-                          //       zeroed by bin_place_kernel (the forward), so the backward needs no memset
+                          //       zeroed by bin_place_kernel / bin_count_kernel (the forward), so the backward needs no memset
+    int64_t list_cap;     // entries of the list-indexed tables above (keys .. live_q): inst capacity, or tiles x bucket
+    int32_t bucket;       // DqoRastCtx::tile_bucket_capacity
     size_t total;
 };
+static inline int64_t dqo_list_cap(int64_t cap, int W, int H, int bucket) {
+    const int64_t T = (int64_t)((W + DQO_TILE - 1) / DQO_TILE) * ((H + DQO_TILE - 1) / DQO_TILE);
+    return bucket > 0 ? T * bucket : cap;
+}
 
-static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap) {
+static inline DqoBinLayout dqo_bin_layout(void* base, int64_t cap, int64_t list_cap, int bucket) {
     DqoBinLayout L;
+    L.list_cap = list_cap, L.bucket = bucket;
     char* p = (char*)base;
     auto take = [&](size_t bytes) {
         char* r = p;
         p += dqo_align_up(bytes, 256);
         return r;
     };
-    L.keys = (uint64_t*)take(8 * (size_t)cap);
-    L.slots = (uint32_t*)take(4 * (size_t)cap);
-    L.point_list = (uint32_t*)take(4 * (size_t)cap);
-    L.slot_list = (uint32_t*)take(4 * (size_t)cap);
-    L.live_q = (uint8_t*)take(4 * (size_t)cap);
+    L.keys = (uint64_t*)take(8 * (size_t)list_cap);
+    L.slots = (uint32_t*)take(4 * (size_t)list_cap);
+    L.point_list = (uint32_t*)take(4 * (size_t)list_cap);
+    L.slot_list = (uint32_t*)take(4 * (size_t)list_cap);
+    L.live_q = (uint8_t*)take(4 * (size_t)list_cap);
     L.slot_info = (uint2*)take(8 * (size_t)cap);
     L.slot_gid = (uint32_t*)take(4 * (size_t)cap);
     L.rec_valid = (uint32_t*)take(4 * (size_t)cap);

@@ -434,7 +434,8 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     const DqoView v = dqo_make_view(p, in);
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
-    DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity);
+    DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity,
+                                      dqo_list_cap(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity), ctx->tile_bucket_capacity);
     const int T = v.gx * v.gy;
     const int64_t cap = (int64_t)ctx->inst_capacity;
     DqoGradRec* recs = (DqoGradRec*)ws;

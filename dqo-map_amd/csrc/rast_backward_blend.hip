@@ -255,7 +255,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     // backward.cu:957-962, evaluated one step earlier: same operands, same rounding)
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
     const int lane_b = lane / 9, lane_f = lane - 9 * lane_b;  // this lane's (entry of the batch, record float) after the butterfly
-    const uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;
+    const uint8_t* live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;
 
     const int chunks = (L + BWD_THREADS - 1) / BWD_THREADS;
     // chunk c covers list positions L-1-c*64 ... descending; lane l looks at position L-1-(c*64+l): lane order == walk order

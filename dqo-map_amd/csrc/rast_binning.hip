@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
             const float4 co = g.conic_opacity[my_idx];
             const float4 xy = g.xy_depth[my_idx];
             s_con[tid] = co;
-            s_xyq[tid] = make_float4(xy.x, xy.y, dqo_q_threshold(co.w), 0.f);
+            s_xyq[tid] = make_float4(xy.x, xy.y, dqo_q_threshold(co.w), xy.z);
         }
         s_cnt[tid] = 0;
         s_prev[tid] = 0;
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
         for (uint32_t w0 = win + tid; w0 < wend; w0 += BIN_THREADS * BIN_FLIGHT) {
             uint32_t slot[BIN_FLIGHT], rank[BIN_FLIGHT];
             int tile[BIN_FLIGHT], gid[BIN_FLIGHT];
+            float depth[BIN_FLIGHT];
             bool ok[BIN_FLIGHT];
 #pragma unroll
             for (int u = 0; u < BIN_FLIGHT; u++) {
@@ -195,14 +196,26 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
                     slot[u] = base + s_gb[c.gi] + s_prev[c.gi] + popcount_range(s_bits, first - win, w - win);
                     tile[u] = c.tile;
                     gid[u] = dqo_spread_index(chunk0 + c.gi, P);
+                    depth[u] = s_xyq[c.gi].w;
                     rank[u] = atomicAdd(&tile_count[(size_t)c.tile * DQO_TSTRIDE], 1u);
                 }
             }
 #pragma unroll
             for (int u = 0; u < BIN_FLIGHT; u++) {
                 if (ok[u] && (int64_t)slot[u] < capacity) {
-                    bin.slot_info[slot[u]] = make_uint2((uint32_t)tile[u], rank[u]);
-                    bin.slot_gid[slot[u]] = (uint32_t)gid[u];
+                    if (bin.bucket > 0) {
+                        // fixed per-tile buckets: the rank IS the list position (what bin_place_kernel derives from the scanned
+                        // ranges in the packed mode); an instance beyond the bucket is dropped — tile_scan_kernel flags the frame
+                        if (rank[u] < (uint32_t)bin.bucket) {
+                            const size_t pos = (size_t)tile[u] * (size_t)bin.bucket + rank[u];
+                            bin.keys[pos] = ((uint64_t)__float_as_uint(depth[u]) << 32) | (uint32_t)gid[u];
+                            bin.slots[pos] = slot[u];
+                        }
+                        bin.rec_valid[slot[u]] = 0u;  // no partial gradient record of this slot exists yet (backward)
+                    } else {
+                        bin.slot_info[slot[u]] = make_uint2((uint32_t)tile[u], rank[u]);
+                        bin.slot_gid[slot[u]] = (uint32_t)gid[u];
+                    }
                 }
             }
         }

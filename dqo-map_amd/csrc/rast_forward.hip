@@ -233,7 +233,7 @@ constexpr int SCAN_THREADS = 1024;
 constexpr int LPT_BUCKETS = 256;
 constexpr int SCAN_CACHE = 8192;
 
-__global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImageLayout img, DqoGeomLayout g, int64_t capacity) {
+__global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImageLayout img, DqoGeomLayout g, int64_t capacity, int bucket) {
     __shared__ uint32_t s_part[SCAN_THREADS / 64];
     __shared__ uint32_t s_carry, s_max;
     __shared__ uint32_t s_bucket[8 * (LPT_BUCKETS + 1)];
@@ -251,13 +251,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor((int)nv, off), nc += __shfl_xor((int)nc, off);
         if (tid == 0) s_stat[0] = nv, s_stat[1] = nc;
     }
-    const bool overflow = (int64_t)g.counters[0] > capacity;  // instance total of bin_count_kernel
+    bool overflow = (int64_t)g.counters[0] > capacity;  // instance total of bin_count_kernel
     // the padded histogram is read from HBM once; the passes below work on an LDS copy (images up to ~2M pixels)
     const bool cached = T <= SCAN_CACHE;
     if (cached)
         for (int t = tid; t < T; t += SCAN_THREADS) s_tc[t] = img.tile_count[(size_t)t * DQO_TSTRIDE];
     __syncthreads();
     auto tcount = [&](int t) { return cached ? s_tc[t] : img.tile_count[(size_t)t * DQO_TSTRIDE]; };
+    if (bucket > 0) {  // fixed per-tile buckets: a tile that outgrew its bucket invalidates the frame like a capacity overflow
+        uint32_t mx0 = 0;
+        for (int t = tid; t < T; t += SCAN_THREADS) mx0 = max(mx0, tcount(t));
+        if (mx0) atomicMax(&s_max, mx0);
+        __syncthreads();
+        overflow = overflow || s_max > (uint32_t)bucket;
+    }
 
     // ---- ranges: chunked block scan ----
     uint32_t local_max = 0;
@@ -280,7 +287,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
             // More instances than the binning buffer holds: the slot tables are incomplete, so every list is emptied (the
             // frame is invalid and flagged as such in the header; nothing indexes past a buffer).
             const bool keep = c != 0u && !overflow;
-            img.ranges[t] = make_uint2(keep ? start : 0u, keep ? start + c : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
+            const uint32_t first = bucket > 0 ? (uint32_t)t * (uint32_t)bucket : start;  // bucket mode: the list sits in the tile's bucket
+            img.ranges[t] = make_uint2(keep ? first : 0u, keep ? first + c : 0u);  // empty tiles keep (0,0): rasterizer_impl.cu:338
             if (cached) s_st[t] = start;
             else img.tile_cursor[(size_t)t * DQO_TSTRIDE] = start;
         }
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         DqoRastHeader h;
         h.num_rendered = s_carry;
         h.num_tiles = (uint32_t)T - n_empty;
-        h.overflow = ((int64_t)s_carry > capacity) ? 1u : 0u;
+        h.overflow = ((int64_t)s_carry > capacity || (bucket > 0 && s_max > (uint32_t)bucket)) ? 1u : 0u;
         h.max_tile_count = s_max;
         h.num_visible = s_stat[0];
         h.num_candidates = s_stat[1];
@@ -652,18 +660,21 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     const DqoView v = dqo_make_view(p, in);
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
-    DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity);
-    const int T = v.gx * v.gy;
+    const int bucket = ctx->tile_bucket_capacity;
     const int64_t cap = (int64_t)ctx->inst_capacity;
+    DqoBinLayout bin = dqo_bin_layout(ctx->binning, cap, dqo_list_cap(cap, p->W, p->H, bucket), bucket);
+    const int T = v.gx * v.gy;
     if (p->P > 0) {
         // footprint test, per-tile histogram + ranks, tiles_touched, gaussian-major slots (forward.cu:344-353, rasterizer_impl.cu:303)
         int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap, s);
         if (rc) return rc;
     }
-    DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, cap);
+    DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, cap, bucket);
     if (p->P > 0) {
-        int rc = dqo_launch_bin_place(g, img, bin, cap, s);
-        if (rc) return rc;
+        if (bucket <= 0) {  // (bucket mode: bin_count_kernel has already written every instance to tile * bucket + rank)
+            int rc = dqo_launch_bin_place(g, img, bin, cap, s);
+            if (rc) return rc;
+        }
         const int slots = 8 * ((T + 7) / 8);  // tile_order is [8][T8]
         DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin);
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(slots), dim3(SORT_THREADS), s, img, bin);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
     float depth_ = 0.f;
     int hit_id = -1, hit_color_id = -1;
     float color_weight_max = -1.f, hit_depth_weight = 0.f;
-    uint8_t* live = bin.live_q + (size_t)quad * (size_t)capacity + range.x;  // this quadrant's live bytes of this tile's segment
+    uint8_t* live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;  // this quadrant's live bytes of this tile's segment
 
     const int chunks = (n + FWD_THREADS - 1) / FWD_THREADS;
     // prologue: loads of chunk 0

@@ -70,7 +70,7 @@ class FusedMapper:
         self.tile_mask = torch.ones(((H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=device)
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
-    def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15):
+    def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay()."""
         lib = N.lib()
@@ -89,11 +89,19 @@ class FusedMapper:
                 probe = dgr._RasterizeGaussians.forward(_Ctx(), self.xyz, self.shs, self._empty, *self._activated_now(), self._empty,
                                                         self.tile_mask if tile_mask is None else tile_mask, st)
             cand = dgr.last_header()["num_candidates"]
+            longest = dgr.last_header()["max_tile_count"]
             dgr.set_sync_mode(dgr_mode)
             del probe
             cap = int(cand * capacity_margin) + 4096
             g = self._g = type("G", (), {})()
             g.cap = cap
+            # fixed per-tile list buckets (DqoRastCtx.tile_bucket_capacity): at least twice the longest list of the current state,
+            # a power of two; a tile that outgrows it raises the same overflow flag as running out of instance capacity
+            g.bucket = 0
+            if tile_buckets:
+                g.bucket = 256
+                while g.bucket < 2 * longest:
+                    g.bucket *= 2
             g.gt_color, g.gt_depth = gt_color, gt_depth
             g.mask = None if render_mask is None else render_mask.to(torch.uint8).contiguous()
             g.tile_mask = self.tile_mask if tile_mask is None else tile_mask
@@ -102,7 +110,7 @@ class FusedMapper:
                      torch.empty((P,), **i32))
             g.geom = torch.empty((lib.dqo_rast_geom_bytes(P, W, H),), **u8)
             g.img = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
-            g.binning = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
+            g.binning = torch.empty((lib.dqo_rast_binning_bytes_bucketed(cap, W, H, g.bucket),), **u8)
             g.ws = torch.empty((lib.dqo_rast_backward_workspace_bytes(cap),), **u8)
             # dL_dcolors / dL_dcov3D / dL_dmeans2D have no consumer in the mapping step: NULL = the backward does not store them
             g.grads = dict(means3D=torch.empty((P, 3), **f), sh=torch.empty((P, M, 3), **f),
@@ -116,7 +124,8 @@ class FusedMapper:
                                          out_hit_depth_weight=o[5].data_ptr(), out_T=o[6].data_ptr(), n_touched=o[7].data_ptr(),
                                          radii=o[8].data_ptr())
             g.cctx = N.DqoRastCtx(geom=g.geom.data_ptr(), geom_bytes=g.geom.numel(), binning=g.binning.data_ptr(),
-                                  binning_bytes=g.binning.numel(), image=g.img.data_ptr(), image_bytes=g.img.numel(), inst_capacity=cap)
+                                  binning_bytes=g.binning.numel(), image=g.img.data_ptr(), image_bytes=g.img.numel(), inst_capacity=cap,
+                                  tile_bucket_capacity=g.bucket)
             gr = g.grads
             g.cgrads = N.DqoRastGrads(dL_dmeans3D=gr["means3D"].data_ptr(), dL_dsh=gr["sh"].data_ptr(), dL_dcolors=None,
                                       dL_dopacity=gr["opacity"].data_ptr(), dL_dscales=gr["scales"].data_ptr(),
@@ -185,6 +194,23 @@ class FusedMapper:
         self.step_count += 1
         g.expected_step = self.step_count + 1
         return g.out
+
+    def step_static(self):
+        """One iteration over the persistent buffers issued eagerly — exactly the calls the captured graph holds (for per-kernel
+        profiling: events cannot be recorded inside a replay)."""
+        g = self._g
+        if g.expected_step != self.step_count + 1:
+            g.step_dev.fill_(self.step_count + 1)
+        with torch.cuda.device(self.device):
+            self._static_iteration()
+        self.step_count += 1
+        g.expected_step = self.step_count + 1
+        return g.out
+
+    def header(self):
+        """Device header of the captured iteration's last forward (one small D2H read, synchronises)."""
+        h = self._g.geom[:32].view(torch.int32).cpu().tolist()
+        return dict(num_rendered=h[0], num_tiles=h[1], overflow=h[2], max_tile_count=h[3], num_visible=h[4], num_candidates=h[5])
 
     def graph_overflowed(self):
         """True if the last replayed iteration produced more instances than the captured capacity (one small D2H read)."""

@@ -100,6 +100,13 @@ typedef struct DqoRastCtx {
     void* image;
     size_t image_bytes;
     int64_t inst_capacity; /* number of (Gaussian, tile) instances `binning` can hold */
+    /* 0 (default): the per-tile lists are packed back to back by a prefix scan — any list length, `binning` sized by
+     * dqo_rast_binning_bytes(inst_capacity).  > 0: every tile owns a fixed bucket of this many list entries (`binning` sized by
+     * dqo_rast_binning_bytes_bucketed): the binning kernel writes an instance straight to tile * bucket + rank, no scan and no
+     * placement pass sit between it and the sort.  A tile that outgrows its bucket raises the same overflow flag as running out
+     * of inst_capacity (outputs invalid, nothing written out of bounds) — for callers that can re-run, like the captured mapping
+     * iteration.  Same lists, same order, same results as the packed mode. */
+    int32_t tile_bucket_capacity;
 } DqoRastCtx;
 
 /* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206).  dL_dcolors, dL_dcov3D and
@@ -149,6 +156,7 @@ int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset);
 size_t dqo_rast_geom_bytes(int32_t P, int32_t W, int32_t H);
 size_t dqo_rast_image_bytes(int32_t W, int32_t H);
 size_t dqo_rast_binning_bytes(int64_t inst_capacity);
+size_t dqo_rast_binning_bytes_bucketed(int64_t inst_capacity, int32_t W, int32_t H, int32_t tile_bucket_capacity);
 size_t dqo_rast_backward_workspace_bytes(int64_t inst_capacity);
 
 /* Stage 1 (per-Gaussian preprocess).  Needs ctx.geom and ctx.image; leaves num_candidates (>= N) in the device

@@ -204,6 +204,36 @@ def test_sparse_moments_are_bitwise_dense_adam(env):
     assert (a.state["xyz"][0][dormant] == 0).all() and (a.state["shs"][1][dormant] == 0).all()
 
 
+def test_tile_buckets_match_packed_lists(env):
+    """DqoRastCtx.tile_bucket_capacity: per-tile buckets instead of scanned list positions — same lists, same order, so the
+    captured iteration must leave bit-identical parameters and moments; a bucket that is too small raises the overflow flag."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch, P=20000, cfg=3)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, settings, dev)
+    a.capture(gt_color, gt_depth, mask, tile_buckets=True)
+    b.capture(gt_color, gt_depth, mask, tile_buckets=False)
+    assert a._g.bucket >= 256 and b._g.bucket == 0
+    for _ in range(3):
+        a.replay()
+        b.replay()
+    torch.cuda.synchronize()
+    assert not a.graph_overflowed() and not b.graph_overflowed()
+    for k, pa in a._params().items():
+        assert torch.equal(pa, b._params()[k]), k
+        assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), k
+    for x, y in zip(a._g.out, b._g.out):
+        assert torch.equal(x, y)
+    # a bucket smaller than the longest list: flagged, never silent
+    c = FusedMapper(scene, settings, dev)
+    c.capture(gt_color, gt_depth, mask, tile_buckets=True)
+    c._g.cctx.tile_bucket_capacity = 8  # (the buffers are sized for the larger bucket: still in bounds)
+    c._static_iteration()
+    torch.cuda.synchronize()
+    assert c.graph_overflowed()
+
+
 def test_graph_capacity_overflow_is_flagged(env):
     """A captured graph has a fixed instance capacity; when the scene needs more, nothing is written out of bounds, the device
     header says so and graph_overflowed() reports it (the frame's outputs are the initial fills)."""
