@@ -176,6 +176,12 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
         g.slot_base[my_idx] = base + my_gb;
     }
     if (block_live == 0) return;
+    if (bin.bucket > 0) {
+        // bucket mode has no placement pass to clear the validity words of the backward's partial gradient records: the block
+        // clears its own contiguous slot range here, coalesced
+        for (uint32_t i = tid; i < block_live; i += BIN_THREADS)
+            if ((int64_t)(base + i) < capacity) bin.rec_valid[base + i] = 0u;
+    }
 
     // ---- sweep 2: every live candidate takes its rank in its tile and records (tile, rank, Gaussian) at its slot ----
     for (uint32_t win = 0; win < total; win += BIN_WINDOW) {
@@ -211,7 +217,6 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
                             bin.keys[pos] = ((uint64_t)__float_as_uint(depth[u]) << 32) | (uint32_t)gid[u];
                             bin.slots[pos] = slot[u];
                         }
-                        bin.rec_valid[slot[u]] = 0u;  // no partial gradient record of this slot exists yet (backward)
                     } else {
                         bin.slot_info[slot[u]] = make_uint2((uint32_t)tile[u], rank[u]);
                         bin.slot_gid[slot[u]] = (uint32_t)gid[u];
