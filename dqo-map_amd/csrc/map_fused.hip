@@ -38,6 +38,49 @@ __device__ __forceinline__ float wave_red(float v) {
     return v;
 }
 
+// Both loss kernels stream eight image planes.  V = 4: four pixels per thread and trip through 16-byte loads (planes 16-byte
+// aligned, H*W a multiple of 4), every load of a trip issued before the first use and none under a lane condition (the mask only
+// selects); V = 1: the general path.
+template <int V>
+struct LossPix {
+    float c[3][V], g[3][V], d[V], gd[V];
+    int di[V];
+    bool m[V];
+};
+template <int V>
+__device__ __forceinline__ LossPix<V> loss_load(int i, int n, const float* color, const float* depth, const int32_t* depth_index,
+                                                const float* gt_color, const float* gt_depth, const uint8_t* render_mask) {
+    LossPix<V> p;
+    if (V == 4) {
+        const float4* C = reinterpret_cast<const float4*>(color);
+        const float4* G = reinterpret_cast<const float4*>(gt_color);
+        float4 cc[3], gg[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) cc[ch] = C[(size_t)ch * n + i], gg[ch] = G[(size_t)ch * n + i];
+        const float4 dd = reinterpret_cast<const float4*>(depth)[i], gdd = reinterpret_cast<const float4*>(gt_depth)[i];
+        const int4 ii = reinterpret_cast<const int4*>(depth_index)[i];
+        const uint32_t mk = render_mask ? reinterpret_cast<const uint32_t*>(render_mask)[i] : 0x01010101u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            p.c[ch][0] = cc[ch].x, p.c[ch][1] = cc[ch].y, p.c[ch][2] = cc[ch].z, p.c[ch][3] = cc[ch].w;
+            p.g[ch][0] = gg[ch].x, p.g[ch][1] = gg[ch].y, p.g[ch][2] = gg[ch].z, p.g[ch][3] = gg[ch].w;
+        }
+        p.d[0] = dd.x, p.d[1] = dd.y, p.d[2] = dd.z, p.d[3] = dd.w;
+        p.gd[0] = gdd.x, p.gd[1] = gdd.y, p.gd[2] = gdd.z, p.gd[3] = gdd.w;
+        p.di[0] = ii.x, p.di[1] = ii.y, p.di[2] = ii.z, p.di[3] = ii.w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) p.m[k] = ((mk >> (8 * k)) & 0xffu) != 0u;
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) p.c[ch][0] = color[(size_t)ch * n + i], p.g[ch][0] = gt_color[(size_t)ch * n + i];
+        p.d[0] = depth[i], p.gd[0] = gt_depth[i], p.di[0] = depth_index[i];
+        const uint8_t mk = render_mask ? render_mask[i] : (uint8_t)1;
+        p.m[0] = mk != 0;
+    }
+    return p;
+}
+
+template <int V>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_reduce_kernel(int HW, const float* __restrict__ color, const float* __restrict__ depth,
                                                                    const int32_t* __restrict__ depth_index,
                                                                    const float* __restrict__ gt_color, const float* __restrict__ gt_depth,
@@ -45,17 +88,18 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_reduce_kernel(int HW, const
                                                                    double* __restrict__ partial /*[gridDim.x][4]*/) {
     __shared__ float s[4][LOSS_THREADS / 64];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-        const bool m = render_mask == nullptr || render_mask[i] != 0;
-        if (m) {
-            a0 += fabsf(color[i] - gt_color[i]) + fabsf(color[HW + i] - gt_color[HW + i]) + fabsf(color[2 * HW + i] - gt_color[2 * HW + i]);
-            a1 += 1.f;
-        }
-        const float gd = gt_depth[i];
-        const float err = depth[i] - gd;
-        if (m && depth_index[i] != -1 && gd > 0.f && err < add_depth_thres) {  // mapper.py:850-856
-            a2 += fabsf(err);
-            a3 += 1.f;
+    const int n = HW / V;  // units of V pixels
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const LossPix<V> p = loss_load<V>(i, n, color, depth, depth_index, gt_color, gt_depth, render_mask);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const float e = fabsf(p.c[0][k] - p.g[0][k]) + fabsf(p.c[1][k] - p.g[1][k]) + fabsf(p.c[2][k] - p.g[2][k]);
+            a0 += p.m[k] ? e : 0.f;
+            a1 += p.m[k] ? 1.f : 0.f;
+            const float err = p.d[k] - p.gd[k];
+            const bool valid = p.m[k] && p.di[k] != -1 && p.gd[k] > 0.f && err < add_depth_thres;  // mapper.py:850-856
+            a2 += valid ? fabsf(err) : 0.f;
+            a3 += valid ? 1.f : 0.f;
         }
     }
     a0 = wave_red(a0), a1 = wave_red(a1), a2 = wave_red(a2), a3 = wave_red(a3);
@@ -69,6 +113,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_reduce_kernel(int HW, const
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_grad_kernel(int HW, int n_partial, const float* __restrict__ color,
                                                                  const float* __restrict__ depth, const int32_t* __restrict__ depth_index,
                                                                  const float* __restrict__ gt_color, const float* __restrict__ gt_depth,
@@ -110,17 +155,31 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_grad_kernel(int HW, int n_p
         loss_out[3] = 0.f;
     }
     const float gc = color_weight / (3.f * n_col), gdw = depth_weight / n_dep;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-        const bool m = render_mask == nullptr || render_mask[i] != 0;
+    const int n = HW / V;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const LossPix<V> p = loss_load<V>(i, n, color, depth, depth_index, gt_color, gt_depth, render_mask);
+        float oc[3][V], od[V];
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const float d = color[ch * HW + i] - gt_color[ch * HW + i];
-            dL_dcolor[ch * HW + i] = m ? (d > 0.f ? gc : (d < 0.f ? -gc : 0.f)) : 0.f;  // d|x|/dx = sign(x), 0 at 0
+        for (int k = 0; k < V; k++) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float d = p.c[ch][k] - p.g[ch][k];
+                oc[ch][k] = p.m[k] ? (d > 0.f ? gc : (d < 0.f ? -gc : 0.f)) : 0.f;  // d|x|/dx = sign(x), 0 at 0
+            }
+            const float err = p.d[k] - p.gd[k];
+            const bool valid = p.m[k] && p.di[k] != -1 && p.gd[k] > 0.f && err < add_depth_thres;
+            od[k] = valid ? (err > 0.f ? gdw : (err < 0.f ? -gdw : 0.f)) : 0.f;
         }
-        const float gd = gt_depth[i];
-        const float err = depth[i] - gd;
-        const bool valid = m && depth_index[i] != -1 && gd > 0.f && err < add_depth_thres;
-        dL_ddepth[i] = valid ? (err > 0.f ? gdw : (err < 0.f ? -gdw : 0.f)) : 0.f;
+        if (V == 4) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                reinterpret_cast<float4*>(dL_dcolor)[(size_t)ch * n + i] = make_float4(oc[ch][0], oc[ch][1], oc[ch][2], oc[ch][3]);
+            reinterpret_cast<float4*>(dL_ddepth)[i] = make_float4(od[0], od[1], od[2], od[3]);
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dL_dcolor[(size_t)ch * n + i] = oc[ch][0];
+            dL_ddepth[i] = od[0];
+        }
     }
 }
 
@@ -309,12 +368,23 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         const float* gt_depth, const uint8_t* render_mask, float color_weight, float depth_weight, float add_depth_thres,
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s) {
     const int HW = W * H;
-    const int nblk = min(1024, (HW + LOSS_THREADS - 1) / LOSS_THREADS);
     double* partial = (double*)ws;
-    DQO_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(nblk), dim3(LOSS_THREADS), s, HW, color, depth, depth_index, gt_color,
-               gt_depth, render_mask, add_depth_thres, partial);
-    DQO_LAUNCH("loss_grad_kernel", loss_grad_kernel, dim3(nblk), dim3(LOSS_THREADS), s, HW, nblk, color, depth, depth_index, gt_color,
-               gt_depth, render_mask, add_depth_thres, color_weight, depth_weight, partial, loss_out, dL_dcolor, dL_ddepth);
+    auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15u) == 0u; };
+    const bool vec = (HW % 4 == 0) && al16(color) && al16(depth) && al16(depth_index) && al16(gt_color) && al16(gt_depth) &&
+                     al16(dL_dcolor) && al16(dL_ddepth) && (render_mask == nullptr || (reinterpret_cast<uintptr_t>(render_mask) & 3u) == 0u);
+    if (vec) {
+        const int nblk = max(1, min(512, (HW / 4 + LOSS_THREADS - 1) / LOSS_THREADS));
+        DQO_LAUNCH("loss_reduce_kernel", loss_reduce_kernel<4>, dim3(nblk), dim3(LOSS_THREADS), s, HW, color, depth, depth_index, gt_color,
+                   gt_depth, render_mask, add_depth_thres, partial);
+        DQO_LAUNCH("loss_grad_kernel", loss_grad_kernel<4>, dim3(nblk), dim3(LOSS_THREADS), s, HW, nblk, color, depth, depth_index, gt_color,
+                   gt_depth, render_mask, add_depth_thres, color_weight, depth_weight, partial, loss_out, dL_dcolor, dL_ddepth);
+    } else {
+        const int nblk = min(1024, (HW + LOSS_THREADS - 1) / LOSS_THREADS);
+        DQO_LAUNCH("loss_reduce_kernel", loss_reduce_kernel<1>, dim3(nblk), dim3(LOSS_THREADS), s, HW, color, depth, depth_index, gt_color,
+                   gt_depth, render_mask, add_depth_thres, partial);
+        DQO_LAUNCH("loss_grad_kernel", loss_grad_kernel<1>, dim3(nblk), dim3(LOSS_THREADS), s, HW, nblk, color, depth, depth_index, gt_color,
+                   gt_depth, render_mask, add_depth_thres, color_weight, depth_weight, partial, loss_out, dL_dcolor, dL_ddepth);
+    }
     return DQO_OK;
 }
 
