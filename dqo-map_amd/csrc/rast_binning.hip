@@ -88,14 +88,17 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
     uint32_t area = 0;
     {
         uint2 rc = make_uint2(0u, 0u);
+        float4 co = make_float4(0.f, 0.f, 0.f, 0.f), xy = co;
         if (my_idx < P) {
+            // all three loads together (the tables of a culled Gaussian hold stale values that are never looked at): loading the
+            // conic only after the rect says "visible" would put two memory latencies in series at the head of every block
             rc = g.rect16[my_idx];
+            co = g.conic_opacity[my_idx];
+            xy = g.xy_depth[my_idx];
             area = ((rc.x >> 16) - (rc.x & 0xffffu)) * ((rc.y >> 16) - (rc.y & 0xffffu));
         }
         s_rect[tid] = rc;
         if (area) {
-            const float4 co = g.conic_opacity[my_idx];
-            const float4 xy = g.xy_depth[my_idx];
             s_con[tid] = co;
             s_xyq[tid] = make_float4(xy.x, xy.y, dqo_q_threshold(co.w), xy.z);
         }
