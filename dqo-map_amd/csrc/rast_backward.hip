@@ -118,18 +118,37 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     const int tid = threadIdx.x;
     const int idx = blockIdx.x * blockDim.x + tid;
     const bool in_range = idx < v.P;
+    // Two rounds of loads, each issued as a whole: (rect, instance count) decide whether the Gaussian has any work; everything
+    // the chain needs follows in one go.  (A load under a lane condition waits for all earlier loads: the original order —
+    // count, then record, then rect, then parameters — put four memory latencies in series at the head of every wave.)
+    uint2 rc = make_uint2(0u, 0u);
+    uint32_t n_inst = 0;
+    if (in_range) {
+        rc = g.rect16[idx];
+        n_inst = g.tiles_touched[idx];
+    }
+    // radii > 0 (backward.cu:285, 513)  <=>  the forward kept a non-empty tile rect for this Gaussian
+    const bool visible = in_range && ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
     float a[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) a[i] = 0.f;
     float4 cop = make_float4(0.f, 0.f, 0.f, 0.f);  // (conic, opacity) of the forward
-    if (in_range && g.tiles_touched[idx] != 0u) {
-        cop = g.conic_opacity[idx];
+    float mx = 0.f, my = 0.f, mz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+    float4 qt = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (visible) {
         const float4* r = reinterpret_cast<const float4*>(recs) + (size_t)idx * 4;
-        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];  // (stale memory for a Gaussian without instances: zeroed below)
+        cop = g.conic_opacity[idx];
+        mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+        sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
+        qt = reinterpret_cast<const float4*>(rotations)[idx];
         a[0] = r0.x, a[1] = r0.y, a[2] = r0.z, a[3] = r0.w;
         a[4] = r1.x, a[5] = r1.y, a[6] = r1.z, a[7] = r1.w;
         a[8] = r2.x, a[9] = r2.y, a[10] = r2.z, a[11] = r2.w;
         a[12] = r3.x, a[13] = r3.y, a[14] = r3.z, a[15] = r3.w;
+    }
+    if (n_inst == 0u) {  // record_sum_kernel only leaves a summed record for Gaussians that own instances
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[i] = 0.f;
+        cop = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (!in_range) return;
     const int M = v.M, D = v.D;
@@ -140,9 +159,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float* drot = gr.dL_drotations + 4 * (size_t)idx;
     float* dcov = gr.dL_dcov3D + 6 * (size_t)idx;
     float* dm2 = gr.dL_dmeans2D + 3 * (size_t)idx;
-    // radii > 0 (backward.cu:285, 513)  <=>  the forward kept a non-empty tile rect for this Gaussian
-    const uint2 rc = g.rect16[idx];
-    const bool visible = ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
     if (!visible) {
         if (gr.skip_culled_rows) return;  // the consumer knows the row is zero from radii (DqoRastGrads)
         dm[0] = dm[1] = dm[2] = 0.f;
@@ -172,9 +188,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float view[16], proj[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) view[i] = v.view[i], proj[i] = v.proj[i];
-    const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
-    const float sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
-    const float4 qt = reinterpret_cast<const float4*>(rotations)[idx];
     // The cov2D-inverse -> cov3D -> (scale, quaternion) chain is ill-conditioned for thin surfels (denom^2, b^2 by
     // cancellation): it is evaluated in fp64 here.  Per Gaussian, not per pixel: a few hundred flops, invisible next to
     // the kernel's memory traffic on MI355X, and it removes the dominant fp32 noise of the reference formulation.
