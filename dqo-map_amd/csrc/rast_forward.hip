@@ -164,7 +164,23 @@ __global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView
                 const float dxx = px - cam0, dyy = py - cam1, dzz = pz - cam2;
                 const float len = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
                 const float x = dxx / len, y = dyy / len, z = dzz / len;
-                const float* sh = shs + (size_t)idx * v.M * 3;
+                // all coefficients of the active degree in ONE batch of loads: fetched inside the per-degree blocks below they
+                // would come in twelve small groups (three channels x four degrees), each waited for before the next is issued
+                const float* shp = shs + (size_t)idx * v.M * 3;
+                float sh[48];
+                if (v.D >= 3) {
+#pragma unroll
+                    for (int i = 0; i < 48; i++) sh[i] = shp[i];
+                } else if (v.D == 2) {
+#pragma unroll
+                    for (int i = 0; i < 27; i++) sh[i] = shp[i];
+                } else if (v.D == 1) {
+#pragma unroll
+                    for (int i = 0; i < 12; i++) sh[i] = shp[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) sh[i] = shp[i];
+                }
                 const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
