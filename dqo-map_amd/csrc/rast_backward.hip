@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float4 cop = make_float4(0.f, 0.f, 0.f, 0.f);  // (conic, opacity) of the forward
     float mx = 0.f, my = 0.f, mz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
     float4 qt = make_float4(1.f, 0.f, 0.f, 0.f);
+    float sh[48];  // SH coefficients 1.. of the active degree (coefficient 0 has no direction gradient)
     if (visible) {
         const float4* r = reinterpret_cast<const float4*>(recs) + (size_t)idx * 4;
         const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];  // (stale memory for a Gaussian without instances: zeroed below)
@@ -140,6 +141,21 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
         sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
         qt = reinterpret_cast<const float4*>(rotations)[idx];
+        if (shs != nullptr && gr.dL_dsh != nullptr) {
+            // the SH coefficients of the active degree in the same round (they are only needed at the end of the chain; fetched
+            // there, inside the per-degree blocks, they would arrive in three waited-for groups)
+            const float* shp = shs + (size_t)idx * v.M * 3;
+            if (v.D >= 3) {
+#pragma unroll
+                for (int i = 3; i < 48; i++) sh[i] = shp[i];
+            } else if (v.D == 2) {
+#pragma unroll
+                for (int i = 3; i < 27; i++) sh[i] = shp[i];
+            } else if (v.D == 1) {
+#pragma unroll
+                for (int i = 3; i < 12; i++) sh[i] = shp[i];
+            }
+        }
         a[0] = r0.x, a[1] = r0.y, a[2] = r0.z, a[3] = r0.w;
         a[4] = r1.x, a[5] = r1.y, a[6] = r1.z, a[7] = r1.w;
         a[8] = r2.x, a[9] = r2.y, a[10] = r2.z, a[11] = r2.w;
@@ -336,7 +352,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         const float dox = mx - v.campos[0], doy = my - v.campos[1], doz = mz - v.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float dx = dox / len, dy = doy / len, dz = doz / len;
-        const float* sh = shs + (size_t)idx * M * 3;
         const uint32_t cl = g.clamped[idx];
         const float dRGB[3] = {dcolr[0] * ((cl & 1u) ? 0.f : 1.f), dcolr[1] * ((cl & 2u) ? 0.f : 1.f), dcolr[2] * ((cl & 4u) ? 0.f : 1.f)};
         float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
