@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float mx = 0.f, my = 0.f, mz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
     float4 qt = make_float4(1.f, 0.f, 0.f, 0.f);
     float sh[48];  // SH coefficients 1.. of the active degree (coefficient 0 has no direction gradient)
+    float4 n_np = make_float4(0.f, 0.f, 0.f, 0.f), pc = n_np;
+    uint32_t cl = 0;
     if (visible) {
         const float4* r = reinterpret_cast<const float4*>(recs) + (size_t)idx * 4;
         const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];  // (stale memory for a Gaussian without instances: zeroed below)
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
         sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
         qt = reinterpret_cast<const float4*>(rotations)[idx];
+        n_np = g.normal_c[idx], pc = g.point_c[idx], cl = g.clamped[idx];  // (depth-hit chain / SH clamp flags: same round)
         if (shs != nullptr && gr.dL_dsh != nullptr) {
             // the SH coefficients of the active degree in the same round (they are only needed at the end of the chain; fetched
             // there, inside the per-degree blocks, they would arrive in three waited-for groups)
@@ -218,8 +221,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     // normal n_c, camera-space point p_c, view matrix, d(normal)/d(quaternion) — is applied here, once, in fp64:
     //   dL/dmean3D = hit1 * V^T n_c + hit0 * V^T e_z,   dL/dn_c = p_c * hit1 - (n_c . p_c) * hit[2..4],   dL/dq = (dn_w/dq)^T V^T dL/dn_c
     if (a[9] != 0.f || a[10] != 0.f || a[11] != 0.f || a[12] != 0.f || a[13] != 0.f) {
-        const float4 n_np = g.normal_c[idx];
-        const float4 pc = g.point_c[idx];
         const real h0 = a[9], h1 = a[10], h2x = a[11], h2y = a[12], h2z = a[13];
         const real nx = n_np.x, ny = n_np.y, nz = n_np.z;
         const real np = nx * pc.x + ny * pc.y + nz * pc.z;
@@ -352,7 +353,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         const float dox = mx - v.campos[0], doy = my - v.campos[1], doz = mz - v.campos[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float dx = dox / len, dy = doy / len, dz = doz / len;
-        const uint32_t cl = g.clamped[idx];
         const float dRGB[3] = {dcolr[0] * ((cl & 1u) ? 0.f : 1.f), dcolr[1] * ((cl & 2u) ? 0.f : 1.f), dcolr[2] * ((cl & 4u) ? 0.f : 1.f)};
         float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
         auto setd = [&](int k, float w) {
