@@ -281,11 +281,15 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
         const uint32_t k = (uint32_t)e / 3u, j = (uint32_t)e - 3u * k, r = s_rows[k];
         const bool has_g = (r >> 31) != 0u;
         const size_t i = (size_t)(r & 0x7fffffffu) * 3 + j;
+        // all eight loads of the element in one round (the gradient rows of a Gaussian without one are unwritten memory: read
+        // at a clamped address and discarded — a load under a lane condition would wait for every earlier load first)
+        const size_t gi = has_g ? i : 0;
         float p = a.xyz[i], m = ldnt(&a.m_xyz[i]), v = ldnt(&a.v_xyz[i]);
-        adam1(p, has_g ? ldnt(&a.g_xyz[i]) : 0.f, m, v, a, a.step_xyz);
-        a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
         float ps = a.scaling_raw[i], ms = ldnt(&a.m_scaling[i]), vs = ldnt(&a.v_scaling[i]);
-        adam1(ps, (has_g ? ldnt(&a.g_scales[i]) : 0.f) * expf(ps), ms, vs, a, a.step_scaling);  // d exp(x)/dx = exp(x)
+        const float gx_ld = ldnt(&a.g_xyz[gi]), gs_ld = ldnt(&a.g_scales[gi]);
+        adam1(p, has_g ? gx_ld : 0.f, m, v, a, a.step_xyz);
+        a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
+        adam1(ps, (has_g ? gs_ld : 0.f) * expf(ps), ms, vs, a, a.step_scaling);  // d exp(x)/dx = exp(x)
         a.scaling_raw[i] = ps, stnt(ms, &a.m_scaling[i]), stnt(vs, &a.v_scaling[i]);
         if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
     }
@@ -294,9 +298,14 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
     // condition makes the compiler drain every earlier load first).
     const uint32_t row = (uint32_t)a.M * 3u;
     const int nsh = n_rows * (int)row;
-    for (int e0 = tid; e0 < nsh; e0 += 4 * ADAM_THREADS) {
-        float p[4], m[4], v[4], gq[4];
+    // The loads of trip t + 1 are issued before trip t is computed and stored (two register sets): the block's memory pipe
+    // never idles between trips.
+    struct ShTrip {
+        float p[4], m[4], v[4], g[4];
         uint32_t ei[4], fl[4];  // element index in the [P * M * 3] arrays; 1 = in range, 2 = has a gradient, 4 = f_dc
+    };
+    auto load_trip = [&](int e0) {
+        ShTrip t;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = e0 + u * ADAM_THREADS;
@@ -304,37 +313,50 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
             const uint32_t ee = in ? (uint32_t)e : 0u;
             const uint32_t k = (uint32_t)(((uint64_t)ee * a.row_magic) >> 39);  // ee / row, exact for ee < 2^31, row < 2^8
             const uint32_t j = ee - k * row, r = s_rows[k];
-            ei[u] = (r & 0x7fffffffu) * row + j;
-            fl[u] = in ? (1u | ((r >> 31) ? 2u : 0u) | (j < 3u ? 4u : 0u)) : 0u;
-            p[u] = a.shs[ei[u]];
-            m[u] = ldnt(&a.m_shs[ei[u]]);
-            v[u] = ldnt(&a.v_shs[ei[u]]);
+            t.ei[u] = (r & 0x7fffffffu) * row + j;
+            t.fl[u] = in ? (1u | ((r >> 31) ? 2u : 0u) | (j < 3u ? 4u : 0u)) : 0u;
+            t.p[u] = a.shs[t.ei[u]];
+            t.m[u] = ldnt(&a.m_shs[t.ei[u]]);
+            t.v[u] = ldnt(&a.v_shs[t.ei[u]]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const float gv = ldnt(&a.g_shs[(fl[u] & 2u) ? ei[u] : ei[0]]);  // (a row without a gradient may be unwritten memory)
-            gq[u] = (fl[u] & 2u) ? gv : 0.f;
-        }
+        for (int u = 0; u < 4; u++)  // (a row without a gradient may be unwritten memory: clamped address, value discarded)
+            t.g[u] = ldnt(&a.g_shs[(t.fl[u] & 2u) ? t.ei[u] : t.ei[0]]);
+        return t;
+    };
+    if (nsh > 0) {
+        ShTrip cur = load_trip(tid);
+        for (int e0 = tid; e0 < nsh; e0 += 4 * ADAM_THREADS) {
+            const bool more = e0 + 4 * ADAM_THREADS < nsh;  // (per thread; the loads of an absent trip are skipped as a whole)
+            ShTrip nxt = cur;
+            if (more) nxt = load_trip(e0 + 4 * ADAM_THREADS);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (!(fl[u] & 1u)) continue;
-            adam1(p[u], gq[u], m[u], v[u], a, (fl[u] & 4u) ? a.step_dc : a.step_rest);
-            a.shs[ei[u]] = p[u], stnt(m[u], &a.m_shs[ei[u]]), stnt(v[u], &a.v_shs[ei[u]]);
+            for (int u = 0; u < 4; u++) {
+                if (!(cur.fl[u] & 1u)) continue;
+                float p = cur.p[u], m = cur.m[u], v = cur.v[u];
+                adam1(p, (cur.fl[u] & 2u) ? cur.g[u] : 0.f, m, v, a, (cur.fl[u] & 4u) ? a.step_dc : a.step_rest);
+                a.shs[cur.ei[u]] = p, stnt(m, &a.m_shs[cur.ei[u]]), stnt(v, &a.v_shs[cur.ei[u]]);
+            }
+            cur = nxt;
         }
     }
     // opacity (sigmoid) [P] and rotation (normalize) [P,4]
     if (tid < n_rows) {
         const uint32_t r = s_rows[tid], i = r & 0x7fffffffu;
         const bool has_g = (r >> 31) != 0u;
+        // all loads of the row in one round (clamped gradient addresses, see above)
+        const uint32_t gi = has_g ? i : 0u;
         float p = a.opacity_raw[i], m = ldnt(&a.m_opacity[i]), v = ldnt(&a.v_opacity[i]);
+        float4 q = reinterpret_cast<float4*>(a.rotation_raw)[i];
+        float4 mq = reinterpret_cast<float4*>(a.m_rotation)[i], vq = reinterpret_cast<float4*>(a.v_rotation)[i];
+        const float go_ld = ldnt(&a.g_opacity[gi]);
+        const float4 gr_ld = reinterpret_cast<const float4*>(a.g_rot)[gi];
         const float sg = 1.0f / (1.0f + expf(-p));
-        adam1(p, (has_g ? ldnt(&a.g_opacity[i]) : 0.f) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
+        adam1(p, (has_g ? go_ld : 0.f) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
         a.opacity_raw[i] = p, stnt(m, &a.m_opacity[i]), stnt(v, &a.v_opacity[i]);
         if (a.act_opacity) a.act_opacity[i] = 1.0f / (1.0f + expf(-p));
 
-        float4 q = reinterpret_cast<float4*>(a.rotation_raw)[i];
-        const float4 g = has_g ? reinterpret_cast<const float4*>(a.g_rot)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 mq = reinterpret_cast<float4*>(a.m_rotation)[i], vq = reinterpret_cast<float4*>(a.v_rotation)[i];
+        const float4 g = has_g ? gr_ld : make_float4(0.f, 0.f, 0.f, 0.f);
         // F.normalize backward: y = q / n, n = max(|q|, eps):  dq = (g - y (y . g)) / n
         const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
         const float yx = q.x / nrm, yy = q.y / nrm, yz = q.z / nrm, yw = q.w / nrm;
