@@ -97,6 +97,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView
             const float tvy = view[1] * px + view[5] * py + view[9] * pz + view[13];
             const float tvz = view[2] * px + view[6] * py + view[10] * pz + view[14];
             if (tvz <= 0.2f || (double)projx < -1.3 || (double)projx > 1.3 || (double)projy < -1.3 || (double)projy > 1.3) break;
+            const float opac = opacities[idx];  // (with the scales / rotation round: used only by the stores at the very end)
             // computeCov3D, forward.cu:202-235
             const float sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
             const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView
             const float npc = tvx * ncx + tvy * ncy + tvz * ncz;
 
             radius = ir;
-            g.conic_opacity[idx] = make_float4(conx, cony, conz, opacities[idx]);
+            g.conic_opacity[idx] = make_float4(conx, cony, conz, opac);
             g.xy_depth[idx] = make_float4(pixx, pixy, tvz, __int_as_float(ir));
             g.rgb_smax[idx] = make_float4(rgb[0], rgb[1], rgb[2], smax);
             g.normal_c[idx] = make_float4(ncx, ncy, ncz, npc);
