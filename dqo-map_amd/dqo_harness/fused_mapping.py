@@ -72,7 +72,13 @@ class FusedMapper:
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
-        hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay()."""
+        hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
+
+        The capture fixes two capacities from the state it is taken on: the instance capacity (candidates x capacity_margin)
+        and, with tile_buckets, the per-tile list bucket (twice the longest list, power of two).  A replay that outgrows
+        either leaves invalid outputs and raises the device-side overflow flag — check graph_overflowed() (one small D2H read,
+        e.g. once per batch of replays) and call capture() again when it is set; tile_buckets=False keeps the packed lists
+        (any list length, one more kernel per iteration)."""
         lib = N.lib()
         dev, P, M = self.device, self.P, self.M
         st = self.settings
