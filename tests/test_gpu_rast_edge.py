@@ -32,10 +32,11 @@ def _check(oracle, cam, sc, dL, **kw):
     return o, st, gs
 
 
-@pytest.mark.parametrize("P,longer_than", [(2800, 1024), (9000, 4096)])
-def test_long_tile_lists_global_sort(torch_cuda, oracle, P, longer_than):
-    """Lists beyond the one-wave register sort (> 1024: block sort in LDS) and beyond the LDS capacity (> 4096 instances in one
-    tile: the sort kernel's in-place global path); semi-transparent so the whole list is walked."""
+@pytest.mark.parametrize("P,longer_than,at_most", [(1300, 512, 1024), (2800, 1024, None), (9000, 4096, None)])
+def test_long_tile_lists_global_sort(torch_cuda, oracle, P, longer_than, at_most):
+    """Lists of 513..1024 entries (two waves: two register sorts + one exchange through LDS), beyond that (> 1024: block sort in
+    LDS) and beyond the LDS capacity (> 4096 instances in one tile: the sort kernel's in-place global path); semi-transparent
+    so the whole list is walked."""
     cam = scenes.Camera(96, 64, 80.0, 80.0, 47.5, 31.5)
     rng = np.random.default_rng(0)
     sc = scenes.frustum_cloud(5, P, cam, zmin=1.0, zmax=4.0)
@@ -47,6 +48,8 @@ def test_long_tile_lists_global_sort(torch_cuda, oracle, P, longer_than):
     o, st, gs = _check(oracle, cam, sc, _dL(cam))
     rg = o.ctx("ranges")
     assert (rg[:, 1] - rg[:, 0]).max() > longer_than, "scene does not exercise the long-list path"
+    if at_most is not None:
+        assert (rg[:, 1] - rg[:, 0]).max() <= at_most, "scene is past the path this case is meant for"
     print("long lists:", (rg[:, 1] - rg[:, 0]).max(), st)
 
 
