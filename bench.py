@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """Mapping-iteration benchmark of the MI355X rasteriser path (BASELINE.json metric).
 
-One step = one mapping iteration of DQO-MAP's local_optimize loop (SLAM/multiprocess/mapper.py:531-605) on synthetic
-data of BASELINE config 3: activations -> rasteriser forward -> loss (0.8 L1 colour + 1.0 depth L1 on the object masks,
-mapper.py:836-875) -> rasteriser backward -> Adam step over the six parameter groups (gaussian_pointcloud.py:331-378).
-500k Gaussians, 1200x680, 8 object ids; inputs resident in HBM before the timed region.
+One step = one mapping iteration of DQO-MAP's local_optimize loop (SLAM/multiprocess/mapper.py:531-605) on synthetic data of a
+BASELINE config (default: config 3, the one the metric is quoted on): activations -> rasteriser forward -> loss (0.8 L1 colour +
+1.0 depth L1 on the object masks, mapper.py:836-875, + the attach loss, :812-829) -> rasteriser backward -> Adam step over the six
+parameter groups (gaussian_pointcloud.py:331-378).  Inputs are resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg 3] [--P 500000]
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank owns its own object
-shard (weak scaling: fixed Gaussians per GPU, per-object losses on disjoint masks), the only exchange is one packed
-all-reduce of the per-iteration loss scalars.  Rank 0 prints ONE JSON line.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg 3] [--P 500000] [--path fused|dropin] [--scaling strong|weak]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Default `--scaling strong`: ONE map is
+built, sharded by object id (dqo_harness.sharding.shard_scene), every rank owns its objects' Gaussians + Adam state and renders
+only the tiles its objects' masks touch; one iteration of the job = every shard stepped once, so value = steps / time whatever N
+is.  The only exchange is one packed all-reduce per iteration of the shards' loss sums (started asynchronously, off the compute
+stream's critical path).  `--scaling weak` keeps round 1's mode (an independent map of P Gaussians per rank).  After the timed
+loop every rank checks its result against the same shard run alone and the job exits non-zero on a mismatch.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +34,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured float4 copy)
+DEBUG = bool(os.environ.get("DQO_BENCH_DEBUG"))
+
+
+def dbg(*a):
+    if DEBUG:
+        print(f"[bench r{os.environ.get('RANK', '0')}]", *a, file=sys.stderr, flush=True)
 
 
 def parse():
@@ -39,37 +53,50 @@ def parse():
     ap.add_argument("--path", default="fused", choices=("fused", "dropin"),
                     help="fused: dqo_harness.FusedMapper (activation / loss / Adam kernels of row f2 around the op); "
                          "dropin: autograd through the drop-in op + torch.optim.Adam, exactly what unchanged DQO-MAP code runs")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="N > 1: strong = ONE map sharded by object id over the ranks; weak = an independent map per rank")
     ap.add_argument("--no-graph", action="store_true", help="fused path: issue the kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--growth-every", type=int, default=None,
+                    help="map-growth step (knn on 40 800 new points + scale init + concat / delete + graph re-capture) every this many "
+                         "iterations, inside the timed region; default: 100 for cfg 5 (its BASELINE workload), off otherwise")
+    ap.add_argument("--view", default="room", choices=("room", "all"),
+                    help="room: camera inside the room (39 %% of the map in the frustum); all: camera outside, every Gaussian in view")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes that measure roofline.traffic")
+    ap.add_argument("--no-aux", action="store_true", help="skip the knn / quadric timings and the all-in-view variant")
+    ap.add_argument("--no-selfcheck", action="store_true")
     ap.add_argument("--cpu-sample-P", type=int, default=500_000)
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child of a --pmc pass: timed loop only
     return ap.parse_args()
 
 
-def object_masks(cam, hit_ids, obj_id, n_objects, device):
-    """Per-object screen masks (16-px tile granularity): a pixel belongs to the object of the Gaussian that
-    fixes its depth in the initial render; the shard's render mask is the union of its objects' masks."""
-    ids = hit_ids[0].long().clamp(min=0)
-    pix_obj = obj_id[ids]
-    pix_obj[hit_ids[0] < 0] = -1
-    return pix_obj
+# ------------------------------------------------------------------------------------------------------------------
+# problem
+# ------------------------------------------------------------------------------------------------------------------
+def all_in_view_camera(cfgd):
+    """Camera outside the 6 x 3 x 4 m room, on its axis, far enough that every Gaussian is inside the frustum."""
+    from dqo_harness import scenes
+    return scenes.replica_camera(cfgd["W"], cfgd["H"], cfgd["fx"], cfgd["fx"], cfgd["cx"], cfgd["cy"], yaw=0.0, pitch=0.0,
+                                 pos=(0.0, 0.0, -5.4))
 
 
-def build_problem(args, rank, world, device):
-    from dqo_harness import scenes, mapping
+def build_scene(args, seed_shift=0):
+    from dqo_harness import scenes
     cfgd = dict(scenes.CONFIGS[args.cfg])
     P = args.P or cfgd["P"]
-    # weak scaling: every rank gets its own shard of P Gaussians (distinct objects / seed), same camera and image size
-    cfgd["seed"] = cfgd["seed"] + 1000 * rank
+    cfgd["seed"] = cfgd["seed"] + seed_shift
     if args.cfg == 1:
         cam, scene = scenes.make_config(1, P=P)
     else:
-        cam = scenes.replica_camera(cfgd["W"], cfgd["H"], cfgd["fx"], cfgd["fx"], cfgd["cx"], cfgd["cy"])
+        cam = (all_in_view_camera(cfgd) if args.view == "all" else
+               scenes.replica_camera(cfgd["W"], cfgd["H"], cfgd["fx"], cfgd["fx"], cfgd["cx"], cfgd["cy"]))
         scene = scenes.surfel_room(cfgd["seed"], P, n_objects=cfgd["n_objects"], rest_sigma=cfgd["rest_sigma"])
     if os.environ.get("DQO_BENCH_MORTON"):  # experiment: storage order of the Gaussians = Morton order of their centres
         q = scene["xyz"]
         lo, hi = q.min(0), q.max(0)
         u = np.clip(((q - lo) / (hi - lo + 1e-9) * 1023).astype(np.uint64), 0, 1023)
+
         def spread(x):
             x = (x | (x << 16)) & 0x030000FF
             x = (x | (x << 8)) & 0x0300F00F
@@ -79,105 +106,460 @@ def build_problem(args, rank, world, device):
         code = spread(u[:, 0]) | (spread(u[:, 1]) << 1) | (spread(u[:, 2]) << 2)
         perm = np.argsort(code, kind="stable")
         scene = {k: (v[perm] if hasattr(v, "shape") and v.shape[:1] == (len(perm),) else v) for k, v in scene.items()}
-    params = mapping.GaussianParams(scene, device)
+    return cam, scene, cfgd, P
+
+
+def build_problem(args, rank, world, device):
+    """Returns the rank's problem: camera, the FULL map, the rank's shard of it, target images, pixel / tile masks."""
+    from dqo_harness import mapping, sharding
+    strong = args.scaling == "strong"
+    cam, full, cfgd, P = build_scene(args, seed_shift=0 if strong else 1000 * rank)
     settings = mapping.make_settings(cam, device)
-    # target = render of a perturbed copy, so the gradients are non-trivial
+    # target = render of a perturbed copy of the FULL map, so the gradients are non-trivial (SURVEY.md §8d); every rank renders
+    # it once (same camera, target image and mask set on every GPU, §8e)
     rng = np.random.default_rng(cfgd["seed"] + 7)
-    pert = dict(scene)
-    pert["xyz"] = (scene["xyz"] + rng.normal(0, 0.004, scene["xyz"].shape)).astype(np.float32)
-    pert["shs"] = scene["shs"].copy()
+    pert = dict(full)
+    pert["xyz"] = (full["xyz"] + rng.normal(0, 0.004, full["xyz"].shape)).astype(np.float32)
+    pert["shs"] = full["shs"].copy()
     pert["shs"][:, 0, :] += rng.normal(0, 0.15, (P, 3)).astype(np.float32)
     with torch.no_grad():
         tgt = mapping.render(settings, mapping.GaussianParams(pert, device).activated())
         gt_color, gt_depth = tgt["render"].clone(), tgt["depth"].clone()
-        pix_obj = object_masks(cam, tgt["depth_index_map"], params.obj_id, cfgd["n_objects"], device)
-        render_mask = pix_obj >= 0  # union of the object masks of this shard
-    return cam, scene, params, settings, gt_color, gt_depth, render_mask, cfgd, P
+        # per-object screen masks: a pixel belongs to the object of the Gaussian that fixes its depth in the target render
+        hit = tgt["depth_index_map"][0]
+        obj_id = torch.tensor(full["obj_id"], device=device)
+        pix_obj = obj_id[hit.long().clamp(min=0)]
+        pix_obj[hit < 0] = -1
+        del tgt
+    if strong and world > 1:
+        mine, assignment = sharding.shard_scene(full, rank, world)
+        my_objs = torch.tensor(sorted(k for k, s in assignment.items() if s == rank), device=device)
+    else:
+        mine, assignment = full, None
+        my_objs = torch.unique(obj_id)
+    render_mask = torch.isin(pix_obj, my_objs)  # union of the masks of the objects this rank owns
+    tile_mask = torch.tensor(sharding.tile_mask_from_pixel_mask(render_mask.cpu().numpy()), device=device)
+    torch.cuda.empty_cache()
+    return dict(cam=cam, full=full, scene=mine, settings=settings, gt_color=gt_color, gt_depth=gt_depth, render_mask=render_mask,
+                tile_mask=tile_mask, cfgd=cfgd, P=P, P_shard=int(mine["xyz"].shape[0]), objects=[int(k) for k in my_objs.tolist()])
 
 
-def make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world):
+# ------------------------------------------------------------------------------------------------------------------
+# step functions
+# ------------------------------------------------------------------------------------------------------------------
+LOSS_SPEC = [("total", 1), ("color", 1), ("depth", 1), ("pad", 1), ("sum_color", 1), ("n_color", 1), ("sum_depth", 1), ("n_depth", 1)]
+
+
+def make_dropin_step(prob, device, loss_buf):
+    """What unchanged DQO-MAP code executes: autograd through the drop-in op, eager torch loss, torch.optim.Adam."""
     from dqo_harness import mapping
+    params = mapping.GaussianParams(prob["scene"], device)
+    opt = mapping.make_optimizer(params)
+    init_stat = params.init_stat()
+    st, gtc, gtd, rm, tm = prob["settings"], prob["gt_color"], prob["gt_depth"], prob["render_mask"], prob["tile_mask"]
 
     def step():
-        out = mapping.render(settings, params.activated())
-        loss, parts = mapping.mapping_loss(out, gt_color, gt_depth, render_mask=render_mask)
-        loss.backward()
+        out = mapping.render(st, params.activated(), tile_mask=tm)
+        loss, parts = mapping.mapping_loss(out, gtc, gtd, render_mask=rm)
+        (loss + mapping.attach_loss(params, init_stat)).backward()  # mapper.py:905
         opt.step()
         opt.zero_grad(set_to_none=True)
         loss_buf.put("total", parts["total_loss"])
         loss_buf.put("color", parts["color_loss"])
         loss_buf.put("depth", parts["depth_loss"])
-        # the path's only exchange: ONE packed fp32 all-reduce of the quantities shared across object shards
-        loss_buf.reduce()
+        loss_buf.reduce()  # the path's only exchange: ONE packed fp32 all-reduce
         return out
 
     return step
 
 
-def make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf, use_graph=True, world=1):
-    from dqo_harness.fused_mapping import FusedMapper
-    fm = FusedMapper(scene, settings, device)
-    mask_u8 = render_mask.to(torch.uint8).contiguous()
+class FusedRunner:
+    """The fused path of one rank: a FusedMapper on the rank's shard, one hipGraph replay per iteration, the packed all-reduce of
+    the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
 
-    def step_eager():
-        out = fm.step(gt_color, gt_depth, mask_u8)
-        loss_buf.buf[:3].copy_(fm.loss[:3])
-        loss_buf.reduce()  # ONE packed all-reduce per iteration (no-op at world size 1)
-        return {"radii": out[8]}
+    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0):
+        from dqo_harness.fused_mapping import FusedMapper
+        self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
+        self.fm = FusedMapper(prob["scene"], prob["settings"], device)
+        self.mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
+        self.use_graph = use_graph
+        self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
+        self.first_loss = None
+        if use_graph:
+            self._capture()
 
-    step_eager.mapper = fm
-    if not use_graph:
-        return step_eager, step_eager
-    try:
-        fm.capture(gt_color, gt_depth, mask_u8)  # the whole iteration as one hipGraph over persistent buffers
-    except Exception as e:  # e.g. a runtime that refuses the capture: the eager path is the same arithmetic
-        print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running the fused path eagerly", file=sys.stderr)
+    def _capture(self):
+        p = self.prob
+        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"])
+        if self.first_loss is None:
+            self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
+
+    def grow(self):
+        """cfg 5's growth step: 40 800 new surfel points -> temp_points_filter (dqo_knn3_query) -> update_geometry
+        (dqo_knn3) -> concat; delete = the per-Gaussian depth error of the last frame above 2 x add_depth_thres
+        (accumulate_gaussian_error, mapper.py:1034-1075); new mapping call (fresh Adam + init_stat, mapper.py:533-548) and graph
+        re-capture on the re-allocated buffers.  Everything on the GPU, no process restart."""
+        from dqo_harness import scenes
+        from cuda_utils._C import accumulate_gaussian_error
+        fm, p = self.fm, self.prob
+        t0 = time.perf_counter()
+        k = len(self.growth_log)
+        new = scenes.surfel_room(9000 + 17 * k + self.growth_seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])
+        out = fm._g.out if getattr(fm, "_g", None) is not None else None
+        delete = None
+        if out is not None:
+            H, W = p["cam"].H, p["cam"].W
+            depth_err = (p["gt_depth"] - out[1]).clamp(min=0)  # mapper.py:1016-1017
+            invalid = (p["gt_depth"] == 0) | (out[3] == -1)
+            depth_err[invalid] = 0
+            color_err = (p["gt_color"] - out[0]).abs().sum(0, keepdim=True)
+            color_err[p["gt_depth"] == 0] = 0
+            zero = torch.zeros_like(depth_err)
+            _, g_depth, _, _ = accumulate_gaussian_error(H, W, fm.P, color_err.reshape(-1), depth_err.reshape(-1), zero.reshape(-1),
+                                                         out[2].reshape(-1), out[3].reshape(-1), 0.1, 0.1, 0.1, True)
+            delete = (g_depth.reshape(-1) > 2 * 0.1)
+        st = fm.grow(new, delete_mask=delete)
+        fm.begin_mapping_call(reset_optimizer=True)
+        if self.use_graph:
+            self._capture()
         torch.cuda.synchronize()
-        return step_eager, step_eager
+        st["ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        st["P_after"] = fm.P
+        self.growth_log.append(st)
 
-    def step_graph():
-        out = fm.replay()
-        if world > 1:  # the per-iteration collective of the sharded path stays outside the graph and off its critical path
-            loss_buf.reduce_async(src=fm.loss[:3])
-        return {"radii": out[8]}
+    def step(self):
+        if self.growth_every and self.iters and self.iters % self.growth_every == 0:
+            self.grow()
+        self.iters += 1
+        if self.use_graph:
+            out = self.fm.replay()
+        else:
+            out = self.fm.step(self.prob["gt_color"], self.prob["gt_depth"], self.mask_u8, tile_mask=self.prob["tile_mask"])
+        if self.world > 1:  # the per-iteration collective stays outside the graph and off its critical path
+            self.loss_buf.reduce_async(src=self.fm.loss)
+        return out
 
-    def finish():
-        if fm.graph_overflowed():
+    def step_static(self):  # the graph's own calls issued eagerly: what the per-kernel profile pass times
+        out = self.fm.step_static()
+        if self.world > 1:
+            self.loss_buf.reduce_async(src=self.fm.loss)
+        return out
+
+    def finish(self):
+        """Outside the timed region: overflow check + loss read-back."""
+        if self.use_graph and self.fm.graph_overflowed():
             raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
-        if world == 1:
-            loss_buf.buf[:3].copy_(fm.loss[:3])
-
-    def step_static():  # the graph's own calls issued eagerly: what the per-kernel profile pass times
-        out = fm.step_static()
-        loss_buf.buf[:3].copy_(fm.loss[:3])
-        loss_buf.reduce()
-        return {"radii": out[8]}
-
-    step_graph.finish = finish
-    step_graph.static = step_static
-    step_graph.mapper = step_eager.mapper = fm
-    return step_graph, step_eager
+        if self.world == 1:
+            self.loss_buf.buf.copy_(self.fm.loss)
 
 
-def cpu_baseline(args, cam, scene, P_sample):
-    """Single-thread CPU oracle (kind 'port': the reference has no CPU renderer) on a bounded sample of the
-    same workload: ONE forward + backward at the same image size with the first P_sample Gaussians of the scene."""
-    from oracle import oracle_lib as ol
-    ol.build()
-    sub = {k: v[:P_sample] for k, v in scene.items()}
+def reduced_losses(buf, world):
+    """[total, colour, depth] over ALL objects from the all-reduced sums (per-shard means do not add up; the sums do)."""
+    v = buf.tolist()
+    if world == 1:
+        return [round(float(x), 6) for x in v[:3]]
+    color = v[4] / (3.0 * max(v[5], 1.0))
+    depth = v[6] / max(v[7], 1.0)
+    return [round(0.8 * color + 1.0 * depth, 6), round(color, 6), round(depth, 6)]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# self checks of the sharded path
+# ------------------------------------------------------------------------------------------------------------------
+def selfcheck(args, prob, runner, device, n_iters):
+    """(1) the fused path's loss of the INITIAL state against the eager autograd path on the same shard (different code: drop-in op
+    + torch ops): catches a blank / invalid frame inside the captured graph; (2) the END state of the timed run against the same
+    shard stepped alone — a second mapper on the same initial state, same number of iterations, no collective in flight — to 1e-5.
+    Returns a list of failure strings (empty = fine)."""
+    from dqo_harness import mapping
+    from dqo_harness.fused_mapping import FusedMapper
+    fails = []
+    params = mapping.GaussianParams(prob["scene"], device)
+    with torch.no_grad():
+        out = mapping.render(prob["settings"], params.activated(), tile_mask=prob["tile_mask"])
+        _, parts = mapping.mapping_loss(out, prob["gt_color"], prob["gt_depth"], render_mask=prob["render_mask"])
+    ref0 = [parts[k].item() for k in ("total_loss", "color_loss", "depth_loss")]
+    got0 = runner.first_loss[:3].tolist()
+    if not np.allclose(got0, ref0, rtol=1e-4, atol=1e-7):
+        fails.append(f"initial loss of the captured path {got0} != eager autograd path {ref0}")
+    if int((out["depth_index_map"] >= 0).sum().item()) == 0:
+        fails.append("the shard renders no depth hit at all (blank frame)")
+    del out, params
+    if not runner.growth_log:  # (a grown map has no stand-alone twin to compare with)
+        end = runner.fm.loss.clone()
+        twin = FusedMapper(prob["scene"], prob["settings"], device)
+        mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
+        if runner.use_graph:
+            twin.capture(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"])
+            for _ in range(n_iters):
+                twin.replay()
+        else:
+            for _ in range(n_iters):
+                twin.step(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"])
+        torch.cuda.synchronize()
+        a, b = end[:3].tolist(), twin.loss[:3].tolist()
+        if not np.allclose(a, b, rtol=1e-5, atol=1e-8):
+            fails.append(f"loss after {n_iters} iterations {a} != the same shard run alone {b}")
+        if not (a[0] < got0[0]):
+            fails.append(f"loss did not decrease: {got0[0]} -> {a[0]}")
+        del twin
+    torch.cuda.empty_cache()
+    return fails
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle, test infrastructure: the checker timed beside the product, never the thing measured)
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_iteration(ol, mo, cam, sub, gt_color, gt_depth, mask, omp):
+    """ONE full mapping iteration on the CPU: oracle raster forward -> masked loss -> oracle raster backward -> activation Jacobians +
+    Adam step over the six groups (numpy).  Returns (seconds per stage, forward result, oracle object)."""
     st = ol.RastSettings(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, normal_threshold=float(np.cos(np.deg2rad(60.0))))
-    o = ol.OracleRasterizer(np.float32)
+    o = ol.OracleRasterizer(np.float32, omp=omp)
     t0 = time.time()
     r = o.forward(st, sub["xyz"], sub["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
                   shs=sub["shs"], scales=sub["scales"], rotations=sub["rotations"])
     t1 = time.time()
-    o.backward(np.ones((3, cam.H, cam.W), np.float32), np.ones((1, cam.H, cam.W), np.float32))
+    _, _, _, dC, dD = mo.masked_loss(r.color, r.depth, r.hit_depth, gt_color, gt_depth, mask)
     t2 = time.time()
-    return dict(value=1.0 / (t2 - t0), unit="iter/s", cores=1, kind="port",
-                sample=f"1 iteration (raster fwd {t1 - t0:.2f}s + bwd {t2 - t1:.2f}s, no loss/Adam) of the single-thread C++ oracle on "
-                       f"the first {P_sample} Gaussians of the workload at {cam.W}x{cam.H} (N={r.num_rendered} instances)")
+    g = o.backward(dC.astype(np.float32), dD.astype(np.float32))
+    t3 = time.time()
+    # raw parameters and their gradients, then Adam (step 1, zero moments) — float32 arrays like the product's
+    f = np.float32
+    op = np.clip(sub["opacity"], 1e-4, 1 - 1e-4)
+    raw_op, raw_sc, raw_rot = np.log(op / (1 - op)), np.log(sub["scales"]), sub["rotations"]
+    g_op, g_sc, g_rot = mo.raw_grads(raw_op, raw_sc, raw_rot, g.opacity, g.scales, g.rotations)
+    for p_, g_, lr in ((sub["xyz"], g.means3D, 0.001), (sub["shs"], g.sh, 0.0005), (raw_op, g_op, 0.0), (raw_sc, g_sc, 0.004),
+                       (raw_rot, g_rot, 0.001)):
+        mo.adam_step(p_.astype(f), np.asarray(g_, f), np.zeros_like(p_, f), np.zeros_like(p_, f), lr, 1)
+    t4 = time.time()
+    return dict(fwd=t1 - t0, loss=t2 - t1, bwd=t3 - t2, adam=t4 - t3, total=t4 - t0), r, o
 
 
+def cpu_baseline(args, prob, hip_render0):
+    """The CPU oracle (kind 'port': the reference has no CPU renderer) on a bounded sample of the same workload —
+    one full iteration with the first P_sample Gaussians of the map at the same image size — on all host cores (OpenMP build of the
+    oracle) and on one core.  Also returns the workload statistics and PSNR(HIP render, oracle render) of that sample."""
+    from oracle import oracle_lib as ol
+    from oracle import map_oracle as mo
+    ol.build()
+    cam, scene = prob["cam"], prob["full"]
+    Ps = min(args.cpu_sample_P, prob["P"])
+    sub = {k: v[:Ps] for k, v in scene.items()}
+    gtc, gtd = prob["gt_color"].cpu().numpy(), prob["gt_depth"].cpu().numpy()
+    mask = (prob["render_mask"].cpu().numpy()) if prob.get("render_mask") is not None else None
+    tm, r, o = cpu_iteration(ol, mo, cam, sub, gtc, gtd, mask, omp=True)
+    cores = ol.num_threads(True)
+    stats = dict(N_reference=int(r.num_rendered), active_tiles=int(r.num_tiles),
+                 mean_contributors_per_pixel=round(float(o.ctx("n_blend").mean()), 3))
+    psnr = None
+    if hip_render0 is not None and Ps == prob["P"]:
+        # SLAM/eval.py:63-65 / utils/loss_utils.py:22-25: 20 log10(1 / sqrt(mse)) per channel, mean — HIP render vs oracle render
+        mse = ((hip_render0.astype(np.float64) - r.color.astype(np.float64)) ** 2).reshape(3, -1).mean(1)
+        psnr = float(np.mean(20 * np.log10(1.0 / np.sqrt(np.maximum(mse, 1e-30)))))
+    del o
+    t1, _, o1 = cpu_iteration(ol, mo, cam, sub, gtc, gtd, mask, omp=False)
+    del o1
+    out = dict(value=round(1.0 / tm["total"], 4), unit="iter/s", cores=cores, kind="port", cpu=cpu_model(),
+               single_thread_value=round(1.0 / t1["total"], 4),
+               sample=f"1 full iteration (raster fwd {tm['fwd']:.2f}s + masked loss {tm['loss']:.2f}s + raster bwd {tm['bwd']:.2f}s + "
+                      f"Adam {tm['adam']:.2f}s; 1 core: {t1['fwd']:.2f} + {t1['loss']:.2f} + {t1['bwd']:.2f} + {t1['adam']:.2f}s) of the C++ "
+                      f"oracle (OpenMP build, {cores} threads; loss / Adam in numpy) on the first {Ps} Gaussians of the workload at "
+                      f"{cam.W}x{cam.H} (N={r.num_rendered} reference instances)")
+    return out, stats, psnr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the other two pieces of the hot path, timed beside their CPU counterparts (SURVEY.md §8d)
+# ------------------------------------------------------------------------------------------------------------------
+def aux_benchmarks(prob, device):
+    import _dqo_native as N
+    out = {}
+    # ---- exact 3-NN: dqo_knn3 (distCUDA2) on 40 800 new points + the existing points inside their bounding box ----
+    try:
+        from simple_knn._C import distCUDA2
+        from dqo_harness import scenes
+        import dqo_mapgrowth as mg
+        new = scenes.surfel_room(4242, 40_800, n_objects=8)
+        nx = torch.tensor(new["xyz"], device=device)
+        ex = torch.tensor(prob["full"]["xyz"], device=device)
+        pts = torch.cat([nx, ex[mg.bbox_filter(nx, ex)]]).contiguous()
+        for _ in range(2):
+            distCUDA2(pts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            distCUDA2(pts)
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        from scipy.spatial import cKDTree
+        h = pts.cpu().numpy()
+        t0 = time.perf_counter()
+        tree = cKDTree(h)
+        tree.query(h, k=4, workers=-1)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        out["knn3"] = dict(points=int(pts.shape[0]), gpu_ms=round(gpu_ms, 3), cpu_ckdtree_ms=round(cpu_ms, 1), cpu="scipy cKDTree build + "
+                           "query(k=4, workers=-1)", alg_bytes=int(28 * pts.shape[0]), gbs=round(28 * pts.shape[0] / (gpu_ms * 1e-3) / 1e9, 2))
+    except Exception as e:  # noqa: BLE001 (an auxiliary timing must not take the headline down)
+        out["knn3"] = dict(error=f"{type(e).__name__}: {e}")
+    # ---- dual-quadric fit: 8 objects x 5 views x 20 Adam steps: dqo_quadric_adam vs the reference's eager per-object loop ----
+    try:
+        import dqo_quadrics as dq
+        rng = np.random.default_rng(3)
+        cam = prob["cam"]
+        n_obj, n_view, n_it = 8, 5, 20
+        axes = rng.uniform(0.15, 0.4, (n_obj, 3)).astype(np.float32)
+        R = np.tile(np.eye(3, dtype=np.float32), (n_obj, 1, 1))
+        center = (rng.uniform(-0.5, 0.5, (n_obj, 3)) + np.array([0.3, 0.1, 0.6])).astype(np.float32)
+        P34, obs = [], []
+        for o_ in range(n_obj):
+            for v_ in range(n_view):
+                c2 = type(cam)(cam.W, cam.H, cam.fx, cam.fy, cam.cx, cam.cy, cam.Rw2c, cam.t + rng.normal(0, 0.05, 3))
+                P34.append(c2.P34())
+                b = dq_bbox_numpy(axes[o_], R[o_], center[o_], P34[-1])
+                obs.append(b + rng.normal(0, 4.0, 4))
+        P34, obs = np.asarray(P34, np.float32), np.asarray(obs, np.float32)
+        offs = np.arange(0, n_obj * n_view + 1, n_view, dtype=np.int32)
+        sched = rng.integers(0, n_view, (n_obj, n_it)).astype(np.int32)
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), device=device)
+        a0, R0, c0, args_ = t(axes * 1.1), t(R), t(center + 0.03), (t(P34), t(obs), t(offs), t(sched))
+        for _ in range(2):
+            dq.optimize_objects(a0, R0, c0, *args_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            dq.optimize_objects(a0, R0, c0, *args_)
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        t0 = time.perf_counter()
+        eager_quadric_loop(axes * 1.1, R, center + 0.03, P34, obs, offs, sched)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        out["quadric_fit"] = dict(objects=n_obj, views=n_view, iters=n_it, gpu_ms=round(gpu_ms, 3), cpu_eager_torch_ms=round(cpu_ms, 1),
+                                  cpu="restated eager PyTorch-CPU loop of Object_Optimize_only (quadrics.py:2251-2285), 1 thread")
+    except Exception as e:  # noqa: BLE001
+        out["quadric_fit"] = dict(error=f"{type(e).__name__}: {e}")
+    return out
+
+
+def dq_bbox_numpy(axes, R, center, P):
+    """Projected bounding box of an ellipsoid, fp64 — only to synthesise observations."""
+    D = np.diag([axes[0] ** 2, axes[1] ** 2, axes[2] ** 2, -1.0])
+    Z = np.eye(4)
+    Z[:3, :3] = R
+    Z[:3, 3] = center
+    Q = Z @ D @ Z.T
+    C = P @ Q @ P.T
+    C = C / -C[2, 2]
+    mu = -C[:2, 2]
+    E = C[:2, :2] + np.outer(mu, mu)
+    X, Y = np.sqrt(abs(E[0, 0])), np.sqrt(abs(E[1, 1]))
+    return np.array([mu[0] - X, mu[1] - Y, mu[0] + X, mu[1] + Y])
+
+
+def eager_quadric_loop(axes, R, center, P34, obs, offs, sched):
+    """The reference's per-object eager loop restated on the CPU (quadrics.py:2251-2285: Adam over axes / R / centre with lrs
+    .01 / .001 / .01, eps 1e-15, 20 steps, one view per step; forward quadrics.py:2178-2220, 2019-2091 with torch.linalg.eig)."""
+    torch.set_num_threads(1)
+    for o_ in range(len(offs) - 1):
+        a = torch.tensor(axes[o_], requires_grad=True)
+        Rm = torch.tensor(R[o_], requires_grad=True)
+        c = torch.tensor(center[o_], requires_grad=True)
+        opt = torch.optim.Adam([{"params": [a], "lr": 0.01}, {"params": [Rm], "lr": 0.001}, {"params": [c], "lr": 0.01}], eps=1e-15)
+        for it in range(sched.shape[1]):
+            v = int(offs[o_] + sched[o_, it])
+            P = torch.tensor(P34[v])
+            D = torch.diag(torch.cat([a ** 2, -torch.ones(1)]))
+            Z = torch.eye(4)
+            Z = torch.cat([torch.cat([Rm, c[:, None]], 1), torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
+            Q = Z @ D @ Z.T
+            Q = 0.5 * (Q + Q.T)
+            Q = Q / -Q[3, 3]
+            C = P @ Q @ P.T
+            C = 0.5 * (C + C.T)
+            C = C / -C[2, 2]
+            mu = -C[:2, 2]
+            T = torch.eye(3)
+            T = torch.cat([torch.cat([torch.eye(2), mu[:, None]], 1), torch.tensor([[0.0, 0.0, 1.0]])], 0)
+            Cc = T @ C @ T.T
+            ev, evec = torch.linalg.eig(Cc[:2, :2])
+            ax2 = torch.sqrt(torch.abs(ev.real))
+            ang = torch.atan2(evec.real[1, 0], evec.real[0, 0])
+            cs, sn = torch.cos(ang), torch.sin(ang)
+            X = torch.sqrt(ax2[0] ** 2 * cs ** 2 + ax2[1] ** 2 * sn ** 2)
+            Y = torch.sqrt(ax2[0] ** 2 * sn ** 2 + ax2[1] ** 2 * cs ** 2)
+            bb = torch.stack([mu[0] - X, mu[1] - Y, mu[0] + X, mu[1] + Y])
+            ob = torch.tensor(obs[v])
+            iw = torch.clamp(torch.min(bb[2], ob[2]) - torch.max(bb[0], ob[0]), min=0)
+            ih = torch.clamp(torch.min(bb[3], ob[3]) - torch.max(bb[1], ob[1]), min=0)
+            inter = iw * ih
+            union = (bb[2] - bb[0]) * (bb[3] - bb[1]) + (ob[2] - ob[0]) * (ob[3] - ob[1]) - inter
+            loss = 1 - inter / union
+            if float(loss.detach()) == 1.0:
+                continue
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel: rocprofv3 --pmc child passes over this same command (MI355X_MICROARCH.md, HBM section)
+# ------------------------------------------------------------------------------------------------------------------
+def pmc_traffic(args, kernel_name):
+    """Memory-side bytes per launch of `kernel_name` from two rocprofv3 --pmc passes (TCC read / write request counters: one
+    counter set per pass, --kernel-trace only beside them) over `python3 bench.py --inner` with this run's workload flags.
+    read = RDREQ x 64 B (the FETCH_SIZE convention; wide coalesced reads are 128-B requests tallied at 64 B and are NOT doubled here:
+    the blend kernels gather 16-B records), write = 64 B x WRREQ_64B + 32 B x the other write requests.  Returns dict or None."""
+    import csv
+    import glob
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    inner = [sys.executable, os.path.abspath(__file__), "--inner", "--cfg", str(args.cfg), "--steps", "3", "--warmup", "1", "--path", args.path,
+             "--view", args.view, "--sync-mode", args.sync_mode]
+    if args.P:
+        inner += ["--P", str(args.P)]
+    if args.no_graph:
+        inner += ["--no-graph"]
+    res = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for tag, counters in (("rd", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]), ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])):
+        d = tempfile.mkdtemp(prefix="dqo_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--"] + inner
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        except (subprocess.SubprocessError, OSError) as e:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"pmc pass {tag} failed: {type(e).__name__}"
+        acc = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kernel_name in row.get("Kernel_Name", ""):
+                        a = acc.setdefault(row.get("Counter_Name"), [0.0, 0])
+                        a[0] += float(row.get("Counter_Value", 0))
+                        a[1] += 1
+        shutil.rmtree(d, ignore_errors=True)
+        for c in counters:
+            if c not in acc or acc[c][1] == 0:
+                return None, f"pmc pass {tag}: no samples of {kernel_name}"
+            res[c] = acc[c][0] / acc[c][1]
+    rd = res["TCC_EA0_RDREQ_sum"] * 64
+    wr = res["TCC_EA0_WRREQ_64B_sum"] * 64 + (res["TCC_EA0_WRREQ_sum"] - res["TCC_EA0_WRREQ_64B_sum"]) * 32
+    return dict(read_bytes=int(rd), write_bytes=int(wr)), "measured in this run: rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ child passes"
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -192,21 +574,33 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.growth_every is None:
+        args.growth_every = 100 if (args.cfg == 5 and args.path == "fused" and not args.inner) else 0
 
     import _dqo_native as N
     import diff_gaussian_rasterization_depth as dgr
     from dqo_harness import mapping
+    from dqo_harness.sharding import PackedAllReduce
     N.lib()
     dgr.set_sync_mode(args.sync_mode)
 
-    cam, scene, params, settings, gt_color, gt_depth, render_mask, cfgd, P = build_problem(args, rank, world, device)
-    opt = mapping.make_optimizer(params)
-    from dqo_harness.sharding import PackedAllReduce
-    loss_buf = PackedAllReduce([("total", 1), ("color", 1), ("depth", 1)], device)
-    step_dropin = make_step(params, settings, gt_color, gt_depth, render_mask, opt, loss_buf, world)
-    step_fused, step_fused_eager = make_fused_step(scene, settings, device, gt_color, gt_depth, render_mask, loss_buf,
-                                                   use_graph=not args.no_graph, world=world)
-    step = step_fused if args.path == "fused" else step_dropin
+    prob = build_problem(args, rank, world, device)
+    cam, cfgd, P = prob["cam"], prob["cfgd"], prob["P"]
+    dbg("problem built: P_shard", prob["P_shard"], "objects", prob["objects"], "mask px", int(prob["render_mask"].sum().item()),
+        "tiles", int(prob["tile_mask"].sum().item()))
+    # HIP render of the initial full map (PSNR against the oracle's render of the same map, rank 0 / N = 1 only)
+    render0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.inner:
+        with torch.no_grad():
+            render0 = mapping.render(prob["settings"], mapping.GaussianParams(prob["full"], device).activated())["render"].cpu().numpy()
+    loss_buf = PackedAllReduce(LOSS_SPEC, device)
+    runner = step_dropin = None
+    if args.path == "fused":
+        runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank)
+        step = runner.step
+    else:
+        step_dropin = make_dropin_step(prob, device, loss_buf)
+        step = step_dropin
 
     def sync_all():
         if world > 1:
@@ -222,45 +616,75 @@ def main():
     loss_buf.finish()  # outstanding asynchronous all-reduces of the sharded path (inside the timed region)
     sync_all()
     dt = time.perf_counter() - t0
-    if hasattr(step, "finish"):
-        step.finish()  # graph path: overflow check + loss read-back, outside the timed region
+    if runner is not None:
+        runner.finish()  # overflow check + loss read-back, outside the timed region
     if args.sync_mode == "lazy":
         dgr._verify_pending(block=True)  # raises if any timed iteration overflowed its instance capacity
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    loss_now = reduced_losses(loss_buf.buf, world)
+    dbg("timed loop done: dt", dt, "rank loss", runner.fm.loss[:3].tolist() if runner else None, "reduced", loss_now)
+    if args.inner:
+        print(json.dumps({"inner": True, "ms_per_step": dt / args.steps * 1e3}))
+        return
 
-    loss_now = [round(float(x) / world, 6) for x in loss_buf.buf.tolist()[:3]]
-    # the other path, timed the same way (single GPU only), so both numbers come from one run
+    # ---- self check of the (sharded) path: every rank, non-zero exit on a mismatch ----
+    fails = []
+    if runner is not None and not args.no_selfcheck:
+        n_iters = args.warmup + args.steps  # replays after the capture (which holds one eager iteration itself)
+        fails = selfcheck(args, prob, runner, device, n_iters)
+        for f in fails:
+            print(f"[bench] SELF-CHECK FAILED on rank {rank}: {f}", file=sys.stderr, flush=True)
+    n_fail = torch.tensor([len(fails)], device=device, dtype=torch.int32)
+    if world > 1:
+        torch.distributed.all_reduce(n_fail)
+    selfcheck_ok = int(n_fail.item()) == 0
+
+    # ---- the other path, timed the same way (single GPU only), so both numbers come from one run ----
     alt = None
     if world == 1:
-        other = step_dropin if args.path == "fused" else step_fused
+        if args.path == "fused":
+            step_other = make_dropin_step(prob, device, PackedAllReduce(LOSS_SPEC, device))
+        else:
+            other_runner = FusedRunner(prob, device, PackedAllReduce(LOSS_SPEC, device), 1, use_graph=not args.no_graph)
+            step_other = other_runner.step
         for _ in range(max(2, args.warmup // 2)):
-            other()
+            step_other()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            other()
+            step_other()
         torch.cuda.synchronize()
         dt_alt = time.perf_counter() - t1
         if args.sync_mode == "lazy":
             dgr._verify_pending(block=True)
         alt = {"path": "dropin" if args.path == "fused" else "fused", "value": round(args.steps / dt_alt, 3), "unit": "iter/s",
                "ms_per_step": round(dt_alt / args.steps * 1e3, 4)}
+        del step_other
+        torch.cuda.empty_cache()
 
-    # workload statistics of the last iteration (reported next to every timing)
-    n_vis = int((out["radii"] > 0).sum().item())
-    stats = dict(P=P, P_visible=n_vis)
-    fm_ = getattr(step_fused, "mapper", None)
-    if args.path == "fused" and fm_ is not None and fm_.moment_live is not None:
+    # ---- workload statistics of the last iteration (reported next to every timing) ----
+    radii = out[8] if isinstance(out, (tuple, list)) else out["radii"]
+    n_vis = int((radii > 0).sum().item())
+    P_now = int(radii.shape[0])
+    stats = dict(P=P, P_shard=prob["P_shard"], P_visible=n_vis, objects_of_rank0=prob["objects"], view=args.view)
+    if args.view == "room":
+        stats["note_view"] = "camera inside the room: only the Gaussians in its frustum are visible (P_visible of P); --view all puts every Gaussian in view"
+    fm_ = runner.fm if runner is not None else None
+    if fm_ is not None and fm_.moment_live is not None:
         # exact sparse Adam (DqoAdamStep.moment_live): Gaussians with all-zero moments and no gradient are fixed points of the
         # update and are skipped; bitwise equal to the dense update (tests/test_gpu_fused_mapping.py)
         stats["adam"] = "exact-sparse"
         stats["adam_rows_touched"] = int(fm_.moment_live.sum().item())
+    if fm_ is not None:
+        stats["attach_loss_members"] = fm_.attach_count
+    if runner is not None and runner.growth_log:
+        stats["growth_every"] = args.growth_every
+        stats["growth_steps"] = runner.growth_log
 
     roofline = None
-    kernels = None
     if not args.no_roofline:  # on every rank: the step function contains the per-iteration collective
         # per-kernel durations with HIP events on the launch stream, over the same step function
         N.profile_enable(True)
@@ -268,83 +692,131 @@ def main():
         torch.cuda.synchronize()
         ksteps = min(args.steps, 20)
         # HIP events cannot be recorded inside a graph replay: the profile pass issues the graph's own calls eagerly
-        step_prof = getattr(step_fused, "static", step_fused_eager) if args.path == "fused" else step_dropin
+        if runner is not None:
+            step_prof = runner.step_static if runner.use_graph else runner.step
+        else:
+            step_prof = step_dropin
         for _ in range(ksteps):
             step_prof()
+        loss_buf.finish()
         torch.cuda.synchronize()
         prof = N.profile_collect(reset=True)
         N.profile_enable(False)
         kernels = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items()}  # average microseconds per launch
-        # read N / active tiles of the current state
-        cap = dgr._cap_hint.get((device.index, P, cam.W, cam.H))
         stats["kernel_us"] = kernels
         dom = max(prof.items(), key=lambda kv: kv[1][0])
         dom_name, dom_ms = dom[0], dom[1][0] / max(dom[1][1], 1)
         # workload counts of the current state from the device header of the last forward
-        hdr = fm_.header() if (args.path == "fused" and fm_ is not None and getattr(fm_, "_g", None) is not None) else dgr.last_header()
+        hdr = fm_.header() if (fm_ is not None and getattr(fm_, "_g", None) is not None) else dgr.last_header()
         n_inst, n_cand = hdr["num_rendered"], hdr["num_candidates"]
-        HWa = cam.W * cam.H
-        stats.update(N_instances=n_inst, N_candidates=n_cand, max_tile_list=hdr["max_tile_count"])
+        HWa = 256 * hdr["num_tiles"]  # pixels in active tiles
+        stats.update(N_instances=n_inst, N_candidates=n_cand, max_tile_list=hdr["max_tile_count"], num_tiles=hdr["num_tiles"],
+                     tiles_total=((cam.W + 15) // 16) * ((cam.H + 15) // 16))
+        Pk = P_now
         # algorithmic bytes per launch (DESIGN.md "Kernels"): what the kernel must move at minimum, per unit
         # (instance = (Gaussian, tile) list entry; Gaussian; pixel) x the units of this launch
         alg = {
-            "preprocess_kernel": 236 * n_vis + 12 * (P - n_vis) + 8 * P + 88 * n_vis,   # params of visible, xyz of culled; radii, rect; 5 tables + rect
-            "bin_count_kernel": 40 * n_vis + 12 * n_inst,                                # rect + 2 tables per visible; (tile, rank, id) per instance
-            "bin_place_kernel": 24 * n_inst,                                             # info + id in, key + slot out
-            "tile_sort_wave_kernel": 20 * n_inst, "tile_sort_kernel": 20 * n_inst,       # key + slot in, id + slot out
-            "blend_forward_kernel": 40 * n_inst + 36 * HWa,                              # id + 2 records (+ rgb for survivors), live bytes; 9 output planes
-            "blend_backward_kernel": 120 * n_inst + 32 * HWa,                            # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
-            "record_sum_kernel": 68 * n_inst + 64 * n_vis,                               # gradient records in, one summed record per visible Gaussian out
+            "preprocess_kernel": 236 * n_vis + 12 * (Pk - n_vis) + 8 * Pk + 88 * n_vis,   # params of visible, xyz of culled; radii, rect; 5 tables + rect
+            "bin_count_kernel": 40 * n_vis + 12 * n_inst,                                 # rect + 2 tables per visible; (tile, rank, id) per instance
+            "bin_place_kernel": 24 * n_inst,                                              # info + id in, key + slot out
+            "tile_sort_wave_kernel": 20 * n_inst, "tile_sort_kernel": 20 * n_inst,        # key + slot in, id + slot out
+            "blend_forward_kernel": 40 * n_inst + 36 * HWa,                               # id + 2 records (+ rgb for survivors), live bytes; 9 output planes
+            "blend_backward_kernel": 120 * n_inst + 32 * HWa,                             # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
+            "record_sum_kernel": 68 * n_inst + 64 * n_vis,                                # gradient records in, one summed record per visible Gaussian out
             # summed record, params, tables in; gradient rows out (fused path: only the rows of visible Gaussians are written)
-            "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * (n_vis if args.path == "fused" else P),
-            "loss_reduce_kernel": 36 * HWa, "loss_grad_kernel": 52 * HWa,
+            "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * (n_vis if args.path == "fused" else Pk),
+            "loss_reduce_kernel": 36 * cam.W * cam.H, "loss_grad_kernel": 52 * cam.W * cam.H,
             # 59 floats x (param, m, v in and out) of the Gaussians Adam touches (all of them in dense mode) + the gradient rows
-            "adam_kernel": 236 * 6 * stats.get("adam_rows_touched", P) + 236 * n_vis,
+            "adam_kernel": 236 * 6 * stats.get("adam_rows_touched", Pk) + 236 * n_vis,
         }
+        # the contract's own per-unit figure for the dominant kernel's share of an iteration: 40 B per instance (bwd
+        # gather) + 16 B per active pixel (dL_dcolor, dL_ddepth) for the backward blend; 28 B + 36 B for the forward blend
+        contract = {"blend_backward_kernel": 40 * n_inst + 16 * HWa, "blend_forward_kernel": 28 * n_inst + 36 * HWa}
         bytes_dom = alg.get(dom_name, 0)
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # memory-side bytes per launch of the dominant kernel, from the separate rocprofv3 --pmc passes committed under profiles/
-        # (tools/pmc_hbm.sh; counters cannot be collected from inside this process)
-        traffic, valu_frac, valu_busy = None, None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as fh:
-                tk = json.load(fh)["kernels"].get(dom_name)
-            if tk is not None and args.cfg == 3 and args.P is None:
-                traffic = int(tk["read_bytes"] + tk["write_bytes"])
-                if "valu_insts" in tk:  # VALU-issue occupancy of the dominant kernel: wave instructions / (CUs x clock x duration)
-                    valu_frac = tk["valu_insts"] / (256 * 2.4e9 * dom_ms * 1e-3)
-                if "valu_active_quadcycles" in tk:  # SQ_ACTIVE_INST_VALU (4-cycle units, summed over the chip) / all SIMD cycles
-                    valu_busy = tk["valu_active_quadcycles"] * 4 / (1024 * 2.4e9 * dom_ms * 1e-3)
-        except OSError:
-            pass
+        traffic, traffic_note = None, "not collected"
+        if rank == 0 and world == 1 and not args.no_pmc:
+            tr, traffic_note = pmc_traffic(args, dom_name)
+            if tr is not None:
+                traffic = tr["read_bytes"] + tr["write_bytes"]
+                stats["traffic_read_write"] = [tr["read_bytes"], tr["write_bytes"]]
+        # whole iteration against HBM: the contract's B_iter (708 B / visible Gaussian + 4 B / Gaussian + 92 B / instance + 52 B / active
+        # pixel + 1652 B / Gaussian Adam touches) over the measured time per iteration
+        b_iter = 708 * n_vis + 4 * Pk + 92 * n_inst + 52 * HWa + 1652 * stats.get("adam_rows_touched", Pk)
+        ms_step = dt / args.steps * 1e3
         roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, avg_launch_us=round(dom_ms * 1e3, 2),
-                        algorithmic_bytes=int(bytes_dom), valu_issue_frac=None if valu_frac is None else round(valu_frac, 3),
-                        valu_busy_frac=None if valu_busy is None else round(valu_busy, 3),
-                        note="the blend kernels are VALU bound, not HBM bound: valu_busy_frac = SQ_ACTIVE_INST_VALU over all SIMD cycles "
-                             "of the launch, valu_issue_frac = SQ_INSTS_VALU x 4 cycles over the same (profiles/README.md); per-kernel "
-                             "GB/s of every kernel: config.kernel_gbs",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_note,
+                        avg_launch_us=round(dom_ms * 1e3, 2), algorithmic_bytes=int(bytes_dom),
+                        contract_bytes=int(contract.get(dom_name, bytes_dom)),
+                        contract_frac=round(contract.get(dom_name, bytes_dom) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom_ms > 0 else None,
+                        iteration=dict(contract_bytes=int(b_iter), gbs=round(b_iter / (ms_step * 1e-3) / 1e9, 1),
+                                       frac=round(b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                        note="algorithmic_bytes = DESIGN.md's per-launch model of the dominant kernel (120 B / instance + 32 B / active pixel for "
+                             "the backward blend); contract_bytes = SURVEY.md §8d's own share for it; the blend kernels are VALU-issue bound, "
+                             "not HBM bound (profiles/README.md); per-kernel GB/s of every kernel: kernel_gbs",
                         kernel_gbs={k: round(alg[k] / (us * 1e-6) / 1e9, 1) for k, us in kernels.items() if k in alg and us > 0})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, cam, scene, min(args.cpu_sample_P, P))
+        cpu, wl, psnr = cpu_baseline(args, prob, render0)
+        stats.update(wl)
+        if psnr is not None:
+            stats["psnr_hip_vs_oracle_render_db"] = round(psnr, 2)
+
+    aux = other = None
+    if rank == 0 and world == 1 and not args.no_aux:
+        aux = aux_benchmarks(prob, device)
+        if args.view == "room" and args.cfg != 1 and args.path == "fused":
+            # the all-in-view variant of the same map (§8d sized its example on it): short run of the fused graph path
+            try:
+                a2 = argparse.Namespace(**vars(args))
+                a2.view = "all"
+                p2 = build_problem(a2, 0, 1, device)
+                r2 = FusedRunner(p2, device, PackedAllReduce(LOSS_SPEC, device), 1, use_graph=not args.no_graph)
+                for _ in range(5):
+                    r2.step()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                k2 = max(10, args.steps // 2)
+                for _ in range(k2):
+                    o2 = r2.step()
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t2
+                r2.finish()
+                h2 = r2.fm.header()
+                other = dict(workload=f"cfg{args.cfg} map, camera outside the room: every Gaussian inside the frustum", value=round(k2 / d2, 2),
+                             unit="iter/s", ms_per_step=round(d2 / k2 * 1e3, 4), P_visible=int((o2[8] > 0).sum().item()),
+                             N_instances=h2["num_rendered"], N_candidates=h2["num_candidates"], max_tile_list=h2["max_tile_count"])
+                del r2, p2
+            except Exception as e:  # noqa: BLE001
+                other = dict(error=f"{type(e).__name__}: {e}")
 
     if rank == 0:
-        value = world * args.steps / dt
+        strong = args.scaling == "strong"
+        value = args.steps / dt if strong else world * args.steps / dt
+        metric = "mapping iters/sec (fwd+bwd raster) @ 500k Gaussians 1200x680"
+        if not strong and world > 1:
+            metric += " — aggregate over independent per-rank maps (weak scaling)"
         line = {
-            "metric": "mapping iters/sec (fwd+bwd raster) @ 500k Gaussians 1200x680",
+            "metric": metric,
             "value": round(value, 3), "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg{args.cfg}: surfel room, {P} Gaussians/GPU, {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, "
-                                   "SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 depth L1), raster fwd+bwd + Adam (6 groups); path=" + args.path
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg{args.cfg}: surfel room, ONE map of {P} Gaussians"
+                                   + (f" sharded by object id over {world} ranks" if (strong and world > 1) else ("/GPU" if world > 1 else ""))
+                                   + f", {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 "
+                                   "depth L1) + attach loss, raster fwd+bwd + Adam (6 groups); path=" + args.path
                                    + ("" if args.path != "fused" or args.no_graph else " (one hipGraph replay per iteration)"),
-                       "shards": world, "sync_mode": args.sync_mode, **stats},
+                       "shards": world, "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
+                                                                                   ("ok" if selfcheck_ok else "FAILED")), **stats},
             "loss": loss_now, "path": args.path,
         }
         if alt is not None:
             line["other_path"] = alt
+        if other is not None:
+            line["other_workload"] = other
+        if aux is not None:
+            line["config"]["aux"] = aux
         if roofline is not None:
             line["roofline"] = roofline
         if cpu is not None:
@@ -352,6 +824,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
+    if not selfcheck_ok:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -54,10 +54,12 @@ class DqoAdamStep(ctypes.Structure):
                  ("lr_f_dc", c_f), ("lr_f_rest", c_f), ("lr_opacity", c_f), ("lr_scaling", c_f), ("lr_rotation", c_f)] +
                 [(n, c_vp) for n in ("xyz", "shs", "opacity_raw", "scaling_raw", "rotation_raw", "g_means3D", "g_sh", "g_opacity",
                                      "g_scales", "g_rotations", "m_xyz", "m_shs", "m_opacity", "m_scaling", "m_rotation", "v_xyz",
-                                     "v_shs", "v_opacity", "v_scaling", "v_rotation", "act_opacity", "act_scales", "act_rotations", "radii", "step_dev", "moment_live")])
+                                     "v_shs", "v_opacity", "v_scaling", "v_rotation", "act_opacity", "act_scales", "act_rotations", "radii", "step_dev", "moment_live",
+                                     "attach_mask", "init_xyz", "init_scaling_raw", "init_rotation_raw")] +
+                [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp)])
 
 
-EXPORTS = ("dqo_abi_version", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
+EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
            "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_adam_step", "dqo_accumulate_gaussian_error", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
            "dqo_rast_binning_bytes", "dqo_rast_binning_bytes_bucketed",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
@@ -118,8 +120,15 @@ def lib():
         L.dqo_tile_color_error.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         L.dqo_profile_enable.argtypes = [ctypes.c_int]
         L.dqo_profile_collect.argtypes = [P(DqoProfileEntry), ctypes.c_int, ctypes.c_int]
-        if L.dqo_abi_version() != 1:
+        if L.dqo_abi_version() != 2:
             raise RuntimeError("libdqoraster.so ABI version mismatch")
+        L.dqo_abi_sizeof.restype = ctypes.c_size_t
+        L.dqo_abi_sizeof.argtypes = [c_i32]
+        for k, st in enumerate((DqoRastParams, DqoRastInputs, DqoRastOutputs, DqoRastCtx, DqoRastGrads, DqoRastHeader, DqoProfileEntry,
+                                DqoAdamStep)):
+            if L.dqo_abi_sizeof(k) != ctypes.sizeof(st):
+                raise RuntimeError(f"libdqoraster.so: struct {st.__name__} is {L.dqo_abi_sizeof(k)} bytes in the library, "
+                                   f"{ctypes.sizeof(st)} in the binding")
         _lib = L
     return _lib
 

@@ -113,6 +113,11 @@ DQO_API int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset
 }
 
 DQO_API int dqo_abi_version(void) { return DQO_ABI_VERSION; }
+DQO_API size_t dqo_abi_sizeof(int32_t which) {
+    static const size_t sz[] = {sizeof(DqoRastParams), sizeof(DqoRastInputs), sizeof(DqoRastOutputs), sizeof(DqoRastCtx), sizeof(DqoRastGrads),
+                                sizeof(DqoRastHeader), sizeof(DqoProfileEntry), sizeof(DqoAdamStep)};
+    return (which >= 0 && which < (int32_t)(sizeof(sz) / sizeof(sz[0]))) ? sz[which] : 0;
+}
 DQO_API const char* dqo_last_error(void) { return g_err; }
 
 DQO_API size_t dqo_rast_geom_bytes(int32_t P, int32_t W, int32_t H) {

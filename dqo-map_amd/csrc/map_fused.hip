@@ -153,6 +153,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_grad_kernel(int HW, int n_p
         loss_out[1] = color_loss;
         loss_out[2] = depth_loss;
         loss_out[3] = 0.f;
+        // the unnormalised sums: what shards of one map exchange (one packed all-reduce) to report the loss over ALL objects
+        loss_out[4] = (float)s_tot[0], loss_out[5] = (float)s_tot[1], loss_out[6] = (float)s_tot[2], loss_out[7] = (float)s_tot[3];
     }
     const float gc = color_weight / (3.f * n_col), gdw = depth_weight / n_dep;
     const int n = HW / V;
@@ -201,6 +203,13 @@ struct AdamArgs {
     uint64_t row_magic;                                                           // ceil(2^39 / (3 M)): division by the SH row length
     const int32_t* step_dev;                                                      // optional: step count on the device (hipGraph replay)
     float lr_xyz, lr_dc, lr_rest, lr_opacity, lr_scaling, lr_rotation;            // used with step_dev
+    // attach loss (mapper.py:812-829): elementwise pull of the raw scaling / xyz / rotation towards their values at the start of
+    // the mapping call, for the Gaussians of attach_mask
+    const uint8_t* attach_mask;
+    const float *init_xyz, *init_scaling, *init_rotation;
+    float attach_g3, attach_g4;                                                   // 2000 / (3 |a|), 2000 / (4 |a|)
+    float* attach_partial;
+    const DqoRastHeader* frame_header;                                            // optional: overflow flag => the launch is a no-op
 };
 
 // The moments and the gradients are touched exactly once per iteration (0.7 GB of the kernel's 0.83 GB): non-temporal loads /
@@ -226,7 +235,10 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
     p = p - step_size * (m / denom);
 }
 
-__global__ void adam_advance_kernel(int32_t* step_dev) { *step_dev += 1; }
+__global__ void adam_advance_kernel(int32_t* step_dev, const DqoRastHeader* frame_header) {
+    if (frame_header != nullptr && frame_header->overflow != 0u) return;  // invalid frame: the step did not happen
+    *step_dev += 1;
+}
 
 // One block per 256 consecutive Gaussians.  The block first lists the Gaussians it has to touch (LDS): all of them in dense mode;
 // in the exact sparse mode (DqoAdamStep.moment_live) those with a gradient row (radii > 0) or non-zero moments — the others are
@@ -235,10 +247,14 @@ __global__ void adam_advance_kernel(int32_t* step_dev) { *step_dev += 1; }
 // whatever its sparsity (no lane conditions on the loads), and a Gaussian's rows are read as whole contiguous pieces.
 constexpr int ADAM_THREADS = 256;
 
-template <bool SPARSE>
+template <bool SPARSE, bool ATTACH>
 __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in, uint8_t* __restrict__ moment_live) {
     AdamArgs a = a_in;
-    __shared__ uint32_t s_rows[ADAM_THREADS];  // Gaussian index | has-gradient << 31
+    // A frame flagged invalid by the forward (instance capacity / tile bucket exceeded: lists emptied, every gradient zero) must
+    // not train: nothing is read or written, the caller re-captures and continues from the state it had.
+    if (a.frame_header != nullptr && a.frame_header->overflow != 0u) return;
+    __shared__ uint32_t s_rows[ADAM_THREADS];  // Gaussian index | has-gradient << 31 | attach-loss member << 30
+    __shared__ float s_att[ADAM_THREADS / 64];
     __shared__ int s_wave_n[ADAM_THREADS / 64];
     __shared__ float s_ss[7];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -252,12 +268,14 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
         s_ss[6] = (float)((double)a.lr_rotation / bc1);
     }
     const int idx = blockIdx.x * ADAM_THREADS + tid;
-    bool hg = false, act = false;
+    bool hg = false, act = false, att = false;
     if (idx < a.P) {
         hg = a.radii == nullptr || a.radii[idx] > 0;
         act = !SPARSE || hg || moment_live[idx] != 0;
         if (SPARSE && hg) moment_live[idx] = 1;  // only this thread ever looks at this byte
+        if (ATTACH) att = a.attach_mask[idx] != 0;
     }
+    float att_sum = 0.f;  // this thread's share of the attach loss at the pre-update parameters
     const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
     if (lane == 0) s_wave_n[wave] = (int)__popcll(am);
     __syncthreads();
@@ -272,24 +290,37 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
         before += w < wave ? c : 0;
         n_rows += c;
     }
-    if (act) s_rows[before + (int)__popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)idx | (hg ? 0x80000000u : 0u);
+    if (act) s_rows[before + (int)__popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)idx | (hg ? 0x80000000u : 0u) | (att ? 0x40000000u : 0u);
     __syncthreads();
-    if (n_rows == 0) return;
+    if (n_rows == 0) {
+        if (ATTACH && a.attach_partial != nullptr && tid == 0) a.attach_partial[blockIdx.x] = 0.f;
+        return;
+    }
 
     // xyz (identity activation) and scaling (exp): element-wise, [P,3]
     for (int e = tid; e < 3 * n_rows; e += ADAM_THREADS) {
         const uint32_t k = (uint32_t)e / 3u, j = (uint32_t)e - 3u * k, r = s_rows[k];
         const bool has_g = (r >> 31) != 0u;
-        const size_t i = (size_t)(r & 0x7fffffffu) * 3 + j;
+        const size_t i = (size_t)(r & 0x3fffffffu) * 3 + j;
         // all eight loads of the element in one round (the gradient rows of a Gaussian without one are unwritten memory: read
         // at a clamped address and discarded — a load under a lane condition would wait for every earlier load first)
         const size_t gi = has_g ? i : 0;
         float p = a.xyz[i], m = ldnt(&a.m_xyz[i]), v = ldnt(&a.v_xyz[i]);
         float ps = a.scaling_raw[i], ms = ldnt(&a.m_scaling[i]), vs = ldnt(&a.v_scaling[i]);
         const float gx_ld = ldnt(&a.g_xyz[gi]), gs_ld = ldnt(&a.g_scales[gi]);
-        adam1(p, has_g ? gx_ld : 0.f, m, v, a, a.step_xyz);
+        float gx = has_g ? gx_ld : 0.f, gs = (has_g ? gs_ld : 0.f) * expf(ps);  // d exp(x)/dx = exp(x)
+        if (ATTACH) {
+            // (same round of loads; a row outside the attach set reads element 0 and discards it)
+            const bool at = ((r >> 30) & 1u) != 0u;
+            const size_t ai = at ? i : 0;
+            const float p0 = a.init_xyz[ai], ps0 = a.init_scaling[ai];
+            const float dx = at ? p - p0 : 0.f, ds = at ? ps - ps0 : 0.f;
+            gx += a.attach_g3 * dx, gs += a.attach_g3 * ds;
+            att_sum += 0.5f * a.attach_g3 * (dx * dx + ds * ds);
+        }
+        adam1(p, gx, m, v, a, a.step_xyz);
         a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
-        adam1(ps, (has_g ? gs_ld : 0.f) * expf(ps), ms, vs, a, a.step_scaling);  // d exp(x)/dx = exp(x)
+        adam1(ps, gs, ms, vs, a, a.step_scaling);
         a.scaling_raw[i] = ps, stnt(ms, &a.m_scaling[i]), stnt(vs, &a.v_scaling[i]);
         if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
     }
@@ -313,7 +344,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
             const uint32_t ee = in ? (uint32_t)e : 0u;
             const uint32_t k = (uint32_t)(((uint64_t)ee * a.row_magic) >> 39);  // ee / row, exact for ee < 2^31, row < 2^8
             const uint32_t j = ee - k * row, r = s_rows[k];
-            t.ei[u] = (r & 0x7fffffffu) * row + j;
+            t.ei[u] = (r & 0x3fffffffu) * row + j;
             t.fl[u] = in ? (1u | ((r >> 31) ? 2u : 0u) | (j < 3u ? 4u : 0u)) : 0u;
             t.p[u] = a.shs[t.ei[u]];
             t.m[u] = ldnt(&a.m_shs[t.ei[u]]);
@@ -342,7 +373,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
     }
     // opacity (sigmoid) [P] and rotation (normalize) [P,4]
     if (tid < n_rows) {
-        const uint32_t r = s_rows[tid], i = r & 0x7fffffffu;
+        const uint32_t r = s_rows[tid], i = r & 0x3fffffffu;
         const bool has_g = (r >> 31) != 0u;
         // all loads of the row in one round (clamped gradient addresses, see above)
         const uint32_t gi = has_g ? i : 0u;
@@ -361,10 +392,18 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
         const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
         const float yx = q.x / nrm, yy = q.y / nrm, yz = q.z / nrm, yw = q.w / nrm;
         const float dot = yx * g.x + yy * g.y + yz * g.z + yw * g.w;
-        adam1(q.x, (g.x - yx * dot) / nrm, mq.x, vq.x, a, a.step_rotation);
-        adam1(q.y, (g.y - yy * dot) / nrm, mq.y, vq.y, a, a.step_rotation);
-        adam1(q.z, (g.z - yz * dot) / nrm, mq.z, vq.z, a, a.step_rotation);
-        adam1(q.w, (g.w - yw * dot) / nrm, mq.w, vq.w, a, a.step_rotation);
+        float4 gq = make_float4((g.x - yx * dot) / nrm, (g.y - yy * dot) / nrm, (g.z - yz * dot) / nrm, (g.w - yw * dot) / nrm);
+        if (ATTACH) {
+            const bool at = ((r >> 30) & 1u) != 0u;
+            const float4 q0 = reinterpret_cast<const float4*>(a.init_rotation)[at ? i : 0u];
+            const float4 d = at ? make_float4(q.x - q0.x, q.y - q0.y, q.z - q0.z, q.w - q0.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gq.x += a.attach_g4 * d.x, gq.y += a.attach_g4 * d.y, gq.z += a.attach_g4 * d.z, gq.w += a.attach_g4 * d.w;
+            att_sum += 0.5f * a.attach_g4 * (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+        }
+        adam1(q.x, gq.x, mq.x, vq.x, a, a.step_rotation);
+        adam1(q.y, gq.y, mq.y, vq.y, a, a.step_rotation);
+        adam1(q.z, gq.z, mq.z, vq.z, a, a.step_rotation);
+        adam1(q.w, gq.w, mq.w, vq.w, a, a.step_rotation);
         reinterpret_cast<float4*>(a.rotation_raw)[i] = q;
         if (a.act_rotations) {
             const float n2 = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
@@ -372,6 +411,12 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in,
         }
         reinterpret_cast<float4*>(a.m_rotation)[i] = mq;
         reinterpret_cast<float4*>(a.v_rotation)[i] = vq;
+    }
+    if (ATTACH && a.attach_partial != nullptr) {  // fixed-order block sum of the attach loss (the reported "scale_loss")
+        att_sum = wave_red(att_sum);
+        if (lane == 0) s_att[wave] = att_sum;
+        __syncthreads();
+        if (tid == 0) a.attach_partial[blockIdx.x] = (s_att[0] + s_att[1]) + (s_att[2] + s_att[3]);
     }
 }
 
@@ -433,17 +478,29 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.step_dev = st->step_dev;
     a.lr_xyz = st->lr_xyz, a.lr_dc = st->lr_f_dc, a.lr_rest = st->lr_f_rest, a.lr_opacity = st->lr_opacity, a.lr_scaling = st->lr_scaling;
     a.lr_rotation = st->lr_rotation;
+    a.attach_mask = st->attach_mask, a.init_xyz = st->init_xyz, a.init_scaling = st->init_scaling_raw, a.init_rotation = st->init_rotation_raw;
+    a.attach_partial = st->attach_partial, a.frame_header = st->frame_header;
+    const bool attach = st->attach_mask != nullptr && st->attach_count > 0;
+    DQO_CHECK_ARG(!attach || (st->init_xyz && st->init_scaling_raw && st->init_rotation_raw), "attach_mask needs the three init_* tensors");
+    DQO_CHECK_ARG(st->P < (1 << 30), "P must stay below 2^30");
+    // d/dp of 1000 * mean((p - p0)^2) over |a| rows of 3 (scaling, xyz) / 4 (rotation) elements = 2000 (p - p0) / (len |a|)
+    a.attach_g3 = attach ? (float)(2000.0 / (3.0 * (double)st->attach_count)) : 0.f;
+    a.attach_g4 = attach ? (float)(2000.0 / (4.0 * (double)st->attach_count)) : 0.f;
     DQO_CHECK_ARG(st->M >= 0 && st->M * 3 < 256, "M out of range");
     a.row_magic = st->M > 0 ? ((1ull << 39) + (uint64_t)(3 * st->M) - 1) / (uint64_t)(3 * st->M) : 0ull;
     DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");
     DQO_CHECK_ARG(st->moment_live == nullptr || st->radii != nullptr, "moment_live needs radii");
     const int blocks = (st->P + ADAM_THREADS - 1) / ADAM_THREADS;
     if (blocks > 0) {  // (an empty map still advances the step count)
-        if (st->moment_live != nullptr)
-            DQO_LAUNCH("adam_kernel", adam_kernel<true>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
-        else
-            DQO_LAUNCH("adam_kernel", adam_kernel<false>, dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+        if (st->moment_live != nullptr) {
+            if (attach) DQO_LAUNCH("adam_kernel", (adam_kernel<true, true>), dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+            else DQO_LAUNCH("adam_kernel", (adam_kernel<true, false>), dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+        } else {
+            if (attach) DQO_LAUNCH("adam_kernel", (adam_kernel<false, true>), dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+            else DQO_LAUNCH("adam_kernel", (adam_kernel<false, false>), dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
+        }
     }
-    if (st->step_dev != nullptr) DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev);
+    if (st->step_dev != nullptr)
+        DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev, st->frame_header);
     return DQO_OK;
 }

@@ -188,7 +188,21 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
     const float ddep = inside ? dL_ddepths[pid] : 0.f;
     // No incoming gradient on any pixel of the quadrant (outside the loss mask): every term of every record would be an exact
     // zero, so nothing is written and the records stay invalid (= zero for the per-Gaussian sum).
-    if (__builtin_amdgcn_ballot_w64(dp0 != 0.f || dp1 != 0.f || dp2 != 0.f || ddep != 0.f) == 0ull) return;
+    // An earlier backward over the same forward context (retain_graph=True, one autograd.grad call per loss term) may have
+    // written this quadrant's records and marked them valid: the marks are taken back, so that record_sum_kernel never adds a
+    // previous call's records (the workspace is the caller's and changes between calls) — the backward is a function of its
+    // arguments only, like the reference's.
+    if (__builtin_amdgcn_ballot_w64(dp0 != 0.f || dp1 != 0.f || dp2 != 0.f || ddep != 0.f) == 0ull) {
+        const uint8_t* live0 = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;
+        for (int p0 = 0; p0 < L; p0 += BWD_THREADS) {
+            const int pos = p0 + lane;
+            if (pos < L && live0[pos] != 0) {
+                const uint32_t slot = bin.slot_list[range.x + pos];
+                if ((int64_t)slot < capacity) valid[(size_t)slot * 4 + quad] = (uint8_t)0;
+            }
+        }
+        return;
+    }
     const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
     const float bg_term = -T_final * bgdot;  // d(background term)/d(alpha) = bg_term / (1 - alpha): end_T, not the running T (quirk B2)
     const int hit_c0 = hit_pos - 1;          // list position of the entry that fixed this pixel's depth (-1: none)

@@ -28,16 +28,17 @@ import _dqo_native as N
 _sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy": reuse / grow the previous capacity, no sync
 _cap_hint = {}
 _pending = []          # lazy mode: (event, pinned header tensor, key) of forwards not yet verified
-_last = {"num_rendered": None, "num_visible": None, "geom": None}
+_last = {"num_rendered": None, "num_visible": None, "header": None}   # header: (event, pinned host copy of the 32-byte header)
 
 
 def last_header():
-    """Device header of the most recent forward (one small D2H read, synchronises): dict with num_rendered = instances kept in
-    the tile lists, num_candidates = the reference's num_rendered, num_tiles, max_tile_count, num_visible, overflow."""
-    g = _last["geom"]
-    if g is None:
+    """Device header of the most recent forward (waits for its asynchronous 32-byte copy): dict with num_rendered = instances kept
+    in the tile lists, num_candidates = the reference's num_rendered, num_tiles, max_tile_count, num_visible, overflow."""
+    if _last["header"] is None:
         return None
-    h = g[:32].view(torch.int32).cpu().tolist()
+    ev, host = _last["header"]
+    ev.synchronize()
+    h = host.tolist()
     return dict(num_rendered=h[0], num_tiles=h[1], overflow=h[2], max_tile_count=h[3], num_visible=h[4], num_candidates=h[5])
 
 
@@ -51,8 +52,9 @@ def set_sync_mode(mode):
     global _sync_mode
     if mode not in ("exact", "lazy"):
         raise ValueError(mode)
+    if _pending:
+        _verify_pending(block=True)  # forwards issued in lazy mode are still checked (raises if one of them overflowed)
     _sync_mode = mode
-    _pending.clear()
 
 
 def _verify_pending(block):
@@ -64,6 +66,7 @@ def _verify_pending(block):
             continue
         ev.synchronize()
         n, overflow = int(host[0]), int(host[2])
+        # the hint only grows: one key serves calls with different tile masks / camera poses, whose N differ
         _cap_hint[key] = max(_cap_hint.get(key, 0), int(n * 1.25) + 4096)
         if overflow:
             _pending[:] = keep
@@ -166,19 +169,20 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if cap is None:  # first call for this shape: measure once
                     hdr = N.DqoRastHeader()
                     N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))
-                    cap = _cap_hint[key] = int(hdr.num_candidates) + 4096  # later calls shrink it to 1.25 x the measured N
+                    cap = _cap_hint[key] = int(hdr.num_candidates) + 4096  # an upper bound of N; later calls keep max(this, 1.25 N)
                 num_rendered = -1
             binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
             cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
             N.check(lib.dqo_rast_forward_render(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
                                                 ctypes.byref(cctx), stream))
+            # asynchronous 32-byte copy of the device header (statistics; in lazy mode also the deferred capacity check)
+            host = torch.empty((8,), dtype=torch.int32).pin_memory()
+            host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
             if _sync_mode == "lazy":
-                host = torch.empty((8,), dtype=torch.int32).pin_memory()
-                host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
                 _pending.append((ev, host, key, cap))
-        _last["geom"] = geomBuffer
+        _last["header"] = (ev, host)  # (not the geometry buffer itself: that would pin ~160 B per Gaussian until the next call)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.inst_capacity = cap

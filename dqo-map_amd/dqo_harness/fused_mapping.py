@@ -24,6 +24,35 @@ import diff_gaussian_rasterization_depth as dgr
 from dqo_harness import mapping
 
 
+def _normalised_settings(st, device):
+    """The op's forward makes its settings tensors fp32 + contiguous on every call (diff_gaussian_rasterization_depth/__init__.py);
+    the captured path takes raw pointers once, so it does the same once.  The reference's cameras hand over
+    `world_view_transform = torch.tensor(...).transpose(0, 1).cuda()` (scene/cameras.py:137-139): a non-contiguous view whose
+    data_ptr() is the UN-transposed matrix."""
+    def fix(t, name, n):
+        if not torch.is_tensor(t):
+            raise RuntimeError(f"raster settings: {name} must be a tensor")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"expected scalar type Float but found {t.dtype} ({name})")
+        if not t.is_cuda:
+            raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+        if t.numel() != n:
+            raise RuntimeError(f"raster settings: {name} must have {n} elements")
+        return t.to(device).contiguous()
+    return st._replace(bg=fix(st.bg, "bg", 3), viewmatrix=fix(st.viewmatrix, "viewmatrix", 16), projmatrix=fix(st.projmatrix, "projmatrix", 16),
+                       campos=fix(st.campos, "campos", 3))
+
+
+def _checked_tile_mask(tm, device, H, W):
+    if tm.dtype != torch.int32:
+        raise RuntimeError(f"expected scalar type Int but found {tm.dtype} (tile_mask)")
+    if not tm.is_cuda:
+        raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+    if tm.numel() != ((H + 15) // 16) * ((W + 15) // 16):
+        raise RuntimeError("tile_mask must have ceil(H/16) x ceil(W/16) elements")
+    return tm.to(device).contiguous()
+
+
 class _Ctx:
     """Stand-in for the autograd ctx when the op's static forward/backward are driven directly."""
 
@@ -36,10 +65,10 @@ class _Ctx:
 
 class FusedMapper:
     def __init__(self, scene, settings, device, lrs=None, betas=(0.9, 0.999), eps=1e-15, color_weight=mapping.COLOR_WEIGHT,
-                 depth_weight=mapping.DEPTH_WEIGHT, add_depth_thres=0.1, sparse_moments=True):
+                 depth_weight=mapping.DEPTH_WEIGHT, add_depth_thres=0.1, sparse_moments=True, attach=True):
         t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=device)
         self.device = device
-        self.settings = settings
+        self.settings = _normalised_settings(settings, device)
         self.xyz = t(scene["xyz"])
         self.shs = t(scene["shs"])  # [P, M, 3]; coefficient 0 is f_dc, the rest f_rest (no torch.cat per iteration)
         op = t(scene["opacity"]).clamp(1e-4, 1 - 1e-4)
@@ -55,6 +84,8 @@ class FusedMapper:
         self.moment_live = torch.zeros((self.xyz.shape[0],), dtype=torch.uint8, device=device) if sparse_moments else None
         self.step_count = 0
         self._act_valid = False  # opacity / scales / rotations hold the activations of the current raw parameters
+        self.use_attach = bool(attach)
+        self.begin_mapping_call(reset_optimizer=False)
         P = self.P
         f = dict(dtype=torch.float32, device=device)
         self.opacity = torch.empty((P, 1), **f)
@@ -63,11 +94,124 @@ class FusedMapper:
         H, W = settings.image_height, settings.image_width
         self.dL_dcolor = torch.empty((3, H, W), **f)
         self.dL_ddepth = torch.empty((1, H, W), **f)
-        self.loss = torch.zeros(4, **f)
+        self.loss = torch.zeros(8, **f)  # dqo_map_loss_fwd_bwd: total, colour, depth, 0, then the four unnormalised sums
         lib = N.lib()
         self.loss_ws = torch.empty((lib.dqo_map_loss_workspace_bytes(),), dtype=torch.uint8, device=device)
         self._empty = torch.Tensor([])
         self.tile_mask = torch.ones(((H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=device)
+
+    def begin_mapping_call(self, reset_optimizer=True):
+        """Start of one `local_optimize` call (SLAM/multiprocess/mapper.py:531-548): snapshot `init_stat` (the raw parameters the
+        attach loss pulls towards, :533-545, and the attach set `sigmoid(opacity) < 0.9`, :812-813) and — reset_optimizer — drop the
+        Adam moments, because the reference builds a fresh torch.optim.Adam per call (:548, B13)."""
+        self.init_xyz, self.init_scaling, self.init_rotation = self.xyz.clone(), self.scaling_raw.clone(), self.rotation_raw.clone()
+        self.attach_mask = (torch.sigmoid(self.opacity_raw) < 0.9).reshape(-1).to(torch.uint8).contiguous()
+        self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
+        self.attach_partial = torch.zeros(((self.xyz.shape[0] + 255) // 256,), dtype=torch.float32, device=self.device)
+        if reset_optimizer:
+            for m, v in self.state.values():
+                m.zero_(), v.zero_()
+            if self.moment_live is not None:
+                self.moment_live.zero_()
+            self.step_count = 0
+            if getattr(self, "_g", None) is not None:
+                self._g.step_dev.fill_(1)
+                self._g.expected_step = 1
+                self._g.stale = True  # the captured kernel arguments (attach set, its size) were fixed at capture time
+
+    # ------------------------------------------------------------------ map growth ---------------------------------------
+    def radius(self):
+        """GaussianPointCloud.get_radius (SLAM/gaussian_pointcloud.py:739-743): mean of the two larger scales."""
+        sc = torch.exp(self.scaling_raw)
+        return (sc.sum(dim=1) - sc.min(dim=1).values) / 2
+
+    @torch.no_grad()
+    def grow(self, new, delete_mask=None, min_radius=0.001, max_radius=0.05, xyz_factor=(1.0, 1.0, 0.1), scale_factor=1.0):
+        """The map-growth step between two mapping calls — Mapping.gaussians_add (SLAM/multiprocess/mapper.py:249-254) and the
+        deletion half of error_gaussians_remove (:1086-1096) — on this mapper's map:
+          1. temp_points_filter (:1351-1380): new points that fall inside an existing Gaussian (one of their 3 nearest existing
+             centres closer than 0.6 x its radius; dqo_knn3_query) are dropped;
+          2. temp_to_optimize -> GaussianPointCloud.update_geometry (:1438-1442, gaussian_pointcloud.py:519-570): the survivors'
+             scales come from the gaps to their 3 nearest neighbours among (survivors + existing points in their bounding box)
+             (distCUDA2 = dqo_knn3), points whose neighbours' 3-sigma spheres already reach them are dropped;
+          3. delete_mask [P] bool (optional): existing Gaussians to delete (the reference derives it from
+             accumulate_gaussian_error's per-Gaussian depth error, cuda_utils._C);
+          4. cat (:1466): the rest joins the map with zero Adam moments.
+        (temp_points_attach, :1384-1436, needs the stable / unstable split of the reference's two point clouds and is not part of
+        this mapper.)  `new`: dict(xyz [Q,3], scales [Q,3], rotations [Q,4], opacity [Q,1], shs [Q,M,3]) of numpy arrays or GPU
+        tensors.  Per-Gaussian buffers are re-allocated: a captured graph is dropped (capture() again), and the next mapping
+        call starts with begin_mapping_call().  Returns the counts of each stage."""
+        import dqo_mapgrowth as mg
+        dev = self.device
+        t = lambda a: a.to(dev).float().contiguous() if torch.is_tensor(a) else torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
+        nx, nsc, nrot, nop, nsh = t(new["xyz"]), t(new["scales"]), t(new["rotations"]), t(new["opacity"]).reshape(-1, 1), t(new["shs"])
+        Q = nx.shape[0]
+        stats = dict(candidates=int(Q), inside_existing=0, invalid_scale=0, added=0, deleted=0)
+        exist_xyz, exist_radius = self.xyz, self.radius()
+        keep = torch.ones((Q,), dtype=torch.bool, device=dev)
+        if Q > 0:
+            inside = mg.temp_points_filter_mask(nx, exist_xyz, exist_radius)
+            if inside is not None:
+                keep &= ~inside
+                stats["inside_existing"] = int(inside.sum().item())
+        idx = keep.nonzero().reshape(-1)
+        nx, nsc, nrot, nop, nsh = nx[idx], nsc[idx], nrot[idx], nop[idx], nsh[idx]
+        log_scales = None
+        if nx.shape[0] > 0:
+            nrad = (nsc.sum(dim=1) - nsc.min(dim=1).values) / 2
+            scales, invalid = mg.update_geometry_scales(nx, nrad, exist_xyz, exist_radius, min_radius, max_radius)
+            stats["invalid_scale"] = int(invalid.sum().item())
+            ok = (~invalid).nonzero().reshape(-1)
+            if ok.numel() > 0:  # gaussian_pointcloud.py:558-568
+                fac = scale_factor * scales[:, None].repeat(1, 3) * torch.tensor(xyz_factor, dtype=torch.float32, device=dev)
+                log_scales = torch.log(fac)[ok]
+            nx, nrot, nop, nsh = nx[ok], nrot[ok], nop[ok], nsh[ok]
+        if log_scales is None:
+            nx, nrot, nop, nsh = nx[:0], nrot[:0], nop[:0], nsh[:0]
+            log_scales = torch.empty((0, 3), dtype=torch.float32, device=dev)
+        keep_old = None
+        if delete_mask is not None:
+            keep_old = (~delete_mask.to(dev).bool().reshape(-1)).nonzero().reshape(-1)
+            stats["deleted"] = int(self.P - keep_old.numel())
+        stats["added"] = int(nx.shape[0])
+        sel = (lambda a: a) if keep_old is None else (lambda a: a[keep_old])
+        opc = nop.clamp(1e-4, 1 - 1e-4)
+        self.xyz = torch.cat([sel(self.xyz), nx]).contiguous()
+        self.shs = torch.cat([sel(self.shs), nsh]).contiguous()
+        self.opacity_raw = torch.cat([sel(self.opacity_raw), torch.log(opc / (1 - opc))]).contiguous()
+        self.scaling_raw = torch.cat([sel(self.scaling_raw), log_scales]).contiguous()
+        self.rotation_raw = torch.cat([sel(self.rotation_raw), nrot]).contiguous()
+        params = self._params()
+        self.state = {k: (torch.cat([sel(m), torch.zeros_like(params[k][m.shape[0] if keep_old is None else keep_old.numel():])]),
+                          torch.cat([sel(v), torch.zeros_like(params[k][v.shape[0] if keep_old is None else keep_old.numel():])]))
+                      for k, (m, v) in self.state.items()}
+        n_new = nx.shape[0]
+        if self.moment_live is not None:
+            self.moment_live = torch.cat([sel(self.moment_live), torch.zeros((n_new,), dtype=torch.uint8, device=dev)])
+        self.P = P = self.xyz.shape[0]
+        f = dict(dtype=torch.float32, device=dev)
+        self.opacity, self.scales, self.rotations = torch.empty((P, 1), **f), torch.empty((P, 3), **f), torch.empty((P, 4), **f)
+        self._act_valid = False
+        self._g = None
+        # init_stat / attach set: kept for the old Gaussians, the new ones start at their own values (they have not moved);
+        # a new mapping call re-snapshots everything (begin_mapping_call)
+        self.init_xyz = torch.cat([sel(self.init_xyz), nx])
+        self.init_scaling = torch.cat([sel(self.init_scaling), log_scales])
+        self.init_rotation = torch.cat([sel(self.init_rotation), nrot])
+        self.attach_mask = torch.cat([sel(self.attach_mask), (nop.reshape(-1) < 0.9).to(torch.uint8)]).contiguous()
+        self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
+        self.attach_partial = torch.zeros(((P + 255) // 256,), **f)
+        return stats
+
+    def attach_loss(self):
+        """The reference's reported "scale_loss" of the most recent iteration (attach loss at its pre-update parameters)."""
+        return self.attach_partial.sum()
+
+    def _attach_fields(self):
+        if not self.use_attach or self.attach_count == 0:
+            return dict(attach_mask=None, init_xyz=None, init_scaling_raw=None, init_rotation_raw=None, attach_count=0, attach_partial=None)
+        return dict(attach_mask=N.ptr(self.attach_mask), init_xyz=N.ptr(self.init_xyz), init_scaling_raw=N.ptr(self.init_scaling),
+                    init_rotation_raw=N.ptr(self.init_rotation), attach_count=self.attach_count, attach_partial=N.ptr(self.attach_partial))
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True):
@@ -86,18 +230,21 @@ class FusedMapper:
         f = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
+        tile_mask = self.tile_mask if tile_mask is None else _checked_tile_mask(tile_mask, dev, H, W)
         with torch.cuda.device(dev):
+            if getattr(self, "_g", None) is not None:
+                # re-capture (e.g. after an overflow): the device-side step count is the truth — replays of invalid frames did
+                # not advance it (DqoAdamStep.frame_header)
+                self.step_count = int(self._g.step_dev.item()) - 1
+                self._g = None
+            if not self._act_valid:
+                N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
+                                             N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
+                self._act_valid = True
             # capacity: the reference's num_rendered of the current state (an upper bound of the instances kept) plus a margin
-            # for the Gaussians that move while the graph is being replayed; the device header flags an overflow
-            dgr_mode = dgr._sync_mode
-            dgr.set_sync_mode("exact")
-            with torch.no_grad():
-                probe = dgr._RasterizeGaussians.forward(_Ctx(), self.xyz, self.shs, self._empty, *self._activated_now(), self._empty,
-                                                        self.tile_mask if tile_mask is None else tile_mask, st)
-            cand = dgr.last_header()["num_candidates"]
-            longest = dgr.last_header()["max_tile_count"]
-            dgr.set_sync_mode(dgr_mode)
-            del probe
+            # for the Gaussians that move while the graph is being replayed; the device header flags an overflow.  The probe runs
+            # through the C ABI on buffers of its own (two header reads), so the operator's global state is not touched.
+            cand, longest = self._probe(tile_mask)
             cap = int(cand * capacity_margin) + 4096
             g = self._g = type("G", (), {})()
             g.cap = cap
@@ -108,9 +255,14 @@ class FusedMapper:
                 g.bucket = 256
                 while g.bucket < 2 * longest:
                     g.bucket *= 2
+            for name, t_, shape in (("gt_color", gt_color, (3, H, W)), ("gt_depth", gt_depth, (1, H, W))):
+                if t_.dtype != torch.float32 or not t_.is_cuda or not t_.is_contiguous() or tuple(t_.shape) != shape:
+                    raise RuntimeError(f"FusedMapper.capture: {name} must be a contiguous float32 GPU tensor of shape {shape} "
+                                       "(the graph reads it in place at every replay)")
             g.gt_color, g.gt_depth = gt_color, gt_depth
             g.mask = None if render_mask is None else render_mask.to(torch.uint8).contiguous()
-            g.tile_mask = self.tile_mask if tile_mask is None else tile_mask
+            g.tile_mask = tile_mask
+            g.stale = False
             g.out = (torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **i32), torch.empty((1, H, W), **i32),
                      torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((P,), **i32),
                      torch.empty((P,), **i32))
@@ -148,19 +300,15 @@ class FusedMapper:
                                    v_shs=N.ptr(stt["shs"][1]), v_opacity=N.ptr(stt["opacity"][1]), v_scaling=N.ptr(stt["scaling"][1]),
                                    v_rotation=N.ptr(stt["rotation"][1]), act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales),
                                    act_rotations=N.ptr(self.rotations), radii=o[8].data_ptr(), step_dev=g.step_dev.data_ptr(),
-                                   moment_live=N.ptr(self.moment_live))
-            if not self._act_valid:
-                stream = N.current_stream()
-                N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
-                                             N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), stream))
-                self._act_valid = True
+                                   moment_live=N.ptr(self.moment_live), frame_header=g.geom.data_ptr(), **self._attach_fields())
             # one eager iteration on a side stream (warms every kernel up), then the capture
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._static_iteration()
             torch.cuda.current_stream().wait_stream(side)
-            self.step_count += 1
+            if not self.graph_overflowed():  # (an invalid frame is a no-op for the optimiser and its step count)
+                self.step_count += 1
             g.graph = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (e.g. a collective library's watchdog) may keep issuing runtime calls
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
@@ -168,12 +316,34 @@ class FusedMapper:
             g.expected_step = self.step_count + 1
         return self
 
-    def _activated_now(self):
-        """(opacity, scales, rotations) of the current raw parameters, computed eagerly (capacity probe only)."""
-        op = torch.sigmoid(self.opacity_raw)
-        sc = torch.exp(self.scaling_raw)
-        rot = torch.nn.functional.normalize(self.rotation_raw)
-        return op, sc, rot
+    def _probe(self, tile_mask):
+        """(num_candidates, longest tile list) of the current state: one forward on scratch buffers with packed lists."""
+        lib, dev, P, M, st = N.lib(), self.device, self.P, self.M, self.settings
+        H, W = int(st.image_height), int(st.image_width)
+        f, i32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev), dict(dtype=torch.uint8, device=dev)
+        out = [torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **i32), torch.empty((1, H, W), **i32),
+               torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((P,), **i32),
+               torch.empty((P,), **i32)]
+        geom = torch.empty((lib.dqo_rast_geom_bytes(P, W, H),), **u8)
+        img = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
+        params = dgr._params(st, P, M)
+        inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, tile_mask)
+        outputs = N.DqoRastOutputs(out_color=out[0].data_ptr(), out_depth=out[1].data_ptr(), out_hit_color=out[2].data_ptr(),
+                                   out_hit_depth=out[3].data_ptr(), out_hit_color_weight=out[4].data_ptr(),
+                                   out_hit_depth_weight=out[5].data_ptr(), out_T=out[6].data_ptr(), n_touched=out[7].data_ptr(),
+                                   radii=out[8].data_ptr())
+        cctx = N.DqoRastCtx(geom=geom.data_ptr(), geom_bytes=geom.numel(), binning=None, binning_bytes=0, image=img.data_ptr(),
+                            image_bytes=img.numel(), inst_capacity=0)
+        stream = N.current_stream()
+        hdr = N.DqoRastHeader()
+        N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs), ctypes.byref(cctx), stream))
+        N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))
+        cand = int(hdr.num_candidates)
+        binning = torch.empty((lib.dqo_rast_binning_bytes(max(cand, 1)),), **u8)
+        cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binning.data_ptr(), binning.numel(), max(cand, 1)
+        N.check(lib.dqo_rast_forward_render(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs), ctypes.byref(cctx), stream))
+        N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))
+        return cand, int(hdr.max_tile_count)
 
     def _static_iteration(self):
         """The five C-ABI calls of one iteration over the persistent buffers (no allocation, no host-side per-step state)."""
@@ -194,10 +364,12 @@ class FusedMapper:
     def replay(self):
         """One mapping iteration by replaying the captured graph; outputs are the persistent tensors in self._g.out."""
         g = self._g
+        if g.stale:
+            raise RuntimeError("FusedMapper: begin_mapping_call() changed the attach set since capture(); capture again")
         if g.expected_step != self.step_count + 1:  # eager step() calls in between: resynchronise the device-side step count
             g.step_dev.fill_(self.step_count + 1)
         g.graph.replay()
-        self.step_count += 1
+        self.step_count += 1  # (assumes a valid frame; capture() re-reads the device-side count after an overflow)
         g.expected_step = self.step_count + 1
         return g.out
 
@@ -238,6 +410,8 @@ class FusedMapper:
             ctx = _Ctx()
             out = dgr._RasterizeGaussians.forward(ctx, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations,
                                                   self._empty, self.tile_mask if tile_mask is None else tile_mask, self.settings)
+            # NOTE: an eager step on an overflowed frame (lazy mode) is a no-op for the optimiser (DqoAdamStep.frame_header), but the
+            # host-side step_count below still advances; the operator raises at its next synchronisation point in that case.
             color, depth, hit_depth = out[0], out[1], out[3]
             H, W = color.shape[1], color.shape[2]
             mask_u8 = None if render_mask is None else render_mask
@@ -263,7 +437,8 @@ class FusedMapper:
                                v_shs=N.ptr(self.state["shs"][1]), v_opacity=N.ptr(self.state["opacity"][1]),
                                v_scaling=N.ptr(self.state["scaling"][1]), v_rotation=N.ptr(self.state["rotation"][1]),
                                act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales), act_rotations=N.ptr(self.rotations),
-                               radii=N.ptr(out[8]), moment_live=N.ptr(self.moment_live))
+                               radii=N.ptr(out[8]), moment_live=N.ptr(self.moment_live), frame_header=N.ptr(ctx.saved_tensors[8]),
+                               **self._attach_fields())
             N.check(lib.dqo_map_adam_step(ctypes.byref(st), stream))
             self._act_valid = True
         return out

@@ -48,6 +48,12 @@ class GaussianParams:
                 dict(params=[self._scaling], lr=LRS["scaling"], name="scaling"),
                 dict(params=[self._rotation], lr=LRS["rotation"], name="rotation")]
 
+    def init_stat(self):
+        """`history_stat` of Mapping.local_optimize (mapper.py:533-545): detached copies of the raw parameters at the start of a
+        mapping call; loss_update's attach loss pulls towards them."""
+        return dict(opacity=self._opacity.detach().clone(), xyz=self._xyz.detach().clone(), scaling=self._scaling.detach().clone(),
+                    rotation_raw=self._rotation.detach().clone())
+
     def activated(self):
         """gaussian_pointcloud.py:732-733, 746-747, 815-822: what the op sees."""
         return dict(xyz=self._xyz, opacity=torch.sigmoid(self._opacity), scales=torch.exp(self._scaling),
@@ -68,23 +74,29 @@ def make_settings(cam, device, sh_degree=3, bg=(0.0, 0.0, 0.0), opaque_threshold
 
 
 def render(settings, gaussian_data, tile_mask=None):
-    """SLAM/render.py:163-240: default all-ones int32 tile mask, 9-tuple unpacked into the reference's dict keys."""
+    """SLAM/render.py:134-272 (`Renderer.render`): default all-ones int32 tile mask (:178-185), the op's 9-tuple unpacked into the
+    reference's dict keys (:213-222, 269-270), the per-pixel normal gathered through the depth hit index (:208-212; ids > -1, so
+    pixels of never-rendered tiles alias Gaussian 0, quirk B7), and the optional second / third pass with `semantics_color` /
+    `instance` as precomputed colours (:224-266; `semantic_seg` / `instance` are None without them).  `normal` is only gathered
+    when the caller supplies per-Gaussian normals (the reference always does)."""
     dev = gaussian_data["xyz"].device
     if tile_mask is None:
         tile_mask = torch.ones(((settings.image_height + 15) // 16, (settings.image_width + 15) // 16), dtype=torch.int32, device=dev)
     rasterizer = GaussianRasterizer(raster_settings=settings)
-    r = rasterizer(means3D=gaussian_data["xyz"], opacities=gaussian_data["opacity"], shs=gaussian_data["shs"], colors_precomp=None,
-                   scales=gaussian_data["scales"], rotations=gaussian_data["rotations"], cov3D_precomp=None,
-                   normal_w=gaussian_data.get("normal"), tile_mask=tile_mask)
+    normal = gaussian_data.get("normal")
+    geo = dict(means3D=gaussian_data["xyz"], opacities=gaussian_data["opacity"], scales=gaussian_data["scales"],
+               rotations=gaussian_data["rotations"], cov3D_precomp=None, normal_w=normal, tile_mask=tile_mask)
+    r = rasterizer(shs=gaussian_data["shs"], colors_precomp=None, **geo)
     out = {"render": r[0], "depth": r[1], "color_index_map": r[2], "depth_index_map": r[3], "color_hit_weight": r[4],
            "depth_hit_weight": r[5], "T_map": r[6], "n_touched": r[7], "radii": r[8]}
-    normal = gaussian_data.get("normal")
     if normal is not None:
-        # render.py:211-214: gather the per-Gaussian normal by the depth hit index
         rn = torch.zeros_like(r[0])
         idx = r[3]
         rn[:, idx[0] > -1] = normal[idx[idx > -1].long()].permute(1, 0)
         out["normal"] = rn
+    for src, key in (("semantics_color", "semantic_seg"), ("instance", "instance")):
+        cp = gaussian_data.get(src)
+        out[key] = rasterizer(shs=None, colors_precomp=cp, **geo)[0] if (cp is not None and cp.numel() > 1) else None
     return out
 
 
@@ -113,9 +125,24 @@ def ssim(img1, img2, window_size=11):
     return ssim_map.mean()
 
 
+def attach_loss(params, init_stat):
+    """mapper.py:812-829: 1000 * (mse(_scaling[a], s0[a]) + mse(_xyz[a], x0[a]) + mse(_rotation[a], q0[a])) over the Gaussians
+    a whose opacity at the start of the mapping call was below 0.9; 0 when there are none.  Written as masked sums / counts: the
+    value of the reference's boolean-index form (up to fp32 summation order) without its gather / scatter launches."""
+    a = (torch.sigmoid(init_stat["opacity"]) < 0.9).reshape(-1)
+    n = a.sum()
+    if int(n.item()) == 0:
+        return params._xyz.new_zeros(())
+    w = a[:, None].to(params._xyz.dtype)
+    mse = lambda p, p0: (((p - p0) ** 2) * w).sum() / (n * p.shape[1])
+    return 1000 * (mse(params._scaling, init_stat["scaling"]) + mse(params._xyz, init_stat["xyz"]) +
+                   mse(params._rotation, init_stat["rotation_raw"]))
+
+
 def mapping_loss(out, gt_color, gt_depth, render_mask=None, add_depth_thres=0.1):
-    """mapper.py:836-875 (normal_weight = 0 in every shipped config; attach loss omitted: it only acts on opacity < 0.9
-    Gaussians of the previous keyframe state).  gt_color [3,H,W], gt_depth [1,H,W], render_mask [H,W] bool or None."""
+    """mapper.py:836-875 (normal_weight = 0 in every shipped config).  gt_color [3,H,W], gt_depth [1,H,W], render_mask [H,W]
+    bool or None.  The attach term of the same function (mapper.py:812-829) is attach_loss(): the reference keeps it out of the
+    reported total and adds it only for the backward, `(loss + attach_loss).backward()` (:905)."""
     image, depth, depth_index = out["render"], out["depth"], out["depth_index_map"]
     ssim_loss = image.new_zeros(())
     if render_mask is None:

@@ -111,10 +111,22 @@ def _surfel_attrs(rng, normals, sh_degree, rest_sigma):
     return scales.astype(f), rot.astype(f), opac.astype(f), shs.astype(f)
 
 
+def object_layout(n_objects):
+    """(wall strips per face, first patch id, number of patch ids).  Object ids of the synthetic room (obj_id only drives the
+    per-object masks / shards of bench.py, never the rasteriser): fewer than 8 ids = the walls are object 0 and the patches share
+    ids 1..n-1; from 8 ids on three quarters of the ids go to the walls, like three quarters of the Gaussians — each of the 6 faces
+    is cut into n // 8 strips (8 ids: 6 faces + 2 patch ids; 16: 12 + 4; 32: 24 + 8), so no single object holds most of the map."""
+    if n_objects < 8:
+        return 0, 1, max(1, n_objects - 1)
+    k = n_objects // 8
+    return k, 6 * k, n_objects - 6 * k
+
+
 def surfel_room(seed, P, n_objects=1, sh_degree=3, rest_sigma=0.0, n_patches=20):
     """Surfel room: points on the 6 faces of a 6 x 3 x 4 m box plus `n_patches` random planar patches (the 'objects').
     Returns dict(xyz, scales, rotations, opacity, shs, obj_id, normals)."""
     rng = np.random.default_rng(seed)
+    strips, patch0, n_patch_ids = object_layout(n_objects)
     half = np.array([3.0, 1.5, 2.0])
     n_patch_pts = P // 4 if n_patches > 0 else 0
     n_wall = P - n_patch_pts
@@ -128,14 +140,20 @@ def surfel_room(seed, P, n_objects=1, sh_degree=3, rest_sigma=0.0, n_patches=20)
     areas = np.array([f[2] for f in faces])
     counts = rng.multinomial(n_wall, areas / areas.sum())
     xyz, nrm, obj = [], [], []
-    for (ax, sgn, _), n in zip(faces, counts):
+    for fi, ((ax, sgn, _), n) in enumerate(zip(faces, counts)):
         p = rng.uniform(-1, 1, (n, 3)) * half
         p[:, ax] = sgn * half[ax]
         nn = np.zeros((n, 3))
         nn[:, ax] = -sgn  # facing inward
         xyz.append(p)
         nrm.append(nn)
-        obj.append(np.zeros(n, np.int32))
+        if strips == 0:
+            obj.append(np.zeros(n, np.int32))
+        else:  # strips along the face's longer in-plane axis
+            o = [a for a in range(3) if a != ax]
+            la = o[0] if half[o[0]] >= half[o[1]] else o[1]
+            cell = np.clip(((p[:, la] / half[la] + 1.0) * 0.5 * strips).astype(np.int32), 0, strips - 1)
+            obj.append((fi * strips + cell).astype(np.int32))
     if n_patches > 0:
         per = rng.multinomial(n_patch_pts, np.ones(n_patches) / n_patches)
         for k, n in enumerate(per):
@@ -150,7 +168,7 @@ def surfel_room(seed, P, n_objects=1, sh_degree=3, rest_sigma=0.0, n_patches=20)
             p = ctr + ab[:, :1] * u + ab[:, 1:] * v
             xyz.append(p)
             nrm.append(np.tile(nn, (n, 1)))
-            obj.append(np.full(n, 1 + (k % max(1, n_objects - 1)) if n_objects > 1 else 0, np.int32))
+            obj.append(np.full(n, patch0 + (k % n_patch_ids) if n_objects > 1 else 0, np.int32))
     xyz = np.concatenate(xyz)
     nrm = np.concatenate(nrm)
     obj = np.concatenate(obj)

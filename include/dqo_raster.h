@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DQO_ABI_VERSION 1
+#define DQO_ABI_VERSION 2
 
 typedef enum DqoStatus {
     DQO_OK = 0,
@@ -141,6 +141,10 @@ typedef struct DqoRastHeader {
 
 int dqo_abi_version(void);
 const char* dqo_last_error(void);
+/* sizeof() of the ABI structs as this library was compiled (a binding checks its own struct definitions against it):
+ * 0 DqoRastParams, 1 DqoRastInputs, 2 DqoRastOutputs, 3 DqoRastCtx, 4 DqoRastGrads, 5 DqoRastHeader, 6 DqoProfileEntry,
+ * 7 DqoAdamStep; 0 for any other index. */
+size_t dqo_abi_sizeof(int32_t which);
 
 /* Optional per-kernel timing (measurement only; the reference has nothing comparable — it times whole frames with
  * time.time(), utils/monitor.py:22-37).  While enabled every kernel launch of this library is bracketed by HIP events
@@ -219,7 +223,9 @@ int dqo_map_activate(int32_t P, const float* opacity_raw, const float* scaling_r
 
 size_t dqo_map_loss_workspace_bytes(void);
 /* color [3,H,W], depth [1,H,W], depth_index int32 [1,H,W] (the op's hit_depth), render_mask uint8 [H,W] or NULL (= all).
- * loss_out[4] = {total, colour, depth, 0}; writes dL_dcolor [3,H,W] and dL_ddepth [1,H,W] of `total`. */
+ * loss_out[8] = {total, colour, depth, 0, sum |colour error| over the mask, mask pixels, sum |depth error| over the valid depth
+ * pixels, valid depth pixels} — the four sums are what object shards of one map add up (one packed all-reduce) to report the loss
+ * over all objects; writes dL_dcolor [3,H,W] and dL_ddepth [1,H,W] of `total`. */
 int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const float* depth, const int32_t* depth_index,
                          const float* gt_color, const float* gt_depth, const uint8_t* render_mask, float color_weight,
                          float depth_weight, float add_depth_thres, float* loss_out, float* dL_dcolor, float* dL_ddepth,
@@ -284,6 +290,24 @@ typedef struct DqoAdamStep {
      * (radii == 0) is a fixed point of Adam — m, v stay 0 and p - step * 0 / (0 + eps) = p bit for bit — so its rows are neither
      * read nor written; the first gradient sets its byte to 1.  Needs `radii`.  Results are identical to the dense update. */
     uint8_t* moment_live;
+    /* Optional (NULL = no such term): the attach loss of Mapping.loss_update (SLAM/multiprocess/mapper.py:812-829),
+     *   1000 * (mse(_scaling[a], scaling0[a]) + mse(_xyz[a], xyz0[a]) + mse(_rotation[a], rotation0[a])),
+     * a = Gaussians whose opacity at the start of the mapping call (init_stat, mapper.py:533-545) was below 0.9.  Its gradient is
+     * elementwise on the RAW parameters and is added here, after the activation Jacobians: attach_mask [P] (1 = in a),
+     * init_* = the raw parameters at the start of the call, attach_count = |a| (the means divide by 3 |a|, 3 |a|, 4 |a|).
+     * attach_partial (optional, [ceil(P / 256)]): per-block sum of 1000 * (d_scaling^2 / (3|a|) + d_xyz^2 / (3|a|) + d_rot^2 /
+     * (4|a|)) over the block's Gaussians at the PRE-update parameters — their sum is the reported "scale_loss" of this
+     * iteration (fixed order, reproducible).  A Gaussian that has never moved contributes an exact zero, so the exact sparse
+     * mode stays exact. */
+    const uint8_t* attach_mask;
+    const float *init_xyz, *init_scaling_raw, *init_rotation_raw;
+    int32_t attach_count;
+    float* attach_partial;
+    /* Optional (NULL = always step): device header of the forward whose gradients this step consumes (start of ctx.geom).  If
+     * its overflow flag is set — the frame was invalid: lists emptied, all gradients zero — the launch is a no-op: parameters,
+     * moments, moment_live and the device step count stay as they were, so the caller can re-capture with a larger capacity and
+     * continue from a clean optimiser state. */
+    const DqoRastHeader* frame_header;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
 

@@ -25,6 +25,22 @@
 #include <cstring>
 #include <vector>
 
+// OpenMP build (oracle/_build/libdqo_oracle_omp.so, `make omp`): the same statements, with the loops over Gaussians / tiles
+// shared between the host cores — tiles are independent in K6 / K7 except for the per-Gaussian sums, which are double
+// accumulators here (order-insensitive to ~1e-16; the reference's float atomicAdd order is not deterministic either, B10) and
+// become `omp atomic` updates.  The serial build stays the parity reference of the small tests; the OpenMP build serves the
+// full-size GPU tests and bench.py's cpu_baseline.
+#ifdef _OPENMP
+#include <omp.h>
+#define ORC_PARALLEL_FOR _Pragma("omp parallel for schedule(dynamic, 64)")
+#define ORC_PARALLEL_FOR_BIG _Pragma("omp parallel for schedule(dynamic, 2048)")
+#define ORC_ATOMIC _Pragma("omp atomic")
+#else
+#define ORC_PARALLEL_FOR
+#define ORC_PARALLEL_FOR_BIG
+#define ORC_ATOMIC
+#endif
+
 namespace {
 
 constexpr int BLOCK_X = 16;  // cuda_rasterizer/config.h:15-16
@@ -69,6 +85,7 @@ struct RastCtx {
     // ImageState (rasterizer_impl.h:46-55)
     std::vector<uint32_t> ranges;  // [T][2]
     std::vector<R> final_T, weight_sum, hit_normal_c, hit_point_c;
+    std::vector<uint32_t> n_blend;  // workload statistic (not a reference quantity): entries blended into each pixel
     std::vector<uint32_t> n_contrib;
     std::vector<int32_t> tile_indices;  // active tiles, row-major
     std::vector<int32_t> hit_depth_id;  // copy of out_hit_depth for backward
@@ -330,6 +347,7 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
     c->ranges.assign(2 * (size_t)T, 0);
     c->final_T.assign(HW, 0);
     c->weight_sum.assign(HW, 0);
+    c->n_blend.assign(HW, 0);
     c->n_contrib.assign(HW, 0);
     c->hit_normal_c.assign(3 * HW, 0);
     c->hit_point_c.assign(3 * HW, 0);
@@ -337,6 +355,7 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
     if (P == 0) return c;  // rasterize_points.cu:103 (B9)
 
     // ---- K1 preprocessCUDA, forward.cu:238-354 ----
+    ORC_PARALLEL_FOR_BIG
     for (int idx = 0; idx < P; idx++) {
         V3<R> p_view;
         if (!in_frustum(means3D, idx, view, proj, p_view)) continue;
@@ -394,6 +413,7 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
         uint32_t id;
     };
     std::vector<Inst> inst(N);
+    ORC_PARALLEL_FOR_BIG
     for (int idx = 0; idx < P; idx++) {
         if (c->radii[idx] <= 0) continue;
         uint32_t off = idx == 0 ? 0 : c->point_offsets[idx - 1];
@@ -433,7 +453,10 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
 
     // ---- K6 renderCUDA_withMask, forward.cu:636-866 ----
     const R* features = c->has_sh ? c->rgb.data() : colors_precomp;
-    for (int real_tile : c->tile_indices) {
+    const int n_active = (int)c->tile_indices.size();
+    ORC_PARALLEL_FOR
+    for (int ti = 0; ti < n_active; ti++) {
+        const int real_tile = c->tile_indices[ti];
         const int tile_x = real_tile % gx, tile_y = real_tile / gx;
         const uint32_t r0 = c->ranges[2 * real_tile], r1 = c->ranges[2 * real_tile + 1];
         for (int ty = 0; ty < BLOCK_Y; ty++)
@@ -450,6 +473,7 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
                 bool hit_gaussian = false, done = false;
                 int hit_id = -1, hit_color_id = -1;
                 R color_weight_max = R(-1), hit_color_weight = 0, hit_depth_weight = 0, weight_sum = 0;
+                uint32_t n_blend = 0;
                 for (uint32_t k = r0; k < r1 && !done; k++) {
                     contributor++;
                     const int g = (int)c->point_list[k];
@@ -498,13 +522,17 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
                     if (test_T >= c->T_thr) {
                         const R color_weight = alpha * Tt;
                         weight_sum += color_weight;
+                        n_blend++;
                         for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * (size_t)g + ch] * color_weight;
                         if (color_weight > color_weight_max) {
                             color_weight_max = color_weight;
                             hit_color_id = g;
                             hit_color_weight = color_weight_max;
                         }
-                        if (test_T > R(0.5f)) n_touched[g] += 1;  // forward.cu:833-835 (B8)
+                        if (test_T > R(0.5f)) {  // forward.cu:833-835 (B8)
+                            ORC_ATOMIC
+                            n_touched[g] += 1;
+                        }
                         last_contributor = contributor;
                         end_T = test_T;
                     }
@@ -520,6 +548,7 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
                 out_hit_color_w[pix_id] = hit_color_weight;
                 out_hit_depth_w[pix_id] = hit_depth_weight;
                 c->weight_sum[pix_id] = weight_sum;
+                c->n_blend[pix_id] = n_blend;
                 out_T[pix_id] = end_T;
             }
     }
@@ -575,7 +604,10 @@ void rast_backward(RastCtx<R>* c, const R* dL_dpixels, const R* dL_dpixel_depths
     const int gx = c->gx;
 
     // ---- K7 renderCUDA_flat ----
-    for (int real_tile : c->tile_indices) {
+    const int n_active = (int)c->tile_indices.size();
+    ORC_PARALLEL_FOR
+    for (int ti = 0; ti < n_active; ti++) {
+        const int real_tile = c->tile_indices[ti];
         const int tile_x = real_tile % gx, tile_y = real_tile / gx;
         const uint32_t r0 = c->ranges[2 * real_tile], r1 = c->ranges[2 * real_tile + 1];
         for (int ty = 0; ty < BLOCK_Y; ty++)
@@ -612,6 +644,7 @@ void rast_backward(RastCtx<R>* c, const R* dL_dpixels, const R* dL_dpixel_depths
                         last_color[ch] = col;
                         const R dL_dchannel = dL_dpixel[ch];
                         dL_dalpha += (col - accum_rec[ch]) * dL_dchannel;
+                        ORC_ATOMIC
                         a_color[3 * (size_t)g + ch] += (double)(dchannel_dcolor * dL_dchannel);
                     }
                     dL_dalpha *= Tt;
@@ -623,11 +656,17 @@ void rast_backward(RastCtx<R>* c, const R* dL_dpixels, const R* dL_dpixel_depths
                     const R gdx = G * dx, gdy = G * dy;
                     const R dG_ddelx = -gdx * co[0] - gdy * co[1];
                     const R dG_ddely = -gdy * co[2] - gdx * co[1];
+                    ORC_ATOMIC
                     a_mean2D[2 * (size_t)g + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                    ORC_ATOMIC
                     a_mean2D[2 * (size_t)g + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                    ORC_ATOMIC
                     a_conic[3 * (size_t)g + 0] += (double)(R(-0.5f) * gdx * dx * dL_dG);
+                    ORC_ATOMIC
                     a_conic[3 * (size_t)g + 1] += (double)(R(-0.5f) * gdx * dy * dL_dG);
+                    ORC_ATOMIC
                     a_conic[3 * (size_t)g + 2] += (double)(R(-0.5f) * gdy * dy * dL_dG);
+                    ORC_ATOMIC
                     a_opac[g] += (double)(G * dL_dalpha);
                 }
                 // hit-Gaussian depth gradient, backward.cu:997-1065
@@ -650,8 +689,11 @@ void rast_backward(RastCtx<R>* c, const R* dL_dpixels, const R* dL_dpixel_depths
                         const R inv_nr = R(1) / nr, inv_nr2 = inv_nr * inv_nr;
                         const R np = n_c.x * p_c.x + n_c.y * p_c.y + n_c.z * p_c.z;
                         const R dpx = ray.z * n_c.x * inv_nr, dpy = ray.z * n_c.y * inv_nr, dpz = ray.z * n_c.z * inv_nr;
+                        ORC_ATOMIC
                         a_mean3D[3 * (size_t)g + 0] += (double)(dL_ddi * (dpx * view[0] + dpy * view[1] + dpz * view[2]));
+                        ORC_ATOMIC
                         a_mean3D[3 * (size_t)g + 1] += (double)(dL_ddi * (dpx * view[4] + dpy * view[5] + dpz * view[6]));
+                        ORC_ATOMIC
                         a_mean3D[3 * (size_t)g + 2] += (double)(dL_ddi * (dpx * view[8] + dpy * view[9] + dpz * view[10]));
                         const int axis = argMin3(sc[0], sc[1], sc[2]);
                         const R n1c = ray.z * (nr * p_c.x - np * ray.x) * inv_nr2;
@@ -662,13 +704,20 @@ void rast_backward(RastCtx<R>* c, const R* dL_dpixels, const R* dL_dpixel_depths
                         const R n3w = n1c * view[8] + n2c * view[9] + n3c * view[10];
                         R d0[3], d1[3], d2[3], d3[3];
                         rotColGrad(&c->rotations[4 * (size_t)g], axis, d0, d1, d2, d3);
+                        ORC_ATOMIC
                         a_rot[4 * (size_t)g + 0] += (double)(dL_ddi * (n1w * d0[0] + n2w * d0[1] + n3w * d0[2]));
+                        ORC_ATOMIC
                         a_rot[4 * (size_t)g + 1] += (double)(dL_ddi * (n1w * d1[0] + n2w * d1[1] + n3w * d1[2]));
+                        ORC_ATOMIC
                         a_rot[4 * (size_t)g + 2] += (double)(dL_ddi * (n1w * d2[0] + n2w * d2[1] + n3w * d2[2]));
+                        ORC_ATOMIC
                         a_rot[4 * (size_t)g + 3] += (double)(dL_ddi * (n1w * d3[0] + n2w * d3[1] + n3w * d3[2]));
                     } else {
+                        ORC_ATOMIC
                         a_mean3D[3 * (size_t)g + 0] += (double)(dL_ddi * view[2]);
+                        ORC_ATOMIC
                         a_mean3D[3 * (size_t)g + 1] += (double)(dL_ddi * view[6]);
+                        ORC_ATOMIC
                         a_mean3D[3 * (size_t)g + 2] += (double)(dL_ddi * view[10]);
                     }
                 }
@@ -684,6 +733,7 @@ void rast_backward(RastCtx<R>* c, const R* dL_dpixels, const R* dL_dpixel_depths
     if (dL_dconic_out) std::copy(dL_dconic.begin(), dL_dconic.end(), dL_dconic_out);
 
     const R* cov3Ds = c->has_scales ? c->cov3D.data() : c->cov3D_precomp.data();
+    ORC_PARALLEL_FOR_BIG
     for (int idx = 0; idx < P; idx++) {
         if (!(c->radii[idx] > 0)) continue;
         // ---- K8 computeCov2DCUDA, backward.cu:273-422 ----
@@ -875,6 +925,7 @@ void ctx_copy(RastCtx<R>* c, int which, void* dst) {
         case 13: cp(c->clamped); break;
         case 14: cp(c->point_tile); break;
         case 15: cp(c->weight_sum); break;
+        case 16: cp(c->n_blend); break;
         default: break;
     }
 }
@@ -913,6 +964,14 @@ DEFINE_RAST_API(f32, float)
 DEFINE_RAST_API(f64, double)
 
 // rasterizer_impl.cu:54-66,145-157 (checkFrustum / markVisible)
+ORC_EXPORT int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 ORC_EXPORT void orc_mark_visible_f32(int P, const float* means3D, const float* view, const float* proj, uint8_t* present) {
     for (int i = 0; i < P; i++) {
         V3<float> pv;

@@ -45,6 +45,25 @@ def raw_grads(opacity_raw, scaling_raw, rotation_raw, g_opacity, g_scales, g_rot
             (g - y * (y * g).sum(1, keepdims=True)) / n)
 
 
+def attach_loss(scaling, xyz, rotation, scaling0, xyz0, rotation0, opacity_raw0):
+    """Attach loss of Mapping.loss_update, /root/reference/SLAM/multiprocess/mapper.py:812-829, with l2_loss = mean of squares
+    (utils/loss_utils.py:34-36):  a = sigmoid(opacity at the start of the call) < 0.9;
+        1000 * (mean((scaling[a] - scaling0[a])^2) + mean((xyz[a] - xyz0[a])^2) + mean((rotation[a] - rotation0[a])^2)),
+    0 when a is empty.  Returns (loss, d/dscaling, d/dxyz, d/drotation) on the RAW parameters, float64."""
+    f = lambda x: np.asarray(x, np.float64)
+    a = (1.0 / (1.0 + np.exp(-f(opacity_raw0).reshape(-1)))) < 0.9
+    n = int(a.sum())
+    outs, loss = [], 0.0
+    for p, p0 in ((scaling, scaling0), (xyz, xyz0), (rotation, rotation0)):
+        d = (f(p) - f(p0)) * a[:, None]
+        if n == 0:
+            outs.append(np.zeros_like(d))
+            continue
+        loss += 1000.0 * (d ** 2).sum() / (n * d.shape[1])
+        outs.append(2000.0 * d / (n * d.shape[1]))
+    return (loss, *outs)
+
+
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-15):
     m = m + (g - m) * (1 - beta1)
     v = v * beta2 + (1 - beta2) * g * g

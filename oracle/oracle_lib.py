@@ -11,23 +11,41 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libdqo_oracle.so")
+_LIB_PATH_OMP = os.path.join(_HERE, "_build", "libdqo_oracle_omp.so")
 _lib = None
+_lib_omp = None
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH):
+    if force or not (os.path.exists(_LIB_PATH) and os.path.exists(_LIB_PATH_OMP)):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
 
-def lib():
-    global _lib
+def _load(path):
+    L = ctypes.CDLL(path)
+    for suf in ("f32", "f64"):
+        getattr(L, f"orc_rast_forward_{suf}").restype = ctypes.c_void_p
+    return L
+
+
+def lib(omp=False):
+    """The serial oracle (parity reference of the small tests) or, omp=True, the OpenMP build of the same sources (full-size
+    GPU tests, bench.py's cpu_baseline; threads = OMP_NUM_THREADS, default all host cores)."""
+    global _lib, _lib_omp
+    if omp:
+        if _lib_omp is None:
+            build()
+            _lib_omp = _load(_LIB_PATH_OMP)
+        return _lib_omp
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        for suf in ("f32", "f64"):
-            getattr(_lib, f"orc_rast_forward_{suf}").restype = ctypes.c_void_p
+        _lib = _load(_LIB_PATH)
     return _lib
+
+
+def num_threads(omp=True):
+    return int(lib(omp).orc_num_threads())
 
 
 def _p(a):
@@ -55,14 +73,17 @@ class RastResult:
 class OracleRasterizer:
     """Forward + backward of the oracle rasteriser for one call. dtype is np.float32 (parity) or np.float64 (FD checks)."""
 
-    def __init__(self, dtype=np.float32):
+    def __init__(self, dtype=np.float32, omp=False):
         self.dt = np.dtype(dtype)
         self.suf = "f32" if self.dt == np.float32 else "f64"
         self.h = None
-        self.lib = lib()
+        self.lib = lib(omp)
 
     def __del__(self):
-        self.free()
+        try:
+            self.free()
+        except Exception:  # interpreter shutdown: ctypes may already be gone
+            pass
 
     def free(self):
         if self.h is not None:
@@ -115,7 +136,8 @@ class OracleRasterizer:
     _CTX = {"point_list": (0, np.uint32), "ranges": (1, np.uint32), "tile_indices": (2, np.int32), "means2D": (3, None),
             "depths": (4, None), "conic_opacity": (5, None), "rgb": (6, None), "cov3D": (7, None),
             "tiles_touched": (8, np.uint32), "final_T": (9, None), "n_contrib": (10, np.uint32), "hit_normal_c": (11, None),
-            "hit_point_c": (12, None), "clamped": (13, np.uint8), "point_tile": (14, np.uint32), "weight_sum": (15, None)}
+            "hit_point_c": (12, None), "clamped": (13, np.uint8), "point_tile": (14, np.uint32), "weight_sum": (15, None),
+            "n_blend": (16, np.uint32)}
 
     def ctx(self, name):
         which, dt = self._CTX[name]
@@ -125,7 +147,7 @@ class OracleRasterizer:
                  "depths": (P,), "conic_opacity": (P, 4), "rgb": (P, 3), "cov3D": (P, 6), "tiles_touched": (P,),
                  "final_T": (self.H, self.W), "n_contrib": (self.H, self.W), "hit_normal_c": (self.H, self.W, 3),
                  "hit_point_c": (self.H, self.W, 3), "clamped": (P, 3), "point_tile": (self.N,),
-                 "weight_sum": (self.H, self.W)}[name]
+                 "weight_sum": (self.H, self.W), "n_blend": (self.H, self.W)}[name]
         out = np.zeros(shape, dt)
         getattr(self.lib, f"orc_rast_ctx_copy_{self.suf}")(ctypes.c_void_p(self.h), which, _p(out))
         return out

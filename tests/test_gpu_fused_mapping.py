@@ -49,7 +49,7 @@ def test_loss_kernel_vs_oracle(env):
     for mask in (rng.uniform(size=(H, W)) < 0.6, None):
         t = lambda a: torch.tensor(a, device="cuda")
         lib = N.lib()
-        loss = torch.zeros(4, device="cuda")
+        loss = torch.zeros(8, device="cuda")
         dC, dD = torch.empty((3, H, W), device="cuda"), torch.empty((1, H, W), device="cuda")
         ws = torch.empty(lib.dqo_map_loss_workspace_bytes(), dtype=torch.uint8, device="cuda")
         tc, td, ti, tgc, tgd = t(color), t(depth), t(idx), t(gt_color), t(gt_depth)
@@ -58,6 +58,10 @@ def test_loss_kernel_vs_oracle(env):
                                          N.ptr(loss), N.ptr(dC), N.ptr(dD), N.ptr(ws), ws.numel(), N.current_stream()))
         tot, cl, dl, oC, oD = mo.masked_loss(color, depth, idx, gt_color, gt_depth, mask)
         np.testing.assert_allclose(loss.cpu().numpy()[:3], [tot, cl, dl], rtol=2e-6)
+        ls = loss.cpu().numpy()
+        m_ = np.ones((H, W), bool) if mask is None else mask
+        np.testing.assert_allclose(ls[4] / (3 * ls[5]), cl, rtol=2e-6)  # the unnormalised sums (what object shards all-reduce)
+        assert int(ls[5]) == int(m_.sum()) and abs(ls[6] / max(ls[7], 1) - dl) <= 2e-6 * dl
         np.testing.assert_allclose(dC.cpu().numpy(), oC, rtol=2e-6, atol=1e-12)
         np.testing.assert_allclose(dD.cpu().numpy(), oD, rtol=2e-6, atol=1e-12)
 
@@ -124,18 +128,25 @@ def test_fused_iteration_matches_autograd_path(env):
     cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
     params = mapping.GaussianParams(scene, dev)
     opt = mapping.make_optimizer(params)
+    init_stat = params.init_stat()  # mapper.py:533-545
     fm = FusedMapper(scene, settings, dev)
-    ref_losses, fused_losses = [], []
-    for it in range(3):
+    assert 0 < fm.attach_count < fm.P  # the synthetic scenes give 10 % of the Gaussians opacity 0.1: the attach loss is live
+    ref_losses, fused_losses, ref_attach, fused_attach = [], [], [], []
+    for it in range(4):
         out = mapping.render(settings, params.activated())
         loss, parts = mapping.mapping_loss(out, gt_color, gt_depth, render_mask=mask)
-        loss.backward()
+        attach = mapping.attach_loss(params, init_stat)
+        (loss + attach).backward()  # mapper.py:905
         opt.step()
         opt.zero_grad(set_to_none=True)
         ref_losses.append([parts[k].item() for k in ("total_loss", "color_loss", "depth_loss")])
+        ref_attach.append(attach.item())
         fm.step(gt_color, gt_depth, mask)
         fused_losses.append(fm.loss.cpu().numpy()[:3].tolist())
+        fused_attach.append(fm.attach_loss().item())
     np.testing.assert_allclose(fused_losses, ref_losses, rtol=2e-5)
+    assert ref_attach[0] == 0.0 and fused_attach[0] == 0.0 and ref_attach[-1] > 0.0  # nothing has moved in the first iteration
+    np.testing.assert_allclose(fused_attach, ref_attach, rtol=2e-2, atol=1e-9)  # (Adam's sign-like first steps: see below)
     ref = dict(xyz=params._xyz, shs=torch.cat([params._features_dc, params._features_rest], 1), opacity=params._opacity,
                scaling=params._scaling, rotation=params._rotation)
     got = fm._params()
@@ -241,14 +252,104 @@ def test_graph_capacity_overflow_is_flagged(env):
     from dqo_harness.fused_mapping import FusedMapper
     cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
     fm = FusedMapper(scene, settings, dev)
+    for _ in range(2):  # two valid eager steps first: the moments are non-zero, so a step on a zero gradient WOULD move things
+        fm.step(gt_color, gt_depth, mask)
     before = {k: v.clone() for k, v in fm._params().items()}
+    state_before = {k: (m.clone(), v.clone()) for k, (m, v) in fm.state.items()}
+    live_before = fm.moment_live.clone()
     fm.capture(gt_color, gt_depth, mask, capacity_margin=0.05)  # room for ~5 % of the candidate pairs only
-    fm.replay()
+    step_before = int(fm._g.step_dev.item())
+    assert fm.step_count == 2  # the capture's own eager iteration overflowed: not counted
+    for _ in range(3):
+        fm.replay()
     torch.cuda.synchronize()
     assert fm.graph_overflowed()
+    # a flagged frame is a no-op for the optimiser (DqoAdamStep.frame_header): parameters, moments, live bytes and the device step
+    # count are exactly what they were, so the caller can re-capture and carry on from a clean state
+    assert int(fm._g.step_dev.item()) == step_before
     for k, v in fm._params().items():
-        assert torch.isfinite(v).all(), k  # an invalid frame must not poison the parameters with NaN / inf
-    ok = FusedMapper(scene, settings, dev).capture(gt_color, gt_depth, mask)
-    ok.replay()
+        assert torch.equal(v, before[k]), k
+        assert torch.equal(fm.state[k][0], state_before[k][0]) and torch.equal(fm.state[k][1], state_before[k][1]), k
+    assert torch.equal(fm.moment_live, live_before)
+    # re-capture with room: continues as if the invalid replays had never happened
+    fm.capture(gt_color, gt_depth, mask)
+    assert fm.step_count == 3
+    fm.replay()
     torch.cuda.synchronize()
-    assert not ok.graph_overflowed()
+    assert not fm.graph_overflowed() and int(fm._g.step_dev.item()) == 5
+    twin = FusedMapper(scene, settings, dev)
+    for _ in range(4):
+        twin.step(gt_color, gt_depth, mask)
+    for k, v in fm._params().items():
+        lr = dict(xyz=0.001, shs=0.0005, opacity=1.0, scaling=0.004, rotation=0.001)[k]
+        assert ((v - twin._params()[k]).abs() > 0.01 * lr + 1e-7).float().mean().item() < 1e-3, k
+
+
+def test_capture_takes_the_reference_cameras_noncontiguous_matrices(env):
+    """scene/cameras.py:137-139 builds world_view_transform as torch.tensor(...).transpose(0, 1).cuda(): a non-contiguous view.  The
+    op's forward makes it contiguous per call; the captured path must do the same once (its raw pointers would otherwise read the
+    un-transposed matrix)."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    view_t = settings.viewmatrix.t().contiguous().t()  # same values, transposed strides
+    proj_t = settings.projmatrix.t().contiguous().t()
+    assert not view_t.is_contiguous() and torch.equal(view_t, settings.viewmatrix)
+    st2 = settings._replace(viewmatrix=view_t, projmatrix=proj_t)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, st2, dev)
+    a.capture(gt_color, gt_depth, mask)
+    b.capture(gt_color, gt_depth, mask)
+    for _ in range(2):
+        a.replay()
+        b.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(a._g.out, b._g.out):
+        assert torch.equal(x, y)
+    for k, v in a._params().items():
+        assert torch.equal(v, b._params()[k]), k
+    with pytest.raises(RuntimeError):
+        FusedMapper(scene, settings, dev).capture(gt_color, gt_depth, mask, tile_mask=torch.ones((3, 3), dtype=torch.int64, device=dev))
+
+
+def test_adam_attach_term_vs_oracle(env):
+    """DqoAdamStep.attach_*: gradient of mapper.py:812-829's attach loss added on the raw parameters, reported loss value; checked
+    against the numpy oracle (itself pinned by the reference's l2_loss fixture, tests/test_harness_loss.py)."""
+    torch = env
+    import ctypes
+    import _dqo_native as N
+    from oracle import map_oracle as mo
+    rng = np.random.default_rng(5)
+    P, M = 1500, 16
+    f = np.float32
+    raw0 = dict(xyz=rng.normal(size=(P, 3)).astype(f), shs=rng.normal(size=(P, M, 3)).astype(f), op=rng.normal(2.0, 2.5, (P, 1)).astype(f),
+                sc=rng.normal(-4, 0.5, (P, 3)).astype(f), rot=rng.normal(size=(P, 4)).astype(f))
+    raw = {k: (v + rng.normal(0, 0.01, v.shape)).astype(f) for k, v in raw0.items()}
+    raw["op"] = raw0["op"].copy()
+    t = {k: torch.tensor(v, device="cuda") for k, v in raw.items()}
+    t0 = {k: torch.tensor(v, device="cuda") for k, v in raw0.items()}
+    amask = (1.0 / (1.0 + np.exp(-raw0["op"].astype(np.float64).reshape(-1)))) < 0.9
+    tmask = torch.tensor(amask.astype(np.uint8), device="cuda")
+    g = {k: rng.normal(size=r.shape).astype(f) for k, r in raw.items()}
+    tg = {k: torch.tensor(x, device="cuda") for k, x in g.items()}
+    m = {k: torch.zeros_like(v) for k, v in t.items()}
+    v = {k: torch.zeros_like(v) for k, v in t.items()}
+    partial = torch.zeros(((P + 255) // 256,), device="cuda")
+    lrs = dict(xyz=0.001, f_dc=0.0005, f_rest=0.0005 / 20, opacity=0.0, scaling=0.004, rotation=0.001)
+    st = N.DqoAdamStep(P=P, M=M, step=1, beta1=0.9, beta2=0.999, eps=1e-15, lr_xyz=lrs["xyz"], lr_f_dc=lrs["f_dc"], lr_f_rest=lrs["f_rest"],
+                       lr_opacity=lrs["opacity"], lr_scaling=lrs["scaling"], lr_rotation=lrs["rotation"], xyz=N.ptr(t["xyz"]),
+                       shs=N.ptr(t["shs"]), opacity_raw=N.ptr(t["op"]), scaling_raw=N.ptr(t["sc"]), rotation_raw=N.ptr(t["rot"]),
+                       g_means3D=N.ptr(tg["xyz"]), g_sh=N.ptr(tg["shs"]), g_opacity=N.ptr(tg["op"]), g_scales=N.ptr(tg["sc"]),
+                       g_rotations=N.ptr(tg["rot"]), m_xyz=N.ptr(m["xyz"]), m_shs=N.ptr(m["shs"]), m_opacity=N.ptr(m["op"]),
+                       m_scaling=N.ptr(m["sc"]), m_rotation=N.ptr(m["rot"]), v_xyz=N.ptr(v["xyz"]), v_shs=N.ptr(v["shs"]),
+                       v_opacity=N.ptr(v["op"]), v_scaling=N.ptr(v["sc"]), v_rotation=N.ptr(v["rot"]), attach_mask=N.ptr(tmask),
+                       init_xyz=N.ptr(t0["xyz"]), init_scaling_raw=N.ptr(t0["sc"]), init_rotation_raw=N.ptr(t0["rot"]),
+                       attach_count=int(amask.sum()), attach_partial=N.ptr(partial))
+    N.check(N.lib().dqo_map_adam_step(ctypes.byref(st), N.current_stream()))
+    loss, a_sc, a_xyz, a_rot = mo.attach_loss(raw["sc"], raw["xyz"], raw["rot"], raw0["sc"], raw0["xyz"], raw0["rot"], raw0["op"])
+    np.testing.assert_allclose(partial.sum().item(), loss, rtol=1e-5)
+    _, rg_sc, rg_rot = mo.raw_grads(raw["op"], raw["sc"], raw["rot"], g["op"], g["sc"], g["rot"])
+    # after ONE step from zero moments m = (1 - beta1) * gradient: read the total raw gradient back from the first moment
+    for k, want in (("xyz", g["xyz"].astype(np.float64) + a_xyz), ("sc", rg_sc + a_sc), ("rot", rg_rot + a_rot)):
+        np.testing.assert_allclose(m[k].cpu().numpy() / 0.1, want, rtol=2e-5, atol=2e-6), k
+    np.testing.assert_allclose(m["shs"].cpu().numpy() / 0.1, g["shs"], rtol=2e-5, atol=2e-6)

@@ -80,3 +80,57 @@ def test_temp_points_filter_and_update_geometry(mg):
     sc = sc.cpu().numpy()
     assert np.isfinite(sc).all() and sc.min() >= 0.002 - 1e-9 and sc.max() <= 0.05 + 1e-9
     assert 0 < inv.float().mean().item() < 1
+
+
+def test_fused_mapper_grow_and_recapture():
+    """Row ★ (cfg 5's growth step): FusedMapper.grow = temp_points_filter + update_geometry + cat (+ delete) on the mapper's own map,
+    then a NEW mapping call (fresh Adam, fresh init_stat) on re-allocated buffers and a re-captured graph — no process restart.
+    The grown mapper must behave exactly like a mapper built directly on the grown map."""
+    import torch
+    from dqo_harness import mapping, scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev = torch.device("cuda")
+    cam, scene = scenes.make_config(3, P=12000)
+    settings = mapping.make_settings(cam, dev)
+    with torch.no_grad():
+        tgt = mapping.render(settings, mapping.GaussianParams(scene, dev).activated())
+    gt_color, gt_depth = tgt["render"].clone(), tgt["depth"].clone()
+    mask = (tgt["depth_index_map"][0] >= 0)
+    fm = FusedMapper(scene, settings, dev)
+    fm.capture(gt_color, gt_depth, mask)
+    for _ in range(3):
+        fm.replay()
+    torch.cuda.synchronize()
+    old = {k: v.clone() for k, v in fm._params().items()}
+    P0 = fm.P
+    new = scenes.surfel_room(77, 3000, n_objects=8)  # other random patches: partly inside the existing map, partly new surface
+    delete = torch.zeros(P0, dtype=torch.bool, device=dev)
+    delete[::17] = True
+    st = fm.grow(new, delete_mask=delete)
+    assert st["candidates"] == 3000 and st["candidates"] == st["inside_existing"] + st["invalid_scale"] + st["added"]
+    assert st["inside_existing"] > 0 and st["added"] > 0 and st["deleted"] == int(delete.sum().item())
+    assert fm.P == P0 - st["deleted"] + st["added"]
+    keep = (~delete).nonzero().reshape(-1)
+    for k, v in fm._params().items():  # the surviving old Gaussians are untouched, in order
+        assert torch.equal(v[: keep.numel()], old[k][keep]), k
+    # the new scales follow gaussian_pointcloud.py:558-568: isotropic in-plane, 0.1 along the third axis, inside [min, max] radius
+    ns = torch.exp(fm.scaling_raw[keep.numel():])
+    assert (ns[:, 0] == ns[:, 1]).all() and torch.allclose(ns[:, 2], 0.1 * ns[:, 0]) and ns[:, 0].min() >= 0.001 - 1e-9 and ns[:, 0].max() <= 0.05 + 1e-9
+    with pytest.raises(Exception):
+        fm.replay()  # the captured graph died with the old buffers
+    fm.begin_mapping_call(reset_optimizer=True)
+    twin = FusedMapper(scenes.surfel_room(5, fm.P, n_objects=8), settings, dev)
+    twin.xyz, twin.shs, twin.opacity_raw = fm.xyz.clone(), fm.shs.clone(), fm.opacity_raw.clone()
+    twin.scaling_raw, twin.rotation_raw = fm.scaling_raw.clone(), fm.rotation_raw.clone()
+    twin.begin_mapping_call(reset_optimizer=True)
+    twin._act_valid = False
+    fm.capture(gt_color, gt_depth, mask)
+    twin.capture(gt_color, gt_depth, mask)
+    for _ in range(3):
+        fm.replay()
+        twin.replay()
+    torch.cuda.synchronize()
+    assert not fm.graph_overflowed() and fm.step_count == twin.step_count == 4
+    for k, v in fm._params().items():
+        assert torch.equal(v, twin._params()[k]), k
+    assert torch.equal(fm.loss, twin.loss) and torch.isfinite(fm.loss).all()

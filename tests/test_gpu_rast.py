@@ -19,14 +19,17 @@ def torch_cuda():
 
 
 def _check(oracle, cam, sc, dL, **kw):
-    """HIP vs fp32 oracle (forward, 1e-4) and vs fp64 oracle as truth for gradients (see util_rast.compare_grads)."""
-    h, hg = U.run_hip(cam, sc, dL=dL, **kw)
-    o, r, og = U.run_oracle(oracle, cam, sc, dL=dL, **kw)
-    _, r64, og64 = U.run_oracle(oracle, cam, sc, dL=dL, dtype=np.float64, **kw)
-    st = U.compare_forward(h, r, r64)
-    gs = U.compare_grads(hg, og, og64)
+    """HIP vs the fp32 oracle, north_star's numbers with no slack: forward 1e-4, gradients 1e-3 (util_rast.parity_case: pixels whose
+    discrete decisions flipped are counted against the budget and get a zero incoming gradient on both sides)."""
+    hr = U.HipRun(cam, sc, **kw)
+    o, r, _ = U.run_oracle(oracle, cam, sc, **kw)
+    bad = U.flipped_pixels(hr.res, r)
+    st = U.compare_forward(hr.res, r)
+    keep = (~bad).astype(np.float32)
+    dLm = (dL[0] * keep[None], dL[1] * keep[None])
+    gs = U.compare_grads(hr.backward(dLm, retain=False), U.oracle_backward(o, dLm, kw.get("colors_precomp") is not None))
     print("fwd", st, "grads (rel-to-max, q99)", gs)
-    return h, r, o
+    return hr.res, r, o
 
 
 def _dL(cam, seed=0):
@@ -63,6 +66,34 @@ def test_lower_sh_degree(torch_cuda, oracle, deg):
     cam, sc = scenes.make_config(1, P=2000)
     sc["shs"][:, 1:, :] = np.random.default_rng(7).normal(0, 0.1, sc["shs"][:, 1:, :].shape).astype(np.float32)
     _check(oracle, cam, sc, _dL(cam, 3), sh_degree=deg)
+
+
+def test_backward_twice_on_one_forward(torch_cuda):
+    """The backward is a function of its arguments only, like the reference's (which is stateless): a second backward over the same
+    saved forward context (retain_graph=True; one autograd.grad call per loss term) must not see anything the first one left behind
+    — in particular not the partial-gradient records of quadrants that now receive no gradient."""
+    cam, sc = scenes.make_config(1, P=5000)
+    dL = _dL(cam, 4)
+    hr = U.HipRun(cam, sc)
+    g_full = hr.backward(dL, retain=True)
+    m = np.zeros((cam.H, cam.W), np.float32)
+    m[:, : cam.W // 2] = 1  # the right half of the image sends no gradient in the second call
+    dLm = (dL[0] * m, dL[1] * m)
+    g2 = hr.backward(dLm, retain=True)
+    fresh = U.HipRun(cam, sc).backward(dLm, retain=False)
+    for k in g2:
+        assert np.array_equal(g2[k], fresh[k]), k
+    # ... and then the full gradient again: identical to the first call, bit for bit
+    g3 = hr.backward(dL, retain=True)
+    for k in g3:
+        assert np.array_equal(g3[k], g_full[k]), k
+    # one call per loss term (colour only, depth only) adds up to the joint call
+    gc = hr.backward((dL[0], np.zeros_like(dL[1])), retain=True)
+    gd = hr.backward((np.zeros_like(dL[0]), dL[1]), retain=False)
+    for k in g_full:
+        want = g_full[k].astype(np.float64)
+        err = np.abs(gc[k].astype(np.float64) + gd[k] - want).max() / (np.abs(want).max() + 1e-30)
+        assert err < 2e-4, (k, err)
 
 
 def test_binning_exact(torch_cuda, oracle):

@@ -305,3 +305,26 @@ def test_fd_gradients_fp64(oracle, seed):
                 assert abs(fd - an) <= 2e-4 * scale + 1e-7, (name, gi, comp, fd, an)
                 checked += 1
     assert checked > 60
+
+
+def test_openmp_build_equals_serial(oracle):
+    """oracle/_build/libdqo_oracle_omp.so (full-size GPU tests, cpu_baseline) runs the same statements as the serial oracle with
+    the Gaussian / tile loops shared between cores: forward outputs are bitwise equal; the backward's per-Gaussian sums are double
+    accumulators in both builds, so their fp32 roundings agree too (to the last bit on this scene)."""
+    import util_rast as U
+    cam, sc = scenes.make_config(2, P=6000)
+    rng = np.random.default_rng(4)
+    dL = (rng.normal(size=(3, cam.H, cam.W)).astype(np.float32), rng.normal(size=(1, cam.H, cam.W)).astype(np.float32))
+    st = U.oracle_settings(oracle, cam)
+    res = []
+    for omp in (False, True):
+        o = oracle.OracleRasterizer(np.float32, omp=omp)
+        r = o.forward(st, sc["xyz"], sc["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
+                      shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"])
+        res.append((r, o.backward(dL[0], dL[1])))
+    assert oracle.num_threads(True) >= 1 and oracle.num_threads(False) == 1
+    for k in ("color", "depth", "hit_color", "hit_depth", "hit_color_weight", "hit_depth_weight", "T_map", "n_touched", "radii"):
+        assert np.array_equal(getattr(res[0][0], k), getattr(res[1][0], k)), k
+    for k in ("means3D", "sh", "opacity", "scales", "rotations", "colors"):
+        a, b = getattr(res[0][1], k), getattr(res[1][1], k)
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max(), k

@@ -56,6 +56,87 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _object_scene_64x48():
+    """64x48 scene with 4 objects (quartiles of the camera-space x coordinate), target = render of a perturbed copy, per-object
+    screen masks from the target's depth-hit ids — the bench's construction (bench.py build_problem) at test size."""
+    from oracle import oracle_lib as ol
+    import util_rast as U
+    cam = scenes.Camera(64, 48, 60.0, 60.0, 31.5, 23.5)
+    sc = scenes.frustum_cloud(23, 700, cam, zmin=0.5, zmax=1.6)
+    xc = sc["xyz"][:, 0] / sc["xyz"][:, 2]
+    sc["obj_id"] = np.digitize(xc, np.quantile(xc, [0.25, 0.5, 0.75])).astype(np.int32)
+    rng = np.random.default_rng(9)
+    pert = dict(sc)
+    pert["xyz"] = (sc["xyz"] + rng.normal(0, 0.004, sc["xyz"].shape)).astype(np.float32)
+    _, tgt, _ = U.run_oracle(ol, cam, pert)
+    hit = tgt["hit_depth"][0]
+    pix_obj = np.where(hit >= 0, sc["obj_id"][np.clip(hit, 0, None)], -1)
+    return cam, sc, tgt["color"], tgt["depth"], pix_obj
+
+
+def _object_sums(cam, sc, gt_color, gt_depth, pix_obj, k):
+    """Per-OBJECT masked render + loss sums with the oracle: object k's Gaussians alone, its tile mask, its pixel mask.
+    Returns [sum |colour err|, mask pixels, sum |depth err|, valid depth pixels]."""
+    from oracle import oracle_lib as ol
+    from oracle import map_oracle as mo
+    import util_rast as U
+    sel = sc["obj_id"] == k
+    sub = {n: v[sel] for n, v in sc.items()}
+    mask = pix_obj == k
+    tm = sharding.tile_mask_from_pixel_mask(mask)
+    _, r, _ = U.run_oracle(ol, cam, sub, tile_mask=tm)
+    tot, cl, dl, _, _ = mo.masked_loss(r["color"], r["depth"], r["hit_depth"], gt_color, gt_depth, mask)
+    err = r["depth"].astype(np.float64) - gt_depth.astype(np.float64)
+    valid = (r["hit_depth"] != -1) & (gt_depth > 0) & (err < 0.1) & mask[None]
+    sums = np.array([np.abs(r["color"].astype(np.float64) - gt_color)[:, mask].sum(), mask.sum(), np.abs(err[valid]).sum(), valid.sum()])
+    # consistency of the sums with the oracle's normalised losses
+    assert abs(sums[0] / (3 * max(sums[1], 1)) - cl) <= 1e-9 + 1e-6 * cl and abs(sums[2] / max(sums[3], 1) - dl) <= 1e-9 + 1e-6 * dl
+    return sums
+
+
+def _worker_objects(rank, world, port, tmp):
+    """Per-object losses of the ranks add up to the unsharded masked loss (L = sum_k L_k(G_k) on disjoint masks)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cam, sc, gt_color, gt_depth, pix_obj = _object_scene_64x48()
+    mine, assignment = sharding.shard_scene(sc, rank, world)
+    my_objs = sorted(k for k, s in assignment.items() if s == rank)
+    assert sorted(np.unique(mine["obj_id"]).tolist()) == my_objs
+    part = np.zeros(4)
+    for k in my_objs:
+        part += _object_sums(cam, mine, gt_color, gt_depth, pix_obj, k)  # from the SHARD's Gaussians only
+    red = sharding.PackedAllReduce([("sum_color", 1), ("n_color", 1), ("sum_depth", 1), ("n_depth", 1)], "cpu")
+    for name, v in zip(("sum_color", "n_color", "sum_depth", "n_depth"), part):
+        red.put(name, torch.tensor([float(v)]))
+    red.reduce_async()
+    red.finish()
+    np.savez(os.path.join(tmp, f"o{rank}.npz"), reduced=red.buf.numpy(), owned=np.array(my_objs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_per_object_losses_of_two_ranks_sum_to_the_unsharded_loss(tmp_path):
+    world = 2
+    mp.spawn(_worker_objects, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"o{i}.npz") for i in range(world)]
+    np.testing.assert_array_equal(r[0]["reduced"], r[1]["reduced"])
+    assert sorted(np.concatenate([r[0]["owned"], r[1]["owned"]]).tolist()) == [0, 1, 2, 3]
+    # unsharded: every object in this one process, from the full map
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    cam, sc, gt_color, gt_depth, pix_obj = _object_scene_64x48()
+    total = sum(_object_sums(cam, sc, gt_color, gt_depth, pix_obj, k) for k in range(4))
+    assert total[1] > 500 and total[3] > 100  # the masks are not empty
+    np.testing.assert_allclose(r[0]["reduced"], total, rtol=2e-6)
+    # the reported loss over ALL objects = the masked loss of the unsharded job
+    got = 0.8 * r[0]["reduced"][0] / (3 * r[0]["reduced"][1]) + r[0]["reduced"][2] / r[0]["reduced"][3]
+    want = 0.8 * total[0] / (3 * total[1]) + total[2] / total[3]
+    assert abs(got - want) <= 2e-6 * want
+
+
 def test_object_shards_world2(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
