@@ -52,6 +52,15 @@ __device__ __forceinline__ bool dqo_splat_hits_rect(float mx, float my, float A,
     return !(qmin > qthr + margin);  // NaN-safe: keeps the entry
 }
 
+// The quadratic form of the blend loops, forward.cu:758-760 / backward.cu:937-939, in the reference's operation order with separate
+// IEEE multiplies and adds.  For a long thin splat seen far from its centre the three terms cancel to a result ~1e4 times smaller
+// than they are, so WHERE the roundings happen decides the fourth digit of alpha: evaluated like this the result is bit-identical
+// to the oracle's (and to a build of the reference without FMA contraction); two extra VALU instructions per (pixel, entry) pair.
+__device__ __forceinline__ float dqo_power(float A, float B, float C, float dx, float dy) {
+#pragma clang fp contract(off)
+    return -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
+}
+
 // exp(power) of the blend loops (forward.cu:770, backward.cu:943).  One v_exp_f32 (|rel err| ~1e-7 for power in [-5.6, 0],
 // the only range that survives the 1/255 cut) instead of the ~15-instruction libm expf; forward and backward share it so
 // the backward reproduces the forward's alpha bit for bit.

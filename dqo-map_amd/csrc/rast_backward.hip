@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
                                                                 const float* __restrict__ rotations, const float* __restrict__ shs,
                                                                 const DqoGradRec* __restrict__ recs, int64_t capacity,
                                                                 DqoRastGrads gr) {
+    // Separate IEEE multiplies and adds throughout, in the reference's statement order (backward.cu:273-548): the cov2D-inverse ->
+    // cov3D -> (scale, quaternion) chain is ill-conditioned for thin surfels (denom^2, b^2 by cancellation), so its result depends
+    // on where the roundings fall; evaluated like this it rounds exactly where the oracle (and an uncontracted build of the
+    // reference) rounds, and the remaining difference is the summation order of the per-pixel terms, which the reference's float
+    // atomics do not fix either (quirk B10).
+#pragma clang fp contract(off)
     // record_sum_kernel left the summed gradient record of every Gaussian that owns instances
     const int tid = threadIdx.x;
     const int idx = blockIdx.x * blockDim.x + tid;
@@ -207,18 +213,23 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float view[16], proj[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) view[i] = v.view[i], proj[i] = v.proj[i];
-    // The cov2D-inverse -> cov3D -> (scale, quaternion) chain is ill-conditioned for thin surfels (denom^2, b^2 by
-    // cancellation): it is evaluated in fp64 here.  Per Gaussian, not per pixel: a few hundred flops, invisible next to
-    // the kernel's memory traffic on MI355X, and it removes the dominant fp32 noise of the reference formulation.
+    // `real` = float reproduces the reference's arithmetic (the parity target).  -DDQO_BWD_CHAIN_FP64 evaluates the chain in double
+    // instead: closer to the exact derivative of the same formulas (DESIGN.md §2 quantifies both), but not what the reference
+    // computes; per Gaussian, not per pixel, so the cost is invisible either way.
+#ifdef DQO_BWD_CHAIN_FP64
     typedef double real;
+#else
+    typedef float real;
+#endif
+#define RL(v) ((real)(v))
     const real r = qt.x, x = qt.y, y = qt.z, z = qt.w;
     real Rm[3][3];
-    Rm[0][0] = 1. - 2. * (y * y + z * z), Rm[0][1] = 2. * (x * y - r * z), Rm[0][2] = 2. * (x * z + r * y);
-    Rm[1][0] = 2. * (x * y + r * z), Rm[1][1] = 1. - 2. * (x * x + z * z), Rm[1][2] = 2. * (y * z - r * x);
-    Rm[2][0] = 2. * (x * z - r * y), Rm[2][1] = 2. * (y * z + r * x), Rm[2][2] = 1. - 2. * (x * x + y * y);
+    Rm[0][0] = RL(1) - RL(2) * (y * y + z * z), Rm[0][1] = RL(2) * (x * y - r * z), Rm[0][2] = RL(2) * (x * z + r * y);
+    Rm[1][0] = RL(2) * (x * y + r * z), Rm[1][1] = RL(1) - RL(2) * (x * x + z * z), Rm[1][2] = RL(2) * (y * z - r * x);
+    Rm[2][0] = RL(2) * (x * z - r * y), Rm[2][1] = RL(2) * (y * z + r * x), Rm[2][2] = RL(1) - RL(2) * (x * x + y * y);
     // ---- depth-hit gradient (backward.cu:997-1065 + propagateRotationGrad :100-148) ----
     // The blend kernel delivered the pixel sums hit[0..4] (DqoGradRec); everything that is constant per Gaussian — surfel
-    // normal n_c, camera-space point p_c, view matrix, d(normal)/d(quaternion) — is applied here, once, in fp64:
+    // normal n_c, camera-space point p_c, view matrix, d(normal)/d(quaternion) — is applied here, once:
     //   dL/dmean3D = hit1 * V^T n_c + hit0 * V^T e_z,   dL/dn_c = p_c * hit1 - (n_c . p_c) * hit[2..4],   dL/dq = (dn_w/dq)^T V^T dL/dn_c
     if (a[9] != 0.f || a[10] != 0.f || a[11] != 0.f || a[12] != 0.f || a[13] != 0.f) {
         const real h0 = a[9], h1 = a[10], h2x = a[11], h2y = a[12], h2z = a[13];
@@ -236,27 +247,27 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         const real q0 = r, q1 = x, q2 = y, q3 = z;
         real d0[3], d1[3], d2[3], d3[3];
         if (axis == 0) {
-            d0[0] = 0, d0[1] = 2 * q3, d0[2] = -2 * q2;
-            d1[0] = 0, d1[1] = 2 * q2, d1[2] = 2 * q3;
-            d2[0] = -4 * q2, d2[1] = 2 * q1, d2[2] = -2 * q0;
-            d3[0] = -4 * q3, d3[1] = 2 * q0, d3[2] = 2 * q1;
+            d0[0] = RL(0), d0[1] = RL(2) * q3, d0[2] = -RL(2) * q2;
+            d1[0] = RL(0), d1[1] = RL(2) * q2, d1[2] = RL(2) * q3;
+            d2[0] = -RL(4) * q2, d2[1] = RL(2) * q1, d2[2] = -RL(2) * q0;
+            d3[0] = -RL(4) * q3, d3[1] = RL(2) * q0, d3[2] = RL(2) * q1;
         } else if (axis == 1) {
-            d0[0] = -2 * q3, d0[1] = 0, d0[2] = 2 * q1;
-            d1[0] = 2 * q2, d1[1] = -4 * q1, d1[2] = 2 * q0;
-            d2[0] = 2 * q1, d2[1] = 0, d2[2] = 2 * q3;
-            d3[0] = -2 * q0, d3[1] = -4 * q3, d3[2] = 2 * q2;
+            d0[0] = -RL(2) * q3, d0[1] = RL(0), d0[2] = RL(2) * q1;
+            d1[0] = RL(2) * q2, d1[1] = -RL(4) * q1, d1[2] = RL(2) * q0;
+            d2[0] = RL(2) * q1, d2[1] = RL(0), d2[2] = RL(2) * q3;
+            d3[0] = -RL(2) * q0, d3[1] = -RL(4) * q3, d3[2] = RL(2) * q2;
         } else {
-            d0[0] = 2 * q2, d0[1] = -2 * q1, d0[2] = 0;
-            d1[0] = 2 * q3, d1[1] = -2 * q0, d1[2] = -4 * q1;
-            d2[0] = 2 * q0, d2[1] = 2 * q3, d2[2] = -4 * q2;
-            d3[0] = 2 * q1, d3[1] = 2 * q2, d3[2] = 0;
+            d0[0] = RL(2) * q2, d0[1] = -RL(2) * q1, d0[2] = RL(0);
+            d1[0] = RL(2) * q3, d1[1] = -RL(2) * q0, d1[2] = -RL(4) * q1;
+            d2[0] = RL(2) * q0, d2[1] = RL(2) * q3, d2[2] = -RL(4) * q2;
+            d3[0] = RL(2) * q1, d3[1] = RL(2) * q2, d3[2] = RL(0);
         }
         rot_g[0] = (float)(n1w * d0[0] + n2w * d0[1] + n3w * d0[2]);
         rot_g[1] = (float)(n1w * d1[0] + n2w * d1[1] + n3w * d1[2]);
         rot_g[2] = (float)(n1w * d2[0] + n2w * d2[1] + n3w * d2[2]);
         rot_g[3] = (float)(n1w * d3[0] + n2w * d3[1] + n3w * d3[2]);
     }
-    const real s[3] = {(real)v.scale_mod * sx, (real)v.scale_mod * sy, (real)v.scale_mod * sz};
+    const real s[3] = {RL(v.scale_mod) * RL(sx), RL(v.scale_mod) * RL(sy), RL(v.scale_mod) * RL(sz)};
     real Mm[3][3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
@@ -271,23 +282,23 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
             for (int j = i; j < 3; j++) c3[o++] = Mm[0][i] * Mm[0][j] + Mm[1][i] * Mm[1][j] + Mm[2][i] * Mm[2][j];
     }
     // ---- K8 computeCov2DCUDA, backward.cu:273-422 ----
-    const real tvx0 = (real)view[0] * mx + (real)view[4] * my + (real)view[8] * mz + view[12];
-    const real tvy0 = (real)view[1] * mx + (real)view[5] * my + (real)view[9] * mz + view[13];
-    const real tvz = (real)view[2] * mx + (real)view[6] * my + (real)view[10] * mz + view[14];
-    const real limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+    const real tvx0 = RL(view[0]) * RL(mx) + RL(view[4]) * RL(my) + RL(view[8]) * RL(mz) + RL(view[12]);
+    const real tvy0 = RL(view[1]) * RL(mx) + RL(view[5]) * RL(my) + RL(view[9]) * RL(mz) + RL(view[13]);
+    const real tvz = RL(view[2]) * RL(mx) + RL(view[6]) * RL(my) + RL(view[10]) * RL(mz) + RL(view[14]);
+    const real limx = RL(1.3f) * RL(v.tanfovx), limy = RL(1.3f) * RL(v.tanfovy);
     const real txtz = tvx0 / tvz, tytz = tvy0 / tvz;
-    const real tx = fmin(limx, fmax(-limx, txtz)) * tvz;
-    const real ty = fmin(limy, fmax(-limy, tytz)) * tvz;
-    const real x_grad_mul = (txtz < -limx || txtz > limx) ? 0. : 1.;
-    const real y_grad_mul = (tytz < -limy || tytz > limy) ? 0. : 1.;
+    const real tx = (txtz > limx ? limx : (txtz < -limx ? -limx : txtz)) * tvz;  // min(lim, max(-lim, t)), backward.cu:300-301
+    const real ty = (tytz > limy ? limy : (tytz < -limy ? -limy : tytz)) * tvz;
+    const real x_grad_mul = (txtz < -limx || txtz > limx) ? RL(0) : RL(1);
+    const real y_grad_mul = (tytz < -limy || tytz > limy) ? RL(0) : RL(1);
     const real fx = v.focal_x, fy = v.focal_y;
     const real J00 = fx / tvz, J02 = -(fx * tx) / (tvz * tvz);
     const real J11 = fy / tvz, J12 = -(fy * ty) / (tvz * tvz);
     real A0[3], A1[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        A0[j] = J00 * view[j * 4 + 0] + J02 * view[j * 4 + 2];
-        A1[j] = J11 * view[j * 4 + 1] + J12 * view[j * 4 + 2];
+        A0[j] = J00 * RL(view[j * 4 + 0]) + J02 * RL(view[j * 4 + 2]);
+        A1[j] = J11 * RL(view[j * 4 + 1]) + J12 * RL(view[j * 4 + 2]);
     }
     const real V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
     real A0V[3], A1V[3];
@@ -296,26 +307,27 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         A0V[j] = A0[0] * V[j][0] + A0[1] * V[j][1] + A0[2] * V[j][2];
         A1V[j] = A1[0] * V[j][0] + A1[1] * V[j][1] + A1[2] * V[j][2];
     }
-    const real ca = A0[0] * A0V[0] + A0[1] * A0V[1] + A0[2] * A0V[2] + 0.3f;
+    const real ca = A0[0] * A0V[0] + A0[1] * A0V[1] + A0[2] * A0V[2] + RL(0.3f);
     const real cb = A0[0] * A1V[0] + A0[1] * A1V[1] + A0[2] * A1V[2];
-    const real cc = A1[0] * A1V[0] + A1[1] * A1V[1] + A1[2] * A1V[2] + 0.3f;
+    const real cc = A1[0] * A1V[0] + A1[1] * A1V[1] + A1[2] * A1V[2] + RL(0.3f);
     const real denom = ca * cc - cb * cb;
     real dL_da = 0, dL_db = 0, dL_dc = 0;
-    const real denom2inv = 1.0 / ((denom * denom) + 0.0000001f);
+    const real denom2inv = RL(1) / ((denom * denom) + RL(0.0000001f));
     real dcv[6];
+    const real dcx_ = RL(dcx), dcy_ = RL(dcy), dcz_ = RL(dcz);
     if (denom2inv != 0) {
-        dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
-        dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
-        dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+        dL_da = denom2inv * (-cc * cc * dcx_ + RL(2) * cb * cc * dcy_ + (denom - ca * cc) * dcz_);
+        dL_dc = denom2inv * (-ca * ca * dcz_ + RL(2) * ca * cb * dcy_ + (denom - ca * cc) * dcx_);
+        dL_db = denom2inv * RL(2) * (cb * cc * dcx_ - (denom + RL(2) * cb * cb) * dcy_ + ca * cb * dcz_);
         dcv[0] = A0[0] * A0[0] * dL_da + A0[0] * A1[0] * dL_db + A1[0] * A1[0] * dL_dc;
         dcv[3] = A0[1] * A0[1] * dL_da + A0[1] * A1[1] * dL_db + A1[1] * A1[1] * dL_dc;
         dcv[5] = A0[2] * A0[2] * dL_da + A0[2] * A1[2] * dL_db + A1[2] * A1[2] * dL_dc;
-        dcv[1] = 2 * A0[0] * A0[1] * dL_da + (A0[0] * A1[1] + A0[1] * A1[0]) * dL_db + 2 * A1[0] * A1[1] * dL_dc;
-        dcv[2] = 2 * A0[0] * A0[2] * dL_da + (A0[0] * A1[2] + A0[2] * A1[0]) * dL_db + 2 * A1[0] * A1[2] * dL_dc;
-        dcv[4] = 2 * A0[2] * A0[1] * dL_da + (A0[1] * A1[2] + A0[2] * A1[1]) * dL_db + 2 * A1[1] * A1[2] * dL_dc;
+        dcv[1] = RL(2) * A0[0] * A0[1] * dL_da + (A0[0] * A1[1] + A0[1] * A1[0]) * dL_db + RL(2) * A1[0] * A1[1] * dL_dc;
+        dcv[2] = RL(2) * A0[0] * A0[2] * dL_da + (A0[0] * A1[2] + A0[2] * A1[0]) * dL_db + RL(2) * A1[0] * A1[2] * dL_dc;
+        dcv[4] = RL(2) * A0[2] * A0[1] * dL_da + (A0[1] * A1[2] + A0[2] * A1[1]) * dL_db + RL(2) * A1[1] * A1[2] * dL_dc;
     } else {
 #pragma unroll
-        for (int i = 0; i < 6; i++) dcv[i] = 0.;
+        for (int i = 0; i < 6; i++) dcv[i] = RL(0);
     }
     if (gr.dL_dcov3D) {
 #pragma unroll
@@ -324,20 +336,20 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     real dT0[3], dT1[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        dT0[j] = 2 * A0V[j] * dL_da + A1V[j] * dL_db;
-        dT1[j] = 2 * A1V[j] * dL_dc + A0V[j] * dL_db;
+        dT0[j] = RL(2) * A0V[j] * dL_da + A1V[j] * dL_db;
+        dT1[j] = RL(2) * A1V[j] * dL_dc + A0V[j] * dL_db;
     }
-    const real dJ00 = view[0] * dT0[0] + view[4] * dT0[1] + view[8] * dT0[2];
-    const real dJ02 = view[2] * dT0[0] + view[6] * dT0[1] + view[10] * dT0[2];
-    const real dJ11 = view[1] * dT1[0] + view[5] * dT1[1] + view[9] * dT1[2];
-    const real dJ12 = view[2] * dT1[0] + view[6] * dT1[1] + view[10] * dT1[2];
-    const real tzi = 1. / tvz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
+    const real dJ00 = RL(view[0]) * dT0[0] + RL(view[4]) * dT0[1] + RL(view[8]) * dT0[2];
+    const real dJ02 = RL(view[2]) * dT0[0] + RL(view[6]) * dT0[1] + RL(view[10]) * dT0[2];
+    const real dJ11 = RL(view[1]) * dT1[0] + RL(view[5]) * dT1[1] + RL(view[9]) * dT1[2];
+    const real dJ12 = RL(view[2]) * dT1[0] + RL(view[6]) * dT1[1] + RL(view[10]) * dT1[2];
+    const real tzi = RL(1) / tvz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
     const real dL_dtx = x_grad_mul * -fx * tz2 * dJ02;
     const real dL_dty = y_grad_mul * -fy * tz2 * dJ12;
-    const real dL_dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * tx) * tz3 * dJ02 + (2 * fy * ty) * tz3 * dJ12;
-    mean_g[0] += (float)(view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz);
-    mean_g[1] += (float)(view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz);
-    mean_g[2] += (float)(view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz);
+    const real dL_dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (RL(2) * fx * tx) * tz3 * dJ02 + (RL(2) * fy * ty) * tz3 * dJ12;
+    mean_g[0] += (float)(RL(view[0]) * dL_dtx + RL(view[1]) * dL_dty + RL(view[2]) * dL_dtz);
+    mean_g[1] += (float)(RL(view[4]) * dL_dtx + RL(view[5]) * dL_dty + RL(view[6]) * dL_dtz);
+    mean_g[2] += (float)(RL(view[8]) * dL_dtx + RL(view[9]) * dL_dty + RL(view[10]) * dL_dtz);
 
     // ---- K9 preprocessCUDA backward, backward.cu:492-548 ----
     const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
@@ -425,13 +437,15 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     }
     // cov3D backward, backward.cu:426-487 (no quaternion-norm Jacobian, B1; ADDS onto the depth-hit rotation grads)
     {
-        const real dS[3][3] = {{dcv[0], 0.5 * dcv[1], 0.5 * dcv[2]}, {0.5 * dcv[1], dcv[3], 0.5 * dcv[4]}, {0.5 * dcv[2], 0.5 * dcv[4], dcv[5]}};
+        const real dS[3][3] = {{dcv[0], RL(0.5f) * dcv[1], RL(0.5f) * dcv[2]},
+                               {RL(0.5f) * dcv[1], dcv[3], RL(0.5f) * dcv[4]},
+                               {RL(0.5f) * dcv[2], RL(0.5f) * dcv[4], dcv[5]}};
         real dM[3][3];
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
             for (int j = 0; j < 3; j++)
-                dM[k][j] = 2. * (s[k] * Rm[0][k] * dS[0][j] + s[k] * Rm[1][k] * dS[1][j] + s[k] * Rm[2][k] * dS[2][j]);
+                dM[k][j] = RL(2) * (s[k] * Rm[0][k] * dS[0][j] + s[k] * Rm[1][k] * dS[1][j] + s[k] * Rm[2][k] * dS[2][j]);
 #pragma unroll
         for (int k = 0; k < 3; k++) dsc[k] = (float)(Rm[0][k] * dM[k][0] + Rm[1][k] * dM[k][1] + Rm[2][k] * dM[k][2]);
         real Mt[3][3];
@@ -439,13 +453,15 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         for (int k = 0; k < 3; k++)
 #pragma unroll
             for (int j = 0; j < 3; j++) Mt[k][j] = dM[k][j] * s[k];
-        rot_g[0] += (float)(2 * z * (Mt[0][1] - Mt[1][0]) + 2 * y * (Mt[2][0] - Mt[0][2]) + 2 * x * (Mt[1][2] - Mt[2][1]));
-        rot_g[1] += (float)(2 * y * (Mt[1][0] + Mt[0][1]) + 2 * z * (Mt[2][0] + Mt[0][2]) + 2 * r * (Mt[1][2] - Mt[2][1]) - 4 * x * (Mt[2][2] + Mt[1][1]));
-        rot_g[2] += (float)(2 * x * (Mt[1][0] + Mt[0][1]) + 2 * r * (Mt[2][0] - Mt[0][2]) + 2 * z * (Mt[1][2] + Mt[2][1]) - 4 * y * (Mt[2][2] + Mt[0][0]));
-        rot_g[3] += (float)(2 * r * (Mt[0][1] - Mt[1][0]) + 2 * x * (Mt[2][0] + Mt[0][2]) + 2 * y * (Mt[1][2] + Mt[2][1]) - 4 * z * (Mt[1][1] + Mt[0][0]));
+        const real c2 = RL(2), c4 = RL(4);
+        rot_g[0] += (float)(c2 * z * (Mt[0][1] - Mt[1][0]) + c2 * y * (Mt[2][0] - Mt[0][2]) + c2 * x * (Mt[1][2] - Mt[2][1]));
+        rot_g[1] += (float)(c2 * y * (Mt[1][0] + Mt[0][1]) + c2 * z * (Mt[2][0] + Mt[0][2]) + c2 * r * (Mt[1][2] - Mt[2][1]) - c4 * x * (Mt[2][2] + Mt[1][1]));
+        rot_g[2] += (float)(c2 * x * (Mt[1][0] + Mt[0][1]) + c2 * r * (Mt[2][0] - Mt[0][2]) + c2 * z * (Mt[1][2] + Mt[2][1]) - c4 * y * (Mt[2][2] + Mt[0][0]));
+        rot_g[3] += (float)(c2 * r * (Mt[0][1] - Mt[1][0]) + c2 * x * (Mt[2][0] + Mt[0][2]) + c2 * y * (Mt[1][2] + Mt[2][1]) - c4 * z * (Mt[1][1] + Mt[0][0]));
     }
     dm[0] = mean_g[0], dm[1] = mean_g[1], dm[2] = mean_g[2];
     drot[0] = rot_g[0], drot[1] = rot_g[1], drot[2] = rot_g[2], drot[3] = rot_g[3];
+#undef RL
 }
 
 }  // namespace

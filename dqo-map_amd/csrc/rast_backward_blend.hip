@@ -312,7 +312,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                     // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
                     // and S + 0 * (c - S) = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
                     const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    const float power = dqo_power(co.x, co.y, co.z, dx, dy);
                     const float Gx = dqo_gauss(power);
                     const float alpha_x = fminf(0.99f, co.w * Gx);
                     const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f;

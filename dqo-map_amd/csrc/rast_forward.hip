@@ -401,7 +401,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         DqoRastHeader h;
         h.num_rendered = s_carry;
         h.num_tiles = (uint32_t)T - n_empty;
-        h.overflow = ((int64_t)s_carry > capacity || (bucket > 0 && s_max > (uint32_t)bucket)) ? 1u : 0u;
+        // (`overflow` covers the slot allocator running past the capacity as well: whenever the lists were emptied the frame says so)
+        h.overflow = (overflow || (int64_t)s_carry > capacity || (bucket > 0 && s_max > (uint32_t)bucket)) ? 1u : 0u;
         h.max_tile_count = s_max;
         h.num_visible = s_stat[0];
         h.num_candidates = s_stat[1];
@@ -633,6 +634,15 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(DqoImageLayout 
     }
 }
 
+// Zero fill of the per-frame scalars (header, slot allocator, statistics counters).  A kernel, not hipMemsetAsync: as a memset NODE
+// of a captured graph the fill was observed (ROCm 7.2, gfx950) to write garbage once enough other runtime activity had happened
+// between the capture and a replay — the lists were then emptied by a slot allocator that started at a random value (round 1's
+// blank frames of the 2-rank rehearsal).  A kernel node carries its arguments by value.
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view,
                                     const float* __restrict__ proj, uint8_t* __restrict__ present) {
 #pragma clang fp contract(off)
@@ -661,9 +671,13 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     const int T = v.gx * v.gy;
-    DQO_CHECK_HIP(hipMemsetAsync(g.header, 0, 512 + 256 * DQO_SPREAD, s));  // header + counters + spread statistics counters
+    {  // header + counters + spread statistics counters
+        const size_t n = (512 + 256 * DQO_SPREAD) / 4;
+        DQO_LAUNCH("zero_words_kernel", zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), s, reinterpret_cast<uint32_t*>(g.header), n);
+    }
     const size_t zero_words = (size_t)((img.tile_flag + T) - img.tile_count);  // histogram (padded) + flags
-    if (p->P <= 0) DQO_CHECK_HIP(hipMemsetAsync(img.tile_count, 0, 4 * zero_words, s));
+    if (p->P <= 0)
+        DQO_LAUNCH("zero_words_kernel", zero_words_kernel, dim3((unsigned)((zero_words + 255) / 256)), dim3(256), s, img.tile_count, zero_words);
     if (p->P > 0) {
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;

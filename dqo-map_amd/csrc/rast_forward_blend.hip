@@ -153,7 +153,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                 // predicates in VGPRs (a lane mask that lives across the loop costs scalar bookkeeping in every trip).  An
                 // entry that is not valid for a pixel acts on it with alpha = 0: T (1 - 0) = T, weight 0.
                 const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
-                const float power = -0.5f * (co_cur.x * dx * dx + co_cur.z * dy * dy) - co_cur.y * dx * dy;
+                const float power = dqo_power(co_cur.x, co_cur.y, co_cur.z, dx, dy);
                 const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
                 const float a_g = power <= 0.0f ? alpha * gate : 0.f;
                 const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)

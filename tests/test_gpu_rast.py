@@ -27,7 +27,9 @@ def _check(oracle, cam, sc, dL, **kw):
     st = U.compare_forward(hr.res, r)
     keep = (~bad).astype(np.float32)
     dLm = (dL[0] * keep[None], dL[1] * keep[None])
-    gs = U.compare_grads(hr.backward(dLm, retain=False), U.oracle_backward(o, dLm, kw.get("colors_precomp") is not None))
+    precomp = kw.get("colors_precomp") is not None
+    o64, _, _ = U.run_oracle(oracle, cam, sc, dtype=np.float64, **kw)  # (only consulted for rows beyond the bar: compare_grads)
+    gs = U.compare_grads(hr.backward(dLm, retain=False), U.oracle_backward(o, dLm, precomp), U.oracle_backward(o64, dLm, precomp))
     print("fwd", st, "grads (rel-to-max, q99)", gs)
     return hr.res, r, o
 
