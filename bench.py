@@ -202,6 +202,7 @@ class FusedRunner:
         from dqo_harness import scenes
         from cuda_utils._C import accumulate_gaussian_error
         fm, p = self.fm, self.prob
+        torch.cuda.synchronize()  # (drain the queued replays first, so that `ms` is the growth step alone)
         t0 = time.perf_counter()
         k = len(self.growth_log)
         new = scenes.surfel_room(9000 + 17 * k + self.growth_seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])

@@ -257,6 +257,11 @@ static inline DqoView dqo_make_view(const DqoRastParams* p, const DqoRastInputs*
     return v;
 }
 
+// Zero fill of caller memory on the launch stream.  The library never uses hipMemsetAsync for this: as a memset NODE of a captured
+// hipGraph the fill was observed (ROCm 7.2, gfx950) to write garbage on replay once other runtime activity had happened since the
+// capture; a kernel node carries its arguments by value.  Defined in rast_forward.hip.
+int dqo_launch_zero_words(uint32_t* p, size_t n_words, hipStream_t s);
+
 // launchers (defined in the .hip files)
 int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);
 int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);

@@ -65,12 +65,14 @@ int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, con
                                 const int32_t* color_index, const int32_t* depth_index, float color_thr, float depth_thr,
                                 float normal_thr, int check_max, float* gs_color, float* gs_depth, float* gs_normal, float* rescale,
                                 int32_t* counters, hipStream_t s) {
-    const size_t nb = sizeof(float) * (size_t)P;
-    DQO_CHECK_HIP(hipMemsetAsync(gs_color, 0, nb, s));
-    DQO_CHECK_HIP(hipMemsetAsync(gs_depth, 0, nb, s));
-    DQO_CHECK_HIP(hipMemsetAsync(gs_normal, 0, nb, s));
-    DQO_CHECK_HIP(hipMemsetAsync(rescale, 0, nb, s));
-    if (!check_max) DQO_CHECK_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int32_t) * (size_t)P, s));
+    for (float* q : {gs_color, gs_depth, gs_normal, rescale}) {
+        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(q), (size_t)P, s);
+        if (rc) return rc;
+    }
+    if (!check_max) {
+        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(counters), 2 * (size_t)P, s);
+        if (rc) return rc;
+    }
     const int HW = H * W;
     DQO_LAUNCH("accumulate_error_kernel", accumulate_error_kernel, dim3((HW + 255) / 256), dim3(256), s, HW, P, color_err, depth_err,
                normal_err, color_index, depth_index, color_thr, depth_thr, normal_thr, check_max, gs_color, gs_depth, gs_normal, rescale,

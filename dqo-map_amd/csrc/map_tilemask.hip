@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void tile_color_error_kernel(int W, int H, int
 int dqo_launch_tile_count(int W, int H, int mode, const uint8_t* mask_in, const float* T_map, uint8_t* mask_out, int32_t* tile_count,
                           int32_t* total, hipStream_t s) {
     const int gx = (W + DQO_TILE - 1) / DQO_TILE, gy = (H + DQO_TILE - 1) / DQO_TILE;
-    if (total) DQO_CHECK_HIP(hipMemsetAsync(total, 0, sizeof(int32_t), s));
+    if (total) {
+        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(total), 1, s);
+        if (rc) return rc;
+    }
     DQO_LAUNCH("tile_count_kernel", tile_count_kernel, dim3(gx * gy), dim3(256), s, W, H, gx, mode, mask_in, T_map, mask_out, tile_count,
                total);
     return DQO_OK;

@@ -16,6 +16,9 @@
 //     (1 = colour-path floats, 3 = depth-hit floats as well).
 // record_sum_kernel adds a Gaussian's valid partial records in a fixed order: bitwise reproducible.  Instruction costs behind the
 // choices (swap = 8 cycles, DPP = 4-5, plain = 3-4): tools/ubench_valu.hip, profiles/r01_ubench_valu.txt.
+#include <cstdlib>
+#include <type_traits>
+
 #include "dqo_common.h"
 #include "dqo_cull.h"
 
@@ -84,19 +87,8 @@ template <int CTRL, int BANK_MASK>
 __device__ __forceinline__ float dpp_pick(float old, float v) {  // lanes of the enabled banks read v through CTRL, the others keep old
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK_MASK, false));
 }
-__device__ __forceinline__ float wave_reduce64(const float (&v)[64], int lane) {
-    float a[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) {  // lanes 0..31 end up with the sum of v[i], lanes 32..63 with that of v[i + 32]
-        const dqo_uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
-        a[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
-    }
-    float b[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {  // rows 0, 2 (lane bit 4 clear): a[i];  rows 1, 3: a[i + 16]
-        const dqo_uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 16]), false, false);
-        b[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
-    }
+// stages lane ^ 8, ^ 4, ^ 2, ^ 1 of the reduce-scatter: 16 values per lane -> 1 (lane bits 3..0 select which)
+__device__ __forceinline__ float wave_reduce_tail16(const float (&b)[16], int lane) {
     // lane bit 3 = DPP banks 2, 3 of every row, partner = row_ror:8: banks 0,1 take b[i] + partner's b[i], banks 2,3 take
     // b[i + 8] + partner's b[i + 8] — two bank-masked v_add_f32_dpp writing the two halves of one register (the builtin only
     // yields v_mov_dpp + select + add: 4 instructions).  Hand-written DPP: the leading s_nop covers the 2 wait states a DPP read
@@ -131,6 +123,38 @@ __device__ __forceinline__ float wave_reduce64(const float (&v)[64], int lane) {
     return keep + dpp_mov<0xB1>(send);  // partner lane ^ 1
 }
 
+__device__ __forceinline__ float wave_reduce64(const float (&v)[64], int lane) {
+    float a[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {  // lanes 0..31 end up with the sum of v[i], lanes 32..63 with that of v[i + 32]
+        const dqo_uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+        a[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    float b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {  // rows 0, 2 (lane bit 4 clear): a[i];  rows 1, 3: a[i + 16]
+        const dqo_uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 16]), false, false);
+        b[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    return wave_reduce_tail16(b, lane);
+}
+
+// The same butterfly for THIRTY-TWO values: lane l (and lane l ^ 32) ends up with the 64-lane total of v[l & 31].  The lane ^ 32
+// exchange comes last, on the one value that is left (a swap of a register with its own copy + one add), instead of first on 32
+// pairs: 73 VALU for 32 sums — more per sum than the 64-value form, but half the registers, which is what decides how many waves
+// share a SIMD (the kernel is bound by per-wave instruction latency, not by VALU throughput: tools/ubench_valu.hip).
+__device__ __forceinline__ float wave_reduce32(const float (&v)[32], int lane) {
+    float b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const dqo_uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+        b[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    const float y = wave_reduce_tail16(b, lane);
+    const dqo_uint2v r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(r32.x) + __uint_as_float(r32.y);
+}
+
 __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
 #pragma clang fp contract(off)
     float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
@@ -139,9 +163,10 @@ __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx
 }
 
 constexpr int BWD_THREADS = 64;
-constexpr int BWD_NB = 7;  // live entries per reduction batch: 7 x 9 = 63 of the butterfly's 64 values
-
-__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+// live entries per reduction batch: BWD_NB x 9 values go through one butterfly — 7 x 9 = 63 of 64 values (wave_reduce64), or
+// 3 x 9 = 27 of 32 (wave_reduce32: fewer registers -> more waves per SIMD)
+template <int BWD_NB>
+__global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                      DqoBinLayout bin, const float* __restrict__ scales,
                                                                      const float* __restrict__ rotations,
                                                                      const float* __restrict__ dL_dpixels,
@@ -295,17 +320,24 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
             s_xy[myk] = g.xy_depth[id];
             s_rgb[myk] = g.rgb_smax[id];
         }
-        // The live entries of the chunk are processed BWD_NB at a time: their 9 colour-path sums each (63 values) go through
-        // ONE 64-value reduce-scatter butterfly, after which lane l = 9 b + f holds float f of entry b's record.
-        for (int k0 = 0; k0 < cnt; k0 += BWD_NB) {
-            float v64[64];
-            v64[63] = 0.f;
+        // The live entries of the chunk are processed BWD_NB at a time: their 9 colour-path sums each go through ONE reduce-scatter
+        // butterfly, after which lane l = 9 b + f holds float f of entry b's record.  A batch whose BWD_NB entries all exist runs as
+        // one straight-line block (FULL): no wave-uniform branch sits between two entries, so the scheduler interleaves the parts of
+        // neighbouring entries that do not depend on each other (footprint, exp, alpha — everything but the T / S recurrences).  A
+        // wave issues a dependent VALU instruction only every ~10 cycles (tools/ubench_valu.hip), so the loop is paced by the length
+        // of its dependency chains, not by the number of instructions: with a branch per entry the chain was one whole entry long.
+        auto batch = [&](const int k0, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            constexpr int NV = BWD_NB == 7 ? 64 : 32;
+            float v64[NV];
+#pragma unroll
+            for (int i = 9 * BWD_NB; i < NV; i++) v64[i] = 0.f;
             uint32_t hitmask = 0u;  // entries of this batch that also carry depth-hit sums (wave-uniform)
 #pragma unroll
             for (int b = 0; b < BWD_NB; b++) {
                 const int k = k0 + b;
                 float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
-                if (k < cnt) {  // wave-uniform
+                if (FULL || k < cnt) {  // wave-uniform
                     const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
                     const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
                     // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
@@ -347,19 +379,24 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
                 v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
                 v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;
             }
-            const float tot = wave_reduce64(v64, lane);
-            // lane 9 b + f stores float f (0..8) of entry b's 64-byte partial record; lanes 0..6 mark the records valid
+            float tot;
+            if constexpr (BWD_NB == 7) tot = wave_reduce64(v64, lane);
+            else tot = wave_reduce32(v64, lane);
+            // lane 9 b + f stores float f (0..8) of entry b's 64-byte partial record; lanes 0..BWD_NB-1 mark the records valid
             // (1 = colour-path floats, 3 = depth-hit floats 9..13 present as well)
             const int kb = k0 + lane_b;
-            if (lane < 9 * BWD_NB && kb < cnt) {
+            if (lane < 9 * BWD_NB && (FULL || kb < cnt)) {
                 const uint32_t slot = s_slot[kb];
                 if ((int64_t)slot < capacity) recs[((size_t)slot * 4 + quad) * 16 + lane_f] = tot;
             }
-            if (lane < BWD_NB && k0 + lane < cnt) {
+            if (lane < BWD_NB && (FULL || k0 + lane < cnt)) {
                 const uint32_t slot = s_slot[k0 + lane];
                 if ((int64_t)slot < capacity) valid[(size_t)slot * 4 + quad] = ((hitmask >> lane) & 1u) ? (uint8_t)3 : (uint8_t)1;
             }
-        }
+        };
+        int k0 = 0;
+        for (; k0 + BWD_NB <= cnt; k0 += BWD_NB) batch(k0, std::true_type{});
+        if (k0 < cnt) batch(k0, std::false_type{});
     }
 }
 
@@ -368,7 +405,17 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(const DqoVi
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
                               DqoGradRec* recs, uint8_t* valid, int64_t capacity, hipStream_t s) {
-    DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
-               dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity);
+    // DQO_BWD_NB=3 (measurement only) selects the 32-value butterfly: 55 instead of 81 VGPRs, 5.4 instead of 3.7 waves resident
+    // per SIMD — and 5 % SLOWER (round 2, profiles/README.md): the kernel is bound by VALU execution, not by latency
+    static const int nb = [] {
+        const char* e = getenv("DQO_BWD_NB");
+        return e ? atoi(e) : 7;
+    }();
+    if (nb == 7)
+        DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel<7>, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales,
+                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity);
+    else
+        DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel<3>, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales,
+                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity);
     return DQO_OK;
 }

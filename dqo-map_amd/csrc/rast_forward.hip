@@ -666,18 +666,26 @@ int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomL
                          int64_t capacity, hipStream_t s);
 int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
 
+int dqo_launch_zero_words(uint32_t* p, size_t n_words, hipStream_t s) {
+    if (n_words == 0) return DQO_OK;
+    DQO_LAUNCH("zero_words_kernel", zero_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), s, p, n_words);
+    return DQO_OK;
+}
+
 int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s) {
     const DqoView v = dqo_make_view(p, in);
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     const int T = v.gx * v.gy;
     {  // header + counters + spread statistics counters
-        const size_t n = (512 + 256 * DQO_SPREAD) / 4;
-        DQO_LAUNCH("zero_words_kernel", zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), s, reinterpret_cast<uint32_t*>(g.header), n);
+        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(g.header), (512 + 256 * DQO_SPREAD) / 4, s);
+        if (rc) return rc;
     }
     const size_t zero_words = (size_t)((img.tile_flag + T) - img.tile_count);  // histogram (padded) + flags
-    if (p->P <= 0)
-        DQO_LAUNCH("zero_words_kernel", zero_words_kernel, dim3((unsigned)((zero_words + 255) / 256)), dim3(256), s, img.tile_count, zero_words);
+    if (p->P <= 0) {
+        int rc = dqo_launch_zero_words(img.tile_count, zero_words, s);
+        if (rc) return rc;
+    }
     if (p->P > 0) {
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;

@@ -86,6 +86,9 @@ struct RastCtx {
     std::vector<uint32_t> ranges;  // [T][2]
     std::vector<R> final_T, weight_sum, hit_normal_c, hit_point_c;
     std::vector<uint32_t> n_blend;  // workload statistic (not a reference quantity): entries blended into each pixel
+    // workload statistic, collected when ip[5] != 0: per list position a 256-bit mask of the tile's pixels (bit ty * 16 + tx) that
+    // saw the entry with alpha >= 1/255 before they finished — the (pixel, entry) pairs a blend kernel has arithmetic for
+    std::vector<uint64_t> pair_mask;
     std::vector<uint32_t> n_contrib;
     std::vector<int32_t> tile_indices;  // active tiles, row-major
     std::vector<int32_t> hit_depth_id;  // copy of out_hit_depth for backward
@@ -451,6 +454,8 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
     for (int t = 0; t < T; t++)
         if (c->ranges[2 * t] != c->ranges[2 * t + 1]) c->tile_indices.push_back(t);
 
+    const bool want_masks = ip[5] != 0;
+    if (want_masks) c->pair_mask.assign(4 * (size_t)N, 0);
     // ---- K6 renderCUDA_withMask, forward.cu:636-866 ----
     const R* features = c->has_sh ? c->rgb.data() : colors_precomp;
     const int n_active = (int)c->tile_indices.size();
@@ -483,6 +488,7 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
                     if (power > R(0)) continue;
                     const R alpha = std::min(R(0.99f), co[3] * std::exp(power));
                     if (alpha < R(1.0f / 255.0f)) continue;
+                    if (want_masks) c->pair_mask[4 * (size_t)k + (ty >> 2)] |= 1ull << ((ty & 3) * 16 + tx);
                     // forward.cu:779-791: surfel normal / ray-plane hit, recomputed per pair in the reference
                     R Rm[3][3];
                     quatToR(&rotations[4 * (size_t)g], Rm);
@@ -926,6 +932,7 @@ void ctx_copy(RastCtx<R>* c, int which, void* dst) {
         case 14: cp(c->point_tile); break;
         case 15: cp(c->weight_sum); break;
         case 16: cp(c->n_blend); break;
+        case 17: cp(c->pair_mask); break;
         default: break;
     }
 }

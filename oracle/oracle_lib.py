@@ -91,7 +91,7 @@ class OracleRasterizer:
             self.h = None
 
     def forward(self, st, means3D, opacities, view, proj, campos, shs=None, colors_precomp=None, scales=None,
-                rotations=None, cov3D_precomp=None, tile_mask=None):
+                rotations=None, cov3D_precomp=None, tile_mask=None, pair_masks=False):
         self.free()
         dt = self.dt
         c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
@@ -107,7 +107,7 @@ class OracleRasterizer:
         assert tile_mask.size == gx * gy
         if scales is None or rotations is None:
             raise ValueError("the depth rasteriser dereferences scales/rotations in its blend kernel (forward.cu:780)")
-        ip = np.array([P, st.sh_degree, M, W, H, 0], np.int32)
+        ip = np.array([P, st.sh_degree, M, W, H, 1 if pair_masks else 0], np.int32)
         fp = np.array([st.tanfovx, st.tanfovy, st.cx, st.cy, st.scale_modifier, st.color_sigma, st.opaque_threshold,
                        st.depth_threshold, st.normal_threshold, st.T_threshold], np.float64)
         bg = np.array(st.bg, dt)
@@ -137,7 +137,7 @@ class OracleRasterizer:
             "depths": (4, None), "conic_opacity": (5, None), "rgb": (6, None), "cov3D": (7, None),
             "tiles_touched": (8, np.uint32), "final_T": (9, None), "n_contrib": (10, np.uint32), "hit_normal_c": (11, None),
             "hit_point_c": (12, None), "clamped": (13, np.uint8), "point_tile": (14, np.uint32), "weight_sum": (15, None),
-            "n_blend": (16, np.uint32)}
+            "n_blend": (16, np.uint32), "pair_mask": (17, np.uint64)}
 
     def ctx(self, name):
         which, dt = self._CTX[name]
@@ -147,7 +147,7 @@ class OracleRasterizer:
                  "depths": (P,), "conic_opacity": (P, 4), "rgb": (P, 3), "cov3D": (P, 6), "tiles_touched": (P,),
                  "final_T": (self.H, self.W), "n_contrib": (self.H, self.W), "hit_normal_c": (self.H, self.W, 3),
                  "hit_point_c": (self.H, self.W, 3), "clamped": (P, 3), "point_tile": (self.N,),
-                 "weight_sum": (self.H, self.W), "n_blend": (self.H, self.W)}[name]
+                 "weight_sum": (self.H, self.W), "n_blend": (self.H, self.W), "pair_mask": (self.N, 4)}[name]
         out = np.zeros(shape, dt)
         getattr(self.lib, f"orc_rast_ctx_copy_{self.suf}")(ctypes.c_void_p(self.h), which, _p(out))
         return out

@@ -1,0 +1,73 @@
+"""Workload statistics of the blend loops from the CPU oracle (test infrastructure used as an analysis tool, never by the product):
+for every list entry of every tile the set of pixels that has arithmetic for it, and from that how well different wave -> pixel
+mappings of a blend kernel would be utilised.   python tools/pair_stats.py [cfg] [P]"""
+import os, sys
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [R, R + '/dqo-map_amd', R + '/tests']
+from dqo_harness import scenes
+from oracle import oracle_lib as ol
+import util_rast as U
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+P = int(sys.argv[2]) if len(sys.argv) > 2 else None
+cam, sc = scenes.make_config(cfg, P=P)
+o = ol.OracleRasterizer(np.float32, omp=True)
+st = U.oracle_settings(ol, cam)
+r = o.forward(st, sc["xyz"], sc["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center, shs=sc["shs"],
+              scales=sc["scales"], rotations=sc["rotations"], pair_masks=True)
+m = o.ctx("pair_mask")  # [N, 4] uint64: rows 0-3, 4-7, 8-11, 12-15 of the tile, 16 bits per row
+N = m.shape[0]
+bits = np.unpackbits(m.view(np.uint8).reshape(N, 32), axis=1, bitorder="little").reshape(N, 16, 16).astype(bool)  # [N, ty, tx]
+live_tile = bits.any((1, 2))
+print(f"cfg {cfg}: reference instances {N}, with any arithmetic {int(live_tile.sum())} ({live_tile.mean():.1%}); (pixel, entry) pairs "
+      f"{int(bits.sum())} = {bits.sum() / (cam.W * cam.H):.1f} per pixel")
+pairs = bits.sum()
+def report(name, blocks):  # blocks: [N, nblocks, lanes] bool
+    live = blocks.any(2)
+    steps = live.sum()
+    print(f"  {name:46s} wave steps {steps / 1e6:6.3f} M   lane utilisation {pairs / (steps * blocks.shape[2]):.1%}")
+    return live
+q = bits.reshape(N, 2, 8, 2, 8).transpose(0, 1, 3, 2, 4).reshape(N, 4, 64)          # 8x8 quadrants
+lq = report("8x8 quadrant per wave (current)", q)
+h = bits.reshape(N, 4, 4, 2, 8).transpose(0, 1, 3, 2, 4).reshape(N, 8, 32)           # 8 wide x 4 high half-quadrants
+lh = report("8x4 half-quadrant (one 32-lane half)", h)
+# a wave = quadrant, but a half with no active lane costs nothing (if the hardware skips an all-zero EXEC half):
+lh4 = lh.reshape(N, 2, 2, 2)  # [N, quad row, half, quad col]
+both = (lh4[:, :, 0, :] & lh4[:, :, 1, :]).sum(); one = (lh4[:, :, 0, :] ^ lh4[:, :, 1, :]).sum()
+print(f"     quadrant steps with both halves active {both / 1e6:.3f} M, with one half only {one / 1e6:.3f} M -> issue cost "
+      f"{(both + 0.5 * one) / 1e6:.3f} M full-wave equivalents if an idle half is skipped; {(both + 0) / 1e6:.3f} + max-packing of the rest")
+b44 = bits.reshape(N, 4, 4, 4, 4).transpose(0, 1, 3, 2, 4).reshape(N, 16, 16)       # 4x4 blocks (one DPP row)
+l44 = report("4x4 block (one DPP row of 16 lanes)", b44)
+w16 = bits.reshape(N, 1, 256)
+report("16x16 tile on 4 waves, all in step", w16)
+s164 = bits.reshape(N, 4, 4, 16).reshape(N, 4, 64)                                    # 16 wide x 4 high strips
+report("16x4 strip per wave", s164)
+s416 = bits.reshape(N, 16, 4, 4).transpose(0, 2, 1, 3).reshape(N, 4, 64)            # 4 wide x 16 high strips
+report("4x16 strip per wave", s416)
+# per-tile packing bound for half-waves: per (tile, quadrant) the live halves could be paired across DIFFERENT entries
+ranges = o.ctx("ranges")
+tile_of = np.repeat(np.arange(ranges.shape[0]), (ranges[:, 1] - ranges[:, 0]).astype(np.int64))
+steps_packed = 0
+for qr in range(2):
+    for qc in range(2):
+        top, bot = lh4[:, qr, 0, qc], lh4[:, qr, 1, qc]
+        bo = np.bincount(tile_of, weights=(top & bot), minlength=ranges.shape[0])
+        to = np.bincount(tile_of, weights=(top & ~bot), minlength=ranges.shape[0])
+        bt = np.bincount(tile_of, weights=(~top & bot), minlength=ranges.shape[0])
+        steps_packed += (bo + np.maximum(to, bt)).sum()
+print(f"  half-entries of one quadrant packed pairwise (top-only with bottom-only): {steps_packed / 1e6:.3f} M wave steps "
+      f"(utilisation {pairs / (steps_packed * 64):.1%})")
+
+# ---- critical path: live entries per (tile, quadrant) wave ----
+T = ranges.shape[0]
+lq_i = lq.astype(np.int64)  # [N, 4]
+per_wave = np.stack([np.bincount(tile_of, weights=lq_i[:, q_], minlength=T) for q_ in range(4)], 1).reshape(-1)
+per_wave = per_wave[per_wave > 0]
+print(f"  quadrant waves with work: {per_wave.size}; live entries per wave: mean {per_wave.mean():.1f}, median {np.median(per_wave):.0f}, "
+      f"p90 {np.quantile(per_wave, .9):.0f}, p99 {np.quantile(per_wave, .99):.0f}, max {per_wave.max():.0f}")
+tot = per_wave.sum()
+for slots in (1024 * 1, 1024 * 2, 1024 * 4):
+    print(f"     perfectly balanced over {slots} wave slots: {tot / slots:.0f} live entries per slot (the longest wave alone has {per_wave.max():.0f})")
+lens = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
+print(f"  reference list length per tile: mean {lens.mean():.0f}, max {lens.max()}")

@@ -1,7 +1,13 @@
 // VALU issue-rate microbenchmark for gfx950 (run on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o /tmp/ubench_valu && /tmp/ubench_valu
-// Prints, per instruction kind and per resident-waves-per-SIMD target, the SIMD cycles one wave64 instruction costs
-// (assuming 2.4 GHz).  Used to decide what "VALU-issue bound" means for the blend kernels (profiles/README.md).
+// Prints, per instruction kind and per resident-waves-per-SIMD, the SIMD cycles one wave64 instruction costs.
+// Round-2 method (round 1's table was contaminated by launch overhead and an assumed 2.4 GHz clock): every wave stamps
+// s_memtime (shader-clock cycles) and s_memrealtime (constant 100 MHz) around its own loop, the kernel is one 256-thread
+// workgroup per CU slot (4 waves = one per SIMD) x w workgroups per CU, and the figure is
+//     median over waves of  (delta s_memtime) / (instructions of the wave x w)
+// = cycles the SIMD spends per wave-instruction when w waves share it; the clock actually held is printed beside it
+// (delta s_memtime / delta s_memrealtime x 100 MHz).  The `half` column repeats w = 2 with EXEC = the lower 32 lanes only: does
+// a wave64 instruction whose upper half is idle cost a SIMD-32 one pass instead of two?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -12,7 +18,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b, unsigned long long* stamps, int half_exec) {
     float acc[16];
     f2 acc2[16];
     const f2 a2 = {a, a}, b2 = {b, b};
@@ -24,6 +30,9 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
     for (int i = 0; i < 8; i++) accd[i] = (double)i;
     if (MODE == 23) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
     for (int i = 0; i < 16; i++) acc[i] = (float)threadIdx.x * 1e-3f + i, acc2[i] = f2{acc[i], acc[i] + 1.f};
+    unsigned long long saved_exec = 0;
+    if (half_exec) asm volatile("s_mov_b64 %0, exec\n s_mov_b64 exec, 0xffffffff" : "=s"(saved_exec));
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
         if (MODE == 0) {  // independent v_fma_f32
 #define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
@@ -139,6 +148,12 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
 #undef X
         }
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (half_exec) asm volatile("s_mov_b64 exec, %0" : : "s"(saved_exec));
+    if (stamps != nullptr && (threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+        stamps[2 * w] = t1 - t0, stamps[2 * w + 1] = r1 - r0;
+    }
     float s = 0.f;
     for (int i = 0; i < 16; i++) s += acc[i] + acc2[i].x + acc2[i].y;
     for (int i = 0; i < 8; i++) s += (float)accd[i];
@@ -146,31 +161,43 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
     if (s == 123.456f) out[0] = s;
 }
 
+#include <algorithm>
+static unsigned long long* g_stamps = nullptr;
+static std::vector<unsigned long long> g_host;
+
 template <int MODE>
 void run(const char* name, float* out) {
-    const int iters = 20000;
+    const int iters = 40000;  // x 16 instructions: ~1-3 ms per wave, launch overhead invisible; stamped inside the kernel anyway
     printf("%-28s", name);
-    for (int w : {1, 2, 4, 8}) {
-        const int grid = 1024 * w;
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
-        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, out, 100, 1.0001f, 1e-6f);
-        (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, out, iters, 1.0001f, 1e-6f);
-        (void)hipEventRecord(e1, 0);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        const double cycles = ms * 1e-3 * 2.4e9;
-        const double instr_per_simd = (double)w * iters * 16;  // wave instructions issued on one SIMD
-        printf("  w=%d: %5.2f cyc/instr", w, cycles / instr_per_simd);
+    double clk = 0.0;
+    for (int pass = 0; pass < 5; pass++) {
+        const int w = pass < 4 ? (1 << pass) : 2;
+        const int half = pass == 4;
+        const int grid = 256 * w;  // 256-thread workgroups: 4 waves = one per SIMD; w workgroups per CU
+        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, out, 200, 1.0001f, 1e-6f, (unsigned long long*)nullptr, half);
+        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f, 1e-6f, g_stamps, half);
+        (void)hipDeviceSynchronize();
+        const size_t nw = (size_t)grid * 4;
+        (void)hipMemcpy(g_host.data(), g_stamps, nw * 16, hipMemcpyDeviceToHost);
+        std::vector<double> cyc(nw), mhz(nw);
+        for (size_t i = 0; i < nw; i++) {
+            cyc[i] = (double)g_host[2 * i] / ((double)iters * 16 * w);
+            mhz[i] = (double)g_host[2 * i] / (double)g_host[2 * i + 1] * 100.0;
+        }
+        std::nth_element(cyc.begin(), cyc.begin() + nw / 2, cyc.end());
+        std::nth_element(mhz.begin(), mhz.begin() + nw / 2, mhz.end());
+        if (!half) printf("  w=%d: %5.2f", w, cyc[nw / 2]);
+        else printf("  half(w=2): %5.2f", cyc[nw / 2]);
+        clk = mhz[nw / 2];
     }
-    printf("\n");
+    printf("  cyc/instr   clock %4.0f MHz\n", clk);
 }
 
 int main() {
     float* out;
     if (hipMalloc(&out, 64) != hipSuccess) return 1;
+    if (hipMalloc(&g_stamps, 2048 * 4 * 16) != hipSuccess) return 1;
+    g_host.resize(2048 * 4 * 2);
     run<0>("v_fma_f32 indep", out);
     run<2>("v_fma_f32 dependent", out);
     run<9>("v_fma_f32 ILP2", out);
