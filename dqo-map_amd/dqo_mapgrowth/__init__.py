@@ -61,18 +61,45 @@ def temp_points_filter_mask(temp_xyz, exist_xyz, exist_radius, topk=3):
     return ((nn_dist < corr_radius) & valid).any(dim=-1)
 
 
-def update_geometry_scales(xyz, radius, extra_xyz, extra_radius, min_radius, max_radius):
+def update_geometry_scales(xyz, radius, extra_xyz, extra_radius, min_radius, max_radius, literal=False):
     """gaussian_pointcloud.py:519-556: (scales [P], invalid_scale_mask [P]) for the P new points `xyz` among the
-    existing `extra_xyz`: root-mean-square gap to the 3 nearest neighbours' 3-sigma spheres, clipped."""
+    existing `extra_xyz`: root-mean-square gap to the 3 nearest neighbours' 3-sigma spheres, clipped.
+
+    literal=True issues the reference's own call — distCUDA2 over the concatenation (new + existing points in the box), i.e. an
+    all-pairs 3-NN over up to the whole map of which only the first P rows are used.  The default computes the same three neighbours
+    per new point without that waste: its nearest 3 among the other new points (dqo_knn3) and among the existing points
+    (dqo_knn3_query), then the 3 nearest of those 6 — the 3 nearest of the union, exactly (equidistant neighbours aside)."""
     n = xyz.shape[0]
     if torch.numel(extra_xyz) > 0:
         inbbox = bbox_filter(xyz, extra_xyz)
         extra_xyz, extra_radius = extra_xyz[inbbox], extra_radius[inbbox]
-    total_xyz = torch.cat([xyz, extra_xyz])
-    total_radius = torch.cat([radius, extra_radius]).reshape(-1)
-    _, knn_indices = distCUDA2(total_xyz.float().cuda())
-    knn_indices = knn_indices[:n].long()
-    d = [torch.norm(xyz - total_xyz[knn_indices[:, j]], p=2, dim=1) - 3 * total_radius[knn_indices[:, j]] for j in range(3)]
+    if literal:
+        total_xyz = torch.cat([xyz, extra_xyz])
+        total_radius = torch.cat([radius, extra_radius]).reshape(-1)
+        _, knn_indices = distCUDA2(total_xyz.float().cuda())
+        knn_indices = knn_indices[:n].long()
+        d = [torch.norm(xyz - total_xyz[knn_indices[:, j]], p=2, dim=1) - 3 * total_radius[knn_indices[:, j]] for j in range(3)]
+    else:
+        xyz = xyz.float().contiguous()
+        radius, extra_radius = radius.reshape(-1), extra_radius.reshape(-1)
+        inf = torch.full((n, 3), float("inf"), device=xyz.device)
+        cand_d, cand_r = [], []
+        if n > 1:
+            _, i_new = distCUDA2(xyz)
+            ok = i_new < n  # (INT_MAX where fewer than 3 other new points exist)
+            j = i_new.long().clamp(max=n - 1)
+            cand_d.append(torch.where(ok, (xyz[:, None, :] - xyz[j]).pow(2).sum(-1), inf))
+            cand_r.append(radius[j])
+        if torch.numel(extra_xyz) > 0:
+            d2, i_old = knn_points_k3(xyz, extra_xyz)
+            ok = i_old >= 0
+            cand_d.append(torch.where(ok, d2, inf))
+            cand_r.append(extra_radius[i_old.clamp(min=0)])
+        cd, cr = torch.cat(cand_d, 1), torch.cat(cand_r, 1)
+        top = torch.topk(cd, 3, dim=1, largest=False)
+        dist = torch.sqrt(top.values)
+        rr = torch.gather(cr, 1, top.indices)
+        d = [dist[:, k] - 3 * rr[:, k] for k in range(3)]
     invalid = (d[0] < 0) | (d[1] < 0) | (d[2] < 0)
     scales = torch.sqrt((d[0] ** 2 + d[1] ** 2 + d[2] ** 2) / 3)
     return torch.clip(scales, min=min_radius, max=max_radius), invalid

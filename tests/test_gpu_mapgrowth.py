@@ -134,3 +134,22 @@ def test_fused_mapper_grow_and_recapture():
     for k, v in fm._params().items():
         assert torch.equal(v, twin._params()[k]), k
     assert torch.equal(fm.loss, twin.loss) and torch.isfinite(fm.loss).all()
+
+
+def test_scale_init_without_the_all_pairs_knn_equals_the_reference_call(mg):
+    """update_geometry_scales: the default path (3 nearest among the other new points + 3 nearest among the existing ones, the 3
+    nearest of those 6) gives what the reference's literal call gives (distCUDA2 over new + existing, first P rows)."""
+    torch, m = mg
+    rng = np.random.default_rng(8)
+    new = torch.tensor(rng.uniform(-1, 1, (3000, 3)).astype(np.float32), device="cuda")
+    old = torch.tensor(rng.uniform(-1.2, 1.2, (50000, 3)).astype(np.float32), device="cuda")
+    r_new = torch.tensor(rng.uniform(0.001, 0.02, 3000).astype(np.float32), device="cuda")
+    r_old = torch.tensor(rng.uniform(0.001, 0.02, 50000).astype(np.float32), device="cuda")
+    s1, inv1 = m.update_geometry_scales(new, r_new, old, r_old, 0.001, 0.05, literal=True)
+    s2, inv2 = m.update_geometry_scales(new, r_new, old, r_old, 0.001, 0.05)
+    assert torch.equal(inv1, inv2)
+    np.testing.assert_allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=2e-6, atol=1e-9)
+    # no existing points / a single new point
+    s3, _ = m.update_geometry_scales(new, r_new, old[:0], r_old[:0], 0.001, 0.05)
+    s4, _ = m.update_geometry_scales(new, r_new, old[:0], r_old[:0], 0.001, 0.05, literal=True)
+    np.testing.assert_allclose(s3.cpu().numpy(), s4.cpu().numpy(), rtol=2e-6, atol=1e-9)
