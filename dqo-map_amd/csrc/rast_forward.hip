@@ -12,6 +12,8 @@
 // tile's (depth, id) keys by one wave, so an instance crosses HBM once as an 8-byte key instead of 6 radix passes over
 // 12-byte pairs; everything the blend loop needs per Gaussian is precomputed once into 16-byte SoA records (the reference
 // rebuilds the quaternion rotation and does four uncoalesced gathers per (pixel, Gaussian) pair, forward.cu:779-791).
+#include <cstdlib>
+
 #include "dqo_common.h"
 #include "dqo_cull.h"
 
@@ -417,14 +419,59 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
 //   tile_sort_wave_kernel : lists up to 1024 entries (in practice all of them): ONE WAVE per tile, four tiles per block,
 //       the whole list in registers (E = 2..16 elements per lane, blocked layout).  Bitonic network: the steps with
 //       distance < E are compare-exchanges between a lane's own registers, the others exchange with lane ^ (distance / E)
-//       through ds_bpermute.  No LDS round trips, no barriers: the sort is latency-bound (a few hundred thousand keys in
-//       all), so the serial chain per tile is what counts.
-//   tile_sort_kernel : longer lists, one block per tile; in LDS up to SORT_LDS_CAP entries, beyond that in place in
+//       through DPP moves and the gfx950 row / half swaps (lane_xor_value).  No LDS round trips, no barriers: the sort is
+//       latency-bound (a few hundred thousand keys in all), so the serial chain per tile is what counts.
+//   tile_sort_kernel : longer lists, one block per tile: registers + LDS + (beyond 4096 entries) in-place steps in
 //       global memory (correctness path, not a fast path).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_LDS_CAP = 2048;
 constexpr int SORTW_CAP = 1024;
+
+// The value of lane ^ D, D a power of two, without the LDS crossbar (ds_bpermute costs 20-60 cycles per dependent use and shares
+// the LDS pipe of the CU; DPP moves 3-5, the gfx950 row / half swaps 4-9: tools/ubench_valu.hip):
+//   D = 1, 2 : DPP quad_perm;  D = 4 : row_shl:4 / row_shr:4 on alternate banks;  D = 8 : row_ror:8
+//   D = 16, 32 : v_permlane16/32_swap of the register with a copy of itself leaves (own rows, partner rows) in the two results
+typedef unsigned dqo_sort_uint2 __attribute__((ext_vector_type(2)));
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor_value(uint32_t x, int lane) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+    else if constexpr (D == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);  // banks 0, 2 read lane + 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);  // banks 1, 3 read lane - 4
+    } else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);
+    else if constexpr (D == 16) {
+        const dqo_sort_uint2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r.x: even rows' values, r.y: odd rows'
+        return (lane & 16) ? r.x : r.y;
+    } else {
+        static_assert(D == 32, "power of two up to 32");
+        const dqo_sort_uint2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r.x: lower half's values, r.y: upper half's
+        return (lane & 32) ? r.x : r.y;
+    }
+}
+
+// one cross-lane step of the network: every register r meets register r of lane ^ D
+template <int E, int D>
+__device__ __forceinline__ void wave_bitonic_cross(uint64_t (&key)[E], uint32_t (&val)[E], int lane, int k) {
+    const bool up = ((lane * E) & k) == 0;  // ascending sub-sequence (k >= 2E here, so the bit is a lane bit)
+    const bool keep_min = (((lane & D) == 0) == up);
+    // all of the step's exchanges are issued before any result is used; the selects are branch-free
+    uint64_t ok[E];
+    uint32_t ov[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const uint32_t olo = lane_xor_value<D>((uint32_t)key[r], lane);
+        const uint32_t ohi = lane_xor_value<D>((uint32_t)(key[r] >> 32), lane);
+        ov[r] = lane_xor_value<D>(val[r], lane);
+        ok[r] = ((uint64_t)ohi << 32) | olo;
+    }
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const bool take = (ok[r] < key[r]) == keep_min;  // keys are distinct (padding carries identical payloads)
+        key[r] = take ? ok[r] : key[r];
+        val[r] = take ? ov[r] : val[r];
+    }
+}
 
 // one merge phase of the bitonic network: the steps j = k/2 ... 1 for sub-sequences of length k
 template <int E>
@@ -432,25 +479,14 @@ __device__ __forceinline__ void wave_bitonic_phase(uint64_t (&key)[E], uint32_t 
     {
 #pragma unroll 1
         for (int j = min(k >> 1, 32 * E); j >= E; j >>= 1) {
-            // partner element lives in lane ^ d, same register
-            const int d = j / E;
-            const bool up = ((lane * E) & k) == 0;  // ascending sub-sequence (k >= 2E here, so the bit is a lane bit)
-            const bool keep_min = (((lane & d) == 0) == up);
-            // all of the step's exchanges are issued before any result is used; the selects are branch-free
-            uint64_t ok[E];
-            uint32_t ov[E];
-#pragma unroll
-            for (int r = 0; r < E; r++) {
-                const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)key[r], d);
-                const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(key[r] >> 32), d);
-                ov[r] = (uint32_t)__shfl_xor((int)val[r], d);
-                ok[r] = ((uint64_t)ohi << 32) | olo;
-            }
-#pragma unroll
-            for (int r = 0; r < E; r++) {
-                const bool take = (ok[r] < key[r]) == keep_min;  // keys are distinct (padding carries identical payloads)
-                key[r] = take ? ok[r] : key[r];
-                val[r] = take ? ov[r] : val[r];
+            // partner element lives in lane ^ d, same register (d stays a run-time value: one copy of each distance's code)
+            switch (j / E) {
+                case 1: wave_bitonic_cross<E, 1>(key, val, lane, k); break;
+                case 2: wave_bitonic_cross<E, 2>(key, val, lane, k); break;
+                case 4: wave_bitonic_cross<E, 4>(key, val, lane, k); break;
+                case 8: wave_bitonic_cross<E, 8>(key, val, lane, k); break;
+                case 16: wave_bitonic_cross<E, 16>(key, val, lane, k); break;
+                default: wave_bitonic_cross<E, 32>(key, val, lane, k); break;
             }
         }
 #pragma unroll
@@ -570,66 +606,130 @@ __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, Dq
     else wave_sort_tile<8>(bin, rg.x, n, lane);
 }
 
-// in-place global version for lists longer than SORT_LDS_CAP, LDS version below that
-template <typename KeyPtr, typename ValPtr>
-__device__ __forceinline__ void bitonic_any(KeyPtr keys, ValPtr vals, int n, int tid) {
-    int n2 = 1;
+// Lists longer than SORTW_CAP: one 256-thread block per tile, three levels of the same ascending network.
+//   registers : runs of 512 keys, one wave each (wave_bitonic<8>): every compare-exchange at distance < 512
+//   LDS       : segments of SORTL_SEG = 4096 keys: the merge steps at distance 512 .. 2048 (flip step + half cleaners), after which
+//               each run finishes in registers again (wave_bitonic_phase)
+//   global    : lists longer than a segment: the merge steps at distance >= 4096 in place in the tile's key / slot arrays (one block
+//               owns the tile; __syncthreads orders its global accesses), then every segment goes through LDS + registers again
+// Entries past the end of the list behave as +infinity: the network only uses ascending comparators, so they never move and need
+// no storage.  (The first version ran the whole network in LDS with 256 threads and a barrier per step — 78 steps for 4096 keys:
+// 193 us on config 4, 515 us on config 5, where 40 % of the tiles are longer than 1024.)
+constexpr int SORTL_SEG = 4096;
+constexpr int SORTL_RUN = SORTP_RUN;  // 512
+
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(DqoImageLayout img, DqoBinLayout bin) {
+    __shared__ uint64_t s_keys[SORTL_SEG];
+    __shared__ uint32_t s_vals[SORTL_SEG];
+    const uint32_t tile = img.tile_order[blockIdx.x];  // [8][T8] slots, unused ones hold ~0
+    if (tile == 0xffffffffu) return;
+    const uint2 rg = img.ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    if (n <= SORTW_CAP) return;  // tile_sort_wave_kernel's
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint64_t* gk = bin.keys + rg.x;
+    uint32_t* gv = bin.slots + rg.x;
+    int n2 = 2 * SORTL_RUN;
     while (n2 < n) n2 <<= 1;
-    const int half = n2 >> 1;
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool flip = (j == (k >> 1));
-            for (int t = tid; t < half; t += SORT_THREADS) {
+    const int seg_len = min(n2, SORTL_SEG);
+
+    // one ascending compare-exchange step of the network on the segment in LDS: `flip` pairs i with its mirror inside blocks of k
+    // (first step of a merge of two ascending halves), otherwise i with i + j
+    auto lds_step = [&](int k, int j, bool flip) {
+        for (int t = tid; t < seg_len / 2; t += SORT_THREADS) {
+            int i, p;
+            if (flip) {
+                const int h = k >> 1, blk = t / h, off = t - blk * h;
+                i = blk * k + off, p = blk * k + k - 1 - off;
+            } else {
+                i = 2 * j * (t / j) + (t % j), p = i + j;
+            }
+            const uint64_t a = s_keys[i], b = s_keys[p];
+            if (a > b) {
+                s_keys[i] = b, s_keys[p] = a;
+                const uint32_t va = s_vals[i];
+                s_vals[i] = s_vals[p], s_vals[p] = va;
+            }
+        }
+        __syncthreads();
+    };
+    // every run of the segment through the registers of one wave: full sort (first) or the last nine steps of a merge
+    auto runs_in_registers = [&](bool full_sort) {
+        for (int run = wave; run < seg_len / SORTL_RUN; run += SORT_THREADS / 64) {
+            uint64_t key[SORTP_E];
+            uint32_t val[SORTP_E];
+            const int base = run * SORTL_RUN + lane * SORTP_E;
+#pragma unroll
+            for (int r = 0; r < SORTP_E; r++) key[r] = s_keys[base + r], val[r] = s_vals[base + r];
+            if (full_sort) wave_bitonic<SORTP_E>(key, val, lane);
+            else wave_bitonic_phase<SORTP_E>(key, val, lane, 2 * SORTL_RUN);
+#pragma unroll
+            for (int r = 0; r < SORTP_E; r++) s_keys[base + r] = key[r], s_vals[base + r] = val[r];
+        }
+        __syncthreads();
+    };
+    auto load_segment = [&](int s0) {
+        for (int i = tid; i < seg_len; i += SORT_THREADS) {
+            const bool in = s0 + i < n;
+            s_keys[i] = in ? gk[s0 + i] : ~0ull;  // padding sorts behind every real key (depth bits of a finite float)
+            s_vals[i] = in ? gv[s0 + i] : 0u;
+        }
+        __syncthreads();
+    };
+    auto store_segment = [&](int s0, bool final_lists) {
+        for (int i = tid; i < seg_len; i += SORT_THREADS) {
+            if (s0 + i >= n) continue;
+            if (final_lists) {
+                bin.point_list[rg.x + s0 + i] = (uint32_t)(s_keys[i] & 0xffffffffu);
+                bin.slot_list[rg.x + s0 + i] = s_vals[i];
+            } else {
+                gk[s0 + i] = s_keys[i], gv[s0 + i] = s_vals[i];
+            }
+        }
+        __syncthreads();
+    };
+    const int nseg = n2 / seg_len;
+    // ---- every segment sorted on its own ----
+    for (int sg = 0; sg < nseg; sg++) {
+        load_segment(sg * seg_len);
+        runs_in_registers(true);
+        for (int k = 2 * SORTL_RUN; k <= seg_len; k <<= 1) {
+            lds_step(k, 0, true);
+            for (int j = k >> 2; j >= SORTL_RUN; j >>= 1) lds_step(k, j, false);
+            runs_in_registers(false);
+        }
+        store_segment(sg * seg_len, nseg == 1);
+    }
+    // ---- merges across segments ----
+    for (int k = 2 * seg_len; k <= n2 && nseg > 1; k <<= 1) {
+        for (int j = k >> 1; j >= seg_len; j >>= 1) {  // global steps: the flip at distance k, then half cleaners down to one segment
+            const bool flip = j == (k >> 1);
+            for (int t = tid; t < n2 / 2; t += SORT_THREADS) {
                 int i, p;
                 if (flip) {
-                    const int blk = t / j, off = t % j;
-                    i = blk * k + off;
-                    p = blk * k + k - 1 - off;
+                    const int blk = t / j, off = t - blk * j;
+                    i = blk * k + off, p = blk * k + k - 1 - off;
                 } else {
-                    i = 2 * j * (t / j) + (t % j);
-                    p = i + j;
+                    i = 2 * j * (t / j) + (t % j), p = i + j;
                 }
-                if (p < n) {  // ascending-comparator network: elements past n behave as +inf and never move
-                    const uint64_t a = keys[i], b = keys[p];
+                if (p < n) {  // (a partner past the end is +infinity: nothing to exchange)
+                    const uint64_t a = gk[i], b = gk[p];
                     if (a > b) {
-                        keys[i] = b;
-                        keys[p] = a;
-                        const uint32_t va = vals[i];
-                        vals[i] = vals[p];
-                        vals[p] = va;
+                        gk[i] = b, gk[p] = a;
+                        const uint32_t va = gv[i];
+                        gv[i] = gv[p], gv[p] = va;
                     }
                 }
             }
             __syncthreads();
         }
-    }
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(DqoImageLayout img, DqoBinLayout bin) {
-    __shared__ uint64_t s_keys[SORT_LDS_CAP];
-    __shared__ uint32_t s_vals[SORT_LDS_CAP];
-    const uint32_t tile = img.tile_order[blockIdx.x];  // [8][T8] slots, unused ones hold ~0
-    if (tile == 0xffffffffu) return;
-    const uint2 rg = img.ranges[tile];
-    const int n = (int)(rg.y - rg.x);
-    const int tid = threadIdx.x;
-    if (n <= SORTW_CAP) return;  // tile_sort_wave_kernel's
-    uint64_t* gk = bin.keys + rg.x;
-    uint32_t* gv = bin.slots + rg.x;
-    if (n <= SORT_LDS_CAP) {
-        for (int i = tid; i < n; i += SORT_THREADS) s_keys[i] = gk[i], s_vals[i] = gv[i];
-        __syncthreads();
-        bitonic_any(s_keys, s_vals, n, tid);
-        for (int i = tid; i < n; i += SORT_THREADS) {
-            bin.point_list[rg.x + i] = (uint32_t)(s_keys[i] & 0xffffffffu);
-            bin.slot_list[rg.x + i] = s_vals[i];
-        }
-    } else {
-        __syncthreads();
-        bitonic_any(gk, gv, n, tid);  // same block wrote / reads: __syncthreads orders global accesses within the block
-        for (int i = tid; i < n; i += SORT_THREADS) {
-            bin.point_list[rg.x + i] = (uint32_t)(gk[i] & 0xffffffffu);
-            bin.slot_list[rg.x + i] = gv[i];
+        const bool last = (k << 1) > n2;
+        for (int sg = 0; sg < nseg; sg++) {
+            if (sg * seg_len >= n) break;  // a segment of padding only
+            load_segment(sg * seg_len);
+            for (int j = seg_len >> 1; j >= SORTL_RUN; j >>= 1) lds_step(2 * j, j, false);
+            runs_in_registers(false);
+            store_segment(sg * seg_len, last);
         }
     }
 }
