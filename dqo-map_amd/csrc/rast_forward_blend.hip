@@ -110,24 +110,27 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
     const int chunks = (n + FWD_THREADS - 1) / FWD_THREADS;
     // prologue: loads of chunk 0
     int id_nx = 0;
-    float4 co_nx = make_float4(0.f, 0.f, 0.f, 0.f), xy_nx = co_nx;
+    float4 co_nx = make_float4(0.f, 0.f, 0.f, 0.f), xy_nx = co_nx, cs_nx = co_nx;
     if (lane < n) {
         id_nx = (int)bin.point_list[range.x + lane];
         co_nx = g.conic_opacity[id_nx];
         xy_nx = g.xy_depth[id_nx];
+        cs_nx = g.rgb_smax[id_nx];
     }
     bool all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;  // wave-uniform
     for (int c = 0; c < chunks && !all_done; c++) {  // a finished quadrant never looks at the entries further back
         const int pos = c * FWD_THREADS + lane;
         const int id = id_nx;
-        const float4 co = co_nx, xy = xy_nx;
-        // issue the next chunk's loads now; they complete while this chunk is blended
+        const float4 co = co_nx, xy = xy_nx, cs_me = cs_nx;
+        // issue the next chunk's loads now; they complete while this chunk is blended (all three records: a gather left for the
+        // compaction below would sit, unhidden, between the cull test and the first entry of every chunk)
         {
             const int pn = pos + FWD_THREADS;
             if (pn < n) {
                 id_nx = (int)bin.point_list[range.x + pn];
                 co_nx = g.conic_opacity[id_nx];
                 xy_nx = g.xy_depth[id_nx];
+                cs_nx = g.rgb_smax[id_nx];
             }
         }
         // which entries of this chunk can reach this quadrant at all (conservative, dqo_cull.h); compact them into LDS
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         if (reach) {
             s_co[myk] = co;
             s_xy[myk] = xy;
-            s_rgb[myk] = g.rgb_smax[id];
+            s_rgb[myk] = cs_me;
             s_id[myk] = id;
             s_pos[myk] = pos + 1;  // the reference's running counter `contributor` = list position + 1
         }
