@@ -585,14 +585,38 @@ __device__ __forceinline__ void pair_sort_tile(const DqoBinLayout& bin, uint32_t
 
 // one block (two waves) per tile slot; the second wave only works on lists longer than 512 entries
 constexpr int SORTW_THREADS = 128;
-__global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin) {
+// keep_order (DqoRastCtx.keep_tile_order, bucket mode): no tile_scan_kernel ran for this frame.  tile_order is the one an earlier
+// frame left in the image buffer (any permutation of the tiles gives the same results), a list's range follows from its own
+// counter, and the frame statistics the header needs go to the spread lines (words 2..3), which tile_sort_kernel's first block
+// sums up (header_from_spread).
+__global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g,
+                                                                       int64_t capacity, int keep_order) {
     __shared__ uint64_t s_key[2 * SORTP_RUN];
     __shared__ uint32_t s_val[2 * SORTP_RUN];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ti = blockIdx.x;
     const uint32_t tile = img.tile_order[ti];  // [8][T8] slots, unused ones hold ~0
-    if (tile == 0xffffffffu) return;
-    const uint2 rg = img.ranges[tile];
+    if (tile >= (uint32_t)T) return;
+    uint2 rg;
+    if (keep_order) {
+        const uint32_t c = img.tile_count[(size_t)tile * DQO_TSTRIDE];
+        // the slot tables are incomplete when the instance capacity ran out: every list is emptied, as tile_scan_kernel does; a
+        // list that outgrew its bucket is cut at the bucket (bin_count_kernel dropped the rest); both invalidate the frame
+        const bool lost = (int64_t)g.counters[0] > capacity;
+        const uint32_t n_keep = lost ? 0u : min(c, (uint32_t)bin.bucket);
+        const uint32_t first = tile * (uint32_t)bin.bucket;
+        rg = make_uint2(n_keep ? first : 0u, n_keep ? first + n_keep : 0u);
+        if (threadIdx.x == 0) {
+            img.ranges[tile] = rg;
+            if (c) {
+                uint32_t* const line = g.spread + (size_t)(ti % DQO_SPREAD) * 64;
+                atomicMax(&line[2], c);
+                atomicAdd(&line[3], 1u);
+            }
+        }
+    } else {
+        rg = img.ranges[tile];
+    }
     const int n = (int)(rg.y - rg.x);
     if (n <= 0 || n > SORTW_CAP) return;
     if (n > SORTP_RUN) {
@@ -618,11 +642,39 @@ __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, Dq
 constexpr int SORTL_SEG = 4096;
 constexpr int SORTL_RUN = SORTP_RUN;  // 512
 
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(DqoImageLayout img, DqoBinLayout bin) {
+// keep_order frames: the header tile_scan_kernel would have written, from the spread statistics lines (one wave)
+__device__ __forceinline__ void header_from_spread(const DqoGeomLayout& g, int64_t capacity, int bucket, int lane) {
+    uint32_t nv = 0, nc = 0, mx = 0, nt = 0;
+    for (int j = lane; j < DQO_SPREAD; j += 64) {
+        const uint32_t* line = g.spread + (size_t)j * 64;
+        nv += line[0], nc += line[1], mx = max(mx, line[2]), nt += line[3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        nv += __shfl_xor((int)nv, off), nc += __shfl_xor((int)nc, off), nt += __shfl_xor((int)nt, off);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    }
+    if (lane == 0) {
+        const uint32_t total = g.counters[0];  // instances counted by bin_count_kernel = the sum of the list lengths
+        DqoRastHeader h;
+        h.num_rendered = total;
+        h.num_tiles = nt;
+        h.overflow = ((int64_t)total > capacity || mx > (uint32_t)bucket) ? 1u : 0u;
+        h.max_tile_count = mx;
+        h.num_visible = nv;
+        h.num_candidates = nc;
+        h.reserved[0] = h.reserved[1] = 0;
+        *g.header = h;
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g, int64_t capacity,
+                                                                 int keep_order) {
     __shared__ uint64_t s_keys[SORTL_SEG];
     __shared__ uint32_t s_vals[SORTL_SEG];
+    if (keep_order && blockIdx.x == 0 && threadIdx.x < 64) header_from_spread(g, capacity, bin.bucket, (int)threadIdx.x);
     const uint32_t tile = img.tile_order[blockIdx.x];  // [8][T8] slots, unused ones hold ~0
-    if (tile == 0xffffffffu) return;
+    if (tile >= (uint32_t)T) return;
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
     if (n <= SORTW_CAP) return;  // tile_sort_wave_kernel's
@@ -808,15 +860,18 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
         int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap, s);
         if (rc) return rc;
     }
-    DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, cap, bucket);
+    // bucket mode with a tile_order kept from an earlier frame on the same image buffer: nothing of tile_scan_kernel is needed
+    // (ranges and header come from the sort kernels)
+    const int keep_order = (bucket > 0 && ctx->keep_tile_order != 0 && p->P > 0) ? 1 : 0;
+    if (!keep_order) DQO_LAUNCH("tile_scan_kernel", tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), s, T, img, g, cap, bucket);
     if (p->P > 0) {
         if (bucket <= 0) {  // (bucket mode: bin_count_kernel has already written every instance to tile * bucket + rank)
             int rc = dqo_launch_bin_place(g, img, bin, cap, s);
             if (rc) return rc;
         }
         const int slots = 8 * ((T + 7) / 8);  // tile_order is [8][T8]
-        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin);
-        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(slots), dim3(SORT_THREADS), s, img, bin);
+        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order);
+        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(slots), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
     }
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, s);
 }

@@ -214,7 +214,7 @@ class FusedMapper:
                     init_rotation_raw=N.ptr(self.init_rotation), attach_count=self.attach_count, attach_partial=N.ptr(self.attach_partial))
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
-    def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True):
+    def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
 
@@ -309,6 +309,9 @@ class FusedMapper:
             torch.cuda.current_stream().wait_stream(side)
             if not self.graph_overflowed():  # (an invalid frame is a no-op for the optimiser and its step count)
                 self.step_count += 1
+            # the eager iteration left its tile launch order in g.img; the replays keep it (DqoRastCtx.keep_tile_order: the order is
+            # a scheduling hint, and the lists of one camera change little between the iterations of a mapping call)
+            g.cctx.keep_tile_order = 1 if (g.bucket > 0 and keep_tile_order) else 0
             g.graph = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (e.g. a collective library's watchdog) may keep issuing runtime calls
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):

@@ -107,6 +107,12 @@ typedef struct DqoRastCtx {
      * of inst_capacity (outputs invalid, nothing written out of bounds) — for callers that can re-run, like the captured mapping
      * iteration.  Same lists, same order, same results as the packed mode. */
     int32_t tile_bucket_capacity;
+    /* Bucket mode only.  Non-zero: keep the tile launch order (longest list first, XCD bands) that an earlier forward left in
+     * `image` instead of recomputing it — the caller guarantees that a forward with this flag at 0 has run on this `image` buffer
+     * for the same W x H (the order only decides which workgroup renders which tile, never a result, so an order computed for a
+     * slightly different state of the map is as good).  The one-block scan kernel between binning and sort then disappears: list
+     * ranges follow from the tile counters, the header from per-line statistics.  For a captured iteration that is replayed. */
+    int32_t keep_tile_order;
 } DqoRastCtx;
 
 /* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206).  dL_dcolors, dL_dcov3D and

@@ -237,13 +237,27 @@ def test_tile_buckets_match_packed_lists(env):
         assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), k
     for x, y in zip(a._g.out, b._g.out):
         assert torch.equal(x, y)
+    # DqoRastCtx.keep_tile_order: the replays of `a` ran without tile_scan_kernel (launch order kept from the capture's eager
+    # iteration, ranges and header produced by the sort kernels) — the header must still be the one the scan kernel writes
+    assert a._g.cctx.keep_tile_order == 1 and b._g.cctx.keep_tile_order == 0
+    assert a.header() == b.header() and a.header()["num_rendered"] > 0 and a.header()["num_tiles"] > 0
+    d = FusedMapper(scene, settings, dev)
+    d.capture(gt_color, gt_depth, mask, tile_buckets=True, keep_tile_order=False)
+    for _ in range(3):
+        d.replay()
+    torch.cuda.synchronize()
+    assert d._g.cctx.keep_tile_order == 0 and d.header() == a.header()
+    for k, pa in a._params().items():
+        assert torch.equal(pa, d._params()[k]), k
     # a bucket smaller than the longest list: flagged, never silent
     c = FusedMapper(scene, settings, dev)
     c.capture(gt_color, gt_depth, mask, tile_buckets=True)
     c._g.cctx.tile_bucket_capacity = 8  # (the buffers are sized for the larger bucket: still in bounds)
-    c._static_iteration()
-    torch.cuda.synchronize()
-    assert c.graph_overflowed()
+    for keep in (1, 0):
+        c._g.cctx.keep_tile_order = keep
+        c._static_iteration()
+        torch.cuda.synchronize()
+        assert c.graph_overflowed() and c.header()["max_tile_count"] > 8
 
 
 def test_graph_capacity_overflow_is_flagged(env):
