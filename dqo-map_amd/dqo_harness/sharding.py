@@ -13,8 +13,8 @@ import numpy as np
 
 
 def assign_objects(obj_sizes, world):
-    """Longest-processing-time greedy: objects sorted by Gaussian count, each to the currently lightest shard.
-    obj_sizes: {object id: #Gaussians}.  Returns {object id: shard}."""
+    """Longest-processing-time greedy: objects sorted by size, each to the currently lightest shard.
+    obj_sizes: {object id: #Gaussians or any other cost}.  Returns {object id: shard}."""
     load = [0] * world
     out = {}
     for k, n in sorted(obj_sizes.items(), key=lambda kv: (-kv[1], kv[0])):
@@ -30,11 +30,28 @@ def shard_indices(obj_id, assignment, rank):
     return np.nonzero(owner == rank)[0]
 
 
-def shard_scene(scene, rank, world):
-    ids, counts = np.unique(scene["obj_id"], return_counts=True)
-    assignment = assign_objects({int(k): int(c) for k, c in zip(ids, counts)}, world)
+def shard_scene(scene, rank, world, work=None):
+    """(the rank's Gaussians, {object id: shard}).  Objects are balanced over the shards by their Gaussian counts, or — `work`, one
+    non-negative number per Gaussian, e.g. the tiles it covers in the current view (view_work) — by the sum of `work` over the
+    object's Gaussians: a shard's time follows the instances its objects put on screen, not how many Gaussians it stores."""
+    ids, inv, counts = np.unique(scene["obj_id"], return_inverse=True, return_counts=True)
+    if work is None:
+        sizes = {int(k): int(c) for k, c in zip(ids, counts)}
+    else:
+        w = np.bincount(inv, weights=np.asarray(work, np.float64), minlength=len(ids))
+        # (the Gaussian count only breaks ties, e.g. between objects that are out of view)
+        sizes = {int(k): float(w[j]) + 1e-3 * int(c) for j, (k, c) in enumerate(zip(ids, counts))}
+    assignment = assign_objects(sizes, world)
     keep = shard_indices(scene["obj_id"], assignment, rank)
     return {k: v[keep] for k, v in scene.items()}, assignment
+
+
+def view_work(radii):
+    """Per-Gaussian work estimate in one view from the op's `radii` output: the tiles inside the bounding square of radius r that
+    the reference lists the Gaussian in (forward.cu:344-353) — 0 for culled Gaussians."""
+    r = np.asarray(radii, np.float64)
+    side = np.floor(2.0 * r / 16.0) + 2.0
+    return np.where(r > 0, side * side, 0.0)
 
 
 def tile_mask_from_pixel_mask(pixel_mask):

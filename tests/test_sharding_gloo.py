@@ -168,3 +168,27 @@ def test_assignment_balanced():
     pm[17, 33] = True
     tm = sharding.tile_mask_from_pixel_mask(pm)
     assert tm.shape == (3, 4) and tm.sum() == 1 and tm[1, 2] == 1
+
+
+def test_assignment_by_view_work():
+    """shard_scene(work=...): objects go to the ranks by the work they put on screen in the current view, not by how many Gaussians
+    they store; the assignment is a pure function of (obj_id, work), so every rank computes the same one without an exchange."""
+    rng = np.random.default_rng(3)
+    obj = rng.integers(0, 8, 4000)
+    radii = rng.integers(0, 40, 4000)
+    radii[obj >= 6] = 0            # two objects entirely out of view
+    radii[obj == 0] *= 4           # one object that fills the screen
+    work = sharding.view_work(radii)
+    assert (work[radii == 0] == 0).all() and (work[radii > 0] >= 4).all()
+    np.testing.assert_array_equal(sharding.view_work(np.array([0, 1, 8, 24])), [0, 4, 9, 25])  # (2r/16 + 2)^2 tiles
+    scene = dict(obj_id=obj, xyz=rng.normal(size=(4000, 3)))
+    per_obj = np.bincount(obj, weights=work, minlength=8)
+    for world in (2, 4):
+        parts = [sharding.shard_scene(scene, r, world, work=work) for r in range(world)]
+        assert all(p[1] == parts[0][1] for p in parts)  # same assignment on every rank
+        assert sum(len(p[0]["obj_id"]) for p in parts) == 4000
+        load = np.array([sum(per_obj[k] for k, s in parts[0][1].items() if s == r) for r in range(world)])
+        assert load.max() <= max(per_obj.max(), 1.34 * load.sum() / world)
+        by_count = sharding.shard_scene(scene, 0, world)[1]
+        load_c = np.array([sum(per_obj[k] for k, s in by_count.items() if s == r) for r in range(world)])
+        assert load.max() <= load_c.max()  # never worse than the count-balanced assignment on the quantity that costs time
