@@ -210,6 +210,8 @@ struct AdamArgs {
     float attach_g3, attach_g4;                                                   // 2000 / (3 |a|), 2000 / (4 |a|)
     float* attach_partial;
     const DqoRastHeader* frame_header;                                            // optional: overflow flag => the launch is a no-op
+    int32_t* step_advance;                                                        // optional: the last block to finish adds 1 to it
+    int32_t* block_ticket;                                                        // (with step_advance) blocks finished so far
 };
 
 // The moments and the gradients are touched exactly once per iteration (0.7 GB of the kernel's 0.83 GB): non-temporal loads /
@@ -248,11 +250,27 @@ __global__ void adam_advance_kernel(int32_t* step_dev, const DqoRastHeader* fram
 constexpr int ADAM_THREADS = 256;
 
 template <bool SPARSE, bool ATTACH>
-__global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a_in, uint8_t* __restrict__ moment_live) {
-    AdamArgs a = a_in;
+__device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ moment_live);
+
+template <bool SPARSE, bool ATTACH>
+__global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a, uint8_t* __restrict__ moment_live) {
     // A frame flagged invalid by the forward (instance capacity / tile bucket exceeded: lists emptied, every gradient zero) must
     // not train: nothing is read or written, the caller re-captures and continues from the state it had.
     if (a.frame_header != nullptr && a.frame_header->overflow != 0u) return;
+    adam_block<SPARSE, ATTACH>(a, moment_live);
+    // DqoAdamStep.block_ticket: the device-side step count advances inside this launch — every block has read it at its start, so
+    // the block that takes the last ticket may bump it (and hands the ticket counter back at zero for the next launch)
+    // (no fence: the only ordering needed is "read of the step count before the ticket", and that load has long been consumed)
+    if (a.step_advance != nullptr && threadIdx.x == 0) {
+        if (atomicAdd(a.block_ticket, 1) == (int)gridDim.x - 1) {
+            *a.block_ticket = 0;
+            *a.step_advance += 1;
+        }
+    }
+}
+
+template <bool SPARSE, bool ATTACH>
+__device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ moment_live) {
     __shared__ uint32_t s_rows[ADAM_THREADS];  // Gaussian index | has-gradient << 31 | attach-loss member << 30
     __shared__ float s_att[ADAM_THREADS / 64];
     __shared__ int s_wave_n[ADAM_THREADS / 64];
@@ -480,6 +498,9 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.lr_rotation = st->lr_rotation;
     a.attach_mask = st->attach_mask, a.init_xyz = st->init_xyz, a.init_scaling = st->init_scaling_raw, a.init_rotation = st->init_rotation_raw;
     a.attach_partial = st->attach_partial, a.frame_header = st->frame_header;
+    const int blocks = (st->P + ADAM_THREADS - 1) / ADAM_THREADS;
+    const bool advance_inside = st->step_dev != nullptr && st->block_ticket != nullptr && blocks > 0;
+    a.step_advance = advance_inside ? st->step_dev : nullptr, a.block_ticket = st->block_ticket;
     const bool attach = st->attach_mask != nullptr && st->attach_count > 0;
     DQO_CHECK_ARG(!attach || (st->init_xyz && st->init_scaling_raw && st->init_rotation_raw), "attach_mask needs the three init_* tensors");
     DQO_CHECK_ARG(st->P < (1 << 30), "P must stay below 2^30");
@@ -490,7 +511,6 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.row_magic = st->M > 0 ? ((1ull << 39) + (uint64_t)(3 * st->M) - 1) / (uint64_t)(3 * st->M) : 0ull;
     DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");
     DQO_CHECK_ARG(st->moment_live == nullptr || st->radii != nullptr, "moment_live needs radii");
-    const int blocks = (st->P + ADAM_THREADS - 1) / ADAM_THREADS;
     if (blocks > 0) {  // (an empty map still advances the step count)
         if (st->moment_live != nullptr) {
             if (attach) DQO_LAUNCH("adam_kernel", (adam_kernel<true, true>), dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
@@ -500,7 +520,7 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
             else DQO_LAUNCH("adam_kernel", (adam_kernel<false, false>), dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);
         }
     }
-    if (st->step_dev != nullptr)
+    if (st->step_dev != nullptr && !advance_inside)
         DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev, st->frame_header);
     return DQO_OK;
 }

@@ -274,6 +274,7 @@ class FusedMapper:
             g.grads = dict(means3D=torch.empty((P, 3), **f), sh=torch.empty((P, M, 3), **f),
                            opacity=torch.empty((P, 1), **f), scales=torch.empty((P, 3), **f), rot=torch.empty((P, 4), **f))
             g.step_dev = torch.full((1,), self.step_count + 1, **i32)
+            g.ticket = torch.zeros((1,), **i32)  # DqoAdamStep.block_ticket: the Adam launch advances step_dev itself
             g.params = dgr._params(st, P, M)
             g.inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, g.tile_mask)
             o = g.out
@@ -300,7 +301,8 @@ class FusedMapper:
                                    v_shs=N.ptr(stt["shs"][1]), v_opacity=N.ptr(stt["opacity"][1]), v_scaling=N.ptr(stt["scaling"][1]),
                                    v_rotation=N.ptr(stt["rotation"][1]), act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales),
                                    act_rotations=N.ptr(self.rotations), radii=o[8].data_ptr(), step_dev=g.step_dev.data_ptr(),
-                                   moment_live=N.ptr(self.moment_live), frame_header=g.geom.data_ptr(), **self._attach_fields())
+                                   moment_live=N.ptr(self.moment_live), frame_header=g.geom.data_ptr(), block_ticket=g.ticket.data_ptr(),
+                                   **self._attach_fields())
             # one eager iteration on a side stream (warms every kernel up), then the capture
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())

@@ -314,6 +314,9 @@ typedef struct DqoAdamStep {
      * moments, moment_live and the device step count stay as they were, so the caller can re-capture with a larger capacity and
      * continue from a clean optimiser state. */
     const DqoRastHeader* frame_header;
+    /* Optional, with step_dev: one int32, zero before the first launch (it is zero again after every launch).  The block that
+     * finishes last advances *step_dev inside the Adam launch itself; NULL = a separate one-thread kernel does it afterwards. */
+    int32_t* block_ticket;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
 

@@ -1,0 +1,17 @@
+#!/bin/bash
+# End-of-round measurements on one MI355X (run through gpurun): default bench, rocprofv3 kernel stats of the same command, the other
+# BASELINE maps, the SQ counters of the blend kernels.  Results under gpurun_out/final/ (copied to profiles/r02_b_* afterwards).
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
+out=gpurun_out/final; mkdir -p $out
+timeout -k 10 500 python bench.py > $out/bench_cfg3.json 2> $out/bench_cfg3.err || exit 1
+echo "cfg3 done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks --output-format csv -- python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-pmc --no-aux > $out/ks.log 2>&1 || exit 1
+cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
+echo "kernel stats done"
+for c in 2 4 5; do
+  steps=50; [ $c = 5 ] && steps=300   # cfg 5: three growth steps (every 100 iterations) inside the timed region
+  timeout -k 10 500 python bench.py --cfg $c --steps $steps --no-cpu-baseline > $out/bench_cfg$c.json 2> $out/bench_cfg$c.err || exit 1
+  echo "cfg$c done"
+done
+timeout -k 10 300 python bench.py --cfg 5 --growth-every 0 --no-cpu-baseline --no-pmc --no-aux > $out/bench_cfg5_nogrowth.json 2> $out/bench_cfg5_nogrowth.err || exit 1
+echo "all done"
