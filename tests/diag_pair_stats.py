@@ -1,6 +1,6 @@
-"""Workload statistics of the blend loops from the CPU oracle (test infrastructure used as an analysis tool, never by the product):
+"""Diagnostic (lives under tests/ because it runs the CPU oracle, which is test infrastructure): workload statistics of the blend loops:
 for every list entry of every tile the set of pixels that has arithmetic for it, and from that how well different wave -> pixel
-mappings of a blend kernel would be utilised.   python tools/pair_stats.py [cfg] [P]"""
+mappings of a blend kernel would be utilised.   python tests/diag_pair_stats.py [cfg] [P]"""
 import os, sys
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

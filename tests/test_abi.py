@@ -88,3 +88,8 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle_lib" not in txt and "libdqo_oracle" not in txt, f"{f} references the oracle"
+    # the analysis scripts under tools/ run on the product only (diagnostics that need the oracle live under tests/)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert "from oracle" not in txt and "import oracle" not in txt and "libdqo_oracle" not in txt, f"tools/{f} references the oracle"
