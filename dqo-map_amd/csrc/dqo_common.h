@@ -105,6 +105,7 @@ struct DqoImageLayout {
     uint32_t* n_contrib;    // [HW] last contributor, 1-based (forward.cu:850)
     uint32_t* hit_pos;      // [HW] bits 0..30: 1-based list position of the Gaussian that fixed the depth, 0 if none;
                             //      bit 31: the backward's ray/plane-depth branch applies to it (backward.cu:1016)
+    uint32_t* long_tiles;   // [T] queue of the tiles whose lists are too long for tile_sort_wave_kernel (count: geom counters[1])
     size_t total;
 };
 
@@ -127,6 +128,7 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
     L.final_T = (float*)take(4 * HW);
     L.n_contrib = (uint32_t*)take(4 * HW);
     L.hit_pos = (uint32_t*)take(4 * HW);
+    L.long_tiles = (uint32_t*)take(4 * T);
     L.total = (size_t)(p - (char*)base);
     return L;
 }

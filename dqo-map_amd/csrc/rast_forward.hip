@@ -424,7 +424,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
 //   tile_sort_kernel : longer lists, one block per tile: registers + LDS + (beyond 4096 entries) in-place steps in
 //       global memory (correctness path, not a fast path).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int SORT_THREADS = 256;
+constexpr int SORT_THREADS = 512;   // tile_sort_kernel: eight waves = the eight 512-key runs of a 4096-key segment in one round
+constexpr int SORT_GRID = 768;      // its persistent grid: 256 CUs x 3 blocks of 48 KB LDS
 constexpr int SORTW_CAP = 1024;
 
 // The value of lane ^ D, D a power of two, without the LDS crossbar (ds_bpermute costs 20-60 cycles per dependent use and shares
@@ -618,7 +619,11 @@ __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, Dq
         rg = img.ranges[tile];
     }
     const int n = (int)(rg.y - rg.x);
-    if (n <= 0 || n > SORTW_CAP) return;
+    if (n <= 0) return;
+    if (n > SORTW_CAP) {  // tile_sort_kernel's: queued (the blocks run longest list first, so the queue is close to that order too)
+        if (threadIdx.x == 0) img.long_tiles[atomicAdd(&g.counters[1], 1u)] = tile;
+        return;
+    }
     if (n > SORTP_RUN) {
         pair_sort_tile(bin, rg.x, n, lane, wave, s_key, s_val);
         return;
@@ -630,7 +635,8 @@ __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, Dq
     else wave_sort_tile<8>(bin, rg.x, n, lane);
 }
 
-// Lists longer than SORTW_CAP: one 256-thread block per tile, three levels of the same ascending network.
+// Lists longer than SORTW_CAP: queued by tile_sort_wave_kernel (img.long_tiles, geom counters[1]) and sorted by a persistent grid of
+// 512-thread blocks, one tile at a time per block, through three levels of the same ascending network.
 //   registers : runs of 512 keys, one wave each (wave_bitonic<8>): every compare-exchange at distance < 512
 //   LDS       : segments of SORTL_SEG = 4096 keys: the merge steps at distance 512 .. 2048 (flip step + half cleaners), after which
 //               each run finishes in registers again (wave_bitonic_phase)
@@ -673,12 +679,12 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImage
     __shared__ uint64_t s_keys[SORTL_SEG];
     __shared__ uint32_t s_vals[SORTL_SEG];
     if (keep_order && blockIdx.x == 0 && threadIdx.x < 64) header_from_spread(g, capacity, bin.bucket, (int)threadIdx.x);
-    const uint32_t tile = img.tile_order[blockIdx.x];  // [8][T8] slots, unused ones hold ~0
-    if (tile >= (uint32_t)T) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t n_long = min(g.counters[1], (uint32_t)T);  // tiles queued by tile_sort_wave_kernel
+    for (uint32_t q = blockIdx.x; q < n_long; q += gridDim.x) {  // (block-uniform trip count; every helper ends with a barrier)
+    const uint32_t tile = img.long_tiles[q];
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
-    if (n <= SORTW_CAP) return;  // tile_sort_wave_kernel's
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint64_t* gk = bin.keys + rg.x;
     uint32_t* gv = bin.slots + rg.x;
     int n2 = 2 * SORTL_RUN;
@@ -784,6 +790,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImage
             store_segment(sg * seg_len, last);
         }
     }
+    }  // queue loop
 }
 
 // Zero fill of the per-frame scalars (header, slot allocator, statistics counters).  A kernel, not hipMemsetAsync: as a memset NODE
@@ -871,7 +878,7 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
         }
         const int slots = 8 * ((T + 7) / 8);  // tile_order is [8][T8]
         DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order);
-        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(slots), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
+        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
     }
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, s);
 }
