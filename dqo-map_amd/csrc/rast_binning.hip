@@ -217,8 +217,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
                         // ranges in the packed mode); an instance beyond the bucket is dropped — tile_scan_kernel flags the frame
                         if (rank[u] < (uint32_t)bin.bucket) {
                             const size_t pos = (size_t)tile[u] * (size_t)bin.bucket + rank[u];
-                            bin.keys[pos] = ((uint64_t)__float_as_uint(depth[u]) << 32) | (uint32_t)gid[u];
-                            bin.slots[pos] = slot[u];
+                            bin.recs[pos] = make_uint4((uint32_t)gid[u], __float_as_uint(depth[u]), slot[u], 0u);
                         }
                     } else {
                         bin.slot_info[slot[u]] = make_uint2((uint32_t)tile[u], rank[u]);
@@ -248,8 +247,7 @@ __global__ __launch_bounds__(256) void bin_place_kernel(DqoGeomLayout g, DqoImag
         bin.rec_valid[slot] = 0u;
         return;
     }
-    bin.keys[pos] = ((uint64_t)__float_as_uint(g.xy_depth[gid].z) << 32) | gid;
-    bin.slots[pos] = (uint32_t)slot;
+    bin.recs[pos] = make_uint4(gid, __float_as_uint(g.xy_depth[gid].z), (uint32_t)slot, 0u);
     bin.rec_valid[slot] = 0u;  // no partial gradient record of this slot exists yet (backward)
 }
 

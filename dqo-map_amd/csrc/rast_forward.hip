@@ -528,8 +528,9 @@ __device__ __forceinline__ void wave_sort_tile(const DqoBinLayout& bin, uint32_t
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const int i = lane * E + r;
-        key[r] = i < n ? bin.keys[base + i] : ~0ull;  // padding sorts behind every real key (depth bits of a finite float)
-        val[r] = i < n ? bin.slots[base + i] : 0u;
+        const uint4 e = i < n ? bin.recs[base + i] : make_uint4(~0u, ~0u, 0u, 0u);  // padding sorts behind every real key
+        key[r] = ((uint64_t)e.y << 32) | e.x;                                        // (depth bits of a finite float)
+        val[r] = e.z;
     }
     wave_bitonic<E>(key, val, lane);
 #pragma unroll
@@ -557,8 +558,9 @@ __device__ __forceinline__ void pair_sort_tile(const DqoBinLayout& bin, uint32_t
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const int i = run0 + lane * E + r;
-        key[r] = i < n ? bin.keys[base + i] : ~0ull;  // padding sorts behind every real key
-        val[r] = i < n ? bin.slots[base + i] : 0u;
+        const uint4 e = i < n ? bin.recs[base + i] : make_uint4(~0u, ~0u, 0u, 0u);  // padding sorts behind every real key
+        key[r] = ((uint64_t)e.y << 32) | e.x;
+        val[r] = e.z;
     }
     wave_bitonic<E>(key, val, lane);
 #pragma unroll
@@ -685,8 +687,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImage
     const uint32_t tile = img.long_tiles[q];
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
-    uint64_t* gk = bin.keys + rg.x;
-    uint32_t* gv = bin.slots + rg.x;
+    uint4* gr = bin.recs + rg.x;
     int n2 = 2 * SORTL_RUN;
     while (n2 < n) n2 <<= 1;
     const int seg_len = min(n2, SORTL_SEG);
@@ -729,8 +730,9 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImage
     auto load_segment = [&](int s0) {
         for (int i = tid; i < seg_len; i += SORT_THREADS) {
             const bool in = s0 + i < n;
-            s_keys[i] = in ? gk[s0 + i] : ~0ull;  // padding sorts behind every real key (depth bits of a finite float)
-            s_vals[i] = in ? gv[s0 + i] : 0u;
+            const uint4 e = in ? gr[s0 + i] : make_uint4(~0u, ~0u, 0u, 0u);  // padding sorts behind every real key
+            s_keys[i] = ((uint64_t)e.y << 32) | e.x;
+            s_vals[i] = e.z;
         }
         __syncthreads();
     };
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImage
                 bin.point_list[rg.x + s0 + i] = (uint32_t)(s_keys[i] & 0xffffffffu);
                 bin.slot_list[rg.x + s0 + i] = s_vals[i];
             } else {
-                gk[s0 + i] = s_keys[i], gv[s0 + i] = s_vals[i];
+                gr[s0 + i] = make_uint4((uint32_t)s_keys[i], (uint32_t)(s_keys[i] >> 32), s_vals[i], 0u);
             }
         }
         __syncthreads();
@@ -771,12 +773,8 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImage
                     i = 2 * j * (t / j) + (t % j), p = i + j;
                 }
                 if (p < n) {  // (a partner past the end is +infinity: nothing to exchange)
-                    const uint64_t a = gk[i], b = gk[p];
-                    if (a > b) {
-                        gk[i] = b, gk[p] = a;
-                        const uint32_t va = gv[i];
-                        gv[i] = gv[p], gv[p] = va;
-                    }
+                    const uint4 a = gr[i], b = gr[p];
+                    if ((((uint64_t)a.y << 32) | a.x) > (((uint64_t)b.y << 32) | b.x)) gr[i] = b, gr[p] = a;
                 }
             }
             __syncthreads();

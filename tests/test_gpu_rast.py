@@ -125,8 +125,8 @@ def test_binning_exact(torch_cuda, oracle):
     gx = (cam.W + 15) // 16
     T = gx * ((cam.H + 15) // 16)
     al = lambda n: (n + 255) // 256 * 256
-    # binning layout: keys u64[cap] | slots u32[cap] | point_list u32[cap] | slot_list u32[cap], each 256-B aligned
-    off_pl = al(8 * Nn) + al(4 * Nn)
+    # binning layout: unsorted 16-byte list records [cap] | point_list u32[cap] | slot_list u32[cap], each 256-B aligned
+    off_pl = al(16 * Nn)
     pl = binning[off_pl:off_pl + 4 * Nn].view(torch.int32).cpu().numpy().astype(np.uint32)
     # image layout: tile_count (one counter per 64 words) | tile_flag | tile_cursor (same stride) | ranges ...  (dqo_common.h)
     off_rg = 2 * al(4 * T * 64) + al(4 * T)
