@@ -40,6 +40,8 @@ int dqo_launch_icp(int H, int W, const float* vertex0, const float* vertex1, con
 int dqo_launch_tile_count(int W, int H, int mode, const uint8_t* mask_in, const float* T_map, uint8_t* mask_out, int32_t* tile_count,
                           int32_t* total, hipStream_t s);
 int dqo_launch_tile_color_error(int W, int H, const float* render, const float* gt, float* err_px, float* tile_sum, hipStream_t s);
+int dqo_launch_accumulate_confidence(int H, int W, int P, const int32_t* index, const float* confidence, float* gmax, float* gmin,
+                                     float* gmean, int32_t* counter, hipStream_t s);
 int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, const float* depth_err, const float* normal_err,
                                 const int32_t* color_index, const int32_t* depth_index, float color_thr, float depth_thr,
                                 float normal_thr, int check_max, float* gs_color, float* gs_depth, float* gs_normal, float* rescale,
@@ -310,6 +312,16 @@ DQO_API int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const
     DQO_CHECK_ARG(check_max || counters, "mean mode needs the counters scratch buffer");
     return dqo_launch_accumulate_error(H, W, P, ce, de, ne, ci, di, color_thr, depth_thr, normal_thr, check_max, gs_color, gs_depth,
                                        gs_normal, rescale, counters, (hipStream_t)stream);
+}
+
+DQO_API int dqo_accumulate_gaussian_confidence(int32_t H, int32_t W, int32_t P, const int32_t* gaussian_index_map,
+                                               const float* gaussian_confidence_map, float* gs_max, float* gs_min, float* gs_mean,
+                                               int32_t* counter, void* stream) {
+    DQO_CHECK_ARG(H > 0 && W > 0 && P >= 0, "bad sizes");
+    if (P == 0) return DQO_OK;
+    DQO_CHECK_ARG(gaussian_index_map && gaussian_confidence_map && gs_max && gs_min && gs_mean && counter, "null pointer");
+    return dqo_launch_accumulate_confidence(H, W, P, gaussian_index_map, gaussian_confidence_map, gs_max, gs_min, gs_mean, counter,
+                                            (hipStream_t)stream);
 }
 
 DQO_API int dqo_tile_count_mask(int32_t W, int32_t H, const uint8_t* pixel_mask, int32_t* tile_count, void* stream) {

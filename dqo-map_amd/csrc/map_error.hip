@@ -1,7 +1,8 @@
 // Per-Gaussian error accumulation for gfx950 — replaces
 // /root/reference/submodules/cuda_utils/map_process.cu:33-245 (acuumulate_error_preprocessCUDA, accumulate_error_meanCUDA) and
 // cuda_utils.cu:17-62 (accumulate_gaussian_error): scatter the per-pixel colour / depth / normal errors onto the Gaussians
-// named by the rasteriser's hit-index maps (max or mean), and count per Gaussian how many pixels exceed the thresholds.
+// named by the rasteriser's hit-index maps (max or mean), and count per Gaussian how many pixels exceed the thresholds; and
+// map_process.cu:247-360 (accumulate_gaussian_confidence), further down.
 //
 // The reference implements float atomicMax as a compare-and-swap loop.  The accumulators start at 0 and only values that
 // compare greater replace them, so only strictly positive floats ever win — and for positive floats the IEEE bit pattern
@@ -59,7 +60,65 @@ __global__ void error_mean_kernel(int P, const int32_t* __restrict__ counters, f
     }
 }
 
+// ---- accumulate_gaussian_confidence (map_process.cu:247-360, cuda_utils.cu:62-83) --------------------------------------------
+// Per Gaussian named by an index map: count, sum, maximum and minimum of a per-pixel confidence; afterwards mean = sum / count, and
+// Gaussians that no pixel named get 0 in all three.  The reference's float atomicMax / atomicMin are compare-and-swap loops that
+// replace only on a strict comparison (NaN never wins).  Here: one hardware integer atomic per value — non-negative floats order like
+// their bit patterns as signed integers, negative floats in reverse as unsigned integers, and the two cases compose because the
+// accumulators start at -FLT_MAX / +FLT_MAX (cuda_utils.cu:71-72).
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+    if (v != v) return;
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+    if (v != v) return;
+    if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void confidence_init_kernel(int P, int32_t* __restrict__ counter, float* __restrict__ gmax, float* __restrict__ gmin,
+                                       float* __restrict__ gmean) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    counter[i] = 0, gmean[i] = 0.f, gmax[i] = -3.402823466e+38f, gmin[i] = 3.402823466e+38f;
+}
+
+__global__ __launch_bounds__(256) void accumulate_confidence_kernel(int HW, int P, const float* __restrict__ confidence,
+                                                                    const int32_t* __restrict__ index, int32_t* __restrict__ counter,
+                                                                    float* __restrict__ gmax, float* __restrict__ gmin,
+                                                                    float* __restrict__ gmean) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const int gi = index[i];
+    if (gi < 0 || gi >= P) return;
+    const float c = confidence[i];
+    atomicAdd(&counter[gi], 1);
+    atomicAdd(&gmean[gi], c);
+    atomic_max_f32(&gmax[gi], c);
+    atomic_min_f32(&gmin[gi], c);
+}
+
+__global__ void confidence_mean_kernel(int P, const int32_t* __restrict__ counter, float* __restrict__ gmax, float* __restrict__ gmin,
+                                       float* __restrict__ gmean) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int n = counter[i];
+    if (n > 0) gmean[i] = gmean[i] / n;
+    else gmean[i] = 0.f, gmax[i] = 0.f, gmin[i] = 0.f;
+}
+
 }  // namespace
+
+int dqo_launch_accumulate_confidence(int H, int W, int P, const int32_t* index, const float* confidence, float* gmax, float* gmin,
+                                     float* gmean, int32_t* counter, hipStream_t s) {
+    const int HW = H * W;
+    DQO_LAUNCH("confidence_init_kernel", confidence_init_kernel, dim3((P + 255) / 256), dim3(256), s, P, counter, gmax, gmin, gmean);
+    DQO_LAUNCH("accumulate_confidence_kernel", accumulate_confidence_kernel, dim3((HW + 255) / 256), dim3(256), s, HW, P, confidence,
+               index, counter, gmax, gmin, gmean);
+    DQO_LAUNCH("confidence_mean_kernel", confidence_mean_kernel, dim3((P + 255) / 256), dim3(256), s, P, counter, gmax, gmin, gmean);
+    return DQO_OK;
+}
 
 int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, const float* depth_err, const float* normal_err,
                                 const int32_t* color_index, const int32_t* depth_index, float color_thr, float depth_thr,

@@ -247,6 +247,14 @@ int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const float* 
                                   float normal_threshold, int32_t check_max, float* gs_color_error, float* gs_depth_error,
                                   float* gs_normal_error, float* gs_rescale_counter, int32_t* counters, void* hipStream);
 
+/* dqo_accumulate_gaussian_confidence <- cuda_utils._C.accumulate_gaussian_confidence (submodules/cuda_utils/ext.cpp:7,
+ * cuda_utils.cu:62-83, map_process.cu:247-360; exported by the reference's extension, no Python caller in the reference).  Maps are
+ * [H*W]; per Gaussian named by gaussian_index_map (entries outside [0, P) are skipped): maximum, minimum and mean of the confidence
+ * over its pixels, 0 / 0 / 0 for a Gaussian no pixel names.  Outputs [P] fully written; `counter` is int32 [P] scratch. */
+int dqo_accumulate_gaussian_confidence(int32_t H, int32_t W, int32_t P, const int32_t* gaussian_index_map,
+                                       const float* gaussian_confidence_map, float* gs_confidence_max, float* gs_confidence_min,
+                                       float* gs_confidence_mean, int32_t* counter, void* hipStream);
+
 /* Row f3 — tile-mask producers of the mapping loop (SLAM/utils.py:720-799, SLAM/multiprocess/mapper.py:930-988), 16x16 tiles
  * with the reference's zero padding (a tile is always divided by 256).  All pointers are device pointers.
  *   dqo_tile_count_mask:   tile_count[t] = number of non-zero pixels of a uint8 pixel mask in tile t

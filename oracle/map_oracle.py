@@ -102,6 +102,30 @@ def accumulate_gaussian_error(H, W, P, color_err, depth_err, normal_err, color_i
     return gc.reshape(P, 1), gd.reshape(P, 1), gn.reshape(P, 1), rs.reshape(P, 1)
 
 
+def accumulate_gaussian_confidence(H, W, P, index_map, confidence_map):
+    """/root/reference/submodules/cuda_utils/map_process.cu:247-360 + cuda_utils.cu:62-83 restated with numpy scatter ops:
+    (max [P,1], min [P,1], mean [P,1]) of the confidence over the pixels that name each Gaussian; 0 / 0 / 0 where none does.  The
+    reference's float atomicMax / atomicMin replace on a strict comparison only, so NaN never wins.  PARITY STATUS: unpinned by
+    reference tests (CUDA source, no fixtures, no caller); max / min are order-independent and exact, the mean is compared with a
+    tolerance."""
+    f = np.float32
+    conf = np.asarray(confidence_map, f).reshape(-1)[:H * W]
+    idx = np.asarray(index_map, np.int64).reshape(-1)[:H * W]
+    ok = (idx >= 0) & (idx < P)
+    gmax = np.full(P, np.finfo(f).min, f)
+    gmin = np.full(P, np.finfo(f).max, f)
+    fin = ok & ~np.isnan(conf)
+    np.maximum.at(gmax, idx[fin], conf[fin])
+    np.minimum.at(gmin, idx[fin], conf[fin])
+    s = np.zeros(P, np.float64)
+    np.add.at(s, idx[ok], conf[ok].astype(np.float64))
+    n = np.bincount(idx[ok], minlength=P)
+    seen = n > 0
+    mean = np.where(seen, s / np.maximum(n, 1), 0.0).astype(f)
+    gmax, gmin = np.where(seen, gmax, f(0)), np.where(seen, gmin, f(0))
+    return gmax.reshape(P, 1), gmin.reshape(P, 1), mean.reshape(P, 1)
+
+
 # ---------------------------------------------------------------- row f3: tile-mask producers ---------------------------
 def _pad_tiles(img, stride, value=0):
     """F.pad(x, (0, pad_w, 0, pad_h), value) of SLAM/utils.py:721-724 and friends."""

@@ -1,4 +1,5 @@
-"""GPU parity of cuda_utils._C.accumulate_gaussian_error (row f1) against the numpy oracle; exact in max mode."""
+"""GPU parity of cuda_utils._C.accumulate_gaussian_error / accumulate_gaussian_confidence (row f1) against the numpy oracle; exact in
+max / min mode."""
 import numpy as np
 import pytest
 
@@ -64,3 +65,32 @@ def test_on_rasteriser_index_maps():
     for a, b in zip(res, ref):
         np.testing.assert_array_equal(a.cpu().numpy(), b)
     assert (res[0] > 0).sum() > 100
+
+
+@pytest.mark.parametrize("H,W,P,seed", [(211, 333, 5000, 3), (17, 9, 4, 4), (64, 48, 100000, 5)])
+def test_accumulate_gaussian_confidence(H, W, P, seed):
+    """cuda_utils.cu:62-83: (max, min, mean) per Gaussian over the pixels that name it; negative, zero and NaN confidences, -1 holes
+    and out-of-range ids in the index map, Gaussians that no pixel names."""
+    import torch
+    from cuda_utils._C import accumulate_gaussian_confidence
+    from oracle import map_oracle as mo
+    rng = np.random.default_rng(seed)
+    conf = rng.normal(0.2, 1.0, (H, W)).astype(np.float32)
+    conf[rng.uniform(size=(H, W)) < 0.05] = 0.0
+    conf[0, :3] = np.nan
+    conf[1, 1] = -0.0
+    idx = (rng.integers(0, P, (H // 4 + 1, W // 4 + 1)).repeat(4, 0).repeat(4, 1)[:H, :W]).astype(np.int32)
+    idx[rng.uniform(size=(H, W)) < 0.1] = -1
+    idx[H // 2, W // 2] = P + 3
+    t = lambda a: torch.tensor(a, device="cuda")
+    out = accumulate_gaussian_confidence(H, W, P, t(idx), t(conf))
+    ref = mo.accumulate_gaussian_confidence(H, W, P, idx, conf)
+    assert all(tuple(o.shape) == (P, 1) and o.dtype == torch.float32 for o in out)
+    for k in (0, 1):  # max / min of the same floats: exact (+0 and -0 compare equal)
+        np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k])
+    np.testing.assert_allclose(out[2].cpu().numpy(), ref[2], rtol=2e-5, atol=1e-6, equal_nan=True)
+    unseen = np.setdiff1d(np.arange(P), idx[(idx >= 0) & (idx < P)])
+    if len(unseen):
+        assert all((o.cpu().numpy()[unseen] == 0).all() for o in out)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        accumulate_gaussian_confidence(H, W, P, torch.tensor(idx), t(conf))

@@ -83,6 +83,17 @@ def test_accumulate_error_oracle_small_hand_case():
     np.testing.assert_array_equal(rs, rs2)
 
 
+def test_accumulate_confidence_oracle_small_hand_case():
+    """map_process.cu:247-360 on a 2x3 image worked by hand: strict comparisons (NaN never wins), 0 / 0 / 0 for unseen Gaussians."""
+    conf = np.array([[0.5, -0.25, 2.0], [np.nan, 0.75, -1.5]], np.float32)
+    idx = np.array([[0, 0, 2], [2, 7, 0]], np.int32)  # 7 is out of range for P = 4; Gaussians 1 and 3 are never named
+    gmax, gmin, mean = mo.accumulate_gaussian_confidence(2, 3, 4, idx, conf)
+    np.testing.assert_array_equal(gmax[:, 0], np.array([0.5, 0.0, 2.0, 0.0], np.float32))
+    np.testing.assert_array_equal(gmin[:, 0], np.array([-1.5, 0.0, 2.0, 0.0], np.float32))
+    np.testing.assert_allclose(mean[[0, 1, 3], 0], [(0.5 - 0.25 - 1.5) / 3, 0.0, 0.0], rtol=1e-6)
+    assert np.isnan(mean[2, 0])  # the NaN pixel enters the sum (atomicAdd) but neither the max nor the min
+
+
 def test_zero_moment_rows_without_gradient_are_fixed_points_of_adam():
     """The property the exact sparse Adam (DqoAdamStep.moment_live) rests on, checked against torch.optim.Adam itself with the
     reference's eps = 1e-15 (mapper.py:548): a row whose moments are zero and whose gradient is zero does not move by a single
