@@ -8,6 +8,10 @@
     update_geometry_scales    the scale initialisation of GaussianPointCloud.update_geometry
                          (SLAM/gaussian_pointcloud.py:519-570) on top of simple_knn's distCUDA2
 
+    temp_points_attach_indices   the decision of Mapping.temp_points_attach (mapper.py:1384-1430): which new points lie on a stable
+                         Gaussian's plane in the current frame (they get opacity 0.1 and thereby become the members of the attach
+                         loss, mapper.py:812-829) — gathers over the stable render's color_index_map, no kernel of its own
+
 The nearest-neighbour search is libdqoraster.so's dqo_knn3_query (Morton-sorted, box-pruned, wave-uniform candidate loads —
 csrc/knn.hip); everything else is a handful of element-wise torch ops exactly as in the reference.  GPU only.
 """
@@ -103,3 +107,34 @@ def update_geometry_scales(xyz, radius, extra_xyz, extra_radius, min_radius, max
     invalid = (d[0] < 0) | (d[1] < 0) | (d[2] < 0)
     scales = torch.sqrt((d[0] ** 2 + d[1] ** 2 + d[2] ** 2) / 3)
     return torch.clip(scales, min=min_radius, max=max_radius), invalid
+
+
+def temp_points_attach_indices(temp_xyz, temp_opacity, w2c, intrinsic, image_width, image_height, stable_color_index_map, stable_xyz,
+                               stable_normal, add_depth_thres, unstable_opacity_low=0.1):
+    """mapper.py:1384-1430: indices (into the temp cloud) of the points whose opacity the reference sets to `unstable_opacity_low`.
+
+    temp_xyz [N,3], temp_opacity [N,1] (activated); w2c [4,4], intrinsic [3,3] (scene/cameras.py:207-214 get_uv: pixel =
+    trunc(K (R x + t) / z), truncation toward zero, so a point up to one pixel left of / above the image still counts as inside);
+    stable_color_index_map int [1,H,W] = the op's hit_color of a render of the STABLE Gaussians only (-1 / 0-fill rules as the op has
+    them: `>= 0` is the reference's test); stable_xyz [S,3], stable_normal [S,3] (gaussian_pointcloud.py:780-791).
+
+    Quirk kept (B15): after the opacity filter the reference indexes the UNFILTERED temp cloud with positions of the FILTERED one when
+    it fetches the points for the point-to-plane test (mapper.py:1419); the two agree whenever no temp point has been attached yet
+    (all opacities 0.99), which is the state the reference calls it in."""
+    n = temp_xyz.shape[0]
+    origin = torch.arange(n, device=temp_xyz.device)
+    keep = (temp_opacity > unstable_opacity_low).reshape(-1)
+    xyz = temp_xyz[keep]
+    xyz_c = xyz @ w2c[:3, :3].T + w2c[:3, 3]
+    uv = xyz_c @ intrinsic.T
+    uv = (uv[:, :2] / uv[:, 2:]).long()
+    idx = torch.arange(xyz.shape[0], device=temp_xyz.device)
+    inside = (uv[:, 0] >= 0) & (uv[:, 0] < image_width) & (uv[:, 1] >= 0) & (uv[:, 1] < image_height)
+    stable_index = stable_color_index_map.permute(1, 2, 0)  # [H,W,1]
+    puv = uv[inside]
+    hit = stable_index[puv[:, 1], puv[:, 0]] >= 0
+    idx = idx[inside][hit[:, 0]]
+    sidx = stable_index[uv[idx, 1], uv[idx, 0]].squeeze(-1).long()
+    d = ((stable_xyz[sidx] - temp_xyz[idx]) * stable_normal[sidx]).sum(dim=-1)  # (temp_xyz, not xyz: quirk B15)
+    idx = idx[d.abs() < 0.5 * add_depth_thres]
+    return origin[keep][idx]

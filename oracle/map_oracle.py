@@ -126,6 +126,28 @@ def accumulate_gaussian_confidence(H, W, P, index_map, confidence_map):
     return gmax.reshape(P, 1), gmin.reshape(P, 1), mean.reshape(P, 1)
 
 
+def temp_points_attach_indices(temp_xyz, temp_opacity, w2c, intrinsic, W, H, stable_color_index_map, stable_xyz, stable_normal,
+                               add_depth_thres, low=0.1):
+    """/root/reference/SLAM/multiprocess/mapper.py:1384-1430 + scene/cameras.py:207-214 restated as a per-point loop (small cases)."""
+    out = []
+    f = np.float32
+    kept = [i for i in range(len(temp_xyz)) if temp_opacity[i, 0] > f(low)]
+    for pos, i in enumerate(kept):
+        pc = (w2c[:3, :3].astype(f) @ temp_xyz[i].astype(f) + w2c[:3, 3].astype(f)).astype(f)
+        q = (intrinsic.astype(f) @ pc).astype(f)
+        u, v = int(np.trunc(f(q[0]) / f(q[2]))), int(np.trunc(f(q[1]) / f(q[2])))
+        if not (0 <= u < W and 0 <= v < H):
+            continue
+        s = int(stable_color_index_map[0, v, u])
+        if s < 0:
+            continue
+        p = temp_xyz[pos]  # the reference reads the UNFILTERED cloud at the FILTERED position (mapper.py:1419)
+        d = float(np.sum(((stable_xyz[s] - p) * stable_normal[s]).astype(f), dtype=f))
+        if abs(d) < 0.5 * add_depth_thres:
+            out.append(i)
+    return np.array(out, np.int64)
+
+
 # ---------------------------------------------------------------- row f3: tile-mask producers ---------------------------
 def _pad_tiles(img, stride, value=0):
     """F.pad(x, (0, pad_w, 0, pad_h), value) of SLAM/utils.py:721-724 and friends."""
