@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-selfcheck", action="store_true")
     ap.add_argument("--cpu-sample-P", type=int, default=500_000)
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child of a --pmc pass: timed loop only
+    ap.add_argument("--no-loss-tap", action="store_true",
+                    help="fused path: the two loss kernels between forward and backward instead of the loss tap inside the blend kernels (A/B)")
     ap.add_argument("--shard-by", default="work", choices=("work", "count"),
                     help="strong scaling: balance the objects over the ranks by their on-screen work in the bench view (default) or by Gaussian count")
     ap.add_argument("--as-shard", default=None, metavar="R/N",
@@ -183,12 +185,12 @@ class FusedRunner:
     """The fused path of one rank: a FusedMapper on the rank's shard, one hipGraph replay per iteration, the packed all-reduce of
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
 
-    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0):
+    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True):
         from dqo_harness.fused_mapping import FusedMapper
         self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
         self.fm = FusedMapper(prob["scene"], prob["settings"], device)
         self.mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
-        self.use_graph = use_graph
+        self.use_graph, self.loss_tap = use_graph, loss_tap
         self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
         self.first_loss = None
         self.growth_pool = []  # the new points of every growth step: input data, resident in HBM before the timed region
@@ -197,7 +199,7 @@ class FusedRunner:
 
     def _capture(self):
         p = self.prob
-        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"])
+        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap)
         if self.first_loss is None:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
 
@@ -646,7 +648,8 @@ def main():
     loss_buf = PackedAllReduce(LOSS_SPEC, device)
     runner = step_dropin = None
     if args.path == "fused":
-        runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank)
+        runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
+                             loss_tap=not args.no_loss_tap)
         step = runner.step
     else:
         step_dropin = make_dropin_step(prob, device, loss_buf)

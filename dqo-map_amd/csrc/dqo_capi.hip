@@ -117,7 +117,7 @@ DQO_API int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset
 DQO_API int dqo_abi_version(void) { return DQO_ABI_VERSION; }
 DQO_API size_t dqo_abi_sizeof(int32_t which) {
     static const size_t sz[] = {sizeof(DqoRastParams), sizeof(DqoRastInputs), sizeof(DqoRastOutputs), sizeof(DqoRastCtx), sizeof(DqoRastGrads),
-                                sizeof(DqoRastHeader), sizeof(DqoProfileEntry), sizeof(DqoAdamStep)};
+                                sizeof(DqoRastHeader), sizeof(DqoProfileEntry), sizeof(DqoAdamStep), sizeof(DqoLossTap)};
     return (which >= 0 && which < (int32_t)(sizeof(sz) / sizeof(sz[0]))) ? sz[which] : 0;
 }
 DQO_API const char* dqo_last_error(void) { return g_err; }
@@ -224,7 +224,7 @@ DQO_API int dqo_rast_backward(const DqoRastParams* p, const DqoRastInputs* in, c
     if (rc) return rc;
     DQO_CHECK_ARG(g, "null grads");
     if (p->P == 0) return DQO_OK;  // rasterize_points.cu:208
-    DQO_CHECK_ARG(dL_dcolor && dL_ddepth, "null upstream gradients");
+    DQO_CHECK_ARG((dL_dcolor && dL_ddepth) || ctx->loss_tap, "null upstream gradients");
     DQO_CHECK_ARG(g->dL_dmeans3D && g->dL_dopacity && g->dL_dscales && g->dL_drotations, "null gradient output");
     DQO_CHECK_ARG(p->M == 0 || g->dL_dsh, "null dL_dsh");
     DQO_CHECK_ARG(ctx->binning || ctx->inst_capacity == 0, "null binning buffer");

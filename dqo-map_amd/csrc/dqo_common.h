@@ -92,6 +92,48 @@ static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
     return L;
 }
 
+// DqoLossTap as the kernels get it (by value); scale == nullptr: no tap.  The per-frame sums live in the geometry buffer's spread
+// lines (words 8..15 of each of the DQO_SPREAD lines, as four 64-bit counters: colour error sum and depth error sum in 2^-32 fixed
+// point, the two pixel counts), the wave ticket in counters[2] — all zeroed with the header by the forward's zero fill.
+struct DqoTapDev {
+    const float* gt_color;
+    const float* gt_depth;
+    const uint8_t* mask;
+    const float* out_color;
+    const float* out_depth;
+    float color_weight, depth_weight, add_depth_thres;
+    float* loss_out;
+    float* scale;
+};
+static inline DqoTapDev dqo_tap_dev(const DqoLossTap* t) {
+    DqoTapDev d;
+    if (t == nullptr) {
+        d.gt_color = d.gt_depth = d.out_color = d.out_depth = nullptr, d.mask = nullptr, d.loss_out = d.scale = nullptr;
+        d.color_weight = d.depth_weight = d.add_depth_thres = 0.f;
+        return d;
+    }
+    d.gt_color = t->gt_color, d.gt_depth = t->gt_depth, d.mask = t->render_mask, d.out_color = t->out_color, d.out_depth = t->out_depth;
+    d.color_weight = t->color_weight, d.depth_weight = t->depth_weight, d.add_depth_thres = t->add_depth_thres;
+    d.loss_out = t->loss_out, d.scale = t->grad_scale;
+    return d;
+}
+constexpr double DQO_TAP_FIXED = 4294967296.0;  // 2^32
+#ifdef __HIPCC__
+// The frame totals of the loss tap, by one wave: lane j reads line j, the wave adds up (fixed order).  tot[0..3] = colour error sum,
+// mask pixels, depth error sum, valid depth pixels.  Called a kernel boundary after the forward blend kernel wrote them.
+__device__ __forceinline__ void dqo_tap_totals(const uint32_t* spread, int lane, double tot[4]) {
+    const unsigned long long* l = reinterpret_cast<const unsigned long long*>(spread + (size_t)(lane % DQO_SPREAD) * 64 + 8);
+    unsigned long long t[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) t[c] = lane < DQO_SPREAD ? l[c] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < 4; c++) t[c] += (unsigned long long)__shfl_xor((long long)t[c], off);
+    tot[0] = (double)t[0] / DQO_TAP_FIXED, tot[1] = (double)t[1], tot[2] = (double)t[2] / DQO_TAP_FIXED, tot[3] = (double)t[3];
+}
+#endif
+
 // image buffer: per-tile tables + per-pixel forward->backward state.
 struct DqoImageLayout {
     uint32_t* tile_count;   // [T] instances per tile (atomic histogram, K1)

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
                                                                      const float* __restrict__ dL_dpixels,
                                                                      const float* __restrict__ dL_ddepths,
                                                                      float* __restrict__ recs, uint8_t* __restrict__ valid,
-                                                                     int64_t capacity) {
+                                                                     int64_t capacity, const DqoTapDev tap) {
     __shared__ float4 s_co[BWD_THREADS];
     __shared__ float4 s_xy[BWD_THREADS];
     __shared__ float4 s_rgb[BWD_THREADS];
@@ -181,6 +181,23 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     __shared__ int s_pos[BWD_THREADS];
     __shared__ float s_hit[BWD_THREADS * 5];
 
+    // DqoLossTap, backward half: every wave that has work derives the two gradient scales from the frame totals the forward left in
+    // the spread lines (one load per lane + a wave sum); the first block also reports the loss
+    float tap_gc = 0.f, tap_gdw = 0.f;
+    auto tap_scales = [&](bool report) {
+        double tot[4];
+        dqo_tap_totals(g.spread, (int)threadIdx.x, tot);
+        const float n_col = fmaxf((float)tot[1], 1.f), n_dep = fmaxf((float)tot[3], 1.f);
+        tap_gc = tap.color_weight / (3.f * n_col), tap_gdw = tap.depth_weight / n_dep;  // = loss_grad_kernel's gc / gdw
+        if (report && threadIdx.x == 0) {
+            const float color_loss = (float)(tot[0] / (3.0 * (double)n_col)), depth_loss = (float)(tot[2] / (double)n_dep);
+            tap.loss_out[0] = tap.depth_weight * depth_loss + tap.color_weight * color_loss;  // mapper.py:870-875
+            tap.loss_out[1] = color_loss, tap.loss_out[2] = depth_loss, tap.loss_out[3] = 0.f;
+            tap.loss_out[4] = (float)tot[0], tap.loss_out[5] = (float)tot[1], tap.loss_out[6] = (float)tot[2], tap.loss_out[7] = (float)tot[3];
+            tap.scale[0] = tap_gc, tap.scale[1] = tap_gdw;
+        }
+    };
+    if (tap.scale != nullptr && blockIdx.x == 0) tap_scales(true);  // (before the early exits below: block 0 may have no list)
     // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
     const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
@@ -192,6 +209,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     if (n == 0) return;
     const int L = min((int)img.walk4[tile * 4 + quad], n);  // list positions [0, L) matter to this quadrant
     if (L == 0) return;
+    if (tap.scale != nullptr && blockIdx.x != 0) tap_scales(false);
     const int lane = threadIdx.x;
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
     const size_t HW = (size_t)v.W * v.H;
@@ -207,10 +225,23 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     const uint32_t hit_word = inside ? img.hit_pos[pid] : 0u;
     const int hit_pos = (int)(hit_word & 0x7fffffffu);
     const bool hit_plane = (hit_word >> 31) != 0u;  // the forward decided backward.cu:1016's branch for this pixel
-    const float dp0 = inside ? dL_dpixels[pid] : 0.f;
-    const float dp1 = inside ? dL_dpixels[HW + pid] : 0.f;
-    const float dp2 = inside ? dL_dpixels[2 * HW + pid] : 0.f;
-    const float ddep = inside ? dL_ddepths[pid] : 0.f;
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, ddep = 0.f;
+    if (tap.scale == nullptr) {
+        if (inside) dp0 = dL_dpixels[pid], dp1 = dL_dpixels[HW + pid], dp2 = dL_dpixels[2 * HW + pid], ddep = dL_ddepths[pid];
+    } else if (inside) {
+        // DqoLossTap, backward half: the gradient images of the masked L1 loss, formed in place (what loss_grad_kernel writes:
+        // sign(error) x weight / count, 0 outside the mask; a tile with a list always has hit id -1 <=> hit_pos 0)
+        const float gc = tap_gc, gdw = tap_gdw;
+        const bool m = tap.mask ? tap.mask[pid] != 0 : true;
+        const float d0 = tap.out_color[pid] - tap.gt_color[pid], d1 = tap.out_color[HW + pid] - tap.gt_color[HW + pid];
+        const float d2 = tap.out_color[2 * HW + pid] - tap.gt_color[2 * HW + pid];
+        const float gd = tap.gt_depth[pid], err = tap.out_depth[pid] - gd;
+        dp0 = m ? (d0 > 0.f ? gc : (d0 < 0.f ? -gc : 0.f)) : 0.f;
+        dp1 = m ? (d1 > 0.f ? gc : (d1 < 0.f ? -gc : 0.f)) : 0.f;
+        dp2 = m ? (d2 > 0.f ? gc : (d2 < 0.f ? -gc : 0.f)) : 0.f;
+        const bool dvalid = m && hit_pos > 0 && gd > 0.f && err < tap.add_depth_thres;
+        ddep = dvalid ? (err > 0.f ? gdw : (err < 0.f ? -gdw : 0.f)) : 0.f;
+    }
     // No incoming gradient on any pixel of the quadrant (outside the loss mask): every term of every record would be an exact
     // zero, so nothing is written and the records stay invalid (= zero for the per-Gaussian sum).
     // An earlier backward over the same forward context (retain_graph=True, one autograd.grad call per loss term) may have
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, hipStream_t s) {
+                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, hipStream_t s) {
     // DQO_BWD_NB=3 (measurement only) selects the 32-value butterfly: 55 instead of 81 VGPRs, 5.4 instead of 3.7 waves resident
     // per SIMD — and 5 % SLOWER (round 2, profiles/README.md): the kernel is bound by VALU execution, not by latency
     static const int nb = [] {
@@ -413,9 +444,9 @@ int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const Dq
     }();
     if (nb == 7)
         DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel<7>, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales,
-                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity);
+                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity, tap);
     else
         DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel<3>, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales,
-                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity);
+                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity, tap);
     return DQO_OK;
 }

@@ -818,7 +818,7 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, int64_t capacity, hipStream_t s);
+                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, hipStream_t s);
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                          int64_t capacity, hipStream_t s);
 int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
@@ -878,7 +878,7 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
         DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order);
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
     }
-    return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, s);
+    return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, dqo_tap_dev(ctx->loss_tap), s);
 }
 
 int dqo_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s) {

@@ -45,8 +45,43 @@ __device__ __forceinline__ HitEval eval_hit(const float3 ray, const float4 n_np)
 
 constexpr int FWD_THREADS = 64;
 
+// DqoLossTap, forward half: this wave's share of the masked loss sums from the values it has just written for its 64 pixels, added to
+// the frame's 64-bit counters (one set per spread line) with fire-and-forget atomics — nothing waits for them; the backward's blend
+// kernel, a kernel boundary later, reads the totals (dqo_tap_totals).  A first version finished the loss here (the wave with the last
+// ticket wrote loss_out and grad_scale): 13 k tickets on one address cost 140 us (same-address atomics are served one per ~11 ns), and
+// with two-level tickets the returning atomics + their s_waitcnt at the end of every wave still cost what the two loss kernels had.
+__device__ __forceinline__ float tap_wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);  // fixed order: reproducible
+    return x;
+}
+__device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeomLayout& g, bool inside, size_t pid, size_t HW, float c0,
+                                              float c1, float c2, float depth, int hit_id, int lane) {
+    float e = 0.f, de = 0.f;
+    bool m = false, valid = false;
+    if (inside) {
+        m = tap.mask ? tap.mask[pid] != 0 : true;
+        const float g0 = tap.gt_color[pid], g1 = tap.gt_color[HW + pid], g2 = tap.gt_color[2 * HW + pid], gd = tap.gt_depth[pid];
+        e = fabsf(c0 - g0) + fabsf(c1 - g1) + fabsf(c2 - g2);
+        const float err = depth - gd;
+        valid = m && hit_id != -1 && gd > 0.f && err < tap.add_depth_thres;  // mapper.py:850-856
+        de = fabsf(err);
+    }
+    const unsigned long long nm = __popcll(__builtin_amdgcn_ballot_w64(m)), nv = __popcll(__builtin_amdgcn_ballot_w64(valid));
+    if (nm == 0ull) return;  // (wave-uniform; valid implies m)
+    const float se = tap_wave_sum(m ? e : 0.f), sd = tap_wave_sum(valid ? de : 0.f);
+    if (lane != 0) return;
+    unsigned long long* line = reinterpret_cast<unsigned long long*>(g.spread + (size_t)(blockIdx.x % DQO_SPREAD) * 64 + 8);
+    // (a non-finite sum — NaN colours — is not representable in fixed point: it poisons the loss by design, as in the float version)
+    const unsigned long long fe = se == se ? (unsigned long long)((double)se * DQO_TAP_FIXED + 0.5) : ~0ull >> 1;
+    const unsigned long long fd = sd == sd ? (unsigned long long)((double)sd * DQO_TAP_FIXED + 0.5) : ~0ull >> 1;
+    atomicAdd(&line[0], fe), atomicAdd(&line[1], nm);
+    if (nv) atomicAdd(&line[2], fd), atomicAdd(&line[3], nv);
+}
+
 __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
-                                                                    DqoBinLayout bin, DqoRastOutputs out, int64_t capacity) {
+                                                                    DqoBinLayout bin, DqoRastOutputs out, int64_t capacity,
+                                                                    const DqoTapDev tap) {
     __shared__ float4 s_co[FWD_THREADS];
     __shared__ float4 s_xy[FWD_THREADS];
     __shared__ float4 s_rgb[FWD_THREADS];
@@ -57,11 +92,11 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
     // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
     const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
+    const int lane = threadIdx.x;
     if (tile_u == 0xffffffffu) return;  // unused slot
     const int tile = (int)tile_u;
     const int quad = jg & 3;
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
-    const int lane = threadIdx.x;
     const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + (lane & 7);
     const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + (lane >> 3);
     const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
@@ -90,6 +125,9 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
             img.hit_pos[pix_id] = 0;
         }
         if (lane == 0) img.walk4[tile * 4 + quad] = 0;
+        if (tap.scale != nullptr)
+            loss_tap_wave(tap, g, inside, pix_id, HW, rendered ? v.bg[0] : 0.f, rendered ? v.bg[1] : 0.f, rendered ? v.bg[2] : 0.f, 0.f,
+                          rendered ? -1 : 0, lane);
         return;
     }
 
@@ -218,14 +256,14 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         // live byte of every list position of this chunk (coalesced 64-byte store)
         if (pos < n) live[pos] = (reach && ((live_m >> myk) & 1ull)) ? (uint8_t)1 : (uint8_t)0;
     }
+    const float oc0 = C0 + T * v.bg[0], oc1 = C1 + T * v.bg[1], oc2 = C2 + T * v.bg[2];  // running T, not end_T (quirk B2, forward.cu:852)
     if (inside) {
-        const float b0 = v.bg[0], b1 = v.bg[1], b2 = v.bg[2];
         img.final_T[pix_id] = end_T;
         img.n_contrib[pix_id] = last_contributor;
         img.hit_pos[pix_id] = hit_pos;
-        out.out_color[pix_id] = C0 + T * b0;  // running T, not end_T (quirk B2, forward.cu:852)
-        out.out_color[HW + pix_id] = C1 + T * b1;
-        out.out_color[2 * HW + pix_id] = C2 + T * b2;
+        out.out_color[pix_id] = oc0;
+        out.out_color[HW + pix_id] = oc1;
+        out.out_color[2 * HW + pix_id] = oc2;
         out.out_depth[pix_id] = depth_;
         out.out_hit_depth[pix_id] = hit_id;
         out.out_hit_color[pix_id] = hit_color_id;
@@ -238,12 +276,14 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) w = max(w, __shfl_xor(w, off));
     if (lane == 0) img.walk4[tile * 4 + quad] = (uint32_t)w;
+    if (tap.scale != nullptr) loss_tap_wave(tap, g, inside, pix_id, HW, oc0, oc1, oc2, depth_, hit_id, lane);
 }
 
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, int64_t capacity, hipStream_t s) {
-    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out, capacity);
+                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, hipStream_t s) {
+    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out, capacity,
+               tap);
     return DQO_OK;
 }

@@ -214,7 +214,8 @@ class FusedMapper:
                     init_rotation_raw=N.ptr(self.init_rotation), attach_count=self.attach_count, attach_partial=N.ptr(self.attach_partial))
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
-    def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True):
+    def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
+                loss_tap=True):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
 
@@ -285,6 +286,15 @@ class FusedMapper:
             g.cctx = N.DqoRastCtx(geom=g.geom.data_ptr(), geom_bytes=g.geom.numel(), binning=g.binning.data_ptr(),
                                   binning_bytes=g.binning.numel(), image=g.img.data_ptr(), image_bytes=g.img.numel(), inst_capacity=cap,
                                   tile_bucket_capacity=g.bucket)
+            # DqoLossTap: the masked loss is summed by the forward's blend kernel and its gradient images are formed inside the
+            # backward's (bit for bit what dqo_map_loss_fwd_bwd computes): no loss kernels, no passes over the full image
+            g.tap = None
+            if loss_tap:
+                g.grad_scale = torch.zeros((2,), **f)
+                g.tap = N.DqoLossTap(gt_color=N.ptr(gt_color), gt_depth=N.ptr(gt_depth), render_mask=N.ptr(g.mask), out_color=o[0].data_ptr(),
+                                     out_depth=o[1].data_ptr(), color_weight=self.color_weight, depth_weight=self.depth_weight,
+                                     add_depth_thres=self.add_depth_thres, loss_out=N.ptr(self.loss), grad_scale=g.grad_scale.data_ptr())
+                g.cctx.loss_tap = ctypes.addressof(g.tap)
             gr = g.grads
             g.cgrads = N.DqoRastGrads(dL_dmeans3D=gr["means3D"].data_ptr(), dL_dsh=gr["sh"].data_ptr(), dL_dcolors=None,
                                       dL_dopacity=gr["opacity"].data_ptr(), dL_dscales=gr["scales"].data_ptr(),
@@ -358,12 +368,13 @@ class FusedMapper:
         stream = N.current_stream()
         N.check(lib.dqo_rast_forward(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.outputs), ctypes.byref(g.cctx), stream))
         o = g.out
-        N.check(lib.dqo_map_loss_fwd_bwd(W, H, o[0].data_ptr(), o[1].data_ptr(), o[3].data_ptr(), N.ptr(g.gt_color), N.ptr(g.gt_depth),
-                                         N.ptr(g.mask), self.color_weight, self.depth_weight, self.add_depth_thres, N.ptr(self.loss),
-                                         N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws), self.loss_ws.numel(), stream))
-        N.check(lib.dqo_rast_backward(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.cctx), self.dL_dcolor.data_ptr(),
-                                      self.dL_ddepth.data_ptr(), o[3].data_ptr(), ctypes.byref(g.cgrads), g.ws.data_ptr(), g.ws.numel(),
-                                      stream))
+        if g.tap is None:
+            N.check(lib.dqo_map_loss_fwd_bwd(W, H, o[0].data_ptr(), o[1].data_ptr(), o[3].data_ptr(), N.ptr(g.gt_color), N.ptr(g.gt_depth),
+                                             N.ptr(g.mask), self.color_weight, self.depth_weight, self.add_depth_thres, N.ptr(self.loss),
+                                             N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws), self.loss_ws.numel(), stream))
+        dLc, dLd = (self.dL_dcolor.data_ptr(), self.dL_ddepth.data_ptr()) if g.tap is None else (None, None)
+        N.check(lib.dqo_rast_backward(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.cctx), dLc, dLd, o[3].data_ptr(),
+                                      ctypes.byref(g.cgrads), g.ws.data_ptr(), g.ws.numel(), stream))
         N.check(lib.dqo_map_adam_step(ctypes.byref(g.adam), stream))
 
     def replay(self):

@@ -92,6 +92,26 @@ typedef struct DqoRastOutputs {
 
 /* Forward->backward context: the three opaque byte buffers the reference keeps as geomBuffer / binningBuffer /
  * imgBuffer (rasterize_points.cu:93-98).  Layout is private to this library; sizes come from the functions below. */
+/* Optional loss tap of the mapping iteration (row f2; SLAM/multiprocess/mapper.py:836-875 with a render mask): the masked
+ * 0.8 L1 colour + 1.0 depth L1 loss is evaluated where its inputs are produced and consumed instead of in two passes over the
+ * images between forward and backward.  The forward's blend kernel adds up, per 8x8-pixel wave, |colour error| over the mask and
+ * |depth error| over the valid depth pixels (fixed point: exact, order-independent, reproducible) and the two pixel counts.  The
+ * backward's blend kernel reads the totals, forms each pixel's dL/dcolour and dL/ddepth from the rendered and the ground-truth
+ * images as sign(error) x {color_weight / (3 n_colour), depth_weight / n_depth} — bit for bit what dqo_map_loss_fwd_bwd would have
+ * written — so its dL_dout_color / dL_dout_depth arguments are not read (may be NULL), and writes loss_out[8] (same layout as
+ * dqo_map_loss_fwd_bwd) and grad_scale[2] (the two factors): the loss is available after the BACKWARD call.  All pointers are
+ * device pointers and must stay valid from the forward to the backward; out_color / out_depth are the forward's own outputs. */
+typedef struct DqoLossTap {
+    const float* gt_color;      /* [3,H,W] */
+    const float* gt_depth;      /* [1,H,W] */
+    const uint8_t* render_mask; /* [H,W] or NULL (= all pixels) */
+    const float* out_color;     /* [3,H,W] = DqoRastOutputs.out_color of the forward (read by the backward) */
+    const float* out_depth;     /* [1,H,W] = DqoRastOutputs.out_depth */
+    float color_weight, depth_weight, add_depth_thres;
+    float* loss_out;            /* [8] */
+    float* grad_scale;          /* [2] */
+} DqoLossTap;
+
 typedef struct DqoRastCtx {
     void* geom;
     size_t geom_bytes;
@@ -113,6 +133,8 @@ typedef struct DqoRastCtx {
      * slightly different state of the map is as good).  The one-block scan kernel between binning and sort then disappears: list
      * ranges follow from the tile counters, the header from per-line statistics.  For a captured iteration that is replayed. */
     int32_t keep_tile_order;
+    /* NULL (default, the drop-in behaviour) or the loss tap described above; read by the forward and by the backward. */
+    const DqoLossTap* loss_tap;
 } DqoRastCtx;
 
 /* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206).  dL_dcolors, dL_dcov3D and
@@ -149,7 +171,7 @@ int dqo_abi_version(void);
 const char* dqo_last_error(void);
 /* sizeof() of the ABI structs as this library was compiled (a binding checks its own struct definitions against it):
  * 0 DqoRastParams, 1 DqoRastInputs, 2 DqoRastOutputs, 3 DqoRastCtx, 4 DqoRastGrads, 5 DqoRastHeader, 6 DqoProfileEntry,
- * 7 DqoAdamStep; 0 for any other index. */
+ * 7 DqoAdamStep, 8 DqoLossTap; 0 for any other index. */
 size_t dqo_abi_sizeof(int32_t which);
 
 /* Optional per-kernel timing (measurement only; the reference has nothing comparable — it times whole frames with

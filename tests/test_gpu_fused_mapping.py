@@ -191,6 +191,44 @@ def test_graph_replay_matches_eager_steps(env):
     assert b.step_count == 6 and int(b._g.step_dev.item()) == 7
 
 
+def test_loss_tap_equals_the_loss_kernels(env):
+    """DqoRastCtx.loss_tap: the masked loss summed inside the forward's blend kernel and its gradient formed inside the backward's
+    must train exactly like the two loss kernels between them — same counts, same gradient scale, hence bit-identical parameters and
+    moments — and report the same loss (fixed-point sums against double partial sums: 1e-6).  Also with a tile mask that leaves
+    masked-in pixels in empty tiles, without a render mask, and on the eagerly issued iteration."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    for cfg, P, use_mask, use_tiles in ((1, 6000, True, False), (3, 20000, True, True), (3, 20000, False, False)):
+        cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch, P=P, cfg=cfg)
+        tile_mask = None
+        if use_tiles:  # every other tile column switched off; the render mask keeps pixels there (they see the 0 / bg fills)
+            tile_mask = torch.ones(((cam.H + 15) // 16, (cam.W + 15) // 16), dtype=torch.int32, device=dev)
+            tile_mask[:, ::2] = 0
+        m = mask if use_mask else None
+        a = FusedMapper(scene, settings, dev)
+        b = FusedMapper(scene, settings, dev)
+        a.capture(gt_color, gt_depth, m, tile_mask=tile_mask, loss_tap=True)
+        b.capture(gt_color, gt_depth, m, tile_mask=tile_mask, loss_tap=False)
+        assert a._g.tap is not None and b._g.tap is None
+        for it in range(4):
+            if it == 2:
+                a.step_static(), b.step_static()
+            else:
+                a.replay(), b.replay()
+            torch.cuda.synchronize()
+            la, lb = a.loss.cpu().numpy(), b.loss.cpu().numpy()
+            assert la[5] == lb[5] and la[7] == lb[7] and la[5] > 0, (la, lb)  # pixel counts: exact
+            np.testing.assert_allclose(la[[0, 1, 2, 4, 6]], lb[[0, 1, 2, 4, 6]], rtol=1e-6, atol=1e-9)
+            gc, gd = 0.8 / (3.0 * max(la[5], 1.0)), 1.0 / max(la[7], 1.0)
+            np.testing.assert_allclose(a._g.grad_scale.cpu().numpy(), [gc, gd], rtol=1e-6)
+        assert not a.graph_overflowed() and not b.graph_overflowed()
+        for k, pa in a._params().items():
+            assert torch.equal(pa, b._params()[k]), (cfg, k)
+            assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), (cfg, k)
+        for x, y in zip(a._g.out, b._g.out):
+            assert torch.equal(x, y)
+
+
 def test_sparse_moments_are_bitwise_dense_adam(env):
     """DqoAdamStep.moment_live: Gaussians whose moments are still all zero and that get no gradient are skipped — parameters,
     moments and activations must come out bit for bit as from the dense update, also when the view (visible set) changes."""
