@@ -770,6 +770,7 @@ def main():
         stats.update(N_instances=n_inst, N_candidates=n_cand, max_tile_list=hdr["max_tile_count"], num_tiles=hdr["num_tiles"],
                      tiles_total=((cam.W + 15) // 16) * ((cam.H + 15) // 16))
         Pk = P_now
+        tap_px = 17 if (runner is not None and runner.use_graph and runner.loss_tap) else 0
         # algorithmic bytes per launch (DESIGN.md "Kernels"): what the kernel must move at minimum, per unit
         # (instance = (Gaussian, tile) list entry; Gaussian; pixel) x the units of this launch
         alg = {
@@ -777,8 +778,10 @@ def main():
             "bin_count_kernel": 40 * n_vis + 12 * n_inst,                                 # rect + 2 tables per visible; (tile, rank, id) per instance
             "bin_place_kernel": 24 * n_inst,                                              # info + id in, key + slot out
             "tile_sort_wave_kernel": 20 * n_inst, "tile_sort_kernel": 20 * n_inst,        # key + slot in, id + slot out
-            "blend_forward_kernel": 40 * n_inst + 36 * HWa,                               # id + 2 records (+ rgb for survivors), live bytes; 9 output planes
-            "blend_backward_kernel": 120 * n_inst + 32 * HWa,                             # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
+            # (loss tap: + ground-truth colour, depth and mask per pixel in the forward; rendered + ground-truth images instead of the
+            # two gradient images in the backward: + 17 B per active pixel each)
+            "blend_forward_kernel": 40 * n_inst + (36 + tap_px) * HWa,                    # id + 3 records, live bytes; 9 output planes
+            "blend_backward_kernel": 120 * n_inst + (32 + tap_px) * HWa,                  # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
             "record_sum_kernel": 68 * n_inst + 64 * n_vis,                                # gradient records in, one summed record per visible Gaussian out
             # summed record, params, tables in; gradient rows out (fused path: only the rows of visible Gaussians are written)
             "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * (n_vis if args.path == "fused" else Pk),
