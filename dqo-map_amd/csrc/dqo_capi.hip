@@ -40,6 +40,7 @@ int dqo_launch_icp(int H, int W, const float* vertex0, const float* vertex1, con
 int dqo_launch_tile_count(int W, int H, int mode, const uint8_t* mask_in, const float* T_map, uint8_t* mask_out, int32_t* tile_count,
                           int32_t* total, hipStream_t s);
 int dqo_launch_tile_color_error(int W, int H, const float* render, const float* gt, float* err_px, float* tile_sum, hipStream_t s);
+int dqo_launch_tap_report(const DqoGeomLayout& g, const DqoTapDev& tap, hipStream_t s);
 int dqo_launch_accumulate_confidence(int H, int W, int P, const int32_t* index, const float* confidence, float* gmax, float* gmin,
                                      float* gmean, int32_t* counter, hipStream_t s);
 int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, const float* depth_err, const float* normal_err,
@@ -204,6 +205,8 @@ DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs*
     DQO_CHECK_ARG(ctx->inst_capacity >= 0 && ctx->inst_capacity < (int64_t)0xffffffffll, "bad inst_capacity");
     DQO_CHECK_ARG(ctx->inst_capacity == 0 || ctx->binning, "null binning buffer");
     DQO_CHECK_ARG(ctx->tile_bucket_capacity >= 0, "negative tile_bucket_capacity");
+    DQO_CHECK_ARG(ctx->loss_tap == nullptr || (ctx->loss_tap->gt_color && ctx->loss_tap->gt_depth && ctx->loss_tap->loss_out &&
+                                               ctx->loss_tap->grad_scale), "loss tap with a null pointer");
     if (ctx->binning_bytes < dqo_rast_binning_bytes_bucketed(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity)) {
         dqo_set_error("binning buffer too small (%zu < %zu)", ctx->binning_bytes,
                       dqo_rast_binning_bytes_bucketed(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity));
@@ -223,8 +226,14 @@ DQO_API int dqo_rast_backward(const DqoRastParams* p, const DqoRastInputs* in, c
     int rc = check_common(p, in, ctx);
     if (rc) return rc;
     DQO_CHECK_ARG(g, "null grads");
-    if (p->P == 0) return DQO_OK;  // rasterize_points.cu:208
+    if (p->P == 0) {  // rasterize_points.cu:208 (with a loss tap the loss of the background-only frame is still reported)
+        if (ctx->loss_tap == nullptr) return DQO_OK;
+        return dqo_launch_tap_report(dqo_geom_layout(ctx->geom, 0), dqo_tap_dev(ctx->loss_tap), (hipStream_t)stream);
+    }
     DQO_CHECK_ARG((dL_dcolor && dL_ddepth) || ctx->loss_tap, "null upstream gradients");
+    DQO_CHECK_ARG(ctx->loss_tap == nullptr || (ctx->loss_tap->gt_color && ctx->loss_tap->gt_depth && ctx->loss_tap->out_color &&
+                                               ctx->loss_tap->out_depth && ctx->loss_tap->loss_out && ctx->loss_tap->grad_scale),
+                  "loss tap with a null pointer");
     DQO_CHECK_ARG(g->dL_dmeans3D && g->dL_dopacity && g->dL_dscales && g->dL_drotations, "null gradient output");
     DQO_CHECK_ARG(p->M == 0 || g->dL_dsh, "null dL_dsh");
     DQO_CHECK_ARG(ctx->binning || ctx->inst_capacity == 0, "null binning buffer");

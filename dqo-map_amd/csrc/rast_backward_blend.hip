@@ -433,6 +433,27 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
 
 }  // namespace
 
+namespace {
+// DqoLossTap on an empty map (P = 0: no blend kernel runs in the backward): the loss of the background-only frame is still reported.
+__global__ void tap_report_kernel(DqoGeomLayout g, const DqoTapDev tap) {
+    double tot[4];
+    dqo_tap_totals(g.spread, (int)threadIdx.x, tot);
+    if (threadIdx.x != 0) return;
+    const float n_col = fmaxf((float)tot[1], 1.f), n_dep = fmaxf((float)tot[3], 1.f);
+    const float color_loss = (float)(tot[0] / (3.0 * (double)n_col)), depth_loss = (float)(tot[2] / (double)n_dep);
+    tap.loss_out[0] = tap.depth_weight * depth_loss + tap.color_weight * color_loss;
+    tap.loss_out[1] = color_loss, tap.loss_out[2] = depth_loss, tap.loss_out[3] = 0.f;
+    tap.loss_out[4] = (float)tot[0], tap.loss_out[5] = (float)tot[1], tap.loss_out[6] = (float)tot[2], tap.loss_out[7] = (float)tot[3];
+    tap.scale[0] = tap.color_weight / (3.f * n_col), tap.scale[1] = tap.depth_weight / n_dep;
+}
+
+}  // namespace
+
+int dqo_launch_tap_report(const DqoGeomLayout& g, const DqoTapDev& tap, hipStream_t s) {
+    DQO_LAUNCH("tap_report_kernel", tap_report_kernel, dim3(1), dim3(64), s, g, tap);
+    return DQO_OK;
+}
+
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
                               DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, hipStream_t s) {

@@ -229,6 +229,52 @@ def test_loss_tap_equals_the_loss_kernels(env):
             assert torch.equal(x, y)
 
 
+def test_loss_tap_on_an_empty_map(env):
+    """P = 0 through the C ABI with a loss tap: the forward writes the background, the backward has no blend kernel to run and still
+    reports the loss of that frame (tap_report_kernel): mean |bg - gt| over the mask, depth term 0 (no depth hit anywhere)."""
+    torch = env
+    import ctypes
+    import _dqo_native as N
+    import diff_gaussian_rasterization_depth as dgr
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    lib = N.lib()
+    H, W = cam.H, cam.W
+    f, i32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev), dict(dtype=torch.uint8, device=dev)
+    st = settings._replace(bg=torch.tensor([0.2, 0.4, 0.6], **f))
+    out = [torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **i32), torch.empty((1, H, W), **i32),
+           torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((0,), **i32), torch.empty((0,), **i32)]
+    geom = torch.empty((lib.dqo_rast_geom_bytes(0, W, H),), **u8)
+    img = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
+    binning = torch.empty((lib.dqo_rast_binning_bytes(1),), **u8)
+    e = torch.empty((0,), **f)
+    params = dgr._params(st, 0, 16)
+    inputs = dgr._inputs(st, e, e, e, e, e, e, e, None)
+    outputs = N.DqoRastOutputs(out_color=out[0].data_ptr(), out_depth=out[1].data_ptr(), out_hit_color=out[2].data_ptr(),
+                               out_hit_depth=out[3].data_ptr(), out_hit_color_weight=out[4].data_ptr(), out_hit_depth_weight=out[5].data_ptr(),
+                               out_T=out[6].data_ptr(), n_touched=None, radii=None)
+    loss, scale = torch.full((8,), -1.0, **f), torch.full((2,), -1.0, **f)
+    m8 = mask.to(torch.uint8).contiguous()
+    tap = N.DqoLossTap(gt_color=N.ptr(gt_color), gt_depth=N.ptr(gt_depth), render_mask=N.ptr(m8), out_color=out[0].data_ptr(),
+                       out_depth=out[1].data_ptr(), color_weight=0.8, depth_weight=1.0, add_depth_thres=0.1, loss_out=N.ptr(loss),
+                       grad_scale=N.ptr(scale))
+    cctx = N.DqoRastCtx(geom=geom.data_ptr(), geom_bytes=geom.numel(), binning=binning.data_ptr(), binning_bytes=binning.numel(),
+                        image=img.data_ptr(), image_bytes=img.numel(), inst_capacity=1, loss_tap=ctypes.addressof(tap))
+    stream = N.current_stream()
+    N.check(lib.dqo_rast_forward(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs), ctypes.byref(cctx), stream))
+    grads = N.DqoRastGrads()
+    N.check(lib.dqo_rast_backward(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(cctx), None, None, out[3].data_ptr(),
+                                  ctypes.byref(grads), None, 0, stream))
+    torch.cuda.synchronize()
+    n = float(mask.sum().item())
+    # an empty map has no active tile: the op leaves the reference's initial fills (colour 0, ids 0), not the background
+    want_c = float((gt_color.abs().sum(0)[mask]).sum().item()) / (3.0 * n)
+    l = loss.cpu().numpy()
+    assert l[5] == n
+    np.testing.assert_allclose(l[1], want_c, rtol=1e-5)
+    np.testing.assert_allclose(scale.cpu().numpy()[0], 0.8 / (3.0 * n), rtol=1e-6)
+    assert (out[0] == 0).all()
+
+
 def test_sparse_moments_are_bitwise_dense_adam(env):
     """DqoAdamStep.moment_live: Gaussians whose moments are still all zero and that get no gradient are skipped — parameters,
     moments and activations must come out bit for bit as from the dense update, also when the view (visible set) changes."""
