@@ -162,7 +162,7 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
         return r;
     };
     L.tile_count = (uint32_t*)take(4 * T * DQO_TSTRIDE);
-    L.tile_flag = (uint32_t*)take(4 * T);  // directly after tile_count: both are zeroed by one memset
+    L.tile_flag = (uint32_t*)take(4 * T);  // directly after tile_count: both are zeroed by one fill
     L.tile_cursor = (uint32_t*)take(4 * T * DQO_TSTRIDE);
     L.ranges = (uint2*)take(8 * T);
     L.walk4 = (uint32_t*)take(16 * T);
