@@ -133,6 +133,15 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         rc = g.rect16[idx];
         n_inst = g.tiles_touched[idx];
     }
+    // The two camera matrices travel with the first round and stay in scalar registers (wave-uniform): left where they are first
+    // used — behind the first gradient stores, which may alias them as far as the compiler knows — they were a third memory round
+    // trip in the middle of every wave.
+    float view[16], proj[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        view[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.view[i])));
+        proj[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.proj[i])));
+    }
     // radii > 0 (backward.cu:285, 513)  <=>  the forward kept a non-empty tile rect for this Gaussian
     const bool visible = in_range && ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
     float a[16];
@@ -210,9 +219,6 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     if (gr.dL_dcolors) dcol[0] = dcolr[0], dcol[1] = dcolr[1], dcol[2] = dcolr[2];
     if (gr.dL_dmeans2D) dm2[0] = g2x, dm2[1] = g2y, dm2[2] = 0.f;
 
-    float view[16], proj[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) view[i] = v.view[i], proj[i] = v.proj[i];
     // `real` = float reproduces the reference's arithmetic (the parity target).  -DDQO_BWD_CHAIN_FP64 evaluates the chain in double
     // instead: closer to the exact derivative of the same formulas (DESIGN.md §2 quantifies both), but not what the reference
     // computes; per Gaussian, not per pixel, so the cost is invisible either way.
