@@ -66,13 +66,16 @@ __global__ void error_mean_kernel(int P, const int32_t* __restrict__ counters, f
 // replace only on a strict comparison (NaN never wins).  Here: one hardware integer atomic per value — non-negative floats order like
 // their bit patterns as signed integers, negative floats in reverse as unsigned integers, and the two cases compose because the
 // accumulators start at -FLT_MAX / +FLT_MAX (cuda_utils.cu:71-72).
+// (-0.0f is folded into +0.0f first: as an integer it is INT_MIN, which the signed minimum would take for the smallest value of all)
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
     if (v != v) return;
+    v += 0.0f;
     if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
     else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
     if (v != v) return;
+    v += 0.0f;
     if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
     else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }

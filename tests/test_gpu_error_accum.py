@@ -79,9 +79,12 @@ def test_accumulate_gaussian_confidence(H, W, P, seed):
     conf[rng.uniform(size=(H, W)) < 0.05] = 0.0
     conf[0, :3] = np.nan
     conf[1, 1] = -0.0
+    conf[H - 1, W - 4:] = [-1.5, -0.25, -3.0, -0.0]  # -0.0 among negatives (as an integer it is INT_MIN: must not win the minimum)
     idx = (rng.integers(0, P, (H // 4 + 1, W // 4 + 1)).repeat(4, 0).repeat(4, 1)[:H, :W]).astype(np.int32)
     idx[rng.uniform(size=(H, W)) < 0.1] = -1
     idx[H // 2, W // 2] = P + 3
+    idx[idx == P - 1] = -1
+    idx[H - 1, W - 4:] = P - 1  # ... and alone on their Gaussian
     t = lambda a: torch.tensor(a, device="cuda")
     out = accumulate_gaussian_confidence(H, W, P, t(idx), t(conf))
     ref = mo.accumulate_gaussian_confidence(H, W, P, idx, conf)
