@@ -389,6 +389,31 @@ class FusedMapper:
         g.expected_step = self.step_count + 1
         return g.out
 
+    def run(self, n_iters, check_every=64, capacity_margin=1.5):
+        """`n_iters` VALID mapping iterations on the captured graph: replays in batches of `check_every`, one small D2H read per batch
+        (device-side step count + overflow flag); if the map outgrew the captured capacities in a batch, the invalid replays were no-ops for the
+        optimiser (DqoAdamStep.frame_header: parameters, moments and the device step count are untouched), so the graph is captured
+        again on the current state with `capacity_margin` and the missing iterations are replayed.  Returns the number of
+        re-captures.  The inputs of the last capture() (ground-truth images, masks) are reused."""
+        g = self._g
+        target = self.step_count + n_iters
+        recaptures = 0
+        while self.step_count < target:
+            k = min(check_every, target - self.step_count)
+            for _ in range(k):
+                self.replay()
+            # the device-side step count only advances on valid frames: one 4-byte read tells whether ANY replay of the batch was invalid
+            # (the header's flag alone would only tell about the last one)
+            if int(self._g.step_dev.item()) - 1 != self.step_count or self.graph_overflowed():
+                if recaptures > 8:
+                    raise RuntimeError("FusedMapper.run: the map keeps outgrowing the captured capacities")
+                g = self._g
+                # (capture() re-reads the device-side step count: the valid replays of this batch stay counted, the others do not)
+                self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
+                             tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0, loss_tap=g.tap is not None)
+                recaptures += 1
+        return recaptures
+
     def step_static(self):
         """One iteration over the persistent buffers issued eagerly — exactly the calls the captured graph holds (for per-kernel
         profiling: events cannot be recorded inside a replay)."""

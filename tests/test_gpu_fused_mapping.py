@@ -384,6 +384,28 @@ def test_graph_capacity_overflow_is_flagged(env):
         assert ((v - twin._params()[k]).abs() > 0.01 * lr + 1e-7).float().mean().item() < 1e-3, k
 
 
+def test_run_recaptures_after_an_overflow_and_delivers_valid_iterations(env):
+    """FusedMapper.run(n): n VALID iterations whatever happens to the capacities — here the graph is captured with room for 5 % of the
+    candidate pairs, so every replay of the first batch is an invalid frame (a no-op for the optimiser); run() notices from the
+    device-side step count, captures again with room, and ends exactly where a mapper with enough room from the start ends."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, settings, dev)
+    a.capture(gt_color, gt_depth, mask, capacity_margin=0.05)
+    assert a.step_count == 0 and a.graph_overflowed()  # (the capture's own eager iteration overflowed: not counted)
+    n_recap = a.run(7, check_every=3)
+    assert n_recap == 1 and a.step_count == 7 and int(a._g.step_dev.item()) == 8 and not a.graph_overflowed()
+    b.capture(gt_color, gt_depth, mask)
+    assert b.run(6, check_every=4) == 0 and b.step_count == 7  # (capture's eager iteration + 6)
+    torch.cuda.synchronize()
+    for k, pa in a._params().items():
+        assert torch.equal(pa, b._params()[k]), k
+        assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), k
+    assert torch.equal(a.loss, b.loss)
+
+
 def test_capture_takes_the_reference_cameras_noncontiguous_matrices(env):
     """scene/cameras.py:137-139 builds world_view_transform as torch.tensor(...).transpose(0, 1).cuda(): a non-contiguous view.  The
     op's forward makes it contiguous per call; the captured path must do the same once (its raw pointers would otherwise read the
