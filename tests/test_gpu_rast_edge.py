@@ -104,3 +104,27 @@ def test_lazy_mode_overflow_is_detected_and_recovers(torch_cuda, oracle):
         dgr.set_sync_mode("exact")
     o, r, _ = U.run_oracle(oracle, cam, sc)
     U.compare_forward(h3, r)
+
+
+@pytest.mark.parametrize("n", [64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193])
+def test_sort_paths_at_their_boundaries(torch_cuda, oracle, n):
+    """A tile list of EXACTLY n entries — the lengths at which the per-tile sort changes path (one wave with 1..8 keys per lane,
+    two waves, the queued block sort with 2048- / 4096-key segments, the two-segment global merge): n tiny surfels inside one tile,
+    semi-transparent so that the whole list is walked, depths with many exact ties (ties fall back to the Gaussian id).  Forward and
+    gradients against the oracle; the hit ids make the comparison sensitive to the order."""
+    cam = scenes.Camera(48, 32, 60.0, 60.0, 23.5, 15.5)
+    rng = np.random.default_rng(n)
+    sc = scenes.frustum_cloud(11, n, cam, zmin=1.0, zmax=4.0)
+    # centres inside the middle of tile (1, 0): pixels 20..27 x 4..11, radius <= 3 px => every Gaussian lists exactly that tile
+    z = np.round(rng.uniform(1.0, 4.0, n) * 8) / 8  # 25 distinct depths: ties by the hundred
+    u, v = rng.uniform(20.5, 27.5, n), rng.uniform(4.5, 11.5, n)
+    pc = np.stack([(u - cam.cx) / cam.fx * z, (v - cam.cy) / cam.fy * z, z], 1)
+    sc["xyz"] = ((pc - cam.t) @ cam.Rw2c).astype(np.float32)
+    sc["scales"] = (rng.uniform(0.004, 0.012, (n, 3)) * z[:, None]).astype(np.float32)
+    sc["opacity"] = rng.uniform(0.01, 0.04, (n, 1)).astype(np.float32)
+    o, st, gs = _check(oracle, cam, sc, _dL(cam, 2))
+    rg = o.ctx("ranges")
+    lens = rg[:, 1] - rg[:, 0]
+    assert lens.max() == n and (lens > 0).sum() == 1, "the scene must put all n Gaussians into one tile"
+    import diff_gaussian_rasterization_depth as dgr
+    assert dgr.last_header()["max_tile_count"] == n  # ... and none of them is culled as dead: the HIP list has n entries as well
