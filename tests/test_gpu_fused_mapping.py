@@ -344,6 +344,51 @@ def test_tile_buckets_match_packed_lists(env):
         assert c.graph_overflowed() and c.header()["max_tile_count"] > 8
 
 
+@pytest.mark.parametrize("n", [700, 1500, 3000, 5000])
+def test_long_lists_in_bucket_mode_match_packed_lists(env, n):
+    """The captured iteration on a map whose Gaussians all fall into one or two tiles: lists of 700 (two-wave sort) to 5 000 entries
+    (queued block sort, two segments) in BUCKET mode with the kept tile order and the loss tap, against the packed lists with the scan
+    and loss kernels — bit-identical parameters, moments, outputs and header after three replays."""
+    torch = env
+    from dqo_harness import mapping
+    from dqo_harness.fused_mapping import FusedMapper
+    cam = scenes.Camera(96, 64, 80.0, 80.0, 47.5, 31.5)
+    rng = np.random.default_rng(n)
+    scene = scenes.frustum_cloud(5, n, cam, zmin=1.0, zmax=4.0)
+    z = rng.uniform(1.0, 4.0, n)
+    u, v = rng.uniform(34.0, 44.0, n), rng.uniform(18.0, 28.0, n)
+    pc = np.stack([(u - cam.cx) / cam.fx * z, (v - cam.cy) / cam.fy * z, z], 1)
+    scene["xyz"] = ((pc - cam.t) @ cam.Rw2c).astype(np.float32)
+    scene["scales"] = (rng.uniform(0.004, 0.02, (n, 3)) * z[:, None]).astype(np.float32)
+    scene["opacity"] = rng.uniform(0.02, 0.08, (n, 1)).astype(np.float32)
+    dev = torch.device("cuda")
+    settings = mapping.make_settings(cam, dev)
+    pert = dict(scene)
+    pert["shs"] = scene["shs"].copy()
+    pert["shs"][:, 0, :] += rng.normal(0, 0.2, (n, 3)).astype(np.float32)
+    with torch.no_grad():
+        tgt = mapping.render(settings, mapping.GaussianParams(pert, dev).activated())
+    gt_color, gt_depth = tgt["render"].clone(), tgt["depth"].clone()
+    mask = torch.ones((cam.H, cam.W), dtype=torch.bool, device=dev)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, settings, dev)
+    a.capture(gt_color, gt_depth, mask)
+    b.capture(gt_color, gt_depth, mask, tile_buckets=False, loss_tap=False)
+    assert a._g.bucket >= 1024 and a._g.cctx.keep_tile_order == 1 and a._g.tap is not None and b._g.bucket == 0
+    for _ in range(3):
+        a.replay()
+        b.replay()
+    torch.cuda.synchronize()
+    ha, hb = a.header(), b.header()
+    assert ha == hb and not ha["overflow"] and ha["max_tile_count"] > n // 6, (ha, hb)
+    for k, pa in a._params().items():
+        assert torch.equal(pa, b._params()[k]), k
+        assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), k
+    for x, y in zip(a._g.out, b._g.out):
+        assert torch.equal(x, y)
+    np.testing.assert_allclose(a.loss.cpu().numpy(), b.loss.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
 def test_graph_capacity_overflow_is_flagged(env):
     """A captured graph has a fixed instance capacity; when the scene needs more, nothing is written out of bounds, the device
     header says so and graph_overflowed() reports it (the frame's outputs are the initial fills)."""
