@@ -197,9 +197,9 @@ class FusedRunner:
         if use_graph:
             self._capture()
 
-    def _capture(self):
+    def _capture(self, reuse_probe=False):
         p = self.prob
-        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap)
+        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap, reuse_probe=reuse_probe)
         if self.first_loss is None:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
 
@@ -249,17 +249,16 @@ class FusedRunner:
             delete = (g_depth.reshape(-1) > 2 * 0.1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        st = fm.grow(new, delete_mask=delete)
+        st = fm.grow(new, delete_mask=delete, new_mapping_call=True)  # (fresh Adam + init_stat: mapper.py:533-548)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        fm.begin_mapping_call(reset_optimizer=True)
         if self.use_graph:
-            self._capture()
+            self._capture(reuse_probe=True)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         st["ms"] = round((t3 - t0) * 1e3, 2)
-        st["ms_parts"] = dict(new_points_and_error_accumulation=round((t1 - t0) * 1e3, 2), filter_knn_scale_init_concat=round((t2 - t1) * 1e3, 2),
-                              new_mapping_call_and_recapture=round((t3 - t2) * 1e3, 2))
+        st["ms_parts"] = dict(new_points_and_error_accumulation=round((t1 - t0) * 1e3, 2), filter_knn_scale_init_concat_new_mapping_call=round((t2 - t1) * 1e3, 2),
+                              recapture=round((t3 - t2) * 1e3, 2))
         st["P_after"] = fm.P
         self.growth_log.append(st)
 

@@ -126,7 +126,8 @@ class FusedMapper:
         return (sc.sum(dim=1) - sc.min(dim=1).values) / 2
 
     @torch.no_grad()
-    def grow(self, new, delete_mask=None, min_radius=0.001, max_radius=0.05, xyz_factor=(1.0, 1.0, 0.1), scale_factor=1.0):
+    def grow(self, new, delete_mask=None, min_radius=0.001, max_radius=0.05, xyz_factor=(1.0, 1.0, 0.1), scale_factor=1.0,
+             new_mapping_call=False):
         """The map-growth step between two mapping calls — Mapping.gaussians_add (SLAM/multiprocess/mapper.py:249-254) and the
         deletion half of error_gaussians_remove (:1086-1096) — on this mapper's map:
           1. temp_points_filter (:1351-1380): new points that fall inside an existing Gaussian (one of their 3 nearest existing
@@ -140,7 +141,9 @@ class FusedMapper:
         (temp_points_attach, :1384-1436, needs the stable / unstable split of the reference's two point clouds and is not part of
         this mapper.)  `new`: dict(xyz [Q,3], scales [Q,3], rotations [Q,4], opacity [Q,1], shs [Q,M,3]) of numpy arrays or GPU
         tensors.  Per-Gaussian buffers are re-allocated: a captured graph is dropped (capture() again), and the next mapping
-        call starts with begin_mapping_call().  Returns the counts of each stage."""
+        call starts with begin_mapping_call() — new_mapping_call=True does that here (fresh Adam, fresh init_stat, as the reference
+        does after every growth step, mapper.py:533-548) and then neither gathers nor concatenates the old moments and snapshots,
+        which the new call would overwrite (a third of the step's copies).  Returns the counts of each stage."""
         import dqo_mapgrowth as mg
         dev = self.device
         t = lambda a: a.to(dev).float().contiguous() if torch.is_tensor(a) else torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
@@ -182,17 +185,25 @@ class FusedMapper:
         self.scaling_raw = torch.cat([sel(self.scaling_raw), log_scales]).contiguous()
         self.rotation_raw = torch.cat([sel(self.rotation_raw), nrot]).contiguous()
         params = self._params()
-        self.state = {k: (torch.cat([sel(m), torch.zeros_like(params[k][m.shape[0] if keep_old is None else keep_old.numel():])]),
-                          torch.cat([sel(v), torch.zeros_like(params[k][v.shape[0] if keep_old is None else keep_old.numel():])]))
-                      for k, (m, v) in self.state.items()}
         n_new = nx.shape[0]
-        if self.moment_live is not None:
-            self.moment_live = torch.cat([sel(self.moment_live), torch.zeros((n_new,), dtype=torch.uint8, device=dev)])
+        if new_mapping_call:
+            self.state = {k: (torch.zeros_like(pv), torch.zeros_like(pv)) for k, pv in params.items()}
+            if self.moment_live is not None:
+                self.moment_live = torch.zeros((self.xyz.shape[0],), dtype=torch.uint8, device=dev)
+        else:
+            self.state = {k: (torch.cat([sel(m), torch.zeros_like(params[k][m.shape[0] if keep_old is None else keep_old.numel():])]),
+                              torch.cat([sel(v), torch.zeros_like(params[k][v.shape[0] if keep_old is None else keep_old.numel():])]))
+                          for k, (m, v) in self.state.items()}
+            if self.moment_live is not None:
+                self.moment_live = torch.cat([sel(self.moment_live), torch.zeros((n_new,), dtype=torch.uint8, device=dev)])
         self.P = P = self.xyz.shape[0]
         f = dict(dtype=torch.float32, device=dev)
         self.opacity, self.scales, self.rotations = torch.empty((P, 1), **f), torch.empty((P, 3), **f), torch.empty((P, 4), **f)
         self._act_valid = False
         self._g = None
+        if new_mapping_call:
+            self.begin_mapping_call(reset_optimizer=True)
+            return stats
         # init_stat / attach set: kept for the old Gaussians, the new ones start at their own values (they have not moved);
         # a new mapping call re-snapshots everything (begin_mapping_call)
         self.init_xyz = torch.cat([sel(self.init_xyz), nx])
@@ -215,7 +226,7 @@ class FusedMapper:
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
-                loss_tap=True):
+                loss_tap=True, reuse_probe=False):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
 
@@ -245,7 +256,17 @@ class FusedMapper:
             # capacity: the reference's num_rendered of the current state (an upper bound of the instances kept) plus a margin
             # for the Gaussians that move while the graph is being replayed; the device header flags an overflow.  The probe runs
             # through the C ABI on buffers of its own (two header reads), so the operator's global state is not touched.
-            cand, longest = self._probe(tile_mask)
+            # (reuse_probe: the counts of the previous capture, scaled by the growth of the map since — for a re-capture right after a
+            # growth step, which changes the map by a fraction of a percent; if the eager iteration below overflows, the capture
+            # is redone with a real probe)
+            last = getattr(self, "_last_probe", None)
+            if reuse_probe and last is not None and last[2] > 0:
+                grown = max(1.0, P / last[2])
+                cand, longest = int(last[0] * grown) + 1, int(last[1] * grown) + 1
+            else:
+                reuse_probe = False
+                cand, longest = self._probe(tile_mask)
+            self._last_probe = (cand, longest, P)
             cap = int(cand * capacity_margin) + 4096
             g = self._g = type("G", (), {})()
             g.cap = cap
@@ -319,6 +340,10 @@ class FusedMapper:
             with torch.cuda.stream(side):
                 self._static_iteration()
             torch.cuda.current_stream().wait_stream(side)
+            if self.graph_overflowed() and reuse_probe:  # the reused counts were too small after all: measure and start over
+                self._last_probe = None
+                return self.capture(gt_color, gt_depth, render_mask, tile_mask=tile_mask, capacity_margin=capacity_margin,
+                                    tile_buckets=tile_buckets, keep_tile_order=keep_tile_order, loss_tap=loss_tap, reuse_probe=False)
             if not self.graph_overflowed():  # (an invalid frame is a no-op for the optimiser and its step count)
                 self.step_count += 1
             # the eager iteration left its tile launch order in g.img; the replays keep it (DqoRastCtx.keep_tile_order: the order is

@@ -153,3 +153,54 @@ def test_scale_init_without_the_all_pairs_knn_equals_the_reference_call(mg):
     s3, _ = m.update_geometry_scales(new, r_new, old[:0], r_old[:0], 0.001, 0.05)
     s4, _ = m.update_geometry_scales(new, r_new, old[:0], r_old[:0], 0.001, 0.05, literal=True)
     np.testing.assert_allclose(s3.cpu().numpy(), s4.cpu().numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_grow_into_a_new_mapping_call_and_recapture_with_reused_counts():
+    """grow(new_mapping_call=True) = grow() + begin_mapping_call(reset_optimizer=True) without carrying the old moments and snapshots
+    along, and capture(reuse_probe=True) = capture() without the probing forward: same buffers' worth of results, bit for bit."""
+    import torch
+    from dqo_harness import mapping, scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev = torch.device("cuda")
+    cam, scene = scenes.make_config(3, P=12000)
+    settings = mapping.make_settings(cam, dev)
+    with torch.no_grad():
+        tgt = mapping.render(settings, mapping.GaussianParams(scene, dev).activated())
+    gt_color, gt_depth = tgt["render"].clone(), tgt["depth"].clone()
+    mask = (tgt["depth_index_map"][0] >= 0)
+    new = scenes.surfel_room(78, 3000, n_objects=8)
+    ms = []
+    for fast in (True, False):
+        fm = FusedMapper(scene, settings, dev)
+        fm.capture(gt_color, gt_depth, mask)
+        for _ in range(3):
+            fm.replay()
+        torch.cuda.synchronize()
+        delete = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+        delete[5::23] = True
+        if fast:
+            st = fm.grow(new, delete_mask=delete, new_mapping_call=True)
+            fm.capture(gt_color, gt_depth, mask, reuse_probe=True)
+            assert fm._last_probe[2] == fm.P
+        else:
+            st = fm.grow(new, delete_mask=delete)
+            fm.begin_mapping_call(reset_optimizer=True)
+            fm.capture(gt_color, gt_depth, mask)
+        assert st["added"] > 0 and st["deleted"] == int(delete.sum().item())
+        for _ in range(3):
+            fm.replay()
+        torch.cuda.synchronize()
+        assert not fm.graph_overflowed() and fm.step_count == 4
+        ms.append(fm)
+    a, b = ms
+    assert a.P == b.P and a.attach_count == b.attach_count
+    for k, v in a._params().items():
+        assert torch.equal(v, b._params()[k]), k
+        assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), k
+    assert torch.equal(a.loss, b.loss) and torch.equal(a.init_xyz, b.init_xyz) and torch.equal(a.attach_mask, b.attach_mask)
+    # reused counts that turn out too small: the capture notices on its own eager iteration and measures after all
+    c = FusedMapper(scene, settings, dev)
+    c.capture(gt_color, gt_depth, mask)
+    c._last_probe = (10, 4, c.P)  # absurdly small
+    c.capture(gt_color, gt_depth, mask, reuse_probe=True)
+    assert not c.graph_overflowed() and c._last_probe[0] > 1000

@@ -1,0 +1,63 @@
+"""Where does a growth step (FusedMapper.grow + new mapping call + re-capture) spend its time?   python tools/profile_grow.py [cfg]"""
+import argparse, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [R, R + "/dqo-map_amd"]
+import numpy as np, torch
+import bench
+import dqo_mapgrowth as mg
+from dqo_harness import scenes
+from dqo_harness.fused_mapping import FusedMapper
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+args = argparse.Namespace(cfg=cfg, P=None, view="room", scaling="strong", shard_by="work")
+dev = torch.device("cuda")
+prob = bench.build_problem(args, 0, 1, dev)
+mask = prob["render_mask"].to(torch.uint8).contiguous()
+fm = FusedMapper(prob["scene"], prob["settings"], dev)
+fm.capture(prob["gt_color"], prob["gt_depth"], mask, tile_mask=prob["tile_mask"])
+for _ in range(20):
+    fm.replay()
+sc = scenes.surfel_room(9000, 40_800, n_objects=prob["cfgd"]["n_objects"], rest_sigma=prob["cfgd"]["rest_sigma"])
+new = {n: torch.tensor(np.ascontiguousarray(sc[n], np.float32), device=dev) for n in ("xyz", "scales", "rotations", "opacity", "shs")}
+delete = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+delete[::1500] = True
+
+
+def timed(name, f, reps=3):
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = f()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"  {name:60s} {min(ts):8.2f} ms")
+    return r
+
+
+print("pieces of grow() on the current map (P =", fm.P, "):")
+nx = new["xyz"]
+rad = timed("radius()", lambda: fm.radius())
+inside = timed("temp_points_filter_mask (bbox filter + knn query)", lambda: mg.temp_points_filter_mask(nx, fm.xyz, rad))
+timed("  of which bbox_filter + boolean gather of the existing points", lambda: (fm.xyz[mg.bbox_filter(nx, fm.xyz)], rad[mg.bbox_filter(nx, fm.xyz)]))
+ex = fm.xyz[mg.bbox_filter(nx, fm.xyz)]
+timed("  of which knn_points_k3 alone", lambda: mg.knn_points_k3(nx, ex))
+keep = (~inside).nonzero().reshape(-1)
+nx2 = nx[keep]
+nrad = (new["scales"][keep].sum(1) - new["scales"][keep].min(1).values) / 2
+timed("update_geometry_scales", lambda: mg.update_geometry_scales(nx2, nrad, fm.xyz, rad, 0.001, 0.05))
+keep_old = (~delete).nonzero().reshape(-1)
+timed("gather of the kept rows: params (5 arrays)", lambda: [a[keep_old] for a in fm._params().values()])
+timed("gather of the kept rows: moments (10 arrays)", lambda: [x[keep_old] for m, v in fm.state.values() for x in (m, v)])
+timed("whole grow()", lambda: None, reps=1)
+t0 = time.perf_counter()
+st = fm.grow(new, delete_mask=delete)
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+fm.begin_mapping_call(reset_optimizer=True)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+fm.capture(prob["gt_color"], prob["gt_depth"], mask, tile_mask=prob["tile_mask"])
+torch.cuda.synchronize()
+t3 = time.perf_counter()
+print(f"grow {1e3 * (t1 - t0):.2f} ms, begin_mapping_call {1e3 * (t2 - t1):.2f} ms, capture {1e3 * (t3 - t2):.2f} ms; {st}")
