@@ -12,6 +12,8 @@
 #include <float.h>
 #include <limits.h>
 
+#include <algorithm>
+
 #include "dqo_common.h"
 
 namespace {
@@ -55,15 +57,11 @@ inline KnnWs knn_ws(void* base, int P) {
 }
 
 // min / max over all points with init {0,0,0}: the bounding box always contains the origin (simple_knn.cu:222-231, B15).
-__global__ __launch_bounds__(1024) void bbox_kernel(int P, const float* __restrict__ xyz, float* __restrict__ bbox) {
+// Two stages: every block reduces a strided slice of the points into a partial box, one block folds the partial boxes (a single
+// block over all points took 0.68 ms on a 2 M-point map — a quarter of a map-growth query).
+constexpr int BBOX_BLOCKS_MAX = 512;
+__device__ __forceinline__ void bbox_block_reduce(float mn[3], float mx[3], float* __restrict__ out) {
     __shared__ float s[6][16];
-    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < P; i += blockDim.x)
-        for (int a = 0; a < 3; a++) {
-            const float v = xyz[3 * i + a];
-            mn[a] = fminf(mn[a], v);
-            mx[a] = fmaxf(mx[a], v);
-        }
     for (int a = 0; a < 3; a++)
         for (int off = 32; off > 0; off >>= 1) {
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
@@ -76,8 +74,24 @@ __global__ __launch_bounds__(1024) void bbox_kernel(int P, const float* __restri
     if (threadIdx.x < 6) {
         float r = s[threadIdx.x][0];
         for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = threadIdx.x < 3 ? fminf(r, s[threadIdx.x][w]) : fmaxf(r, s[threadIdx.x][w]);
-        bbox[threadIdx.x] = r;
+        out[threadIdx.x] = r;
     }
+}
+__global__ __launch_bounds__(1024) void bbox_kernel(int P, const float* __restrict__ xyz, float* __restrict__ partial) {
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; a++) {
+            const float v = xyz[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    bbox_block_reduce(mn, mx, partial + 8 * blockIdx.x);
+}
+__global__ __launch_bounds__(512) void bbox_fold_kernel(int n, const float* __restrict__ partial, float* __restrict__ bbox) {
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        for (int a = 0; a < 3; a++) mn[a] = fminf(mn[a], partial[8 * i + a]), mx[a] = fmaxf(mx[a], partial[8 * i + 3 + a]);
+    bbox_block_reduce(mn, mx, bbox);
 }
 
 __device__ __forceinline__ uint32_t prep_morton(uint32_t x) {
@@ -382,7 +396,12 @@ size_t dqo_knn3_ws_bytes(int P) { return knn_ws(nullptr, P).total; }
 // bounding box -> Morton keys -> sort -> gather into Morton order (-> boxes)
 static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, hipStream_t s) {
     const int P2 = next_pow2(P < SORT_RUN ? SORT_RUN : P);
-    DQO_LAUNCH("bbox_kernel", bbox_kernel, dim3(1), dim3(1024), s, P, xyz, w.bbox);
+    {   // (the partial boxes live at the start of the key array: P2 >= 4096 keys = 32 KB, and the keys are written after the fold)
+        const int nb = std::min(BBOX_BLOCKS_MAX, (P + 1023) / 1024);
+        float* partial = reinterpret_cast<float*>(w.keys);
+        DQO_LAUNCH("bbox_kernel", bbox_kernel, dim3(nb), dim3(1024), s, P, xyz, partial);
+        DQO_LAUNCH("bbox_fold_kernel", bbox_fold_kernel, dim3(1), dim3(512), s, nb, partial, w.bbox);
+    }
     DQO_LAUNCH("morton_kernel", morton_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
     const int runs = P2 / SORT_RUN;
     DQO_LAUNCH("bitonic_lds_kernel", bitonic_lds_kernel, dim3(runs), dim3(SORT_T), s, w.keys, SORT_RUN, 1);
