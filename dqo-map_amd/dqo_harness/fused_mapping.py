@@ -233,8 +233,15 @@ class FusedMapper:
         The capture fixes two capacities from the state it is taken on: the instance capacity (candidates x capacity_margin)
         and, with tile_buckets, the per-tile list bucket (twice the longest list, power of two).  A replay that outgrows
         either leaves invalid outputs and raises the device-side overflow flag — check graph_overflowed() (one small D2H read,
-        e.g. once per batch of replays) and call capture() again when it is set; tile_buckets=False keeps the packed lists
-        (any list length, one more kernel per iteration)."""
+        e.g. once per batch of replays) and call capture() again when it is set, or use run(), which does both; tile_buckets=False
+        keeps the packed lists (any list length, two more kernels per iteration).
+
+        keep_tile_order (bucket mode): the replays keep the tile launch order of the capture's eager iteration instead of
+        recomputing it (DqoRastCtx.keep_tile_order: no scan kernel in a replay).  loss_tap: the masked loss is summed inside the
+        forward's blend kernel and its gradient is formed inside the backward's (DqoRastCtx.loss_tap: no loss kernels; self.loss is
+        written by the backward).  Both leave every result bit for bit as it is without them.  reuse_probe: size the capacities from
+        the previous capture's counts (scaled by the map's growth) instead of a probing forward — for a re-capture right after a small
+        change of the map; falls back to probing if the eager iteration overflows."""
         lib = N.lib()
         dev, P, M = self.device, self.P, self.M
         st = self.settings
