@@ -8,7 +8,9 @@ parameter groups (gaussian_pointcloud.py:331-378).  Inputs are resident in HBM b
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg 3] [--P 500000] [--path fused|dropin] [--scaling strong|weak]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Default `--scaling strong`: ONE map is
+N > 1: one rank per GPU over RCCL.  Under a launcher (torch.distributed.run sets WORLD_SIZE, which must equal --gpus) the process
+is one rank; started plainly as `python bench.py --gpus N`, the script launches its N ranks itself as a child job BEFORE anything
+touches the GPU (launch_ranks) and exits with the child's code.  Default `--scaling strong`: ONE map is
 built, sharded by object id (dqo_harness.sharding.shard_scene), every rank owns its objects' Gaussians + Adam state and renders
 only the tiles its objects' masks touch; one iteration of the job = every shard stepped once, so value = steps / time whatever N
 is.  The only exchange is one packed all-reduce per iteration of the shards' loss sums (started asynchronously, off the compute
@@ -45,8 +47,9 @@ def dbg(*a):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: an unparameterised run times >= 0.1 s of GPU work (200 iterations of ~0.5 ms)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cfg", type=int, default=3)
     ap.add_argument("--P", type=int, default=None)
     ap.add_argument("--sync-mode", default="lazy", choices=("lazy", "exact"))
@@ -70,11 +73,53 @@ def parse():
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child of a --pmc pass: timed loop only
     ap.add_argument("--no-loss-tap", action="store_true",
                     help="fused path: the two loss kernels between forward and backward instead of the loss tap inside the blend kernels (A/B)")
+    ap.add_argument("--no-fused-tail", action="store_true",
+                    help="fused path: record_sum + gaussian_backward + adam as three kernels instead of the one fused per-Gaussian tail (A/B)")
+    ap.add_argument("--no-object-gate", action="store_true",
+                    help="strong scaling: a shard's objects occlude each other (round 2's job definition) instead of the per-object gate that "
+                         "makes every N compute the N = 1 function")
     ap.add_argument("--shard-by", default="work", choices=("work", "count"),
                     help="strong scaling: balance the objects over the ranks by their on-screen work in the bench view (default) or by Gaussian count")
     ap.add_argument("--as-shard", default=None, metavar="R/N",
                     help="analysis on one GPU: run shard R of an N-rank strong-scaling job alone (no collective partner; not a scaling measurement)")
     return ap.parse_args()
+
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N ranks from a plain `python bench.py --gpus N`
+# ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """`--gpus N` (N > 1) without a launcher's environment: start the N ranks as a child job — python -m torch.distributed.run, one
+    process per GPU, rendezvous on 127.0.0.1 — forward its output (rank 0's ONE JSON line) and return its exit code.  Called before
+    any GPU call of this process (no torch.cuda.*, libdqoraster.so not loaded): the parent never initialises the GPU, and nothing is
+    exec'ed over a process that has."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def resolve_world(args):
+    """(rank, world, local rank) of this process, or None after having run the N ranks as a child job (exit code in args._rc)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1 and not args.as_shard and not args.inner:
+            args._rc = launch_ranks(args)
+            return None
+        return 0, 1, 0
+    world = int(env_world)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch as many ranks as --gpus says "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...), or start "
+                         f"`python bench.py --gpus {args.gpus}` without a launcher and it starts them itself")
+    return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -568,19 +613,39 @@ def pmc_traffic(args, kernel_name):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    # every flag that changes the workload or the kernel variant travels to the child, so the counters belong to what the parent timed
     inner = [sys.executable, os.path.abspath(__file__), "--inner", "--cfg", str(args.cfg), "--steps", "3", "--warmup", "1", "--path", args.path,
-             "--view", args.view, "--sync-mode", args.sync_mode]
+             "--view", args.view, "--sync-mode", args.sync_mode, "--scaling", args.scaling, "--shard-by", args.shard_by]
     if args.P:
         inner += ["--P", str(args.P)]
-    if args.no_graph:
-        inner += ["--no-graph"]
+    for flag, on in (("--no-graph", args.no_graph), ("--no-loss-tap", args.no_loss_tap), ("--no-fused-tail", args.no_fused_tail),
+                     ("--no-object-gate", args.no_object_gate)):
+        if on:
+            inner += [flag]
+    if args.as_shard:
+        inner += ["--as-shard", args.as_shard]
     res = {}
     env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("WORLD_SIZE", None)
     for tag, counters in (("rd", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]), ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])):
         d = tempfile.mkdtemp(prefix="dqo_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--"] + inner
+        # a session of its own: on a timeout the whole group goes (rocprofv3 AND the python it started — killing only the profiler would
+        # leave the grandchild on the GPU for the rest of the bench)
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc_ = pr.wait(timeout=420)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                raise
+            if rc_ != 0:
+                raise subprocess.CalledProcessError(rc_, cmd)
         except (subprocess.SubprocessError, OSError) as e:
             shutil.rmtree(d, ignore_errors=True)
             return None, f"pmc pass {tag} failed: {type(e).__name__}"
@@ -599,15 +664,17 @@ def pmc_traffic(args, kernel_name):
             res[c] = acc[c][0] / acc[c][1]
     rd = res["TCC_EA0_RDREQ_sum"] * 64
     wr = res["TCC_EA0_WRREQ_64B_sum"] * 64 + (res["TCC_EA0_WRREQ_sum"] - res["TCC_EA0_WRREQ_64B_sum"]) * 32
-    return dict(read_bytes=int(rd), write_bytes=int(wr)), "measured in this run: rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ child passes"
+    return dict(read_bytes=int(rd), write_bytes=int(wr)), ("measured in this run: rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ child passes over `bench.py "
+                                                           + " ".join(inner[2:]) + "`")
 
 
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rw = resolve_world(args)  # before any GPU call: with --gpus N > 1 and no launcher the ranks run as a child job
+    if rw is None:
+        sys.exit(args._rc)
+    rank, world, local = rw
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP rasteriser has no CPU path")
     backend = os.environ.get("DQO_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
@@ -619,6 +686,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one process per GPU; device_id binds the communicator to this rank's GPU up front (no guessing at the first barrier)
         torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+        if torch.distributed.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
+        # every rank's device index, for config.devices (which GPU each rank of the job ran on)
+        dv = torch.zeros(world, dtype=torch.int32, device=device)
+        dv[rank] = local
+        torch.distributed.all_reduce(dv)
+        rank_devices = [int(x) for x in dv.tolist()]
+    else:
+        rank_devices = [local]
     if args.growth_every is None:
         args.growth_every = 100 if (args.cfg == 5 and args.path == "fused" and not args.inner) else 0
 
@@ -868,7 +944,9 @@ def main():
                                    + f", {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 "
                                    "depth L1) + attach loss, raster fwd+bwd + Adam (6 groups); path=" + args.path
                                    + ("" if args.path != "fused" or args.no_graph else " (one hipGraph replay per iteration)"),
-                       "shards": world, **({"as_shard": args.as_shard} if args.as_shard else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
+                       "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
+                       "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
+                       "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
                                                                                    ("ok" if selfcheck_ok else "FAILED")), **stats},
             "loss": loss_now, "path": args.path,
         }

@@ -50,10 +50,12 @@ int dqo_launch_accumulate_error(int H, int W, int P, const float* color_err, con
 
 // ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -------------------------------
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 int g_dqo_profile_on = 0;
 namespace {
+std::mutex g_profile_mu;  // the timing tables are process-wide: launches may come from several host threads (one per stream)
 struct Pending {
     std::string name;
     hipEvent_t start, stop;
@@ -72,12 +74,20 @@ hipEvent_t take_event() {
     return e;
 }
 }  // namespace
+// before / after bracket ONE launch of the calling thread: the index of its pending entry is kept per thread, so brackets of
+// different threads may interleave
+static thread_local size_t t_pending_idx = 0;
 void dqo_profile_before(const char* name, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_profile_mu);
     Pending p{name, take_event(), take_event()};
     (void)hipEventRecord(p.start, s);
+    t_pending_idx = g_pending.size();
     g_pending.push_back(p);
 }
-void dqo_profile_after(hipStream_t s) { (void)hipEventRecord(g_pending.back().stop, s); }
+void dqo_profile_after(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_profile_mu);
+    if (t_pending_idx < g_pending.size()) (void)hipEventRecord(g_pending[t_pending_idx].stop, s);
+}
 
 extern "C" {
 
@@ -91,6 +101,7 @@ DQO_API int dqo_profile_enable(int on) {
 // Waits for every bracketed launch recorded so far, accumulates elapsed times per kernel name and copies up to
 // max_entries accumulated rows out (returns the number of rows).  reset != 0 clears the accumulators afterwards.
 DQO_API int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset) {
+    std::lock_guard<std::mutex> lk(g_profile_mu);
     for (auto& p : g_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {

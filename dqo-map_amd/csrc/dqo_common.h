@@ -122,15 +122,23 @@ constexpr double DQO_TAP_FIXED = 4294967296.0;  // 2^32
 // The frame totals of the loss tap, by one wave: lane j reads line j, the wave adds up (fixed order).  tot[0..3] = colour error sum,
 // mask pixels, depth error sum, valid depth pixels.  Called a kernel boundary after the forward blend kernel wrote them.
 __device__ __forceinline__ void dqo_tap_totals(const uint32_t* spread, int lane, double tot[4]) {
-    const unsigned long long* l = reinterpret_cast<const unsigned long long*>(spread + (size_t)(lane % DQO_SPREAD) * 64 + 8);
-    unsigned long long t[4];
+    unsigned long long t[4] = {0ull, 0ull, 0ull, 0ull};
+    for (int j = lane; j < DQO_SPREAD; j += 64) {  // (any DQO_SPREAD: the forward scatters to blockIdx.x % DQO_SPREAD)
+        const unsigned long long* l = reinterpret_cast<const unsigned long long*>(spread + (size_t)j * 64 + 8);
 #pragma unroll
-    for (int c = 0; c < 4; c++) t[c] = lane < DQO_SPREAD ? l[c] : 0ull;
+        for (int c = 0; c < 4; c++) t[c] += l[c];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
         for (int c = 0; c < 4; c++) t[c] += (unsigned long long)__shfl_xor((long long)t[c], off);
     tot[0] = (double)t[0] / DQO_TAP_FIXED, tot[1] = (double)t[1], tot[2] = (double)t[2] / DQO_TAP_FIXED, tot[3] = (double)t[3];
+}
+// A wave's float sum as a 2^-32 fixed-point addend.  A sum the format cannot hold — NaN, an infinity, anything beyond 2^31 — becomes
+// the largest addend (it poisons the loss by design, as a NaN poisons the float version); the float -> integer conversion of such a
+// value would be undefined.
+__device__ __forceinline__ unsigned long long dqo_tap_fixed(float s) {
+    return (s >= 0.f && s < 2147483648.f) ? (unsigned long long)((double)s * DQO_TAP_FIXED + 0.5) : ~0ull >> 1;
 }
 #endif
 

@@ -72,9 +72,8 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
     const float se = tap_wave_sum(m ? e : 0.f), sd = tap_wave_sum(valid ? de : 0.f);
     if (lane != 0) return;
     unsigned long long* line = reinterpret_cast<unsigned long long*>(g.spread + (size_t)(blockIdx.x % DQO_SPREAD) * 64 + 8);
-    // (a non-finite sum — NaN colours — is not representable in fixed point: it poisons the loss by design, as in the float version)
-    const unsigned long long fe = se == se ? (unsigned long long)((double)se * DQO_TAP_FIXED + 0.5) : ~0ull >> 1;
-    const unsigned long long fd = sd == sd ? (unsigned long long)((double)sd * DQO_TAP_FIXED + 0.5) : ~0ull >> 1;
+    // (a non-finite sum — NaN / infinite colours — is not representable in fixed point: dqo_tap_fixed)
+    const unsigned long long fe = dqo_tap_fixed(se), fd = dqo_tap_fixed(sd);
     atomicAdd(&line[0], fe), atomicAdd(&line[1], nm);
     if (nv) atomicAdd(&line[2], fd), atomicAdd(&line[3], nv);
 }

@@ -252,9 +252,14 @@ class FusedMapper:
         tile_mask = self.tile_mask if tile_mask is None else _checked_tile_mask(tile_mask, dev, H, W)
         with torch.cuda.device(dev):
             if getattr(self, "_g", None) is not None:
-                # re-capture (e.g. after an overflow): the device-side step count is the truth — replays of invalid frames did
-                # not advance it (DqoAdamStep.frame_header)
-                self.step_count = int(self._g.step_dev.item()) - 1
+                # re-capture (e.g. after an overflow): replays of invalid frames did not advance the device-side step count
+                # (DqoAdamStep.frame_header), the host count assumed they did.  After the last replay the device count was expected to
+                # be g.expected_step; what it falls short of that is the number of invalid replays, and only those are taken back —
+                # eager step() calls since then advanced the host count alone (they never touch g.step_dev) and stay counted.
+                g_old = self._g
+                invalid = int(g_old.expected_step) - int(g_old.step_dev.item())
+                if invalid > 0:
+                    self.step_count -= invalid
                 self._g = None
             if not self._act_valid:
                 N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
@@ -303,6 +308,7 @@ class FusedMapper:
             g.grads = dict(means3D=torch.empty((P, 3), **f), sh=torch.empty((P, M, 3), **f),
                            opacity=torch.empty((P, 1), **f), scales=torch.empty((P, 3), **f), rot=torch.empty((P, 4), **f))
             g.step_dev = torch.full((1,), self.step_count + 1, **i32)
+            g.expected_step = self.step_count + 1  # what step_dev holds while host and device counts agree
             g.ticket = torch.zeros((1,), **i32)  # DqoAdamStep.block_ticket: the Adam launch advances step_dev itself
             g.params = dgr._params(st, P, M)
             g.inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, g.tile_mask)

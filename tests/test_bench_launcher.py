@@ -1,0 +1,58 @@
+"""CPU: bench.py's rank resolution — `--gpus N` without a launcher starts N ranks as a child job before anything touches the GPU;
+under a launcher WORLD_SIZE must equal --gpus (a mismatch exits non-zero instead of silently measuring one GPU)."""
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _args(**kw):
+    d = dict(gpus=1, as_shard=None, inner=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_resolve_world(monkeypatch):
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.resolve_world(_args(gpus=1)) == (0, 1, 0)
+    # analysis modes stay one process whatever --gpus says
+    assert bench.resolve_world(_args(gpus=4, as_shard="1/4")) == (0, 1, 0)
+    assert bench.resolve_world(_args(gpus=4, inner=True)) == (0, 1, 0)
+    # no launcher, N > 1: the ranks run as a child job and the parent only relays the exit code
+    calls = []
+    monkeypatch.setattr(bench, "launch_ranks", lambda a: calls.append(a.gpus) or 7)
+    a = _args(gpus=8)
+    assert bench.resolve_world(a) is None and a._rc == 7 and calls == [8]
+    # under a launcher
+    monkeypatch.setenv("WORLD_SIZE", "2"), monkeypatch.setenv("RANK", "1"), monkeypatch.setenv("LOCAL_RANK", "1")
+    assert bench.resolve_world(_args(gpus=2)) == (1, 2, 1)
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_world(_args(gpus=8))
+    assert "WORLD_SIZE=2" in str(e.value)
+
+
+def test_plain_gpus_n_starts_n_ranks_and_relays_the_exit_code():
+    """`python bench.py --gpus 2` on a box without a GPU: two ranks are started (each reports that it needs a GPU and exits non-zero),
+    the parent never imports the HIP library and exits non-zero as well — it does not fall back to one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by test_two_rank_rehearsal_on_one_gpu")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+
+
+def test_world_size_mismatch_exits_nonzero():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 8" in r.stderr

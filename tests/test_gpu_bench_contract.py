@@ -37,19 +37,18 @@ def test_two_rank_rehearsal_on_one_gpu():
     """The N > 1 code path of bench.py end to end — one map sharded by object id over two ranks, hipGraph replay per rank, the packed
     asynchronous all-reduce of the loss sums, every rank's self check — with two processes sharing this box's one GPU and gloo as the
     transport (RCCL refuses two ranks on one device; the collective calls are the same).  A rehearsal of the path, not a measurement."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # plain `python bench.py --gpus 2`: the script starts its two ranks itself (bench.launch_ranks), before it touches the GPU
     env = dict(os.environ, DQO_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shards"] == 2 and d["config"]["selfcheck"] == "ok"
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo" and d["config"]["devices"] == [0, 0]
     assert "sharded by object id over 2 ranks" in d["config"]["workload"]
     assert 0 < d["config"]["P_shard"] < d["config"]["P"] and d["loss"][0] > 0
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only

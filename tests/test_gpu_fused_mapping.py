@@ -191,6 +191,36 @@ def test_graph_replay_matches_eager_steps(env):
     assert b.step_count == 6 and int(b._g.step_dev.item()) == 7
 
 
+def test_recapture_after_eager_steps_keeps_the_step_count(env):
+    """capture -> replays -> eager step() calls -> capture(): the eager steps advance only the host-side step count (they never touch
+    the graph's device counter), so a re-capture must not roll the count back to the device value — every later Adam step would use
+    the bias corrections of an earlier step.  The sequence must end where the same number of plain eager steps ends."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, settings, dev)
+    b.capture(gt_color, gt_depth, mask)          # iteration 1 (the capture's eager one)
+    b.replay(), b.replay()                       # 2, 3
+    b.step(gt_color, gt_depth, mask)             # 4, 5: eager, host count only
+    b.step(gt_color, gt_depth, mask)
+    assert b.step_count == 5
+    b.capture(gt_color, gt_depth, mask)          # 6: must see step_count 5, not the device counter's 3
+    assert b.step_count == 6 and int(b._g.step_dev.item()) == 7
+    b.replay()                                   # 7
+    torch.cuda.synchronize()
+    assert b.step_count == 7 and int(b._g.step_dev.item()) == 8
+    for _ in range(7):
+        a.step(gt_color, gt_depth, mask)
+    for k, pa in a._params().items():
+        lr = dict(xyz=0.001, shs=0.0005, opacity=1.0, scaling=0.004, rotation=0.001)[k]
+        d = (pa - b._params()[k]).abs()
+        # (a rolled-back count changes the bias corrections of every later step by tens of percent of a step)
+        assert (d > 0.01 * lr + 1e-7).float().mean().item() < 1e-3, (k, d.max().item())
+        for i in (0, 1):
+            np.testing.assert_allclose(b.state[k][i].cpu().numpy(), a.state[k][i].cpu().numpy(), rtol=1e-3, atol=1e-9)
+
+
 def test_loss_tap_equals_the_loss_kernels(env):
     """DqoRastCtx.loss_tap: the masked loss summed inside the forward's blend kernel and its gradient formed inside the backward's
     must train exactly like the two loss kernels between them — same counts, same gradient scale, hence bit-identical parameters and

@@ -160,33 +160,45 @@ def _row_err(a, truth):
     return np.abs(a.reshape(rows_t.shape) - rows_t).max(1) / scale
 
 
-def compare_grads(hg, og, og64=None, rtol=1e-3, row_budget=1e-3):
+def unexplained_cap(rows):
+    """Rows that may sit beyond the bar WITHOUT an explanation: max(4, 1e-5 x rows) — what the data uses (round 2 measured 1 + 1 rows of
+    1 M and 2 + 8 of 2 M), not the 0.1 % of the rows that round 2's harness tolerated."""
+    return max(4, int(1e-5 * rows))
+
+
+def compare_grads(hg, og, og64=None, rtol=1e-3):
     """Gradients within 1e-3 of the fp32 oracle (north_star), per Gaussian row, relative to the tensor's largest magnitude — no
     slack term.  Callers zero the incoming gradient on flipped_pixels() for both sides first.
 
     The reference's per-Gaussian chain (dL/dconic -> cov2D -> cov3D -> scale / quaternion, backward.cu:331-355, 426-487) is
     ill-conditioned for thin surfels: on a few rows ANY two float32 evaluations disagree in the second digit, the reference with
-    itself included (its float atomicAdd order changes from run to run, quirk B10).  Those rows are handled like the flipped pixels
-    of the forward: counted against a budget of 0.1 % of the rows — and, where the fp64 oracle is at hand, each of
-    them must be a row on which the fp32 ORACLE ITSELF is off its fp64 twin by more than a third of the bar, with the HIP result no
-    further from fp64 than 3x the oracle is: an outlier must be ill-conditioned, not wrong.  Returns per tensor
-    (max row error, 99th percentile of the row error relative to the row's own magnitude, outlier rows, rows)."""
+    itself included (its float atomicAdd order changes from run to run, quirk B10).  A row beyond the bar must therefore be EXPLAINED:
+    with the fp64 oracle beside (every full-size configuration runs it), the fp32 ORACLE ITSELF is off its fp64 twin by more than a
+    third of the bar on that row and the HIP result is no further from fp64 than 3x the oracle is — ill-conditioned, not wrong.
+    Unexplained rows (all rows beyond the bar when there is no fp64 oracle) are capped at unexplained_cap(rows) = max(4, 1e-5 x rows).
+    Returns per tensor a dict: max_row_err, q99 (99th percentile of the row error relative to the row's own magnitude), rows,
+    beyond_bar, explained, unexplained, worst_explained, worst_unexplained."""
     stats = {}
     for k in og:
         e = _row_err(hg[k], og[k])
         out = e > rtol
         n_out, n = int(out.sum()), int(e.size)
         tmax, q99 = grad_errors(hg[k], og[k])
-        stats[k] = (float(e.max()) if n else 0.0, q99, n_out, n)
-        if n_out:
-            explained = False
-            if og64 is not None:
-                e_o = _row_err(og[k], og64[k])
-                e_h = _row_err(hg[k], og64[k])
-                explained = bool(np.all(e_o[out] > 0.3 * rtol) and np.all(e_h[out] <= 3 * e_o[out] + rtol))
-            assert explained or n_out <= int(row_budget * n), (
-                f"grad {k}: {n_out} of {n} rows off the fp32 oracle by more than {rtol:.0e} of the largest magnitude (worst {e.max():.3e}); "
-                f"budget {int(row_budget * n)} rows" + ("" if og64 is None else ", and not explained by the fp32 oracle's own error against fp64"))
+        expl = np.zeros_like(out)
+        if n_out and og64 is not None:
+            e_o = _row_err(og[k], og64[k])
+            e_h = _row_err(hg[k], og64[k])
+            expl = out & (e_o > 0.3 * rtol) & (e_h <= 3 * e_o + rtol)
+        unexp = out & ~expl
+        n_unexp = int(unexp.sum())
+        stats[k] = dict(max_row_err=float(e.max()) if n else 0.0, q99=q99, rows=n, beyond_bar=n_out, explained=int(expl.sum()),
+                        unexplained=n_unexp, worst_explained=float(e[expl].max()) if expl.any() else 0.0,
+                        worst_unexplained=float(e[unexp].max()) if n_unexp else 0.0)
+        assert n_unexp <= unexplained_cap(n), (
+            f"grad {k}: {n_unexp} of {n} rows are off the fp32 oracle by more than {rtol:.0e} of the largest magnitude (worst "
+            f"{stats[k]['worst_unexplained']:.3e})" + (" with no fp64 oracle to explain them" if og64 is None else
+                                                        " and are NOT explained by the fp32 oracle's own error against fp64")
+            + f"; cap {unexplained_cap(n)} rows")
         if n >= 1000:
             assert q99 <= rtol, f"grad {k}: 99% row-wise error {q99:.3e} > {rtol:.1e} (vs fp32 oracle)"
     if og64 is not None:
