@@ -230,12 +230,12 @@ class FusedRunner:
     """The fused path of one rank: a FusedMapper on the rank's shard, one hipGraph replay per iteration, the packed all-reduce of
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
 
-    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True):
+    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True):
         from dqo_harness.fused_mapping import FusedMapper
         self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
         self.fm = FusedMapper(prob["scene"], prob["settings"], device)
         self.mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
-        self.use_graph, self.loss_tap = use_graph, loss_tap
+        self.use_graph, self.loss_tap, self.fused_tail = use_graph, loss_tap, fused_tail
         self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
         self.first_loss = None
         self.growth_pool = []  # the new points of every growth step: input data, resident in HBM before the timed region
@@ -244,7 +244,8 @@ class FusedRunner:
 
     def _capture(self, reuse_probe=False):
         p = self.prob
-        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap, reuse_probe=reuse_probe)
+        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap, reuse_probe=reuse_probe,
+                        fused_tail=self.fused_tail)
         if self.first_loss is None:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
 
@@ -724,7 +725,7 @@ def main():
     runner = step_dropin = None
     if args.path == "fused":
         runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
-                             loss_tap=not args.no_loss_tap)
+                             loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail)
         step = runner.step
     else:
         step_dropin = make_dropin_step(prob, device, loss_buf)
@@ -863,6 +864,9 @@ def main():
             "loss_reduce_kernel": 36 * cam.W * cam.H, "loss_grad_kernel": 52 * cam.W * cam.H,
             # 59 floats x (param, m, v in and out) of the Gaussians Adam touches (all of them in dense mode) + the gradient rows
             "adam_kernel": 236 * 6 * stats.get("adam_rows_touched", Pk) + 236 * n_vis,
+            # fused per-Gaussian tail: gradient records in, the forward's tables of the visible Gaussians in, 59 floats x (param, m, v
+            # in and out) of the Gaussians Adam touches — no gradient rows, no summed records
+            "gaussian_tail_kernel": 68 * n_inst + 72 * n_vis + 236 * 6 * stats.get("adam_rows_touched", Pk),
         }
         # the contract's own per-unit figure for the dominant kernel's share of an iteration: 40 B per instance (bwd
         # gather) + 16 B per active pixel (dL_dcolor, dL_ddepth) for the backward blend; 28 B + 36 B for the forward blend

@@ -61,14 +61,14 @@ class DqoAdamStep(ctypes.Structure):
                                      "g_scales", "g_rotations", "m_xyz", "m_shs", "m_opacity", "m_scaling", "m_rotation", "v_xyz",
                                      "v_shs", "v_opacity", "v_scaling", "v_rotation", "act_opacity", "act_scales", "act_rotations", "radii", "step_dev", "moment_live",
                                      "attach_mask", "init_xyz", "init_scaling_raw", "init_rotation_raw")] +
-                [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp), ("block_ticket", c_vp)])
+                [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp), ("block_ticket", c_vp), ("bias_table", c_vp)])
 
 
 EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
            "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_adam_step", "dqo_accumulate_gaussian_error", "dqo_accumulate_gaussian_confidence", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
            "dqo_rast_binning_bytes", "dqo_rast_binning_bytes_bucketed",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
-           "dqo_rast_forward", "dqo_rast_backward", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
+           "dqo_rast_forward", "dqo_rast_backward", "dqo_rast_backward_adam", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
            "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam", "dqo_tile_count_mask", "dqo_transmission_mask", "dqo_tile_color_error", "dqo_knn3_query_workspace_bytes",
            "dqo_knn3_query", "dqo_icp_workspace_bytes", "dqo_icp_normal_equations")
 
@@ -104,6 +104,8 @@ def lib():
         L.dqo_rast_read_header.argtypes = [P(DqoRastCtx), P(DqoRastHeader), c_vp]
         L.dqo_rast_backward.argtypes = [P(DqoRastParams), P(DqoRastInputs), P(DqoRastCtx), c_vp, c_vp, c_vp, P(DqoRastGrads), c_vp,
                                         ctypes.c_size_t, c_vp]
+        L.dqo_rast_backward_adam.argtypes = [P(DqoRastParams), P(DqoRastInputs), P(DqoRastCtx), c_vp, c_vp, P(DqoAdamStep), c_vp,
+                                             ctypes.c_size_t, c_vp]
         L.dqo_mark_visible.argtypes = [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         L.dqo_knn3.argtypes = [c_i32, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
         L.dqo_quadric_iou_fwd_bwd.argtypes = [c_i32] + [c_vp] * 12
@@ -126,7 +128,7 @@ def lib():
         L.dqo_tile_color_error.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         L.dqo_profile_enable.argtypes = [ctypes.c_int]
         L.dqo_profile_collect.argtypes = [P(DqoProfileEntry), ctypes.c_int, ctypes.c_int]
-        if L.dqo_abi_version() != 2:
+        if L.dqo_abi_version() != 3:
             raise RuntimeError("libdqoraster.so ABI version mismatch")
         L.dqo_abi_sizeof.restype = ctypes.c_size_t
         L.dqo_abi_sizeof.argtypes = [c_i32]

@@ -1,0 +1,378 @@
+// Adam over the six parameter groups of the Gaussian map with the activation Jacobians and the attach loss folded in
+// (SLAM/gaussian_pointcloud.py:331-378, SLAM/multiprocess/mapper.py:548, :812-829) as device code shared by
+//   adam_kernel          (map_fused.hip)      : gradient rows come from HBM (dqo_rast_backward wrote them)
+//   gaussian_tail_kernel (map_fused_tail.hip) : gradient rows come from LDS (the same block has just computed them)
+// Both run the SAME statements on the same operands (one template, the gradient source is its parameter), so parameters and moments
+// come out bit-identical whichever path produced the gradient.
+#pragma once
+#include "dqo_common.h"
+
+struct AdamArgs {
+    int P, M;
+    float beta1, beta2, eps, bc2_sqrt;
+    float step_xyz, step_dc, step_rest, step_opacity, step_scaling, step_rotation;
+    float *xyz, *shs, *opacity_raw, *scaling_raw, *rotation_raw;                 // parameters (raw), updated in place
+    const float *g_xyz, *g_shs, *g_opacity, *g_scales, *g_rot;                    // gradients w.r.t. the ACTIVATED parameters
+    float *m_xyz, *m_shs, *m_opacity, *m_scaling, *m_rotation;                    // exp_avg
+    float *v_xyz, *v_shs, *v_opacity, *v_scaling, *v_rotation;                    // exp_avg_sq
+    float *act_opacity, *act_scales, *act_rotations;                              // optional: activations of the updated parameters
+    const int32_t* radii;                                                         // optional: radii == 0 => the gradient row is zero and unread
+    uint64_t row_magic;                                                           // ceil(2^39 / (3 M)): division by the SH row length
+    const int32_t* step_dev;                                                      // optional: step count on the device (hipGraph replay)
+    float lr_xyz, lr_dc, lr_rest, lr_opacity, lr_scaling, lr_rotation;            // used with step_dev
+    // attach loss (mapper.py:812-829): elementwise pull of the raw scaling / xyz / rotation towards their values at the start of
+    // the mapping call, for the Gaussians of attach_mask
+    const uint8_t* attach_mask;
+    const float *init_xyz, *init_scaling, *init_rotation;
+    float attach_g3, attach_g4;                                                   // 2000 / (3 |a|), 2000 / (4 |a|)
+    float* attach_partial;
+    const DqoRastHeader* frame_header;                                            // optional: overflow flag => the launch is a no-op
+    int32_t* step_advance;                                                        // optional: the last block to finish adds 1 to it
+    int32_t* block_ticket;                                                        // (with step_advance) blocks finished so far
+    float* bias_table;                                                            // optional (with step_dev): DqoAdamStep.bias_table
+};
+
+// host side: DqoAdamStep -> AdamArgs (argument checks included); blocks = the launch's grid size (for the step-advance ticket)
+int dqo_adam_args(const DqoAdamStep* st, int blocks, AdamArgs* out, bool* attach);
+
+#ifdef __HIPCC__
+constexpr int ADAM_THREADS = 256;
+
+// The moments and the gradients are touched exactly once per iteration (0.7 GB of the kernel's 0.83 GB): non-temporal loads /
+// stores keep them from evicting the rasteriser's tables and the parameters out of L2 / Infinity Cache.
+template <typename T>
+__device__ __forceinline__ T ldnt(const T* p) {
+    return __builtin_nontemporal_load(p);
+}
+template <typename T>
+__device__ __forceinline__ void stnt(T v, T* p) {
+    __builtin_nontemporal_store(v, p);
+}
+
+__device__ __forceinline__ float adam_wave_red(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float step_size) {
+    // torch.optim.Adam (single-/multi-tensor and fused paths share this math):
+    //   m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g^2; p -= step_size * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+    // Separate IEEE operations (no FMA contraction): every instantiation of the kernel then produces the same bits, which the
+    // exact sparse mode's equivalence to the dense update is tested against.
+#pragma clang fp contract(off)
+    m = m + (g - m) * (1.f - a.beta1);
+    v = v * a.beta2 + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - step_size * (m / denom);
+}
+
+// Gradient source of adam_kernel: the rows dqo_rast_backward wrote to HBM (a row without a gradient may be unwritten memory: it is read
+// at a clamped address and discarded — a load under a lane condition would make the compiler drain every earlier load first).
+// k = list row of the block, i = element index in the parameter tensor, has_g = the Gaussian has a gradient row.
+struct AdamGradGlobal {
+    const AdamArgs& a;
+    __device__ __forceinline__ float xyz(int, uint32_t, size_t i, bool has_g) const { return ldnt(&a.g_xyz[has_g ? i : 0]); }
+    __device__ __forceinline__ float scales(int, uint32_t, size_t i, bool has_g) const { return ldnt(&a.g_scales[has_g ? i : 0]); }
+    // SH element j of the row; ei = its element index, e0 = a valid element index of the same trip
+    __device__ __forceinline__ float sh(int, uint32_t, uint32_t ei, uint32_t e0, bool has_g) const { return ldnt(&a.g_shs[has_g ? ei : e0]); }
+    __device__ __forceinline__ float opacity(int, uint32_t i, bool has_g) const { return ldnt(&a.g_opacity[has_g ? i : 0u]); }
+    __device__ __forceinline__ float4 rot(int, uint32_t i, bool has_g) const { return reinterpret_cast<const float4*>(a.g_rot)[has_g ? i : 0u]; }
+};
+
+// The bias corrections of step t (double, like the host path / torch's python floats): out[0] = sqrt(1 - beta2^t), out[1..6] = the six
+// learning rates / (1 - beta1^t).  Two double-precision pow() calls, a square root and six divisions: several hundred instructions.
+__device__ __forceinline__ void adam_bias_compute(const AdamArgs& a, const int step, float* out /*[7]*/) {
+    const double t = (double)step;
+    const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+    out[0] = (float)sqrt(bc2);
+    out[1] = (float)((double)a.lr_xyz / bc1), out[2] = (float)((double)a.lr_dc / bc1), out[3] = (float)((double)a.lr_rest / bc1);
+    out[4] = (float)((double)a.lr_opacity / bc1), out[5] = (float)((double)a.lr_scaling / bc1);
+    out[6] = (float)((double)a.lr_rotation / bc1);
+}
+// ... of the launch's step (the device-resident count), by the calling thread(s): from DqoAdamStep.bias_table when it holds this step
+// (seven loads from uniform addresses), computed otherwise — the same function either way, so the same bits.
+__device__ __forceinline__ void adam_bias_to_lds(const AdamArgs& a, float* s_ss /*[7]*/) {
+    const int step = *a.step_dev;
+    if (a.bias_table != nullptr && __float_as_int(a.bias_table[7]) == step) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) s_ss[i] = a.bias_table[i];
+        return;
+    }
+    adam_bias_compute(a, step, s_ss);
+}
+__device__ __forceinline__ void adam_bias_from_lds(AdamArgs& a, const float* s_ss) {
+    a.bc2_sqrt = s_ss[0], a.step_xyz = s_ss[1], a.step_dc = s_ss[2], a.step_rest = s_ss[3], a.step_opacity = s_ss[4];
+    a.step_scaling = s_ss[5], a.step_rotation = s_ss[6];
+}
+
+// ---- the element updates of the passes: loaded values in, stores out ----
+struct AdamXyzVals {  // one element of the xyz / scaling pass
+    float p, m, v, ps, ms, vs, gx_ld, gs_ld, p0, ps0;
+};
+template <bool ATTACH>
+__device__ __forceinline__ void adam_xyz_update(const AdamArgs& a, const uint32_t r, const size_t i, AdamXyzVals x, float& att_sum) {
+    const bool has_g = (r >> 31) != 0u;
+    float p = x.p, m = x.m, v = x.v, ps = x.ps, ms = x.ms, vs = x.vs;
+    float gx = has_g ? x.gx_ld : 0.f, gs = (has_g ? x.gs_ld : 0.f) * expf(ps);  // d exp(x)/dx = exp(x)
+    if (ATTACH) {
+        const bool at = ((r >> 30) & 1u) != 0u;
+        const float dx = at ? p - x.p0 : 0.f, ds = at ? ps - x.ps0 : 0.f;
+        gx += a.attach_g3 * dx, gs += a.attach_g3 * ds;
+        att_sum += 0.5f * a.attach_g3 * (dx * dx + ds * ds);
+    }
+    adam1(p, gx, m, v, a, a.step_xyz);
+    a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
+    adam1(ps, gs, ms, vs, a, a.step_scaling);
+    a.scaling_raw[i] = ps, stnt(ms, &a.m_scaling[i]), stnt(vs, &a.v_scaling[i]);
+    if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
+}
+
+struct AdamRowVals {  // one row of the opacity / rotation pass
+    float p, m, v, go_ld;
+    float4 q, mq, vq, gr_ld, q0;
+};
+template <bool ATTACH>
+__device__ __forceinline__ void adam_row_update(const AdamArgs& a, const uint32_t r, AdamRowVals x, float& att_sum) {
+    const uint32_t i = r & 0x3fffffffu;
+    const bool has_g = (r >> 31) != 0u;
+    float p = x.p, m = x.m, v = x.v;
+    float4 q = x.q, mq = x.mq, vq = x.vq;
+    const float sg = 1.0f / (1.0f + expf(-p));
+    adam1(p, (has_g ? x.go_ld : 0.f) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
+    a.opacity_raw[i] = p, stnt(m, &a.m_opacity[i]), stnt(v, &a.v_opacity[i]);
+    if (a.act_opacity) a.act_opacity[i] = 1.0f / (1.0f + expf(-p));
+
+    const float4 g = has_g ? x.gr_ld : make_float4(0.f, 0.f, 0.f, 0.f);
+    // F.normalize backward: y = q / n, n = max(|q|, eps):  dq = (g - y (y . g)) / n
+    const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float yx = q.x / nrm, yy = q.y / nrm, yz = q.z / nrm, yw = q.w / nrm;
+    const float dot = yx * g.x + yy * g.y + yz * g.z + yw * g.w;
+    float4 gq = make_float4((g.x - yx * dot) / nrm, (g.y - yy * dot) / nrm, (g.z - yz * dot) / nrm, (g.w - yw * dot) / nrm);
+    if (ATTACH) {
+        const bool at = ((r >> 30) & 1u) != 0u;
+        const float4 q0 = x.q0;
+        const float4 d = at ? make_float4(q.x - q0.x, q.y - q0.y, q.z - q0.z, q.w - q0.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gq.x += a.attach_g4 * d.x, gq.y += a.attach_g4 * d.y, gq.z += a.attach_g4 * d.z, gq.w += a.attach_g4 * d.w;
+        att_sum += 0.5f * a.attach_g4 * (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+    }
+    adam1(q.x, gq.x, mq.x, vq.x, a, a.step_rotation);
+    adam1(q.y, gq.y, mq.y, vq.y, a, a.step_rotation);
+    adam1(q.z, gq.z, mq.z, vq.z, a, a.step_rotation);
+    adam1(q.w, gq.w, mq.w, vq.w, a, a.step_rotation);
+    reinterpret_cast<float4*>(a.rotation_raw)[i] = q;
+    if (a.act_rotations) {
+        const float n2 = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        reinterpret_cast<float4*>(a.act_rotations)[i] = make_float4(q.x / n2, q.y / n2, q.z / n2, q.w / n2);
+    }
+    reinterpret_cast<float4*>(a.m_rotation)[i] = mq;
+    reinterpret_cast<float4*>(a.v_rotation)[i] = vq;
+}
+
+// One pass per parameter group over the block's list of rows (s_rows[k] = Gaussian index | has-gradient << 31 | attach-loss member
+// << 30, k < n_rows); element e of a group with rows of `len` floats belongs to list row e / len, so the passes stay dense over the
+// list whatever its sparsity (no lane conditions on the loads), and a Gaussian's rows are read as whole contiguous pieces.
+// Returns this thread's share of the attach loss at the pre-update parameters.
+// THREADS = threads of the block that shares the list (n_rows <= THREADS).
+template <bool ATTACH, int THREADS, typename GradSrc>
+__device__ __forceinline__ float adam_passes(const AdamArgs& a, const uint32_t* s_rows, const int n_rows, const GradSrc& gsrc) {
+    const int tid = threadIdx.x;
+    float att_sum = 0.f;
+    // xyz (identity activation) and scaling (exp): element-wise, [P,3]
+    for (int e = tid; e < 3 * n_rows; e += THREADS) {
+        const uint32_t k = (uint32_t)e / 3u, j = (uint32_t)e - 3u * k, r = s_rows[k];
+        const bool has_g = (r >> 31) != 0u;
+        const size_t i = (size_t)(r & 0x3fffffffu) * 3 + j;
+        // all loads of the element in one round (a row outside the attach set reads element 0 and discards it)
+        AdamXyzVals x;
+        x.p = a.xyz[i], x.m = ldnt(&a.m_xyz[i]), x.v = ldnt(&a.v_xyz[i]);
+        x.ps = a.scaling_raw[i], x.ms = ldnt(&a.m_scaling[i]), x.vs = ldnt(&a.v_scaling[i]);
+        x.gx_ld = gsrc.xyz((int)k, j, i, has_g), x.gs_ld = gsrc.scales((int)k, j, i, has_g);
+        x.p0 = x.ps0 = 0.f;
+        if (ATTACH) {
+            const size_t ai = ((r >> 30) & 1u) ? i : 0;
+            x.p0 = a.init_xyz[ai], x.ps0 = a.init_scaling[ai];
+        }
+        adam_xyz_update<ATTACH>(a, r, i, x, att_sum);
+    }
+    // SH coefficients [P,M,3]: coefficient 0 = f_dc (lr feature_lr), the rest = f_rest (feature_lr / 20).  Four elements per
+    // trip with every load issued before the first use; all loads unconditional on clamped addresses (a load under a lane
+    // condition makes the compiler drain every earlier load first).
+    const uint32_t row = (uint32_t)a.M * 3u;
+    const int nsh = n_rows * (int)row;
+    // The loads of trip t + 1 are issued before trip t is computed and stored (two register sets): the block's memory pipe
+    // never idles between trips.
+    struct ShTrip {
+        float p[4], m[4], v[4], g[4];
+        uint32_t ei[4], fl[4];  // element index in the [P * M * 3] arrays; 1 = in range, 2 = has a gradient, 4 = f_dc
+    };
+    auto load_trip = [&](int e0) {
+        ShTrip t;
+        uint32_t kk[4], jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * THREADS;
+            const bool in = e < nsh;
+            const uint32_t ee = in ? (uint32_t)e : 0u;
+            const uint32_t k = (uint32_t)(((uint64_t)ee * a.row_magic) >> 39);  // ee / row, exact for ee < 2^31, row < 2^8
+            const uint32_t j = ee - k * row, r = s_rows[k];
+            kk[u] = k, jj[u] = j;
+            t.ei[u] = (r & 0x3fffffffu) * row + j;
+            t.fl[u] = in ? (1u | ((r >> 31) ? 2u : 0u) | (j < 3u ? 4u : 0u)) : 0u;
+            t.p[u] = a.shs[t.ei[u]];
+            t.m[u] = ldnt(&a.m_shs[t.ei[u]]);
+            t.v[u] = ldnt(&a.v_shs[t.ei[u]]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) t.g[u] = gsrc.sh((int)kk[u], jj[u], t.ei[u], t.ei[0], (t.fl[u] & 2u) != 0u);
+        return t;
+    };
+    if (nsh > 0) {
+        ShTrip cur = load_trip(tid);
+        for (int e0 = tid; e0 < nsh; e0 += 4 * THREADS) {
+            const bool more = e0 + 4 * THREADS < nsh;  // (per thread; the loads of an absent trip are skipped as a whole)
+            ShTrip nxt = cur;
+            if (more) nxt = load_trip(e0 + 4 * THREADS);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!(cur.fl[u] & 1u)) continue;
+                float p = cur.p[u], m = cur.m[u], v = cur.v[u];
+                adam1(p, (cur.fl[u] & 2u) ? cur.g[u] : 0.f, m, v, a, (cur.fl[u] & 4u) ? a.step_dc : a.step_rest);
+                a.shs[cur.ei[u]] = p, stnt(m, &a.m_shs[cur.ei[u]]), stnt(v, &a.v_shs[cur.ei[u]]);
+            }
+            cur = nxt;
+        }
+    }
+    // opacity (sigmoid) [P] and rotation (normalize) [P,4]
+    if (tid < n_rows) {
+        const uint32_t r = s_rows[tid], i = r & 0x3fffffffu;
+        const bool has_g = (r >> 31) != 0u;
+        // all loads of the row in one round
+        AdamRowVals x;
+        x.p = a.opacity_raw[i], x.m = ldnt(&a.m_opacity[i]), x.v = ldnt(&a.v_opacity[i]);
+        x.q = reinterpret_cast<float4*>(a.rotation_raw)[i];
+        x.mq = reinterpret_cast<float4*>(a.m_rotation)[i], x.vq = reinterpret_cast<float4*>(a.v_rotation)[i];
+        x.go_ld = gsrc.opacity(tid, i, has_g);
+        x.gr_ld = gsrc.rot(tid, i, has_g);
+        x.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ATTACH) x.q0 = reinterpret_cast<const float4*>(a.init_rotation)[((r >> 30) & 1u) ? i : 0u];
+        adam_row_update<ATTACH>(a, r, x, att_sum);
+    }
+    return att_sum;
+}
+
+// 16-byte non-temporal forms (the builtins want a native vector type, not HIP's float4 class)
+typedef float dqo_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+    const dqo_f4v t = __builtin_nontemporal_load(reinterpret_cast<const dqo_f4v*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void stnt4(const float4 v, float* p) {
+    dqo_f4v t;
+    t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<dqo_f4v*>(p));
+}
+
+// adam_passes with the SH pass in float4s, for the fused tail where ONE WAVE owns the list and its lifetime is a chain of dependent
+// memory rounds: rows of 48 floats (M = 16, 16-byte aligned tensors) move as float4s, U per thread and trip — U x THREADS x 4 floats per
+// trip instead of 4 x THREADS.  Element for element the arithmetic is adam_passes': same bits.
+template <bool ATTACH, int THREADS, bool VEC4, int U, typename GradSrc>
+__device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint32_t* s_rows, const int n_rows, const GradSrc& gsrc) {
+    static_assert(VEC4, "the scalar form is adam_passes");
+    const int tid = threadIdx.x;
+    float att_sum = 0.f;
+    // xyz (identity activation) and scaling (exp): element-wise, [P,3]
+    for (int e = tid; e < 3 * n_rows; e += THREADS) {
+        const uint32_t k = (uint32_t)e / 3u, j = (uint32_t)e - 3u * k, r = s_rows[k];
+        const bool has_g = (r >> 31) != 0u;
+        const size_t i = (size_t)(r & 0x3fffffffu) * 3 + j;
+        AdamXyzVals x;
+        x.p = a.xyz[i], x.m = ldnt(&a.m_xyz[i]), x.v = ldnt(&a.v_xyz[i]);
+        x.ps = a.scaling_raw[i], x.ms = ldnt(&a.m_scaling[i]), x.vs = ldnt(&a.v_scaling[i]);
+        x.gx_ld = gsrc.xyz((int)k, j, i, has_g), x.gs_ld = gsrc.scales((int)k, j, i, has_g);
+        x.p0 = x.ps0 = 0.f;
+        if (ATTACH) {
+            const size_t ai = ((r >> 30) & 1u) ? i : 0;
+            x.p0 = a.init_xyz[ai], x.ps0 = a.init_scaling[ai];
+        }
+        adam_xyz_update<ATTACH>(a, r, i, x, att_sum);
+    }
+    // SH pass: a row of 48 floats = 12 float4s; float4 f of the list belongs to list row f / 12
+    {
+        struct ShTrip4 {
+            float4 p[U], m[U], v[U], g[U];
+            uint32_t ei[U], fl[U];  // first element index of the float4; 1 = in range, 2 = has a gradient, 4 = elements 0..2 are f_dc
+        };
+        const int n4 = n_rows * 12;
+        auto load_trip4 = [&](int f0) {
+            ShTrip4 t;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int f = f0 + u * THREADS;
+                const bool in = f < n4;
+                const uint32_t fc = in ? (uint32_t)f : 0u;
+                const uint32_t k = (fc * 10923u) >> 17, j4 = fc - 12u * k, r = s_rows[k];  // fc / 12, exact for fc < 2^15
+                t.ei[u] = (r & 0x3fffffffu) * 48u + 4u * j4;
+                t.fl[u] = in ? (1u | ((r >> 31) ? 2u : 0u) | (j4 == 0u ? 4u : 0u)) : 0u;
+                t.p[u] = *reinterpret_cast<const float4*>(&a.shs[t.ei[u]]);
+                t.m[u] = ldnt4(&a.m_shs[t.ei[u]]);
+                t.v[u] = ldnt4(&a.v_shs[t.ei[u]]);
+                t.g[u] = gsrc.sh4((int)k, 4u * j4);
+            }
+            return t;
+        };
+        for (int f0 = tid; f0 < n4; f0 += U * THREADS) {
+            const ShTrip4 cur = load_trip4(f0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!(cur.fl[u] & 1u)) continue;
+                const bool hg = (cur.fl[u] & 2u) != 0u, dc = (cur.fl[u] & 4u) != 0u;
+                float4 p = cur.p[u], m = cur.m[u], v = cur.v[u];
+                const float4 g = cur.g[u];
+                adam1(p.x, hg ? g.x : 0.f, m.x, v.x, a, dc ? a.step_dc : a.step_rest);
+                adam1(p.y, hg ? g.y : 0.f, m.y, v.y, a, dc ? a.step_dc : a.step_rest);
+                adam1(p.z, hg ? g.z : 0.f, m.z, v.z, a, dc ? a.step_dc : a.step_rest);
+                adam1(p.w, hg ? g.w : 0.f, m.w, v.w, a, a.step_rest);  // (element 3 of a row is f_rest)
+                *reinterpret_cast<float4*>(&a.shs[cur.ei[u]]) = p;
+                stnt4(m, &a.m_shs[cur.ei[u]]);
+                stnt4(v, &a.v_shs[cur.ei[u]]);
+            }
+        }
+    }
+    // opacity (sigmoid) [P] and rotation (normalize) [P,4]
+    if (tid < n_rows) {
+        const uint32_t r = s_rows[tid], i = r & 0x3fffffffu;
+        const bool has_g = (r >> 31) != 0u;
+        AdamRowVals x;
+        x.p = a.opacity_raw[i], x.m = ldnt(&a.m_opacity[i]), x.v = ldnt(&a.v_opacity[i]);
+        x.q = reinterpret_cast<float4*>(a.rotation_raw)[i];
+        x.mq = reinterpret_cast<float4*>(a.m_rotation)[i], x.vq = reinterpret_cast<float4*>(a.v_rotation)[i];
+        x.go_ld = gsrc.opacity(tid, i, has_g);
+        x.gr_ld = gsrc.rot(tid, i, has_g);
+        x.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ATTACH) x.q0 = reinterpret_cast<const float4*>(a.init_rotation)[((r >> 30) & 1u) ? i : 0u];
+        adam_row_update<ATTACH>(a, r, x, att_sum);
+    }
+    return att_sum;
+}
+
+// DqoAdamStep.block_ticket: the device-side step count advances inside the launch — every block has read it at its start, so the
+// block that takes the last ticket may bump it (and hands the ticket counter back at zero for the next launch).
+// (no fence: the only ordering needed is "read of the step count before the ticket", and that load has long been consumed)
+__device__ __forceinline__ void adam_take_ticket(const AdamArgs& a) {
+    if (a.step_advance != nullptr && threadIdx.x == 0) {
+        if (atomicAdd(a.block_ticket, 1) == (int)gridDim.x - 1) {
+            *a.block_ticket = 0;
+            const int next = *a.step_advance + 1;
+            *a.step_advance = next;
+            if (a.bias_table != nullptr) {  // the next launch's bias corrections, once, instead of once per block / wave there
+                float b[7];
+                adam_bias_compute(a, next, b);
+#pragma unroll
+                for (int i = 0; i < 7; i++) a.bias_table[i] = b[i];
+                a.bias_table[7] = __int_as_float(next);
+            }
+        }
+    }
+}
+#endif  // __HIPCC__

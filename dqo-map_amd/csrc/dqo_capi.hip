@@ -33,6 +33,8 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         const float* gt_depth, const uint8_t* render_mask, float color_weight, float depth_weight, float add_depth_thres,
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
+int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
+                             const float* dL_ddepth, const DqoAdamStep* st, void* ws, hipStream_t s);
 size_t dqo_icp_ws_bytes(void);
 int dqo_launch_icp(int H, int W, const float* vertex0, const float* vertex1, const float* normal0, const float* normal1, const float* pose10,
                    float fx, float fy, float cx, float cy, float dist_thr, float normal_thr, float* JtJ, float* JtR, int32_t* valid_count,
@@ -255,6 +257,43 @@ DQO_API int dqo_rast_backward(const DqoRastParams* p, const DqoRastInputs* in, c
     return dqo_launch_backward(p, in, ctx, dL_dcolor, dL_ddepth, hit_image, g, ws, ws_bytes, (hipStream_t)stream);
 }
 
+static int check_adam_step(const DqoAdamStep* st, bool need_grads) {
+    DQO_CHECK_ARG(st, "null step");
+    DQO_CHECK_ARG(st->P >= 0 && st->M >= 1 && (st->step >= 1 || st->step_dev != nullptr), "bad P / M / step");
+    if (st->P == 0) return DQO_OK;
+    DQO_CHECK_ARG(st->xyz && st->shs && st->opacity_raw && st->scaling_raw && st->rotation_raw, "null parameter");
+    if (need_grads) DQO_CHECK_ARG(st->g_means3D && st->g_sh && st->g_opacity && st->g_scales && st->g_rotations, "null gradient");
+    DQO_CHECK_ARG(st->m_xyz && st->m_shs && st->m_opacity && st->m_scaling && st->m_rotation && st->v_xyz && st->v_shs &&
+                      st->v_opacity && st->v_scaling && st->v_rotation,
+                  "null optimiser state");
+    return DQO_OK;
+}
+
+DQO_API int dqo_rast_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
+                                   const float* dL_ddepth, const DqoAdamStep* st, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(p, in, ctx);
+    if (rc) return rc;
+    rc = check_adam_step(st, false);
+    if (rc) return rc;
+    DQO_CHECK_ARG(st->P == p->P && st->M == p->M, "step is for P=%d M=%d, the rasteriser call for P=%d M=%d", st->P, st->M, p->P, p->M);
+    if (p->P == 0) {
+        if (ctx->loss_tap == nullptr) return DQO_OK;
+        return dqo_launch_tap_report(dqo_geom_layout(ctx->geom, 0), dqo_tap_dev(ctx->loss_tap), (hipStream_t)stream);
+    }
+    DQO_CHECK_ARG(in->shs != nullptr, "the fused backward + Adam step needs SH colours (precomputed colours have no parameter group)");
+    DQO_CHECK_ARG(p->M <= 16, "the fused backward + Adam step holds gradient rows of at most 16 SH coefficients (M = %d)", p->M);
+    DQO_CHECK_ARG((dL_dcolor && dL_ddepth) || ctx->loss_tap, "null upstream gradients");
+    DQO_CHECK_ARG(ctx->loss_tap == nullptr || (ctx->loss_tap->gt_color && ctx->loss_tap->gt_depth && ctx->loss_tap->out_color &&
+                                               ctx->loss_tap->out_depth && ctx->loss_tap->loss_out && ctx->loss_tap->grad_scale),
+                  "loss tap with a null pointer");
+    DQO_CHECK_ARG(ctx->binning || ctx->inst_capacity == 0, "null binning buffer");
+    if (ws_bytes < dqo_rast_backward_workspace_bytes(ctx->inst_capacity) || (ws == nullptr && ctx->inst_capacity > 0)) {
+        dqo_set_error("backward workspace too small (%zu < %zu)", ws_bytes, dqo_rast_backward_workspace_bytes(ctx->inst_capacity));
+        return DQO_ERR_WORKSPACE;
+    }
+    return dqo_launch_backward_adam(p, in, ctx, dL_dcolor, dL_ddepth, st, ws, (hipStream_t)stream);
+}
+
 DQO_API int dqo_mark_visible(int32_t P, const float* means3D, const float* view, const float* proj, uint8_t* present, void* stream) {
     DQO_CHECK_ARG(P >= 0, "bad P");
     if (P == 0) return DQO_OK;
@@ -378,14 +417,9 @@ DQO_API int dqo_icp_normal_equations(int32_t H, int32_t W, const float* vertex0,
 }
 
 DQO_API int dqo_map_adam_step(const DqoAdamStep* st, void* stream) {
-    DQO_CHECK_ARG(st, "null step");
-    DQO_CHECK_ARG(st->P >= 0 && st->M >= 1 && (st->step >= 1 || st->step_dev != nullptr), "bad P / M / step");
+    const int rc = check_adam_step(st, true);
+    if (rc) return rc;
     if (st->P == 0) return DQO_OK;
-    DQO_CHECK_ARG(st->xyz && st->shs && st->opacity_raw && st->scaling_raw && st->rotation_raw, "null parameter");
-    DQO_CHECK_ARG(st->g_means3D && st->g_sh && st->g_opacity && st->g_scales && st->g_rotations, "null gradient");
-    DQO_CHECK_ARG(st->m_xyz && st->m_shs && st->m_opacity && st->m_scaling && st->m_rotation && st->v_xyz && st->v_shs &&
-                      st->v_opacity && st->v_scaling && st->v_rotation,
-                  "null optimiser state");
     return dqo_launch_map_adam(st, (hipStream_t)stream);
 }
 

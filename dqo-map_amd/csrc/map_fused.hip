@@ -10,6 +10,7 @@
 // here they are 4 launches and every tensor crosses HBM once: the loss never materialises |x|, masks or index tensors,
 // the optimiser reads the gradient w.r.t. the ACTIVATED parameters straight from the rasteriser's backward and applies
 // the activation Jacobians in registers.
+#include "dqo_adam.h"
 #include "dqo_common.h"
 
 namespace {
@@ -186,57 +187,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_grad_kernel(int HW, int n_p
 }
 
 // ---------------------------------------------------------------- Adam ------------------------------------------------
-struct AdamGroup {
-    float step_size;  // lr / (1 - beta1^t)
-    float lr;
-};
-struct AdamArgs {
-    int P, M;
-    float beta1, beta2, eps, bc2_sqrt;
-    float step_xyz, step_dc, step_rest, step_opacity, step_scaling, step_rotation;
-    float *xyz, *shs, *opacity_raw, *scaling_raw, *rotation_raw;                 // parameters (raw), updated in place
-    const float *g_xyz, *g_shs, *g_opacity, *g_scales, *g_rot;                    // gradients w.r.t. the ACTIVATED parameters
-    float *m_xyz, *m_shs, *m_opacity, *m_scaling, *m_rotation;                    // exp_avg
-    float *v_xyz, *v_shs, *v_opacity, *v_scaling, *v_rotation;                    // exp_avg_sq
-    float *act_opacity, *act_scales, *act_rotations;                              // optional: activations of the updated parameters
-    const int32_t* radii;                                                         // optional: radii == 0 => the gradient row is zero and unread
-    uint64_t row_magic;                                                           // ceil(2^39 / (3 M)): division by the SH row length
-    const int32_t* step_dev;                                                      // optional: step count on the device (hipGraph replay)
-    float lr_xyz, lr_dc, lr_rest, lr_opacity, lr_scaling, lr_rotation;            // used with step_dev
-    // attach loss (mapper.py:812-829): elementwise pull of the raw scaling / xyz / rotation towards their values at the start of
-    // the mapping call, for the Gaussians of attach_mask
-    const uint8_t* attach_mask;
-    const float *init_xyz, *init_scaling, *init_rotation;
-    float attach_g3, attach_g4;                                                   // 2000 / (3 |a|), 2000 / (4 |a|)
-    float* attach_partial;
-    const DqoRastHeader* frame_header;                                            // optional: overflow flag => the launch is a no-op
-    int32_t* step_advance;                                                        // optional: the last block to finish adds 1 to it
-    int32_t* block_ticket;                                                        // (with step_advance) blocks finished so far
-};
-
-// The moments and the gradients are touched exactly once per iteration (0.7 GB of the kernel's 0.83 GB): non-temporal loads /
-// stores keep them from evicting the rasteriser's tables and the parameters out of L2 / Infinity Cache.
-template <typename T>
-__device__ __forceinline__ T ldnt(const T* p) {
-    return __builtin_nontemporal_load(p);
-}
-template <typename T>
-__device__ __forceinline__ void stnt(T v, T* p) {
-    __builtin_nontemporal_store(v, p);
-}
-
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float step_size) {
-    // torch.optim.Adam (single-/multi-tensor and fused paths share this math):
-    //   m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g^2; p -= step_size * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
-    // Separate IEEE operations (no FMA contraction): every instantiation of the kernel then produces the same bits, which the
-    // exact sparse mode's equivalence to the dense update is tested against.
-#pragma clang fp contract(off)
-    m = m + (g - m) * (1.f - a.beta1);
-    v = v * a.beta2 + (1.f - a.beta2) * g * g;
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-    p = p - step_size * (m / denom);
-}
-
+// (AdamArgs, adam1, the per-group passes: dqo_adam.h — shared with the fused per-Gaussian tail, map_fused_tail.hip)
 __global__ void adam_advance_kernel(int32_t* step_dev, const DqoRastHeader* frame_header) {
     if (frame_header != nullptr && frame_header->overflow != 0u) return;  // invalid frame: the step did not happen
     *step_dev += 1;
@@ -245,10 +196,7 @@ __global__ void adam_advance_kernel(int32_t* step_dev, const DqoRastHeader* fram
 // One block per 256 consecutive Gaussians.  The block first lists the Gaussians it has to touch (LDS): all of them in dense mode;
 // in the exact sparse mode (DqoAdamStep.moment_live) those with a gradient row (radii > 0) or non-zero moments — the others are
 // fixed points of the update and their rows are neither read nor written.  It then runs one pass per parameter group over the
-// list; element e of a group with rows of `len` floats belongs to list row e / len, so the passes stay dense over the list
-// whatever its sparsity (no lane conditions on the loads), and a Gaussian's rows are read as whole contiguous pieces.
-constexpr int ADAM_THREADS = 256;
-
+// list (adam_passes).
 template <bool SPARSE, bool ATTACH>
 __device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ moment_live);
 
@@ -258,15 +206,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamArgs a, ui
     // not train: nothing is read or written, the caller re-captures and continues from the state it had.
     if (a.frame_header != nullptr && a.frame_header->overflow != 0u) return;
     adam_block<SPARSE, ATTACH>(a, moment_live);
-    // DqoAdamStep.block_ticket: the device-side step count advances inside this launch — every block has read it at its start, so
-    // the block that takes the last ticket may bump it (and hands the ticket counter back at zero for the next launch)
-    // (no fence: the only ordering needed is "read of the step count before the ticket", and that load has long been consumed)
-    if (a.step_advance != nullptr && threadIdx.x == 0) {
-        if (atomicAdd(a.block_ticket, 1) == (int)gridDim.x - 1) {
-            *a.block_ticket = 0;
-            *a.step_advance += 1;
-        }
-    }
+    adam_take_ticket(a);
 }
 
 template <bool SPARSE, bool ATTACH>
@@ -276,15 +216,7 @@ __device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ mom
     __shared__ int s_wave_n[ADAM_THREADS / 64];
     __shared__ float s_ss[7];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.step_dev != nullptr && tid == 0) {
-        // bias corrections from the device-resident step count (double, like the host path / torch's python floats)
-        const double t = (double)*a.step_dev;
-        const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
-        s_ss[0] = (float)sqrt(bc2);
-        s_ss[1] = (float)((double)a.lr_xyz / bc1), s_ss[2] = (float)((double)a.lr_dc / bc1), s_ss[3] = (float)((double)a.lr_rest / bc1);
-        s_ss[4] = (float)((double)a.lr_opacity / bc1), s_ss[5] = (float)((double)a.lr_scaling / bc1);
-        s_ss[6] = (float)((double)a.lr_rotation / bc1);
-    }
+    if (a.step_dev != nullptr && tid == 0) adam_bias_to_lds(a, s_ss);
     const int idx = blockIdx.x * ADAM_THREADS + tid;
     bool hg = false, act = false, att = false;
     if (idx < a.P) {
@@ -293,14 +225,10 @@ __device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ mom
         if (SPARSE && hg) moment_live[idx] = 1;  // only this thread ever looks at this byte
         if (ATTACH) att = a.attach_mask[idx] != 0;
     }
-    float att_sum = 0.f;  // this thread's share of the attach loss at the pre-update parameters
     const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
     if (lane == 0) s_wave_n[wave] = (int)__popcll(am);
     __syncthreads();
-    if (a.step_dev != nullptr) {
-        a.bc2_sqrt = s_ss[0], a.step_xyz = s_ss[1], a.step_dc = s_ss[2], a.step_rest = s_ss[3], a.step_opacity = s_ss[4];
-        a.step_scaling = s_ss[5], a.step_rotation = s_ss[6];
-    }
+    if (a.step_dev != nullptr) adam_bias_from_lds(a, s_ss);
     int before = 0, n_rows = 0;
 #pragma unroll
     for (int w = 0; w < ADAM_THREADS / 64; w++) {
@@ -314,122 +242,7 @@ __device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ mom
         if (ATTACH && a.attach_partial != nullptr && tid == 0) a.attach_partial[blockIdx.x] = 0.f;
         return;
     }
-
-    // xyz (identity activation) and scaling (exp): element-wise, [P,3]
-    for (int e = tid; e < 3 * n_rows; e += ADAM_THREADS) {
-        const uint32_t k = (uint32_t)e / 3u, j = (uint32_t)e - 3u * k, r = s_rows[k];
-        const bool has_g = (r >> 31) != 0u;
-        const size_t i = (size_t)(r & 0x3fffffffu) * 3 + j;
-        // all eight loads of the element in one round (the gradient rows of a Gaussian without one are unwritten memory: read
-        // at a clamped address and discarded — a load under a lane condition would wait for every earlier load first)
-        const size_t gi = has_g ? i : 0;
-        float p = a.xyz[i], m = ldnt(&a.m_xyz[i]), v = ldnt(&a.v_xyz[i]);
-        float ps = a.scaling_raw[i], ms = ldnt(&a.m_scaling[i]), vs = ldnt(&a.v_scaling[i]);
-        const float gx_ld = ldnt(&a.g_xyz[gi]), gs_ld = ldnt(&a.g_scales[gi]);
-        float gx = has_g ? gx_ld : 0.f, gs = (has_g ? gs_ld : 0.f) * expf(ps);  // d exp(x)/dx = exp(x)
-        if (ATTACH) {
-            // (same round of loads; a row outside the attach set reads element 0 and discards it)
-            const bool at = ((r >> 30) & 1u) != 0u;
-            const size_t ai = at ? i : 0;
-            const float p0 = a.init_xyz[ai], ps0 = a.init_scaling[ai];
-            const float dx = at ? p - p0 : 0.f, ds = at ? ps - ps0 : 0.f;
-            gx += a.attach_g3 * dx, gs += a.attach_g3 * ds;
-            att_sum += 0.5f * a.attach_g3 * (dx * dx + ds * ds);
-        }
-        adam1(p, gx, m, v, a, a.step_xyz);
-        a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
-        adam1(ps, gs, ms, vs, a, a.step_scaling);
-        a.scaling_raw[i] = ps, stnt(ms, &a.m_scaling[i]), stnt(vs, &a.v_scaling[i]);
-        if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
-    }
-    // SH coefficients [P,M,3]: coefficient 0 = f_dc (lr feature_lr), the rest = f_rest (feature_lr / 20).  Four elements per
-    // trip with every load issued before the first use; all loads unconditional on clamped addresses (a load under a lane
-    // condition makes the compiler drain every earlier load first).
-    const uint32_t row = (uint32_t)a.M * 3u;
-    const int nsh = n_rows * (int)row;
-    // The loads of trip t + 1 are issued before trip t is computed and stored (two register sets): the block's memory pipe
-    // never idles between trips.
-    struct ShTrip {
-        float p[4], m[4], v[4], g[4];
-        uint32_t ei[4], fl[4];  // element index in the [P * M * 3] arrays; 1 = in range, 2 = has a gradient, 4 = f_dc
-    };
-    auto load_trip = [&](int e0) {
-        ShTrip t;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = e0 + u * ADAM_THREADS;
-            const bool in = e < nsh;
-            const uint32_t ee = in ? (uint32_t)e : 0u;
-            const uint32_t k = (uint32_t)(((uint64_t)ee * a.row_magic) >> 39);  // ee / row, exact for ee < 2^31, row < 2^8
-            const uint32_t j = ee - k * row, r = s_rows[k];
-            t.ei[u] = (r & 0x3fffffffu) * row + j;
-            t.fl[u] = in ? (1u | ((r >> 31) ? 2u : 0u) | (j < 3u ? 4u : 0u)) : 0u;
-            t.p[u] = a.shs[t.ei[u]];
-            t.m[u] = ldnt(&a.m_shs[t.ei[u]]);
-            t.v[u] = ldnt(&a.v_shs[t.ei[u]]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)  // (a row without a gradient may be unwritten memory: clamped address, value discarded)
-            t.g[u] = ldnt(&a.g_shs[(t.fl[u] & 2u) ? t.ei[u] : t.ei[0]]);
-        return t;
-    };
-    if (nsh > 0) {
-        ShTrip cur = load_trip(tid);
-        for (int e0 = tid; e0 < nsh; e0 += 4 * ADAM_THREADS) {
-            const bool more = e0 + 4 * ADAM_THREADS < nsh;  // (per thread; the loads of an absent trip are skipped as a whole)
-            ShTrip nxt = cur;
-            if (more) nxt = load_trip(e0 + 4 * ADAM_THREADS);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (!(cur.fl[u] & 1u)) continue;
-                float p = cur.p[u], m = cur.m[u], v = cur.v[u];
-                adam1(p, (cur.fl[u] & 2u) ? cur.g[u] : 0.f, m, v, a, (cur.fl[u] & 4u) ? a.step_dc : a.step_rest);
-                a.shs[cur.ei[u]] = p, stnt(m, &a.m_shs[cur.ei[u]]), stnt(v, &a.v_shs[cur.ei[u]]);
-            }
-            cur = nxt;
-        }
-    }
-    // opacity (sigmoid) [P] and rotation (normalize) [P,4]
-    if (tid < n_rows) {
-        const uint32_t r = s_rows[tid], i = r & 0x3fffffffu;
-        const bool has_g = (r >> 31) != 0u;
-        // all loads of the row in one round (clamped gradient addresses, see above)
-        const uint32_t gi = has_g ? i : 0u;
-        float p = a.opacity_raw[i], m = ldnt(&a.m_opacity[i]), v = ldnt(&a.v_opacity[i]);
-        float4 q = reinterpret_cast<float4*>(a.rotation_raw)[i];
-        float4 mq = reinterpret_cast<float4*>(a.m_rotation)[i], vq = reinterpret_cast<float4*>(a.v_rotation)[i];
-        const float go_ld = ldnt(&a.g_opacity[gi]);
-        const float4 gr_ld = reinterpret_cast<const float4*>(a.g_rot)[gi];
-        const float sg = 1.0f / (1.0f + expf(-p));
-        adam1(p, (has_g ? go_ld : 0.f) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
-        a.opacity_raw[i] = p, stnt(m, &a.m_opacity[i]), stnt(v, &a.v_opacity[i]);
-        if (a.act_opacity) a.act_opacity[i] = 1.0f / (1.0f + expf(-p));
-
-        const float4 g = has_g ? gr_ld : make_float4(0.f, 0.f, 0.f, 0.f);
-        // F.normalize backward: y = q / n, n = max(|q|, eps):  dq = (g - y (y . g)) / n
-        const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        const float yx = q.x / nrm, yy = q.y / nrm, yz = q.z / nrm, yw = q.w / nrm;
-        const float dot = yx * g.x + yy * g.y + yz * g.z + yw * g.w;
-        float4 gq = make_float4((g.x - yx * dot) / nrm, (g.y - yy * dot) / nrm, (g.z - yz * dot) / nrm, (g.w - yw * dot) / nrm);
-        if (ATTACH) {
-            const bool at = ((r >> 30) & 1u) != 0u;
-            const float4 q0 = reinterpret_cast<const float4*>(a.init_rotation)[at ? i : 0u];
-            const float4 d = at ? make_float4(q.x - q0.x, q.y - q0.y, q.z - q0.z, q.w - q0.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-            gq.x += a.attach_g4 * d.x, gq.y += a.attach_g4 * d.y, gq.z += a.attach_g4 * d.z, gq.w += a.attach_g4 * d.w;
-            att_sum += 0.5f * a.attach_g4 * (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
-        }
-        adam1(q.x, gq.x, mq.x, vq.x, a, a.step_rotation);
-        adam1(q.y, gq.y, mq.y, vq.y, a, a.step_rotation);
-        adam1(q.z, gq.z, mq.z, vq.z, a, a.step_rotation);
-        adam1(q.w, gq.w, mq.w, vq.w, a, a.step_rotation);
-        reinterpret_cast<float4*>(a.rotation_raw)[i] = q;
-        if (a.act_rotations) {
-            const float n2 = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-            reinterpret_cast<float4*>(a.act_rotations)[i] = make_float4(q.x / n2, q.y / n2, q.z / n2, q.w / n2);
-        }
-        reinterpret_cast<float4*>(a.m_rotation)[i] = mq;
-        reinterpret_cast<float4*>(a.v_rotation)[i] = vq;
-    }
+    float att_sum = adam_passes<ATTACH, ADAM_THREADS>(a, s_rows, n_rows, AdamGradGlobal{a});
     if (ATTACH && a.attach_partial != nullptr) {  // fixed-order block sum of the attach loss (the reported "scale_loss")
         att_sum = wave_red(att_sum);
         if (lane == 0) s_att[wave] = att_sum;
@@ -473,7 +286,7 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
     return DQO_OK;
 }
 
-int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
+int dqo_adam_args(const DqoAdamStep* st, int blocks, AdamArgs* out, bool* attach_out) {
     AdamArgs a;
     a.P = st->P, a.M = st->M;
     a.beta1 = st->beta1, a.beta2 = st->beta2, a.eps = st->eps;
@@ -498,9 +311,9 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.lr_rotation = st->lr_rotation;
     a.attach_mask = st->attach_mask, a.init_xyz = st->init_xyz, a.init_scaling = st->init_scaling_raw, a.init_rotation = st->init_rotation_raw;
     a.attach_partial = st->attach_partial, a.frame_header = st->frame_header;
-    const int blocks = (st->P + ADAM_THREADS - 1) / ADAM_THREADS;
     const bool advance_inside = st->step_dev != nullptr && st->block_ticket != nullptr && blocks > 0;
     a.step_advance = advance_inside ? st->step_dev : nullptr, a.block_ticket = st->block_ticket;
+    a.bias_table = (advance_inside && st->step_dev != nullptr) ? st->bias_table : nullptr;
     const bool attach = st->attach_mask != nullptr && st->attach_count > 0;
     DQO_CHECK_ARG(!attach || (st->init_xyz && st->init_scaling_raw && st->init_rotation_raw), "attach_mask needs the three init_* tensors");
     DQO_CHECK_ARG(st->P < (1 << 30), "P must stay below 2^30");
@@ -511,6 +324,18 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     a.row_magic = st->M > 0 ? ((1ull << 39) + (uint64_t)(3 * st->M) - 1) / (uint64_t)(3 * st->M) : 0ull;
     DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");
     DQO_CHECK_ARG(st->moment_live == nullptr || st->radii != nullptr, "moment_live needs radii");
+    *out = a;
+    *attach_out = attach;
+    return DQO_OK;
+}
+
+int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
+    const int blocks = (st->P + ADAM_THREADS - 1) / ADAM_THREADS;
+    AdamArgs a;
+    bool attach = false;
+    const int rc = dqo_adam_args(st, blocks, &a, &attach);
+    if (rc) return rc;
+    const bool advance_inside = a.step_advance != nullptr;
     if (blocks > 0) {  // (an empty map still advances the step count)
         if (st->moment_live != nullptr) {
             if (attach) DQO_LAUNCH("adam_kernel", (adam_kernel<true, true>), dim3(blocks), dim3(ADAM_THREADS), s, a, st->moment_live);

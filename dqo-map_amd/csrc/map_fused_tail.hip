@@ -1,0 +1,317 @@
+// Fused per-Gaussian tail of one mapping iteration for gfx950: record sum -> per-Gaussian backward chain -> Adam in ONE pass over
+// the Gaussians (dqo_rast_backward_adam, include/dqo_raster.h).
+//
+// Replaces, for the fused mapping iteration only (the drop-in backward keeps its kernels: its gradient rows are outputs),
+//   record_sum_kernel + gaussian_backward_kernel (rast_backward.hip)  <- cuda_rasterizer/backward.cu:273-548 (K8, K9)
+//   adam_kernel (map_fused.hip)                                       <- SLAM/gaussian_pointcloud.py:331-378, mapper.py:548, 812-829
+// As three kernels the 59-float gradient row of every visible Gaussian made a round trip through HBM between two kernels that
+// visit the same Gaussians (284 B written + 236 B re-read), and so did its 64-byte summed record.  Here a workgroup owns 128
+// Gaussians (the thread -> Gaussian assignment of bin_count_kernel / record_sum_kernel, so their instance slots are one contiguous
+// range):
+//   A  lists the rows Adam has to touch (LDS: visible Gaussians and, in the exact sparse mode, those with non-zero moments),
+//   B  sums its Gaussians' partial gradient records in the fixed (slot, quadrant) order of record_sum_kernel,
+//   C  runs the per-Gaussian chain (dqo_gauss_chain.h: the same statements as gaussian_backward_kernel) and leaves each gradient row
+//      in LDS — factored: dL/dsh[k][c] = w[k] * dRGB[c], so a row is 30 floats instead of 59 (15.5 KB per workgroup),
+//   D  runs Adam's passes over the list with the gradient read from LDS (dqo_adam.h: the same statements as adam_kernel).
+// Every float that reaches a parameter or a moment is produced by the same operations on the same operands as in the three-kernel
+// path: bit-identical results (tests/test_gpu_fused_mapping.py::test_fused_tail_is_bitwise_the_three_kernels).
+//
+// What bounds it (round 3 measurements, cfg 3): the latency of a workgroup's dependent memory rounds — SQ counters: 60 % of
+// the wave cycles parked at s_waitcnt, 20 % issue stalls, 20 % active; in-kernel stamps: list 9 %, chain inputs 14 %, record gather
+// 27 %, chain 20 %, Adam 29 % of a wave's lifetime.  Not bandwidth (475 MB in 150 us), not the number of memory transactions (without
+// any moment store — 20 % of all requests — the time is the same), not VALU or address-unit work (compacting the visible Gaussians,
+// 16-byte SH loads: no change).  Register pressure decides the rest: the chain needs ~160 VGPRs, and a spill of a loaded value
+// WAITS for the load (-DDQO_TAIL_WAVES=4: 372 bytes of scratch per lane, +25 % time).
+#include "dqo_adam.h"
+#include "dqo_common.h"
+#include "dqo_gauss_chain.h"
+
+namespace {
+
+#ifndef DQO_TAIL_THREADS
+#define DQO_TAIL_THREADS 128
+#endif
+constexpr int TAIL_THREADS = DQO_TAIL_THREADS;  // Gaussians (= threads) per workgroup; measured on cfg 3: 64 -> 160 us, 128 -> 150, 256 -> 152
+// gradient row in LDS: [0..2] dL/dmean, [3..18] SH basis weights w, [19..21] dRGB, [22] dL/dopacity, [23..25] dL/dscales,
+// [26..29] dL/drotation; stride 31 (odd: the per-thread row writes of phase C fall on distinct banks)
+constexpr int ROW_MEAN = 0, ROW_W = 3, ROW_RGB = 19, ROW_OP = 22, ROW_SC = 23, ROW_ROT = 26, ROW_STRIDE = 31;
+
+// Gradient source of Adam's passes: the rows phase C left in LDS (k = list row).  The SH gradient is formed here from its two factors
+// — one IEEE multiply, the reference's per-coefficient statement (backward.cu:152-268) and what gaussian_backward_kernel stores.
+struct AdamGradLds {
+    const float* s_g;
+    int used3;  // 3 x (coefficients of the active SH degree): elements beyond it have a zero gradient (rasterize_points.cu:204)
+    __device__ __forceinline__ float xyz(int k, uint32_t j, size_t, bool) const { return s_g[k * ROW_STRIDE + ROW_MEAN + (int)j]; }
+    __device__ __forceinline__ float scales(int k, uint32_t j, size_t, bool) const { return s_g[k * ROW_STRIDE + ROW_SC + (int)j]; }
+    __device__ __forceinline__ float sh(int k, uint32_t j, uint32_t, uint32_t, bool) const {
+#pragma clang fp contract(off)
+        const uint32_t jc = j < (uint32_t)used3 ? j : 0u;
+        const uint32_t c = (jc * 171u) >> 9, ch = jc - 3u * c;  // jc / 3, jc % 3 for jc < 256
+        const float g = s_g[k * ROW_STRIDE + ROW_W + (int)c] * s_g[k * ROW_STRIDE + ROW_RGB + (int)ch];
+        return j < (uint32_t)used3 ? g : 0.f;
+    }
+    // elements j .. j + 3 of the row (j a multiple of 4)
+    __device__ __forceinline__ float4 sh4(int k, uint32_t j) const {
+        return make_float4(sh(k, j, 0u, 0u, true), sh(k, j + 1u, 0u, 0u, true), sh(k, j + 2u, 0u, 0u, true), sh(k, j + 3u, 0u, 0u, true));
+    }
+    __device__ __forceinline__ float opacity(int k, uint32_t, bool) const { return s_g[k * ROW_STRIDE + ROW_OP]; }
+    __device__ __forceinline__ float4 rot(int k, uint32_t, bool) const {
+        const float* r = s_g + k * ROW_STRIDE + ROW_ROT;
+        return make_float4(r[0], r[1], r[2], r[3]);
+    }
+};
+
+#ifndef DQO_TAIL_WAVES
+#define DQO_TAIL_WAVES 3  // waves per SIMD the register allocation leaves room for
+#endif
+template <bool SPARSE, bool ATTACH>
+__global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_kernel(const DqoView v, DqoGeomLayout g, const float* means3D,
+                                                                        const float* scales, const float* rotations, const float* shs,
+                                                                        const float4* __restrict__ partial,
+                                                                        const uint32_t* __restrict__ valid, int64_t capacity, AdamArgs a,
+                                                                        uint8_t* __restrict__ moment_live) {
+#pragma clang fp contract(off)
+    // A frame flagged invalid by the forward must not train: nothing is read or written (adam_kernel's rule)
+    if (a.frame_header != nullptr && a.frame_header->overflow != 0u) return;
+    // one buffer: phase B's slot staging (4 KB), then phase C / D's gradient rows (7.75 KB)
+    __shared__ float4 s_buf[(TAIL_THREADS * ROW_STRIDE * 4 + 15) / 16];
+    float4* const s_rec = s_buf;
+    float* const s_g = reinterpret_cast<float*>(s_buf);
+    static_assert(sizeof(float4) * TAIL_THREADS * 4 <= sizeof(s_buf), "the slot staging must fit the buffer");
+    __shared__ uint32_t s_rows[TAIL_THREADS];  // Gaussian index | has-gradient << 31 | attach-loss member << 30
+    __shared__ uint32_t s_lohi[2];
+    __shared__ int s_wave_n[TAIL_THREADS / 64];
+    __shared__ float s_att[TAIL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.step_dev != nullptr) {  // bias corrections of this step (DqoAdamStep.bias_table, or computed: every thread, uniform)
+        float ss[7];
+        adam_bias_to_lds(a, ss);
+        adam_bias_from_lds(a, ss);
+    }
+    if (tid == 0) s_lohi[0] = 0xffffffffu, s_lohi[1] = 0u;
+    const int idx = dqo_spread_index(blockIdx.x * TAIL_THREADS + tid, v.P);  // bin_count_kernel's thread -> Gaussian assignment
+    const bool in_range = idx < v.P;
+
+    // ---- A: first round of loads (rect, instance count, slot base, list flags); Adam's row list ----
+    uint2 rc = make_uint2(0u, 0u);
+    uint32_t base = 0, cnt = 0;
+    bool live_m = false, att = false;
+    if (in_range) {
+        rc = g.rect16[idx];
+        cnt = g.tiles_touched[idx];
+        base = g.slot_base[idx];
+        if (SPARSE) live_m = moment_live[idx] != 0;
+        if (ATTACH) att = a.attach_mask[idx] != 0;
+    }
+    float view[16], proj[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        view[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.view[i])));
+        proj[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.proj[i])));
+    }
+    // radii > 0 (backward.cu:285, 513; DqoAdamStep.radii)  <=>  the forward kept a non-empty tile rect for this Gaussian
+    const bool visible = in_range && ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
+    const bool act = in_range && (!SPARSE || visible || live_m);
+    if (SPARSE && visible) moment_live[idx] = 1;  // only this thread ever looks at this byte
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+    if (lane == 0) s_wave_n[wave] = (int)__popcll(am);
+    __syncthreads();  // (a one-wave workgroup's __syncthreads is a wave-level fence, not an s_barrier)
+    if (cnt) {  // the workgroup's slot range: its Gaussians' slots are contiguous and in thread order (rast_binning.hip)
+        atomicMin(&s_lohi[0], base);
+        atomicMax(&s_lohi[1], base + cnt);
+    }
+    int before = 0, n_rows = 0;
+#pragma unroll
+    for (int w = 0; w < TAIL_THREADS / 64; w++) {
+        const int c = s_wave_n[w];
+        before += w < wave ? c : 0;
+        n_rows += c;
+    }
+    const int my_row = before + (int)__popcll(am & ((1ull << lane) - 1ull));  // this Gaussian's list row (if act)
+    if (act) s_rows[my_row] = (uint32_t)idx | (visible ? 0x80000000u : 0u) | (att ? 0x40000000u : 0u);
+    __syncthreads();  // s_lohi, s_rows complete
+    const uint32_t lo = s_lohi[0];
+    const uint32_t hi = (uint32_t)min((int64_t)s_lohi[1], capacity);  // (an overflowed forward never gets here; belt and braces)
+
+    // ---- second round of loads: everything the chain needs of this lane's Gaussian, issued as a whole before the record gather (the
+    //      same round structure as gaussian_backward_kernel; in flight while phase B runs).  (Compacting the visible Gaussians of a
+    //      256-thread block into as few waves as they fill — cfg 3: 39 % are visible — was built and measured: no gain; the chain is a
+    //      long dependent instruction sequence whose duration does not depend on how many lanes run it.) ----
+    const bool sh_vec4 = v.M == 16 && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0u;
+    DqoChainIn ci;
+    ci.cop = make_float4(0.f, 0.f, 0.f, 0.f);
+    ci.mx = ci.my = ci.mz = ci.sx = ci.sy = ci.sz = 0.f;
+    ci.qt = make_float4(1.f, 0.f, 0.f, 0.f);
+    ci.n_np = ci.pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    ci.cl = 0;
+    if (visible) {
+        ci.cop = g.conic_opacity[idx];
+        ci.mx = means3D[3 * idx], ci.my = means3D[3 * idx + 1], ci.mz = means3D[3 * idx + 2];
+        ci.sx = scales[3 * idx], ci.sy = scales[3 * idx + 1], ci.sz = scales[3 * idx + 2];
+        ci.qt = reinterpret_cast<const float4*>(rotations)[idx];
+        ci.n_np = g.normal_c[idx], ci.pc = g.point_c[idx], ci.cl = g.clamped[idx];
+        // the SH coefficients of the active degree (the view-direction gradient at the end of the chain reads them).  Issued here, with
+        // the other inputs, their latency overlaps the record gather; fetched behind the gather instead (where they would not compete
+        // with its sixteen 16-byte records for registers) the kernel measured 6 % slower.
+        const float* shp = shs + (size_t)idx * v.M * 3;
+        if (v.D >= 3 && sh_vec4) {  // rows of 48 floats as twelve 16-byte pieces
+            const float4* shp4 = reinterpret_cast<const float4*>(shp);
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const float4 t = shp4[i];
+                ci.sh[4 * i] = t.x, ci.sh[4 * i + 1] = t.y, ci.sh[4 * i + 2] = t.z, ci.sh[4 * i + 3] = t.w;
+            }
+        } else if (v.D >= 3) {
+#pragma unroll
+            for (int i = 3; i < 48; i++) ci.sh[i] = shp[i];
+        } else if (v.D == 2) {
+#pragma unroll
+            for (int i = 3; i < 27; i++) ci.sh[i] = shp[i];
+        } else if (v.D == 1) {
+#pragma unroll
+            for (int i = 3; i < 12; i++) ci.sh[i] = shp[i];
+        }
+    }
+
+    // ---- B: fixed-order sum of this lane's Gaussian's partial gradient records (record_sum_kernel's statements; one slot per thread and trip) ----
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (lo < hi) {  // (wave-uniform)
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t c0 = lo; c0 < hi; c0 += TAIL_THREADS) {
+            const uint32_t slot = c0 + tid;
+            if (slot < hi) {
+                const uint32_t vw = valid[slot];
+                const float4* p = partial + (size_t)slot * 16;
+                // all sixteen loads unconditionally and back to back; the lanes of an invalid quadrant read one shared dummy record
+                float4 r[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4* src = ((vw >> (8 * q)) & 0xffu) ? p + 4 * q : partial;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) r[q][i] = src[i];
+                }
+                float4 m0 = z, m1 = z, m2 = z, m3 = z;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t bq = (vw >> (8 * q)) & 0xffu;  // 1: floats 0..8 written, 3: depth-hit floats 9..13 as well
+                    if (bq) {
+                        const float4 r0 = r[q][0], r1 = r[q][1], r2 = r[q][2], r3 = r[q][3];
+                        m0.x += r0.x, m0.y += r0.y, m0.z += r0.z, m0.w += r0.w;
+                        m1.x += r1.x, m1.y += r1.y, m1.z += r1.z, m1.w += r1.w;
+                        m2.x += r2.x;
+                        if (bq & 2u) {
+                            m2.y += r2.y, m2.z += r2.z, m2.w += r2.w;
+                            m3.x += r3.x, m3.y += r3.y;
+                        }
+                    }
+                }
+                s_rec[tid * 4] = m0, s_rec[tid * 4 + 1] = m1, s_rec[tid * 4 + 2] = m2, s_rec[tid * 4 + 3] = m3;
+            }
+            __syncthreads();
+            const uint32_t k0 = max(base, c0), k1 = min(base + cnt, min(c0 + (uint32_t)TAIL_THREADS, hi));
+            for (uint32_t k = k0; k < k1; k++) {
+                const float4 r0 = s_rec[(k - c0) * 4], r1 = s_rec[(k - c0) * 4 + 1], r2 = s_rec[(k - c0) * 4 + 2], r3 = s_rec[(k - c0) * 4 + 3];
+                a0.x += r0.x, a0.y += r0.y, a0.z += r0.z, a0.w += r0.w;
+                a1.x += r1.x, a1.y += r1.y, a1.z += r1.z, a1.w += r1.w;
+                a2.x += r2.x, a2.y += r2.y, a2.z += r2.z, a2.w += r2.w;
+                a3.x += r3.x, a3.y += r3.y, a3.z += r3.z, a3.w += r3.w;
+            }
+            __syncthreads();  // (the staging area is overwritten — by the next trip or by phase C's rows)
+        }
+    }
+    if (n_rows == 0) {  // (wave-uniform) nothing to update: no visible Gaussian, no live moment
+        if (ATTACH && a.attach_partial != nullptr && tid == 0) a.attach_partial[blockIdx.x] = 0.f;
+        adam_take_ticket(a);
+        return;
+    }
+
+    // ---- C: the per-Gaussian chain; the gradient row goes to LDS at the Gaussian's list row ----
+    if (visible) {
+        ci.a[0] = a0.x, ci.a[1] = a0.y, ci.a[2] = a0.z, ci.a[3] = a0.w;
+        ci.a[4] = a1.x, ci.a[5] = a1.y, ci.a[6] = a1.z, ci.a[7] = a1.w;
+        ci.a[8] = a2.x, ci.a[9] = a2.y, ci.a[10] = a2.z, ci.a[11] = a2.w;
+        ci.a[12] = a3.x, ci.a[13] = a3.y, ci.a[14] = a3.z, ci.a[15] = a3.w;
+        if (cnt == 0u) ci.cop = make_float4(0.f, 0.f, 0.f, 0.f);  // (a Gaussian without instances: gaussian_backward_kernel's rule)
+        DqoChainOut co;
+        dqo_gauss_chain(v, view, proj, ci, true, co);
+        float* row = s_g + my_row * ROW_STRIDE;
+        row[ROW_MEAN] = co.mean_g[0], row[ROW_MEAN + 1] = co.mean_g[1], row[ROW_MEAN + 2] = co.mean_g[2];
+#pragma unroll
+        for (int k = 0; k < 16; k++) row[ROW_W + k] = co.w[k];
+        row[ROW_RGB] = co.dRGB[0], row[ROW_RGB + 1] = co.dRGB[1], row[ROW_RGB + 2] = co.dRGB[2];
+        row[ROW_OP] = co.dop;
+        row[ROW_SC] = co.dsc[0], row[ROW_SC + 1] = co.dsc[1], row[ROW_SC + 2] = co.dsc[2];
+        row[ROW_ROT] = co.rot_g[0], row[ROW_ROT + 1] = co.rot_g[1], row[ROW_ROT + 2] = co.rot_g[2], row[ROW_ROT + 3] = co.rot_g[3];
+    }
+    __syncthreads();
+
+    // ---- D: Adam over the wave's list, gradient from LDS (adam_kernel's statements) ----
+    const int used = (v.D + 1) * (v.D + 1);
+    // SH pass in float4s (rows of 48 floats, 16-byte aligned tensors), four per lane and trip: 1024 floats per wave and trip instead of
+    // 256 — a wave's ~25 rows in 1-2 dependent rounds instead of 5 (-3 % on the kernel).  (Also issuing the loads of the two small
+    // passes together with the first SH trip measured 4 % SLOWER, and twice that when it pushed the kernel into register spills.)
+    const bool vec4 = v.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) | reinterpret_cast<uintptr_t>(a.m_shs) |
+                                     reinterpret_cast<uintptr_t>(a.v_shs)) & 15u) == 0u;
+    float att_sum;
+    if (vec4) att_sum = adam_passes_tail<ATTACH, TAIL_THREADS, true, 4>(a, s_rows, n_rows, AdamGradLds{s_g, 3 * used});
+    else att_sum = adam_passes<ATTACH, TAIL_THREADS>(a, s_rows, n_rows, AdamGradLds{s_g, 3 * used});
+    if (ATTACH && a.attach_partial != nullptr) {  // fixed-order sum of the attach loss (the reported "scale_loss")
+        att_sum = adam_wave_red(att_sum);
+        if (TAIL_THREADS == 64) {
+            if (lane == 0) a.attach_partial[blockIdx.x] = att_sum;
+        } else {
+            if (lane == 0) s_att[wave] = att_sum;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (int w = 0; w < TAIL_THREADS / 64; w++) t += s_att[w];
+                a.attach_partial[blockIdx.x] = t;
+            }
+        }
+    }
+    adam_take_ticket(a);
+}
+
+}  // namespace
+
+int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
+                              const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
+                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, hipStream_t s);
+
+// blend backward + the fused per-Gaussian tail.  The caller (dqo_rast_backward_adam) has checked the arguments.
+int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
+                             const float* dL_ddepth, const DqoAdamStep* st, void* ws, hipStream_t s) {
+    if (p->P <= 0) return DQO_OK;
+    const DqoView v = dqo_make_view(p, in);
+    DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
+    DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
+    DqoBinLayout bin = dqo_bin_layout(ctx->binning, ctx->inst_capacity,
+                                      dqo_list_cap(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity), ctx->tile_bucket_capacity);
+    const int T = v.gx * v.gy;
+    const int64_t cap = (int64_t)ctx->inst_capacity;
+    DqoGradRec* recs = (DqoGradRec*)ws;
+    uint8_t* valid = reinterpret_cast<uint8_t*>(bin.rec_valid);  // zeroed by the forward
+    const int blocks = dqo_spread_blocks(p->P) * (256 / TAIL_THREADS);  // TAIL_THREADS logical positions of the spread mapping each
+    AdamArgs a;
+    bool attach = false;
+    int rc = dqo_adam_args(st, blocks, &a, &attach);
+    if (rc) return rc;
+    a.frame_header = g.header;  // the frame whose gradients this step consumes is this context's
+    rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap,
+                                   dqo_tap_dev(ctx->loss_tap), s);
+    if (rc) return rc;
+    const float4* partial = reinterpret_cast<const float4*>(recs);
+    const uint32_t* vw = reinterpret_cast<const uint32_t*>(valid);
+#define DQO_TAIL(SP, AT)                                                                                                              \
+    DQO_LAUNCH("gaussian_tail_kernel", (gaussian_tail_kernel<SP, AT>), dim3(blocks), dim3(TAIL_THREADS), s, v, g, in->means3D, in->scales, \
+               in->rotations, in->shs, partial, vw, cap, a, st->moment_live)
+    if (st->moment_live != nullptr) {
+        if (attach) DQO_TAIL(true, true);
+        else DQO_TAIL(true, false);
+    } else {
+        if (attach) DQO_TAIL(false, true);
+        else DQO_TAIL(false, false);
+    }
+#undef DQO_TAIL
+    return DQO_OK;
+}

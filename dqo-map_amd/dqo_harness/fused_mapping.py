@@ -107,7 +107,9 @@ class FusedMapper:
         self.init_xyz, self.init_scaling, self.init_rotation = self.xyz.clone(), self.scaling_raw.clone(), self.rotation_raw.clone()
         self.attach_mask = (torch.sigmoid(self.opacity_raw) < 0.9).reshape(-1).to(torch.uint8).contiguous()
         self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
-        self.attach_partial = torch.zeros(((self.xyz.shape[0] + 255) // 256,), dtype=torch.float32, device=self.device)
+        # (one partial sum per block of 256 Gaussians from dqo_map_adam_step, per wave of 64 from dqo_rast_backward_adam)
+        self.attach_partial = torch.zeros((4 * ((self.xyz.shape[0] + 255) // 256),), dtype=torch.float32, device=self.device)
+        self._attach_n = 0
         if reset_optimizer:
             for m, v in self.state.values():
                 m.zero_(), v.zero_()
@@ -211,12 +213,13 @@ class FusedMapper:
         self.init_rotation = torch.cat([sel(self.init_rotation), nrot])
         self.attach_mask = torch.cat([sel(self.attach_mask), (nop.reshape(-1) < 0.9).to(torch.uint8)]).contiguous()
         self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
-        self.attach_partial = torch.zeros(((P + 255) // 256,), **f)
+        self.attach_partial = torch.zeros((4 * ((P + 255) // 256),), **f)
+        self._attach_n = 0
         return stats
 
     def attach_loss(self):
         """The reference's reported "scale_loss" of the most recent iteration (attach loss at its pre-update parameters)."""
-        return self.attach_partial.sum()
+        return self.attach_partial[:self._attach_n].sum()
 
     def _attach_fields(self):
         if not self.use_attach or self.attach_count == 0:
@@ -226,7 +229,7 @@ class FusedMapper:
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
-                loss_tap=True, reuse_probe=False):
+                loss_tap=True, reuse_probe=False, fused_tail=True):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
 
@@ -239,7 +242,10 @@ class FusedMapper:
         keep_tile_order (bucket mode): the replays keep the tile launch order of the capture's eager iteration instead of
         recomputing it (DqoRastCtx.keep_tile_order: no scan kernel in a replay).  loss_tap: the masked loss is summed inside the
         forward's blend kernel and its gradient is formed inside the backward's (DqoRastCtx.loss_tap: no loss kernels; self.loss is
-        written by the backward).  Both leave every result bit for bit as it is without them.  reuse_probe: size the capacities from
+        written by the backward).  fused_tail: the per-Gaussian half of the backward and the Adam step run as ONE kernel
+        (dqo_rast_backward_adam: record sum -> per-Gaussian chain -> Adam per block of 256 Gaussians, gradient rows in LDS) instead of
+        three (gradient rows and summed records through HBM).  All three leave every parameter and moment bit for bit as it is without
+        them.  reuse_probe: size the capacities from
         the previous capture's counts (scaled by the map's growth) instead of a probing forward — for a re-capture right after a small
         change of the map; falls back to probing if the eager iteration overflows."""
         lib = N.lib()
@@ -297,6 +303,7 @@ class FusedMapper:
             g.mask = None if render_mask is None else render_mask.to(torch.uint8).contiguous()
             g.tile_mask = tile_mask
             g.stale = False
+            g.fused_tail = bool(fused_tail) and M <= 16
             g.out = (torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **i32), torch.empty((1, H, W), **i32),
                      torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((P,), **i32),
                      torch.empty((P,), **i32))
@@ -310,6 +317,7 @@ class FusedMapper:
             g.step_dev = torch.full((1,), self.step_count + 1, **i32)
             g.expected_step = self.step_count + 1  # what step_dev holds while host and device counts agree
             g.ticket = torch.zeros((1,), **i32)  # DqoAdamStep.block_ticket: the Adam launch advances step_dev itself
+            g.bias = torch.zeros((8,), **f)      # DqoAdamStep.bias_table: the bias corrections, computed once per step
             g.params = dgr._params(st, P, M)
             g.inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, g.tile_mask)
             o = g.out
@@ -346,7 +354,7 @@ class FusedMapper:
                                    v_rotation=N.ptr(stt["rotation"][1]), act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales),
                                    act_rotations=N.ptr(self.rotations), radii=o[8].data_ptr(), step_dev=g.step_dev.data_ptr(),
                                    moment_live=N.ptr(self.moment_live), frame_header=g.geom.data_ptr(), block_ticket=g.ticket.data_ptr(),
-                                   **self._attach_fields())
+                                   bias_table=g.bias.data_ptr(), **self._attach_fields())
             # one eager iteration on a side stream (warms every kernel up), then the capture
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -356,7 +364,8 @@ class FusedMapper:
             if self.graph_overflowed() and reuse_probe:  # the reused counts were too small after all: measure and start over
                 self._last_probe = None
                 return self.capture(gt_color, gt_depth, render_mask, tile_mask=tile_mask, capacity_margin=capacity_margin,
-                                    tile_buckets=tile_buckets, keep_tile_order=keep_tile_order, loss_tap=loss_tap, reuse_probe=False)
+                                    tile_buckets=tile_buckets, keep_tile_order=keep_tile_order, loss_tap=loss_tap, reuse_probe=False,
+                                    fused_tail=fused_tail)
             if not self.graph_overflowed():  # (an invalid frame is a no-op for the optimiser and its step count)
                 self.step_count += 1
             # the eager iteration left its tile launch order in g.img; the replays keep it (DqoRastCtx.keep_tile_order: the order is
@@ -411,6 +420,11 @@ class FusedMapper:
                                              N.ptr(g.mask), self.color_weight, self.depth_weight, self.add_depth_thres, N.ptr(self.loss),
                                              N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws), self.loss_ws.numel(), stream))
         dLc, dLd = (self.dL_dcolor.data_ptr(), self.dL_ddepth.data_ptr()) if g.tap is None else (None, None)
+        self._attach_n = ((self.P + 255) // 256) * (4 if g.fused_tail else 1)
+        if g.fused_tail:
+            N.check(lib.dqo_rast_backward_adam(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.cctx), dLc, dLd,
+                                               ctypes.byref(g.adam), g.ws.data_ptr(), g.ws.numel(), stream))
+            return
         N.check(lib.dqo_rast_backward(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.cctx), dLc, dLd, o[3].data_ptr(),
                                       ctypes.byref(g.cgrads), g.ws.data_ptr(), g.ws.numel(), stream))
         N.check(lib.dqo_map_adam_step(ctypes.byref(g.adam), stream))
@@ -448,7 +462,8 @@ class FusedMapper:
                 g = self._g
                 # (capture() re-reads the device-side step count: the valid replays of this batch stay counted, the others do not)
                 self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
-                             tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0, loss_tap=g.tap is not None)
+                             tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0, loss_tap=g.tap is not None,
+                             fused_tail=g.fused_tail)
                 recaptures += 1
         return recaptures
 
@@ -519,5 +534,6 @@ class FusedMapper:
                                radii=N.ptr(out[8]), moment_live=N.ptr(self.moment_live), frame_header=N.ptr(ctx.saved_tensors[8]),
                                **self._attach_fields())
             N.check(lib.dqo_map_adam_step(ctypes.byref(st), stream))
+            self._attach_n = (P + 255) // 256
             self._act_valid = True
         return out

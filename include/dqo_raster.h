@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DQO_ABI_VERSION 2
+#define DQO_ABI_VERSION 3
 
 typedef enum DqoStatus {
     DQO_OK = 0,
@@ -347,8 +347,28 @@ typedef struct DqoAdamStep {
     /* Optional, with step_dev: one int32, zero before the first launch (it is zero again after every launch).  The block that
      * finishes last advances *step_dev inside the Adam launch itself; NULL = a separate one-thread kernel does it afterwards. */
     int32_t* block_ticket;
+    /* Optional, with step_dev and block_ticket (ABI 3): eight floats, zero before the first launch.  The bias corrections of a step
+     * (two double-precision pow() calls + six divisions) are then computed ONCE per step — by the block that advances *step_dev, for the
+     * step it advances to — instead of once per block of every launch; a launch whose step the table does not hold (the first one,
+     * or after the caller rewrote *step_dev) computes them itself.  Same function either way: same bits. */
+    float* bias_table;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
+
+/* Fused mapping iteration, backward half (ABI 3): the blend kernel of dqo_rast_backward followed by ONE kernel that, per block of 256
+ * Gaussians, sums the per-instance gradient records, runs the per-Gaussian backward (rasterizer_impl.cu:445-564's K8 + K9,
+ * backward.cu:273-548) and applies dqo_map_adam_step's update (SLAM/gaussian_pointcloud.py:331-378, SLAM/multiprocess/mapper.py:548,
+ * 812-829) with the gradient rows held in LDS: neither the 59-float gradient rows nor the summed records reach HBM, two launches
+ * fewer.  Parameters, moments, activations, moment_live and the device step count come out BIT-IDENTICAL to
+ *     dqo_rast_backward(grads with skip_culled_rows = 1)  +  dqo_map_adam_step(step with radii = the forward's radii)
+ * (same statements on the same operands).  Only step->attach_partial differs: here it must hold 4 * ceil(P / 256) floats — one
+ * partial sum per wave of 64 Gaussians instead of one per block of 256 — whose total agrees with dqo_map_adam_step's to rounding.
+ * `step`: the g_* and radii fields are not read (visibility comes from ctx); frame_header is taken from ctx (an overflowed frame is a
+ * no-op, as in dqo_map_adam_step).  inputs->shs is required (precomputed colours have no Adam group) with params->M == step->M <= 16
+ * and params->P == step->P.  workspace as for dqo_rast_backward.  With a loss tap in ctx, dL_dout_* may be NULL. */
+int dqo_rast_backward_adam(const DqoRastParams*, const DqoRastInputs*, const DqoRastCtx*, const float* dL_dout_color,
+                           const float* dL_dout_depth, const DqoAdamStep* step, void* workspace, size_t workspace_bytes,
+                           void* hipStream);
 
 #ifdef __cplusplus
 }

@@ -221,6 +221,64 @@ def test_recapture_after_eager_steps_keeps_the_step_count(env):
             np.testing.assert_allclose(b.state[k][i].cpu().numpy(), a.state[k][i].cpu().numpy(), rtol=1e-3, atol=1e-9)
 
 
+@pytest.mark.parametrize("cfg,P,sparse,attach", [(1, 6000, True, True), (1, 6000, False, False), (3, 60000, True, True), (2, 30011, True, False)])
+def test_fused_tail_is_bitwise_the_three_kernels(env, cfg, P, sparse, attach):
+    """dqo_rast_backward_adam (record sum -> per-Gaussian chain -> Adam in ONE kernel, gradient rows in LDS) against
+    dqo_rast_backward + dqo_map_adam_step (three kernels, gradient rows and summed records through HBM): the same statements on the
+    same operands, so parameters, moments, activations, live bytes and the loss must be BIT-identical after several iterations — with
+    and without the exact sparse mode and the attach loss, on maps whose blocks span several record chunks (cfg 3 layout) and whose
+    size is not a multiple of the block (30011).  Only the reported attach loss is a differently grouped sum."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch, P=P, cfg=cfg)
+    a = FusedMapper(scene, settings, dev, sparse_moments=sparse, attach=attach)
+    b = FusedMapper(scene, settings, dev, sparse_moments=sparse, attach=attach)
+    a.capture(gt_color, gt_depth, mask, fused_tail=True)
+    b.capture(gt_color, gt_depth, mask, fused_tail=False)
+    assert a._g.fused_tail and not b._g.fused_tail
+    for it in range(5):
+        a.replay(), b.replay()
+        torch.cuda.synchronize()
+        for k, pa in a._params().items():
+            assert torch.equal(pa, b._params()[k]), (it, k, (pa - b._params()[k]).abs().max().item())
+            assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), (it, k)
+        assert torch.equal(a.opacity, b.opacity) and torch.equal(a.scales, b.scales) and torch.equal(a.rotations, b.rotations)
+        if sparse:
+            assert torch.equal(a.moment_live, b.moment_live)
+        assert torch.equal(a.loss, b.loss)
+        if attach:
+            np.testing.assert_allclose(a.attach_loss().item(), b.attach_loss().item(), rtol=1e-5, atol=1e-12)
+    assert not a.graph_overflowed() and a.step_count == b.step_count == 6
+    assert int(a._g.step_dev.item()) == int(b._g.step_dev.item()) == 7
+    if attach:
+        assert a.attach_loss().item() > 0
+
+
+def test_fused_tail_is_a_noop_on_an_overflowed_frame(env):
+    """The fused tail keeps adam_kernel's rule: a frame whose header says overflow trains nothing (parameters, moments, live bytes
+    and the device step count stay bit for bit)."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    fm = FusedMapper(scene, settings, dev)
+    for _ in range(2):
+        fm.step(gt_color, gt_depth, mask)
+    before = {k: v.clone() for k, v in fm._params().items()}
+    state_before = {k: (m.clone(), v.clone()) for k, (m, v) in fm.state.items()}
+    live_before = fm.moment_live.clone()
+    fm.capture(gt_color, gt_depth, mask, capacity_margin=0.05, fused_tail=True)
+    assert fm._g.fused_tail and fm.step_count == 2
+    step_before = int(fm._g.step_dev.item())
+    for _ in range(3):
+        fm.replay()
+    torch.cuda.synchronize()
+    assert fm.graph_overflowed() and int(fm._g.step_dev.item()) == step_before
+    for k, v in fm._params().items():
+        assert torch.equal(v, before[k]), k
+        assert torch.equal(fm.state[k][0], state_before[k][0]) and torch.equal(fm.state[k][1], state_before[k][1]), k
+    assert torch.equal(fm.moment_live, live_before)
+
+
 def test_loss_tap_equals_the_loss_kernels(env):
     """DqoRastCtx.loss_tap: the masked loss summed inside the forward's blend kernel and its gradient formed inside the backward's
     must train exactly like the two loss kernels between them — same counts, same gradient scale, hence bit-identical parameters and
