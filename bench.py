@@ -192,9 +192,18 @@ def build_problem(args, rank, world, device):
         my_objs = torch.unique(obj_id)
     render_mask = torch.isin(pix_obj, my_objs)  # union of the masks of the objects this rank owns
     tile_mask = torch.tensor(sharding.tile_mask_from_pixel_mask(render_mask.cpu().numpy()), device=device)
+    # the per-object job (DqoObjectGate + DqoLossTap.per_object): every pixel belongs to ONE object and sees only that
+    # object's Gaussians, every object's loss is normalised by its own pixel counts, the attach loss by the WHOLE map's attach count —
+    # so what an object learns does not depend on which rank holds it, and every N computes the N = 1 function
+    gate = None
+    if not args.no_object_gate and args.cfg != 1:
+        gate = (torch.tensor(np.asarray(mine["obj_id"], np.int32), device=device), pix_obj.to(torch.int32).contiguous())
+    op_full = np.clip(np.asarray(full["opacity"], np.float32).reshape(-1), 1e-4, 1 - 1e-4)
+    n_attach_full = int((op_full < 0.9).sum())
     torch.cuda.empty_cache()
     return dict(cam=cam, full=full, scene=mine, settings=settings, gt_color=gt_color, gt_depth=gt_depth, render_mask=render_mask,
-                tile_mask=tile_mask, cfgd=cfgd, P=P, P_shard=int(mine["xyz"].shape[0]), objects=[int(k) for k in my_objs.tolist()])
+                tile_mask=tile_mask, cfgd=cfgd, P=P, P_shard=int(mine["xyz"].shape[0]), objects=[int(k) for k in my_objs.tolist()],
+                gate=gate, pix_obj=pix_obj.to(torch.int32).contiguous(), n_attach_full=n_attach_full, sharded=bool(strong and world > 1))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -211,10 +220,18 @@ def make_dropin_step(prob, device, loss_buf):
     init_stat = params.init_stat()
     st, gtc, gtd, rm, tm = prob["settings"], prob["gt_color"], prob["gt_depth"], prob["render_mask"], prob["tile_mask"]
 
+    gate = prob.get("gate")
+    # (a shard's attach loss is a mean over the WHOLE map's attach set: scale the shard's own mean accordingly)
+    n_att_local = int((torch.sigmoid(init_stat["opacity"]) < 0.9).sum().item())
+    att_scale = (n_att_local / max(prob["n_attach_full"], 1)) if prob.get("sharded") else 1.0
+
     def step():
-        out = mapping.render(st, params.activated(), tile_mask=tm)
-        loss, parts = mapping.mapping_loss(out, gtc, gtd, render_mask=rm)
-        (loss + mapping.attach_loss(params, init_stat)).backward()  # mapper.py:905
+        out = mapping.render(st, params.activated(), tile_mask=tm, object_gate=gate)
+        if gate is None:
+            loss, parts = mapping.mapping_loss(out, gtc, gtd, render_mask=rm)
+        else:
+            loss, parts = mapping.per_object_loss(out, gtc, gtd, gate[1], render_mask=rm)
+        (loss + att_scale * mapping.attach_loss(params, init_stat)).backward()  # mapper.py:905
         opt.step()
         opt.zero_grad(set_to_none=True)
         loss_buf.put("total", parts["total_loss"])
@@ -226,6 +243,21 @@ def make_dropin_step(prob, device, loss_buf):
     return step
 
 
+def attach_reducer(prob, world):
+    """FusedMapper.attach_count_reducer of a rank: the attach loss is a mean over the attach set of the WHOLE map, so a shard divides by the
+    whole map's count — one all-reduce of one integer per mapping call (never per iteration); a shard run alone (--as-shard) takes the
+    count of the full map it was cut from.  None at N = 1."""
+    if not prob.get("sharded"):
+        return None
+    if world > 1:
+        def reduce(n):
+            t = torch.tensor([n], dtype=torch.int64, device=prob["gt_color"].device)
+            torch.distributed.all_reduce(t)
+            return int(t.item())
+        return reduce
+    return lambda n: prob["n_attach_full"]
+
+
 class FusedRunner:
     """The fused path of one rank: a FusedMapper on the rank's shard, one hipGraph replay per iteration, the packed all-reduce of
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
@@ -233,7 +265,9 @@ class FusedRunner:
     def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True):
         from dqo_harness.fused_mapping import FusedMapper
         self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
-        self.fm = FusedMapper(prob["scene"], prob["settings"], device)
+        self.fm = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=attach_reducer(prob, world))
+        if prob.get("gate") is not None:
+            self.fm.set_object_gate(prob["gate"][0], prob["gate"][1])
         self.mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
         self.use_graph, self.loss_tap, self.fused_tail = use_graph, loss_tap, fused_tail
         self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
@@ -253,7 +287,9 @@ class FusedRunner:
         from dqo_harness import scenes
         p = self.prob
         sc = scenes.surfel_room(9000 + 17 * k + self.growth_seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])
-        return {n: torch.tensor(np.ascontiguousarray(sc[n], np.float32), device=self.device) for n in ("xyz", "scales", "rotations", "opacity", "shs")}
+        b = {n: torch.tensor(np.ascontiguousarray(sc[n], np.float32), device=self.device) for n in ("xyz", "scales", "rotations", "opacity", "shs")}
+        b["obj_id"] = torch.tensor(np.asarray(sc["obj_id"], np.int32), device=self.device)
+        return b
 
     def prepare_growth(self, n_iters):
         if self.growth_every:
@@ -334,10 +370,12 @@ class FusedRunner:
             self.loss_buf.buf.copy_(self.fm.loss)
 
 
-def reduced_losses(buf, world):
-    """[total, colour, depth] over ALL objects from the all-reduced sums (per-shard means do not add up; the sums do)."""
+def reduced_losses(buf, world, per_object=False):
+    """[total, colour, depth] over ALL objects from the all-reduced buffer.  Per-object job: every rank's loss is the sum of its objects'
+    own terms, so the reduced [0..2] ARE the job's loss; one masked loss per shard (--no-object-gate): per-shard means do not add up,
+    the raw sums [4..7] do."""
     v = buf.tolist()
-    if world == 1:
+    if world == 1 or per_object:
         return [round(float(x), 6) for x in v[:3]]
     color = v[4] / (3.0 * max(v[5], 1.0))
     depth = v[6] / max(v[7], 1.0)
@@ -356,9 +394,13 @@ def selfcheck(args, prob, runner, device, n_iters):
     from dqo_harness.fused_mapping import FusedMapper
     fails = []
     params = mapping.GaussianParams(prob["scene"], device)
+    gate = prob.get("gate")
     with torch.no_grad():
-        out = mapping.render(prob["settings"], params.activated(), tile_mask=prob["tile_mask"])
-        _, parts = mapping.mapping_loss(out, prob["gt_color"], prob["gt_depth"], render_mask=prob["render_mask"])
+        out = mapping.render(prob["settings"], params.activated(), tile_mask=prob["tile_mask"], object_gate=gate)
+        if gate is None:
+            _, parts = mapping.mapping_loss(out, prob["gt_color"], prob["gt_depth"], render_mask=prob["render_mask"])
+        else:
+            _, parts = mapping.per_object_loss(out, prob["gt_color"], prob["gt_depth"], gate[1], render_mask=prob["render_mask"])
     ref0 = [parts[k].item() for k in ("total_loss", "color_loss", "depth_loss")]
     got0 = runner.first_loss[:3].tolist()
     if not np.allclose(got0, ref0, rtol=1e-4, atol=1e-7):
@@ -370,7 +412,10 @@ def selfcheck(args, prob, runner, device, n_iters):
     del out, params
     if not runner.growth_log:  # (a grown map has no stand-alone twin to compare with)
         end = runner.fm.loss.clone()
-        twin = FusedMapper(prob["scene"], prob["settings"], device)
+        twin = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=(None if not prob.get("sharded") else
+                                                                                          (lambda n: prob["n_attach_full"])))
+        if gate is not None:
+            twin.set_object_gate(gate[0], gate[1])
         mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
         if runner.use_graph:
             twin.capture(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"])
@@ -396,6 +441,21 @@ def selfcheck(args, prob, runner, device, n_iters):
     return fails
 
 
+def unsharded_initial_loss(prob, device):
+    """[total, colour, depth] of the UNSHARDED job at the initial state: the per-object loss of the gated render of the full map over
+    every object's pixels (eager torch through the gated op).  What the all-reduced losses of the N shards must add up to."""
+    from dqo_harness import mapping
+    full = prob["full"]
+    params = mapping.GaussianParams(full, device)
+    gate = (torch.tensor(np.asarray(full["obj_id"], np.int32), device=device), prob["pix_obj"])
+    with torch.no_grad():
+        out = mapping.render(prob["settings"], params.activated(), object_gate=gate)
+        _, parts = mapping.per_object_loss(out, prob["gt_color"], prob["gt_depth"], gate[1], render_mask=None)
+    del out, params
+    torch.cuda.empty_cache()
+    return [parts[k].item() for k in ("total_loss", "color_loss", "depth_loss")]
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle, test infrastructure: the checker timed beside the product, never the thing measured)
 # ------------------------------------------------------------------------------------------------------------------
@@ -409,16 +469,20 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_iteration(ol, mo, cam, sub, gt_color, gt_depth, mask, omp):
+def cpu_iteration(ol, mo, cam, sub, gt_color, gt_depth, mask, omp, pix_obj=None):
     """ONE full mapping iteration on the CPU: oracle raster forward -> masked loss -> oracle raster backward -> activation Jacobians +
     Adam step over the six groups (numpy).  Returns (seconds per stage, forward result, oracle object)."""
     st = ol.RastSettings(cam.W, cam.H, cam.tanfovx, cam.tanfovy, cam.cx, cam.cy, normal_threshold=float(np.cos(np.deg2rad(60.0))))
     o = ol.OracleRasterizer(np.float32, omp=omp)
     t0 = time.time()
+    gate = {} if pix_obj is None else dict(gaussian_object=np.asarray(sub["obj_id"], np.int32), pixel_object=pix_obj)
     r = o.forward(st, sub["xyz"], sub["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
-                  shs=sub["shs"], scales=sub["scales"], rotations=sub["rotations"])
+                  shs=sub["shs"], scales=sub["scales"], rotations=sub["rotations"], **gate)
     t1 = time.time()
-    _, _, _, dC, dD = mo.masked_loss(r.color, r.depth, r.hit_depth, gt_color, gt_depth, mask)
+    if pix_obj is None:
+        _, _, _, dC, dD = mo.masked_loss(r.color, r.depth, r.hit_depth, gt_color, gt_depth, mask)
+    else:
+        _, _, _, dC, dD = mo.per_object_masked_loss(r.color, r.depth, r.hit_depth, gt_color, gt_depth, pix_obj, mask)
     t2 = time.time()
     g = o.backward(dC.astype(np.float32), dD.astype(np.float32))
     t3 = time.time()
@@ -446,7 +510,8 @@ def cpu_baseline(args, prob, hip_render0):
     sub = {k: v[:Ps] for k, v in scene.items()}
     gtc, gtd = prob["gt_color"].cpu().numpy(), prob["gt_depth"].cpu().numpy()
     mask = (prob["render_mask"].cpu().numpy()) if prob.get("render_mask") is not None else None
-    tm, r, o = cpu_iteration(ol, mo, cam, sub, gtc, gtd, mask, omp=True)
+    pix_obj = prob["pix_obj"].cpu().numpy() if prob.get("gate") is not None else None  # the same per-object job on the CPU
+    tm, r, o = cpu_iteration(ol, mo, cam, sub, gtc, gtd, mask, omp=True, pix_obj=pix_obj)
     cores = ol.num_threads(True)
     stats = dict(N_reference=int(r.num_rendered), active_tiles=int(r.num_tiles),
                  mean_contributors_per_pixel=round(float(o.ctx("n_blend").mean()), 3))
@@ -456,7 +521,7 @@ def cpu_baseline(args, prob, hip_render0):
         mse = ((hip_render0.astype(np.float64) - r.color.astype(np.float64)) ** 2).reshape(3, -1).mean(1)
         psnr = float(np.mean(20 * np.log10(1.0 / np.sqrt(np.maximum(mse, 1e-30)))))
     del o
-    t1, _, o1 = cpu_iteration(ol, mo, cam, sub, gtc, gtd, mask, omp=False)
+    t1, _, o1 = cpu_iteration(ol, mo, cam, sub, gtc, gtd, mask, omp=False, pix_obj=pix_obj)
     del o1
     out = dict(value=round(1.0 / tm["total"], 4), unit="iter/s", cores=cores, kind="port", cpu=cpu_model(),
                single_thread_value=round(1.0 / t1["total"], 4),
@@ -720,7 +785,8 @@ def main():
     render0 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.inner:
         with torch.no_grad():
-            render0 = mapping.render(prob["settings"], mapping.GaussianParams(prob["full"], device).activated())["render"].cpu().numpy()
+            g0 = None if prob.get("gate") is None else (torch.tensor(np.asarray(prob["full"]["obj_id"], np.int32), device=device), prob["pix_obj"])
+            render0 = mapping.render(prob["settings"], mapping.GaussianParams(prob["full"], device).activated(), object_gate=g0)["render"].cpu().numpy()
     loss_buf = PackedAllReduce(LOSS_SPEC, device)
     runner = step_dropin = None
     if args.path == "fused":
@@ -755,7 +821,8 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    loss_now = reduced_losses(loss_buf.buf, world)
+    per_object = prob.get("gate") is not None
+    loss_now = reduced_losses(loss_buf.buf, world, per_object)
     dbg("timed loop done: dt", dt, "rank loss", runner.fm.loss[:3].tolist() if runner else None, "reduced", loss_now)
     if args.inner:
         print(json.dumps({"inner": True, "ms_per_step": dt / args.steps * 1e3}))
@@ -768,6 +835,17 @@ def main():
         fails = selfcheck(args, prob, runner, device, n_iters)
         for f in fails:
             print(f"[bench] SELF-CHECK FAILED on rank {rank}: {f}", file=sys.stderr, flush=True)
+    # the sharded per-object job computes the N = 1 function: the shards' losses of the initial state, all-reduced, against the unsharded
+    # job's loss of the same state (every rank has the full map on the host: it rendered the target from it)
+    n1_check = None
+    if world > 1 and per_object and runner is not None and not args.no_selfcheck and args.scaling == "strong":
+        fl = runner.first_loss[:3].clone().double()
+        torch.distributed.all_reduce(fl)
+        want = unsharded_initial_loss(prob, device)
+        n1_check = dict(reduced_initial_loss=[round(x, 7) for x in fl.tolist()], unsharded_initial_loss=[round(x, 7) for x in want])
+        if not np.allclose(fl.tolist(), want, rtol=1e-5, atol=1e-8):
+            fails.append(f"all-reduced initial loss of the {world} shards {fl.tolist()} != the unsharded job's {want}")
+            print(f"[bench] SELF-CHECK FAILED on rank {rank}: {fails[-1]}", file=sys.stderr, flush=True)
     n_fail = torch.tensor([len(fails)], device=device, dtype=torch.int32)
     if world > 1:
         torch.distributed.all_reduce(n_fail)
@@ -811,6 +889,8 @@ def main():
         stats["adam_rows_touched"] = int(fm_.moment_live.sum().item())
     if fm_ is not None:
         stats["attach_loss_members"] = fm_.attach_count
+        if n1_check is not None:
+            stats["n1_equivalence"] = n1_check
         if runner.first_loss is not None:  # [total, colour, depth] of the initial state and after the last iteration (this rank's shard)
             stats["loss_first_last"] = [[round(x, 6) for x in runner.first_loss[:3].tolist()], [round(x, 6) for x in fm_.loss[:3].tolist()]]
     if runner is not None and runner.growth_log:
@@ -847,6 +927,7 @@ def main():
                      tiles_total=((cam.W + 15) // 16) * ((cam.H + 15) // 16))
         Pk = P_now
         tap_px = 17 if (runner is not None and runner.use_graph and runner.loss_tap) else 0
+        gate_i, gate_px = (4, 4) if per_object else (0, 0)  # object gate: one id per list entry gathered, one owner id per pixel
         # algorithmic bytes per launch (DESIGN.md "Kernels"): what the kernel must move at minimum, per unit
         # (instance = (Gaussian, tile) list entry; Gaussian; pixel) x the units of this launch
         alg = {
@@ -856,8 +937,8 @@ def main():
             "tile_sort_wave_kernel": 20 * n_inst, "tile_sort_kernel": 20 * n_inst,        # key + slot in, id + slot out
             # (loss tap: + ground-truth colour, depth and mask per pixel in the forward; rendered + ground-truth images instead of the
             # two gradient images in the backward: + 17 B per active pixel each)
-            "blend_forward_kernel": 40 * n_inst + (36 + tap_px) * HWa,                    # id + 3 records, live bytes; 9 output planes
-            "blend_backward_kernel": 120 * n_inst + (32 + tap_px) * HWa,                  # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
+            "blend_forward_kernel": (40 + gate_i) * n_inst + (36 + tap_px + gate_px) * HWa,        # id + 3 records, live bytes; 9 output planes
+            "blend_backward_kernel": (120 + gate_i) * n_inst + (32 + tap_px + gate_px) * HWa,      # id, slot, 3 records in, one 64-byte gradient record out; 8 pixel planes
             "record_sum_kernel": 68 * n_inst + 64 * n_vis,                                # gradient records in, one summed record per visible Gaussian out
             # summed record, params, tables in; gradient rows out (fused path: only the rows of visible Gaussians are written)
             "gaussian_backward_kernel": (64 + 236 + 96) * n_vis + 284 * (n_vis if args.path == "fused" else Pk),
@@ -945,8 +1026,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg{args.cfg}: surfel room, ONE map of {P} Gaussians"
                                    + (f" sharded by object id over {world} ranks" if (strong and world > 1) else ("/GPU" if world > 1 else ""))
-                                   + f", {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, SH degree 3, per-object masked loss (0.8 L1 colour + 1.0 "
-                                   "depth L1) + attach loss, raster fwd+bwd + Adam (6 groups); path=" + args.path
+                                   + f", {cam.W}x{cam.H}, {cfgd['n_objects']} object ids, SH degree 3, "
+                                   + ("per-object render (object gate) + per-object masked loss (sum over objects of 0.8 L1 colour + 1.0 "
+                                      "depth L1 on the object's own mask)" if per_object else
+                                      "one masked loss (0.8 L1 colour + 1.0 depth L1) over the rank's objects, objects of a rank occlude each other")
+                                   + " + attach loss, raster fwd+bwd + Adam (6 groups); path=" + args.path
                                    + ("" if args.path != "fused" or args.no_graph else " (one hipGraph replay per iteration)"),
                        "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
                        "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",

@@ -31,12 +31,18 @@ class DqoRastOutputs(ctypes.Structure):
 
 class DqoLossTap(ctypes.Structure):
     _fields_ = [("gt_color", c_vp), ("gt_depth", c_vp), ("render_mask", c_vp), ("out_color", c_vp), ("out_depth", c_vp),
-                ("color_weight", c_f), ("depth_weight", c_f), ("add_depth_thres", c_f), ("loss_out", c_vp), ("grad_scale", c_vp)]
+                ("color_weight", c_f), ("depth_weight", c_f), ("add_depth_thres", c_f), ("loss_out", c_vp), ("grad_scale", c_vp),
+                ("per_object", c_i32)]
+
+
+class DqoObjectGate(ctypes.Structure):
+    _fields_ = [("gaussian_object", c_vp), ("pixel_object", c_vp)]
 
 
 class DqoRastCtx(ctypes.Structure):
     _fields_ = [("geom", c_vp), ("geom_bytes", ctypes.c_size_t), ("binning", c_vp), ("binning_bytes", ctypes.c_size_t),
-                ("image", c_vp), ("image_bytes", ctypes.c_size_t), ("inst_capacity", ctypes.c_int64), ("tile_bucket_capacity", c_i32), ("keep_tile_order", c_i32), ("loss_tap", c_vp)]
+                ("image", c_vp), ("image_bytes", ctypes.c_size_t), ("inst_capacity", ctypes.c_int64), ("tile_bucket_capacity", c_i32), ("keep_tile_order", c_i32), ("loss_tap", c_vp),
+                ("object_gate", c_vp)]
 
 
 class DqoRastGrads(ctypes.Structure):
@@ -133,7 +139,7 @@ def lib():
         L.dqo_abi_sizeof.restype = ctypes.c_size_t
         L.dqo_abi_sizeof.argtypes = [c_i32]
         for k, st in enumerate((DqoRastParams, DqoRastInputs, DqoRastOutputs, DqoRastCtx, DqoRastGrads, DqoRastHeader, DqoProfileEntry,
-                                DqoAdamStep, DqoLossTap)):
+                                DqoAdamStep, DqoLossTap, DqoObjectGate)):
             if L.dqo_abi_sizeof(k) != ctypes.sizeof(st):
                 raise RuntimeError(f"libdqoraster.so: struct {st.__name__} is {L.dqo_abi_sizeof(k)} bytes in the library, "
                                    f"{ctypes.sizeof(st)} in the binding")

@@ -131,7 +131,7 @@ DQO_API int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset
 DQO_API int dqo_abi_version(void) { return DQO_ABI_VERSION; }
 DQO_API size_t dqo_abi_sizeof(int32_t which) {
     static const size_t sz[] = {sizeof(DqoRastParams), sizeof(DqoRastInputs), sizeof(DqoRastOutputs), sizeof(DqoRastCtx), sizeof(DqoRastGrads),
-                                sizeof(DqoRastHeader), sizeof(DqoProfileEntry), sizeof(DqoAdamStep), sizeof(DqoLossTap)};
+                                sizeof(DqoRastHeader), sizeof(DqoProfileEntry), sizeof(DqoAdamStep), sizeof(DqoLossTap), sizeof(DqoObjectGate)};
     return (which >= 0 && which < (int32_t)(sizeof(sz) / sizeof(sz[0]))) ? sz[which] : 0;
 }
 DQO_API const char* dqo_last_error(void) { return g_err; }
@@ -220,6 +220,9 @@ DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs*
     DQO_CHECK_ARG(ctx->tile_bucket_capacity >= 0, "negative tile_bucket_capacity");
     DQO_CHECK_ARG(ctx->loss_tap == nullptr || (ctx->loss_tap->gt_color && ctx->loss_tap->gt_depth && ctx->loss_tap->loss_out &&
                                                ctx->loss_tap->grad_scale), "loss tap with a null pointer");
+    DQO_CHECK_ARG(ctx->object_gate == nullptr || (ctx->object_gate->gaussian_object && ctx->object_gate->pixel_object),
+                  "object gate with a null pointer");
+    DQO_CHECK_ARG(ctx->loss_tap == nullptr || !ctx->loss_tap->per_object || ctx->object_gate, "a per-object loss tap needs the object gate");
     if (ctx->binning_bytes < dqo_rast_binning_bytes_bucketed(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity)) {
         dqo_set_error("binning buffer too small (%zu < %zu)", ctx->binning_bytes,
                       dqo_rast_binning_bytes_bucketed(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity));

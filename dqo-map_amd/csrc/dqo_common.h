@@ -8,6 +8,8 @@
 #define DQO_TILE 16  // reference BLOCK_X = BLOCK_Y = 16 (cuda_rasterizer/config.h:15-16); part of the op's semantics
 #define DQO_WAVE 64
 #define DQO_SPREAD 64  // lines the per-block statistics atomics of K1 are spread over
+#define DQO_GATE_OBJECTS 64  // object ids of the per-object loss tap lie in [0, 64) (DqoLossTap.per_object)
+#define DQO_OBJ_SPREAD 16    // copies of the per-object loss counters the forward's atomics are spread over
 // The per-tile atomic counters (histogram, emit cursors) are spread one per DQO_TSTRIDE words: device-scope atomics execute
 // memory-side on MI355X, and counters sharing a line / channel serialise there.
 #ifndef DQO_TSTRIDE
@@ -54,8 +56,10 @@ struct DqoGeomLayout {
     uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator)
     uint32_t* spread;        // [DQO_SPREAD][64] statistics counters spread over DQO_SPREAD lines (same-address atomics serialise
                              //       memory-side): word 0 = visible Gaussians, word 1 = (Gaussian, tile) pairs in the tile rects
+    unsigned long long* obj_tap;  // [DQO_OBJ_SPREAD][DQO_GATE_OBJECTS][4] per-object loss tap: colour error sum, mask pixels, depth error
+                                  //   sum, valid depth pixels (2^-32 fixed point / counts), zeroed with the header when the tap is per object
     float4* conic_opacity;   // [P] (conic.x, conic.y, conic.z, opacity)           forward.cu:343
-    float4* xy_depth;        // [P] (pix.x, pix.y, depth = p_view.z, bits(radius))  forward.cu:339-341
+    float4* xy_depth;        // [P] (pix.x, pix.y, depth = p_view.z, bits(radius) — or, with a DqoObjectGate, bits(object id))  forward.cu:339-341
     float4* rgb_smax;        // [P] (r, g, b, max(scale)*scale_mod)                 forward.cu:333-335, 73
     float4* normal_c;        // [P] (n_c.xyz, n_c . p_c)   surfel normal in camera space, hoisted out of the blend loop
     float4* point_c;         // [P] (p_c.xyz, max raw scale)   forward.cu:782-783, backward.cu:1009
@@ -78,6 +82,7 @@ static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
     L.header = (DqoRastHeader*)take(256);
     L.counters = (uint32_t*)take(256);
     L.spread = (uint32_t*)take(256 * DQO_SPREAD);
+    L.obj_tap = (unsigned long long*)take(sizeof(unsigned long long) * 4 * DQO_GATE_OBJECTS * DQO_OBJ_SPREAD);  // (directly after spread)
     L.conic_opacity = (float4*)take(sizeof(float4) * P);
     L.xy_depth = (float4*)take(sizeof(float4) * P);
     L.rgb_smax = (float4*)take(sizeof(float4) * P);
@@ -104,14 +109,27 @@ struct DqoTapDev {
     float color_weight, depth_weight, add_depth_thres;
     float* loss_out;
     float* scale;
+    int per_object;  // DqoLossTap.per_object
 };
+// DqoObjectGate as the kernels get it (by value); gobj == nullptr: no gate
+struct DqoGateDev {
+    const int32_t* gobj;  // [P]
+    const int32_t* pobj;  // [H*W]
+};
+static inline DqoGateDev dqo_gate_dev(const DqoObjectGate* g) {
+    DqoGateDev d;
+    d.gobj = g ? g->gaussian_object : nullptr, d.pobj = g ? g->pixel_object : nullptr;
+    return d;
+}
 static inline DqoTapDev dqo_tap_dev(const DqoLossTap* t) {
     DqoTapDev d;
+    d.per_object = 0;
     if (t == nullptr) {
         d.gt_color = d.gt_depth = d.out_color = d.out_depth = nullptr, d.mask = nullptr, d.loss_out = d.scale = nullptr;
         d.color_weight = d.depth_weight = d.add_depth_thres = 0.f;
         return d;
     }
+    d.per_object = t->per_object;
     d.gt_color = t->gt_color, d.gt_depth = t->gt_depth, d.mask = t->render_mask, d.out_color = t->out_color, d.out_depth = t->out_depth;
     d.color_weight = t->color_weight, d.depth_weight = t->depth_weight, d.add_depth_thres = t->add_depth_thres;
     d.loss_out = t->loss_out, d.scale = t->grad_scale;

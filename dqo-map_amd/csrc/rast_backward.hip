@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, hipStream_t s);
+                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate,
+                              hipStream_t s);
 
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                         const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* gr, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -253,7 +254,7 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     DqoGradRec* recs = (DqoGradRec*)ws;
     uint8_t* valid = reinterpret_cast<uint8_t*>(bin.rec_valid);  // zeroed by the forward (bin_place_kernel)
     int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap,
-                                       dqo_tap_dev(ctx->loss_tap), s);
+                                       dqo_tap_dev(ctx->loss_tap), dqo_gate_dev(ctx->object_gate), s);
     if (rc) return rc;
     DqoGradRec* sums = reinterpret_cast<DqoGradRec*>(g.grad_sum);  // [P], lives in the forward's geometry buffer
     DQO_LAUNCH("record_sum_kernel", record_sum_kernel, dim3(dqo_spread_blocks(p->P)), dim3(256), s, p->P, g, reinterpret_cast<const float4*>(recs),

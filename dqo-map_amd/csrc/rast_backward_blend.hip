@@ -162,17 +162,43 @@ __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx
     return make_float3(rx * n, ry * n, rz * n);
 }
 
+// DqoLossTap.per_object: the loss is the sum of the objects' own masked losses, so the report adds up one term per object (lane o =
+// object o, its counters summed over the spread copies); every pixel's gradient scale is its OWNER's (blend_backward_kernel).  One
+// whole wave, all lanes active.
+__device__ __forceinline__ void tap_report_per_object(const DqoGeomLayout& g, const DqoTapDev& tap) {
+    const int o = (int)threadIdx.x;  // DQO_GATE_OBJECTS == 64 == the wave
+    static_assert(DQO_GATE_OBJECTS == 64, "one lane per object id");
+    unsigned long long t[4] = {0ull, 0ull, 0ull, 0ull};
+    for (int j = 0; j < DQO_OBJ_SPREAD; j++) {
+        const unsigned long long* l = g.obj_tap + ((size_t)j * DQO_GATE_OBJECTS + (size_t)o) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; c++) t[c] += l[c];
+    }
+    const double s_c = (double)t[0] / DQO_TAP_FIXED, s_d = (double)t[2] / DQO_TAP_FIXED;
+    const float n_col = fmaxf((float)t[1], 1.f), n_dep = fmaxf((float)t[3], 1.f);
+    const float color_o = (float)(s_c / (3.0 * (double)n_col)), depth_o = (float)(s_d / (double)n_dep);
+    const float color_loss = wave_sum(color_o), depth_loss = wave_sum(depth_o);
+    const float total = wave_sum(tap.depth_weight * depth_o + tap.color_weight * color_o);
+    const float r4 = wave_sum((float)s_c), r5 = wave_sum((float)t[1]), r6 = wave_sum((float)s_d), r7 = wave_sum((float)t[3]);
+    if (threadIdx.x == 0) {
+        tap.loss_out[0] = total, tap.loss_out[1] = color_loss, tap.loss_out[2] = depth_loss, tap.loss_out[3] = 0.f;
+        tap.loss_out[4] = r4, tap.loss_out[5] = r5, tap.loss_out[6] = r6, tap.loss_out[7] = r7;
+    }
+}
+
 constexpr int BWD_THREADS = 64;
 // live entries per reduction batch: BWD_NB x 9 values go through one butterfly — 7 x 9 = 63 of 64 values (wave_reduce64), or
 // 3 x 9 = 27 of 32 (wave_reduce32: fewer registers -> more waves per SIMD)
-template <int BWD_NB>
+// GATE: DqoObjectGate (an entry acts on a pixel only if the Gaussian's object id equals the pixel's owner id) — a template parameter,
+// so that the ungated kernel keeps its instruction stream.
+template <int BWD_NB, bool GATE>
 __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                      DqoBinLayout bin, const float* __restrict__ scales,
                                                                      const float* __restrict__ rotations,
                                                                      const float* __restrict__ dL_dpixels,
                                                                      const float* __restrict__ dL_ddepths,
                                                                      float* __restrict__ recs, uint8_t* __restrict__ valid,
-                                                                     int64_t capacity, const DqoTapDev tap) {
+                                                                     int64_t capacity, const DqoTapDev tap, const DqoGateDev gate) {
     __shared__ float4 s_co[BWD_THREADS];
     __shared__ float4 s_xy[BWD_THREADS];
     __shared__ float4 s_rgb[BWD_THREADS];
@@ -197,7 +223,10 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
             tap.scale[0] = tap_gc, tap.scale[1] = tap_gdw;
         }
     };
-    if (tap.scale != nullptr && blockIdx.x == 0) tap_scales(true);  // (before the early exits below: block 0 may have no list)
+    if (tap.scale != nullptr && blockIdx.x == 0) {  // (before the early exits below: block 0 may have no list)
+        if (GATE && tap.per_object) tap_report_per_object(g, tap);
+        else tap_scales(true);
+    }
     // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
     const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     if (n == 0) return;
     const int L = min((int)img.walk4[tile * 4 + quad], n);  // list positions [0, L) matter to this quadrant
     if (L == 0) return;
-    if (tap.scale != nullptr && blockIdx.x != 0) tap_scales(false);
+    if (tap.scale != nullptr && blockIdx.x != 0 && !(GATE && tap.per_object)) tap_scales(false);
     const int lane = threadIdx.x;
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
     const size_t HW = (size_t)v.W * v.H;
@@ -225,6 +254,33 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     const uint32_t hit_word = inside ? img.hit_pos[pid] : 0u;
     const int hit_pos = (int)(hit_word & 0x7fffffffu);
     const bool hit_plane = (hit_word >> 31) != 0u;  // the forward decided backward.cu:1016's branch for this pixel
+    int owner = (int)0x80000000;  // object gate: this pixel's owner ("none" equals no Gaussian's non-negative object id)
+    if (GATE) {
+        if (inside) owner = gate.pobj[pid];
+        if (owner < 0) owner = (int)0x80000000;
+        if (tap.scale != nullptr && tap.per_object) {
+            // per-object gradient scales: one trip per distinct owner among the quadrant's pixels (usually one or two, wave-uniform);
+            // lanes 0..15 each read one spread copy of the owner's two pixel counts
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(owner >= 0);
+            while (todo != 0ull) {
+                const int f = (int)__builtin_ctzll(todo);
+                const int o = __builtin_amdgcn_readlane(owner, f);
+                const unsigned long long* l = g.obj_tap + ((size_t)(lane & (DQO_OBJ_SPREAD - 1)) * DQO_GATE_OBJECTS + (size_t)(o & (DQO_GATE_OBJECTS - 1))) * 4;
+                unsigned long long n1 = lane < DQO_OBJ_SPREAD ? l[1] : 0ull, n3 = lane < DQO_OBJ_SPREAD ? l[3] : 0ull;
+#pragma unroll
+                for (int off = DQO_OBJ_SPREAD / 2; off > 0; off >>= 1) {
+                    n1 += (unsigned long long)__shfl_xor((long long)n1, off);
+                    n3 += (unsigned long long)__shfl_xor((long long)n3, off);
+                }
+                n1 = (unsigned long long)__shfl((long long)n1, 0), n3 = (unsigned long long)__shfl((long long)n3, 0);
+                const float n_col = fmaxf((float)n1, 1.f), n_dep = fmaxf((float)n3, 1.f);
+                const bool mine = owner == o;
+                tap_gc = mine ? tap.color_weight / (3.f * n_col) : tap_gc;
+                tap_gdw = mine ? tap.depth_weight / n_dep : tap_gdw;
+                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+            }
+        }
+    }
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, ddep = 0.f;
     if (tap.scale == nullptr) {
         if (inside) dp0 = dL_dpixels[pid], dp1 = dL_dpixels[HW + pid], dp2 = dL_dpixels[2 * HW + pid], ddep = dL_ddepths[pid];
@@ -232,7 +288,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
         // DqoLossTap, backward half: the gradient images of the masked L1 loss, formed in place (what loss_grad_kernel writes:
         // sign(error) x weight / count, 0 outside the mask; a tile with a list always has hit id -1 <=> hit_pos 0)
         const float gc = tap_gc, gdw = tap_gdw;
-        const bool m = tap.mask ? tap.mask[pid] != 0 : true;
+        const bool m = (tap.mask ? tap.mask[pid] != 0 : true) && (!(GATE && tap.per_object) || owner >= 0);
         const float d0 = tap.out_color[pid] - tap.gt_color[pid], d1 = tap.out_color[HW + pid] - tap.gt_color[HW + pid];
         const float d2 = tap.out_color[2 * HW + pid] - tap.gt_color[2 * HW + pid];
         const float gd = tap.gt_depth[pid], err = tap.out_depth[pid] - gd;
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
                     const float power = dqo_power(co.x, co.y, co.z, dx, dy);
                     const float Gx = dqo_gauss(power);
                     const float alpha_x = fminf(0.99f, co.w * Gx);
-                    const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f;
+                    const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f && (!GATE || __float_as_int(xy.w) == owner);
                     const float alpha = did_color ? alpha_x : 0.f;
                     const float G = did_color ? Gx : 0.f;
                     const float inv_1ma = dqo_rcp(1.f - alpha);
@@ -436,6 +492,10 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
 namespace {
 // DqoLossTap on an empty map (P = 0: no blend kernel runs in the backward): the loss of the background-only frame is still reported.
 __global__ void tap_report_kernel(DqoGeomLayout g, const DqoTapDev tap) {
+    if (tap.per_object) {
+        tap_report_per_object(g, tap);
+        return;
+    }
     double tot[4];
     dqo_tap_totals(g.spread, (int)threadIdx.x, tot);
     if (threadIdx.x != 0) return;
@@ -456,18 +516,24 @@ int dqo_launch_tap_report(const DqoGeomLayout& g, const DqoTapDev& tap, hipStrea
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, hipStream_t s) {
+                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate,
+                              hipStream_t s) {
     // DQO_BWD_NB=3 (measurement only) selects the 32-value butterfly: 55 instead of 81 VGPRs, 5.4 instead of 3.7 waves resident
     // per SIMD — and 5 % SLOWER (round 2, profiles/README.md): the kernel is bound by VALU execution, not by latency
     static const int nb = [] {
         const char* e = getenv("DQO_BWD_NB");
         return e ? atoi(e) : 7;
     }();
-    if (nb == 7)
-        DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel<7>, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales,
-                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity, tap);
+    const dim3 grid(8 * ((T + 7) / 8) * 4);
+    float* r = reinterpret_cast<float*>(recs);
+    if (gate.gobj != nullptr)
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true>), grid, dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
+                   dL_dcolor, dL_ddepth, r, valid, capacity, tap, gate);
+    else if (nb == 7)
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
+                   dL_dcolor, dL_ddepth, r, valid, capacity, tap, gate);
     else
-        DQO_LAUNCH("blend_backward_kernel", blend_backward_kernel<3>, dim3(8 * ((T + 7) / 8) * 4), dim3(BWD_THREADS), s, v, g, img, bin, scales,
-                   rotations, dL_dcolor, dL_ddepth, reinterpret_cast<float*>(recs), valid, capacity, tap);
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<3, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
+                   dL_dcolor, dL_ddepth, r, valid, capacity, tap, gate);
     return DQO_OK;
 }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView
                                                                 const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
                                                                 int32_t* __restrict__ radii_out,
                                                                 int32_t* __restrict__ n_touched_out, uint32_t* __restrict__ zero_base,
-                                                                size_t zero_words) {
+                                                                size_t zero_words, const int32_t* __restrict__ gobj) {
 #pragma clang fp contract(off)
     __shared__ uint32_t s_visible;
     const int tid = threadIdx.x;
@@ -100,6 +100,8 @@ __global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView
             const float tvz = view[2] * px + view[6] * py + view[10] * pz + view[14];
             if (tvz <= 0.2f || (double)projx < -1.3 || (double)projx > 1.3 || (double)projy < -1.3 || (double)projy > 1.3) break;
             const float opac = opacities[idx];  // (with the scales / rotation round: used only by the stores at the very end)
+            // DqoObjectGate: the Gaussian's object id travels to the blend kernels in the spare word of its xy record
+            const int obj_id = gobj != nullptr ? gobj[idx] : 0;
             // computeCov3D, forward.cu:202-235
             const float sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
             const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView
 
             radius = ir;
             g.conic_opacity[idx] = make_float4(conx, cony, conz, opac);
-            g.xy_depth[idx] = make_float4(pixx, pixy, tvz, __int_as_float(ir));
+            g.xy_depth[idx] = make_float4(pixx, pixy, tvz, __int_as_float(gobj != nullptr ? obj_id : ir));
             g.rgb_smax[idx] = make_float4(rgb[0], rgb[1], rgb[2], smax);
             g.normal_c[idx] = make_float4(ncx, ncy, ncz, npc);
             // .w = max of the RAW scales: the backward's depth test uses it without scale_modifier (backward.cu:1009, quirk B6)
@@ -818,7 +820,7 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, hipStream_t s);
+                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate, hipStream_t s);
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                          int64_t capacity, hipStream_t s);
 int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
@@ -835,7 +837,10 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     const int T = v.gx * v.gy;
     {  // header + counters + spread statistics counters
-        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(g.header), (512 + 256 * DQO_SPREAD) / 4, s);
+        // (+ the per-object loss counters, which sit directly behind them, when the loss tap is per object)
+        const size_t obj_words = (ctx->loss_tap != nullptr && ctx->loss_tap->per_object)
+                                     ? sizeof(unsigned long long) * 4 * DQO_GATE_OBJECTS * DQO_OBJ_SPREAD / 4 : 0;
+        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(g.header), (512 + 256 * DQO_SPREAD) / 4 + obj_words, s);
         if (rc) return rc;
     }
     const size_t zero_words = (size_t)((img.tile_flag + T) - img.tile_count);  // histogram (padded) + flags
@@ -847,7 +852,8 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;
         DQO_LAUNCH("preprocess_kernel", preprocess_kernel, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
-                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words);
+                           in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words,
+                           ctx->object_gate ? ctx->object_gate->gaussian_object : nullptr);
     }
     return DQO_OK;
 }
@@ -878,7 +884,8 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
         DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order);
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
     }
-    return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, dqo_tap_dev(ctx->loss_tap), s);
+    return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, dqo_tap_dev(ctx->loss_tap),
+                                    dqo_gate_dev(ctx->object_gate), s);
 }
 
 int dqo_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s) {

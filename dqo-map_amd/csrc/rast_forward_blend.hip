@@ -55,8 +55,9 @@ __device__ __forceinline__ float tap_wave_sum(float x) {
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);  // fixed order: reproducible
     return x;
 }
+// owner: the pixel's object id (DqoObjectGate.pixel_object; only read when tap.per_object)
 __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeomLayout& g, bool inside, size_t pid, size_t HW, float c0,
-                                              float c1, float c2, float depth, int hit_id, int lane) {
+                                              float c1, float c2, float depth, int hit_id, int lane, int owner) {
     float e = 0.f, de = 0.f;
     bool m = false, valid = false;
     if (inside) {
@@ -66,6 +67,26 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
         const float err = depth - gd;
         valid = m && hit_id != -1 && gd > 0.f && err < tap.add_depth_thres;  // mapper.py:850-856
         de = fabsf(err);
+    }
+    if (tap.per_object) {
+        // DqoLossTap.per_object: one set of sums per object id among the wave's mask pixels (usually one or two: a wave-uniform loop)
+        m = m && owner >= 0;
+        valid = valid && m;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(m);
+        while (todo != 0ull) {
+            const int f = (int)__builtin_ctzll(todo);
+            const int o = __builtin_amdgcn_readlane(owner, f);
+            const bool sel = m && owner == o, selv = valid && owner == o;
+            const unsigned long long sm = __builtin_amdgcn_ballot_w64(sel), sv = __builtin_amdgcn_ballot_w64(selv);
+            const float se = tap_wave_sum(sel ? e : 0.f), sd = tap_wave_sum(selv ? de : 0.f);
+            if (lane == 0) {
+                unsigned long long* line = g.obj_tap + ((size_t)(blockIdx.x % DQO_OBJ_SPREAD) * DQO_GATE_OBJECTS + (size_t)(o & (DQO_GATE_OBJECTS - 1))) * 4;
+                atomicAdd(&line[0], dqo_tap_fixed(se)), atomicAdd(&line[1], (unsigned long long)__popcll(sm));
+                if (sv) atomicAdd(&line[2], dqo_tap_fixed(sd)), atomicAdd(&line[3], (unsigned long long)__popcll(sv));
+            }
+            todo &= ~sm;
+        }
+        return;
     }
     const unsigned long long nm = __popcll(__builtin_amdgcn_ballot_w64(m)), nv = __popcll(__builtin_amdgcn_ballot_w64(valid));
     if (nm == 0ull) return;  // (wave-uniform; valid implies m)
@@ -78,9 +99,15 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
     if (nv) atomicAdd(&line[2], fd), atomicAdd(&line[3], nv);
 }
 
-__global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+// GATE: DqoObjectGate — a list entry acts on a pixel only if the Gaussian's object id equals the pixel's owner id.  A template
+// parameter, so that the ungated kernel (the reference's semantics, the drop-in op) keeps its instruction stream.  (The gated
+// instantiation is held to 80 registers: left alone it takes 83-92 and loses two waves per SIMD, which is where its time goes — the
+// instruction counts of the two kernels are equal to 0.1 %; a duplicate of the entry loop without the owner comparison for the
+// one-owner quadrants measured nothing.)
+template <bool GATE>
+__global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                     DqoBinLayout bin, DqoRastOutputs out, int64_t capacity,
-                                                                    const DqoTapDev tap) {
+                                                                    const DqoTapDev tap, const DqoGateDev gate) {
     __shared__ float4 s_co[FWD_THREADS];
     __shared__ float4 s_xy[FWD_THREADS];
     __shared__ float4 s_rgb[FWD_THREADS];
@@ -103,6 +130,25 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
     const size_t pix_id = (size_t)v.W * py + px;
     const uint2 range = img.ranges[tile];
     const int n = (int)(range.y - range.x);
+    // object gate: this pixel's owner, and the owners present in the quadrant as a 64-bit set of (id mod 64) — an entry whose object's
+    // bit is not in the set matches no pixel of the quadrant and is culled with the entries that cannot reach it
+    // (object ids lie in [0, 64), so the set is exact: in a quadrant with ONE owner — all but the object boundaries — the entries that
+    // pass it are exactly the owner's, ownerless pixels simply start finished, and the per-pixel comparison is only made in `mixed`
+    // quadrants; the Gaussian's object id arrives in the spare word of its xy record, no gather of its own)
+    int owner = -1;
+    unsigned long long present = 0ull;
+    bool mixed = false;
+    if (GATE) {
+        if (inside) owner = gate.pobj[pix_id];
+        if (owner < 0) owner = (int)0x80000000;  // "no owner": equal to no Gaussian's (non-negative) object id
+        present = owner >= 0 ? 1ull << (owner & 63) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) present |= (unsigned long long)__shfl_xor((long long)present, off);
+        // (wave-uniform: keep the set in scalar registers)
+        present = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(present >> 32)) << 32) |
+                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)present);
+        mixed = __popcll(present) > 1;
+    }
 
     if (n == 0) {
         // masked or empty tile: the reference's torch::full initial values (rasterize_points.cu:79-89).  A tile that is
@@ -126,14 +172,14 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         if (lane == 0) img.walk4[tile * 4 + quad] = 0;
         if (tap.scale != nullptr)
             loss_tap_wave(tap, g, inside, pix_id, HW, rendered ? v.bg[0] : 0.f, rendered ? v.bg[1] : 0.f, rendered ? v.bg[2] : 0.f, 0.f,
-                          rendered ? -1 : 0, lane);
+                          rendered ? -1 : 0, lane, owner);
         return;
     }
 
     const float qx0 = (float)(tile_x * DQO_TILE + (quad & 1) * 8), qy0 = (float)(tile_y * DQO_TILE + (quad >> 1) * 8);
     const float pixfx = (float)px, pixfy = (float)py;
     const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
-    float gate = inside ? 1.f : 0.f;   // 0 = this pixel is finished (or outside the image)
+    float pix_gate = (inside && (!GATE || owner >= 0)) ? 1.f : 0.f;   // 0 = this pixel is finished (outside the image; no owner)
     float nohit = 1.f;                 // 0 = the pixel's depth has been fixed by an opaque hit
     const float hit_thr = fmaxf(v.opaque_thr, 1.0f / 255.0f);
     float T = 1.0f, end_T = 1.0f;
@@ -154,7 +200,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         xy_nx = g.xy_depth[id_nx];
         cs_nx = g.rgb_smax[id_nx];
     }
-    bool all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;  // wave-uniform
+    bool all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;  // wave-uniform
     for (int c = 0; c < chunks && !all_done; c++) {  // a finished quadrant never looks at the entries further back
         const int pos = c * FWD_THREADS + lane;
         const int id = id_nx;
@@ -171,7 +217,8 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
             }
         }
         // which entries of this chunk can reach this quadrant at all (conservative, dqo_cull.h); compact them into LDS
-        const bool reach = pos < n && dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, dqo_q_threshold(co.w), qx0, qy0, qx0 + 7.f, qy0 + 7.f);
+        bool reach = pos < n && dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, dqo_q_threshold(co.w), qx0, qy0, qx0 + 7.f, qy0 + 7.f);
+        if (GATE) reach = reach && ((present >> (__float_as_int(xy.w) & 63)) & 1ull) != 0ull;
         const unsigned long long rm = __builtin_amdgcn_ballot_w64(reach);
         const int cnt = (int)__popcll(rm);
         const int myk = (int)__popcll(rm & ((1ull << lane) - 1ull));
@@ -185,7 +232,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
         // per-entry results of compacted entry k: was it live for this quadrant (bit k of live_m), and how many of the
         // quadrant's pixels saw it with T' > 0.5 (s_half[k]; n_touched, forward.cu:833-835, quirk B8)
         unsigned long long live_m = 0ull;  // compacted entries of this chunk that were live (wave-uniform)
-        if (cnt > 0) {
+        auto entries = [&]() {
             for (int k = 0; k < cnt && !all_done; k++) {
                 const float4 xy_cur = s_xy[k], co_cur = s_co[k];
                 // ---- per-pixel update (forward.cu:750-842), arithmetic gating instead of per-lane control flow ----
@@ -195,7 +242,9 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                 const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
                 const float power = dqo_power(co_cur.x, co_cur.y, co_cur.z, dx, dy);
                 const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
-                const float a_g = power <= 0.0f ? alpha * gate : 0.f;
+                // (object gate, mixed quadrants only: the entry acts on the pixels of its own object)
+                const bool other = GATE && mixed && __float_as_int(xy_cur.w) != owner;
+                const float a_g = (power <= 0.0f && !other) ? alpha * pix_gate : 0.f;
                 const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
                 if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
                     const uint32_t contributor = (uint32_t)s_pos[k];
@@ -233,7 +282,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                     last_contributor = blend ? contributor : last_contributor;
                     end_T = blend ? test_T : end_T;
                     T = finish ? T : test_T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
-                    gate = finish ? 0.f : gate;
+                    pix_gate = finish ? 0.f : pix_gate;
                     // live for the backward: some pixel of the quadrant saw the entry with alpha >= 1/255 while unfinished — a
                     // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
                     // below T_threshold), so the backward never misses a pair it has work for.  The per-entry results are
@@ -245,9 +294,12 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
                     asm volatile("v_cmp_lt_f32 %0, 0.5, %1" : "=s"(half_m) : "v"(t_half));
                     s_half[k] = (int)__popcll(half_m);
                     live_m |= 1ull << k;
-                    all_done = __builtin_amdgcn_ballot_w64(gate != 0.f) == 0ull;
+                    all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;
                 }
             }
+        };
+        if (cnt > 0) {
+            entries();
         }
         // one scattered integer atomic per touched Gaussian of this chunk
         const int half_k = ((live_m >> lane) & 1ull) ? s_half[lane] : 0;
@@ -275,14 +327,18 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(const DqoVie
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) w = max(w, __shfl_xor(w, off));
     if (lane == 0) img.walk4[tile * 4 + quad] = (uint32_t)w;
-    if (tap.scale != nullptr) loss_tap_wave(tap, g, inside, pix_id, HW, oc0, oc1, oc2, depth_, hit_id, lane);
+    if (tap.scale != nullptr) loss_tap_wave(tap, g, inside, pix_id, HW, oc0, oc1, oc2, depth_, hit_id, lane, owner);
 }
 
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, hipStream_t s) {
-    DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out, capacity,
-               tap);
+                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate, hipStream_t s) {
+    if (gate.gobj != nullptr)
+        DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<true>, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out,
+                   capacity, tap, gate);
+    else
+        DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<false>, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out,
+                   capacity, tap, gate);
     return DQO_OK;
 }

@@ -87,6 +87,16 @@ def rasterize_gaussians(means3D, sh, colors_precomp, opacities, scales, rotation
                                      raster_settings)
 
 
+def rasterize_gaussians_gated(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, raster_settings,
+                              gaussian_object, pixel_object):
+    """NOT part of the reference's surface: the same op with libdqoraster's object gate (include/dqo_raster.h, DqoObjectGate) — a list
+    entry acts on a pixel only if gaussian_object[id] == pixel_object[pixel] (int32 [P] / [H, W]; a negative pixel id: nothing
+    acts), in the forward and in the backward.  The per-object render of the sharded mapping job: every pixel sees its
+    own object alone, so a shard that holds some of the objects computes exactly its pixels of the unsharded render."""
+    return _RasterizeGaussians.apply(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask,
+                                     raster_settings, gaussian_object, pixel_object)
+
+
 def _params(rs, P, M):
     return N.DqoRastParams(P=P, D=int(rs.sh_degree), M=M, W=int(rs.image_width), H=int(rs.image_height),
                            prefiltered=int(bool(rs.prefiltered)), debug=int(bool(rs.debug)), tanfovx=float(rs.tanfovx),
@@ -105,7 +115,8 @@ def _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, raster_settings):
+    def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, raster_settings,
+                gaussian_object=None, pixel_object=None):
         rs = raster_settings
         lib = N.lib()
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
@@ -128,6 +139,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = means3D.size(0)
         H, W = int(rs.image_height), int(rs.image_width)
         M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:105-109
+        gate = None
+        if (gaussian_object is None) != (pixel_object is None):
+            raise RuntimeError("object gate: gaussian_object and pixel_object go together")
+        if gaussian_object is not None:
+            N.require_gpu(gaussian_object, pixel_object)
+            if gaussian_object.dtype != torch.int32 or pixel_object.dtype != torch.int32:
+                raise RuntimeError("expected scalar type Int (object gate)")
+            if gaussian_object.numel() != P or pixel_object.numel() != H * W:
+                raise RuntimeError("object gate: gaussian_object must have num_points elements, pixel_object H x W")
+            gaussian_object, pixel_object = gaussian_object.contiguous(), pixel_object.contiguous()
+            gate = N.DqoObjectGate(gaussian_object=N.ptr(gaussian_object), pixel_object=N.ptr(pixel_object))
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -152,6 +174,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        n_touched=N.ptr(n_touched), radii=N.ptr(radii))
             cctx = N.DqoRastCtx(geom=geomBuffer.data_ptr(), geom_bytes=geomBuffer.numel(), binning=None, binning_bytes=0,
                                 image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(), inst_capacity=0)
+            if gate is not None:
+                cctx.object_gate = ctypes.addressof(gate)
             N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
                                                  ctypes.byref(cctx), stream))
             key = (dev.index, P, W, H)
@@ -187,6 +211,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.inst_capacity = cap
         ctx.M = M
+        ctx.object_gate = None if gate is None else (gaussian_object, pixel_object)
         ctx.save_for_backward(colors_precomp, hit_depth, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer, opacities, tile_mask if tile_mask is not None else torch.empty(0))
         ctx.mark_non_differentiable(hit_color, hit_depth, n_touched, radii)
@@ -231,6 +256,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cctx = N.DqoRastCtx(geom=geomBuffer.data_ptr(), geom_bytes=geomBuffer.numel(), binning=binningBuffer.data_ptr(),
                                     binning_bytes=binningBuffer.numel(), image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(),
                                     inst_capacity=cap)
+                if getattr(ctx, "object_gate", None) is not None:
+                    gate = N.DqoObjectGate(gaussian_object=N.ptr(ctx.object_gate[0]), pixel_object=N.ptr(ctx.object_gate[1]))
+                    cctx.object_gate = ctypes.addressof(gate)
                 grads = N.DqoRastGrads(dL_dmeans3D=g_means3D.data_ptr(), dL_dsh=N.ptr(g_sh), dL_dcolors=g_colors.data_ptr(),
                                        dL_dopacity=g_opacity.data_ptr(), dL_dscales=g_scales.data_ptr(),
                                        dL_drotations=g_rot.data_ptr(), dL_dcov3D=g_cov3D.data_ptr(), dL_dmeans2D=g_means2D.data_ptr(),
@@ -242,7 +270,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         def slot(g, inp):
             return g if inp.numel() != 0 else None
         return (g_means3D, slot(g_sh, sh), slot(g_colors, colors_precomp), g_opacity.view_as(opacities) if opacities.numel() else None,
-                slot(g_scales, scales), slot(g_rot, rotations), slot(g_cov3D, cov3Ds_precomp), None, None)
+                slot(g_scales, scales), slot(g_rot, rotations), slot(g_cov3D, cov3Ds_precomp), None, None, None, None)
 
 
 class GaussianRasterizationSettings(NamedTuple):

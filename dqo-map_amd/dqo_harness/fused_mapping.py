@@ -65,7 +65,7 @@ class _Ctx:
 
 class FusedMapper:
     def __init__(self, scene, settings, device, lrs=None, betas=(0.9, 0.999), eps=1e-15, color_weight=mapping.COLOR_WEIGHT,
-                 depth_weight=mapping.DEPTH_WEIGHT, add_depth_thres=0.1, sparse_moments=True, attach=True):
+                 depth_weight=mapping.DEPTH_WEIGHT, add_depth_thres=0.1, sparse_moments=True, attach=True, attach_count_reducer=None):
         t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=device)
         self.device = device
         self.settings = _normalised_settings(settings, device)
@@ -85,6 +85,12 @@ class FusedMapper:
         self.step_count = 0
         self._act_valid = False  # opacity / scales / rotations hold the activations of the current raw parameters
         self.use_attach = bool(attach)
+        # The attach loss is a mean over the attach set of the WHOLE map (mapper.py:812-829).  A mapper that holds a shard of the map
+        # must divide by the whole map's count for the shards to add up to the unsharded job: attach_count_reducer(local count) -> global
+        # count (e.g. one all-reduce of one integer per mapping call — not per iteration); None = this mapper holds the whole map.
+        self.attach_count_reducer = attach_count_reducer
+        self.gaussian_object = self.pixel_object = None  # set_object_gate()
+        self.per_object_loss = False
         self.begin_mapping_call(reset_optimizer=False)
         P = self.P
         f = dict(dtype=torch.float32, device=device)
@@ -100,6 +106,26 @@ class FusedMapper:
         self._empty = torch.Tensor([])
         self.tile_mask = torch.ones(((H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=device)
 
+    def set_object_gate(self, gaussian_object, pixel_object, per_object_loss=True):
+        """The per-object job of SURVEY.md §8(e) (not a reference feature): gaussian_object int32 [P] (every Gaussian's object id, >= 0),
+        pixel_object int32 [H, W] (every pixel's owner, < 0 = none).  A list entry then acts on a pixel only if the ids agree
+        (DqoObjectGate), and — per_object_loss — the loss is the sum of the objects' own masked losses (DqoLossTap.per_object;
+        ids in [0, 64)), so that what an object learns does not depend on which other objects this mapper holds: shards of one map add up
+        to the unsharded job.  None, None switches the gate off (the reference's semantics).  A captured graph must be captured again."""
+        if gaussian_object is None:
+            self.gaussian_object = self.pixel_object = None
+            self.per_object_loss = False
+        else:
+            H, W = int(self.settings.image_height), int(self.settings.image_width)
+            go = torch.as_tensor(gaussian_object).to(self.device, torch.int32).contiguous().reshape(-1)
+            po = torch.as_tensor(pixel_object).to(self.device, torch.int32).contiguous().reshape(H, W)
+            if go.numel() != self.P:
+                raise RuntimeError("set_object_gate: gaussian_object must have one id per Gaussian")
+            self.gaussian_object, self.pixel_object, self.per_object_loss = go, po, bool(per_object_loss)
+        if getattr(self, "_g", None) is not None:
+            self._g.stale = True
+        return self
+
     def begin_mapping_call(self, reset_optimizer=True):
         """Start of one `local_optimize` call (SLAM/multiprocess/mapper.py:531-548): snapshot `init_stat` (the raw parameters the
         attach loss pulls towards, :533-545, and the attach set `sigmoid(opacity) < 0.9`, :812-813) and — reset_optimizer — drop the
@@ -107,6 +133,8 @@ class FusedMapper:
         self.init_xyz, self.init_scaling, self.init_rotation = self.xyz.clone(), self.scaling_raw.clone(), self.rotation_raw.clone()
         self.attach_mask = (torch.sigmoid(self.opacity_raw) < 0.9).reshape(-1).to(torch.uint8).contiguous()
         self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
+        if self.use_attach and self.attach_count_reducer is not None:
+            self.attach_count = int(self.attach_count_reducer(self.attach_count))
         # (one partial sum per block of 256 Gaussians from dqo_map_adam_step, per wave of 64 from dqo_rast_backward_adam)
         self.attach_partial = torch.zeros((4 * ((self.xyz.shape[0] + 255) // 256),), dtype=torch.float32, device=self.device)
         self._attach_n = 0
@@ -151,6 +179,11 @@ class FusedMapper:
         t = lambda a: a.to(dev).float().contiguous() if torch.is_tensor(a) else torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
         nx, nsc, nrot, nop, nsh = t(new["xyz"]), t(new["scales"]), t(new["rotations"]), t(new["opacity"]).reshape(-1, 1), t(new["shs"])
         Q = nx.shape[0]
+        nobj = None
+        if self.gaussian_object is not None:  # the object gate needs every new Gaussian's object id (`_obj_id`, gaussian_pointcloud.py:497)
+            if new.get("obj_id") is None:
+                raise RuntimeError("FusedMapper.grow: with an object gate the new points need 'obj_id'")
+            nobj = torch.as_tensor(new["obj_id"]).to(dev, torch.int32).reshape(-1)
         stats = dict(candidates=int(Q), inside_existing=0, invalid_scale=0, added=0, deleted=0)
         exist_xyz, exist_radius = self.xyz, self.radius()
         keep = torch.ones((Q,), dtype=torch.bool, device=dev)
@@ -161,6 +194,7 @@ class FusedMapper:
                 stats["inside_existing"] = int(inside.sum().item())
         idx = keep.nonzero().reshape(-1)
         nx, nsc, nrot, nop, nsh = nx[idx], nsc[idx], nrot[idx], nop[idx], nsh[idx]
+        nobj = None if nobj is None else nobj[idx]
         log_scales = None
         if nx.shape[0] > 0:
             nrad = (nsc.sum(dim=1) - nsc.min(dim=1).values) / 2
@@ -171,8 +205,10 @@ class FusedMapper:
                 fac = scale_factor * scales[:, None].repeat(1, 3) * torch.tensor(xyz_factor, dtype=torch.float32, device=dev)
                 log_scales = torch.log(fac)[ok]
             nx, nrot, nop, nsh = nx[ok], nrot[ok], nop[ok], nsh[ok]
+            nobj = None if nobj is None else nobj[ok]
         if log_scales is None:
             nx, nrot, nop, nsh = nx[:0], nrot[:0], nop[:0], nsh[:0]
+            nobj = None if nobj is None else nobj[:0]
             log_scales = torch.empty((0, 3), dtype=torch.float32, device=dev)
         keep_old = None
         if delete_mask is not None:
@@ -186,6 +222,8 @@ class FusedMapper:
         self.opacity_raw = torch.cat([sel(self.opacity_raw), torch.log(opc / (1 - opc))]).contiguous()
         self.scaling_raw = torch.cat([sel(self.scaling_raw), log_scales]).contiguous()
         self.rotation_raw = torch.cat([sel(self.rotation_raw), nrot]).contiguous()
+        if self.gaussian_object is not None:
+            self.gaussian_object = torch.cat([sel(self.gaussian_object), nobj]).contiguous()
         params = self._params()
         n_new = nx.shape[0]
         if new_mapping_call:
@@ -213,6 +251,8 @@ class FusedMapper:
         self.init_rotation = torch.cat([sel(self.init_rotation), nrot])
         self.attach_mask = torch.cat([sel(self.attach_mask), (nop.reshape(-1) < 0.9).to(torch.uint8)]).contiguous()
         self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
+        if self.use_attach and self.attach_count_reducer is not None:
+            self.attach_count = int(self.attach_count_reducer(self.attach_count))
         self.attach_partial = torch.zeros((4 * ((P + 255) // 256),), **f)
         self._attach_n = 0
         return stats
@@ -335,8 +375,15 @@ class FusedMapper:
                 g.grad_scale = torch.zeros((2,), **f)
                 g.tap = N.DqoLossTap(gt_color=N.ptr(gt_color), gt_depth=N.ptr(gt_depth), render_mask=N.ptr(g.mask), out_color=o[0].data_ptr(),
                                      out_depth=o[1].data_ptr(), color_weight=self.color_weight, depth_weight=self.depth_weight,
-                                     add_depth_thres=self.add_depth_thres, loss_out=N.ptr(self.loss), grad_scale=g.grad_scale.data_ptr())
+                                     add_depth_thres=self.add_depth_thres, loss_out=N.ptr(self.loss), grad_scale=g.grad_scale.data_ptr(),
+                                     per_object=1 if (self.per_object_loss and self.gaussian_object is not None) else 0)
                 g.cctx.loss_tap = ctypes.addressof(g.tap)
+            g.gate = None
+            if self.gaussian_object is not None:
+                g.gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(self.pixel_object))
+                g.cctx.object_gate = ctypes.addressof(g.gate)
+                if self.per_object_loss and not loss_tap:
+                    raise RuntimeError("FusedMapper.capture: the per-object loss is computed by the loss tap (loss_tap=True)")
             gr = g.grads
             g.cgrads = N.DqoRastGrads(dL_dmeans3D=gr["means3D"].data_ptr(), dL_dsh=gr["sh"].data_ptr(), dL_dcolors=None,
                                       dL_dopacity=gr["opacity"].data_ptr(), dL_dscales=gr["scales"].data_ptr(),
@@ -503,7 +550,8 @@ class FusedMapper:
                                              N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), stream))
             ctx = _Ctx()
             out = dgr._RasterizeGaussians.forward(ctx, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations,
-                                                  self._empty, self.tile_mask if tile_mask is None else tile_mask, self.settings)
+                                                  self._empty, self.tile_mask if tile_mask is None else tile_mask, self.settings,
+                                                  self.gaussian_object, self.pixel_object)
             # NOTE: an eager step on an overflowed frame (lazy mode) is a no-op for the optimiser (DqoAdamStep.frame_header), but the
             # host-side step_count below still advances; the operator raises at its next synchronisation point in that case.
             color, depth, hit_depth = out[0], out[1], out[3]
@@ -511,10 +559,20 @@ class FusedMapper:
             mask_u8 = None if render_mask is None else render_mask
             if mask_u8 is not None and mask_u8.dtype != torch.uint8:
                 mask_u8 = mask_u8.to(torch.uint8)
-            N.check(lib.dqo_map_loss_fwd_bwd(W, H, N.ptr(color), N.ptr(depth), N.ptr(hit_depth), N.ptr(gt_color), N.ptr(gt_depth),
-                                             N.ptr(mask_u8), self.color_weight, self.depth_weight, self.add_depth_thres,
-                                             N.ptr(self.loss), N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws),
-                                             self.loss_ws.numel(), stream))
+            if self.per_object_loss and self.gaussian_object is not None:
+                # the per-object loss in eager torch (the captured path computes it in the blend kernels: DqoLossTap.per_object)
+                with torch.enable_grad():
+                    c_, d_ = color.detach().requires_grad_(True), depth.detach().requires_grad_(True)
+                    tot, parts = mapping.per_object_loss(dict(render=c_, depth=d_, depth_index_map=hit_depth), gt_color, gt_depth,
+                                                         self.pixel_object, render_mask=mask_u8, add_depth_thres=self.add_depth_thres)
+                    gc_, gd_ = torch.autograd.grad(tot, [c_, d_])
+                self.dL_dcolor.copy_(gc_), self.dL_ddepth.copy_(gd_)
+                self.loss[:3] = torch.stack([parts["total_loss"], parts["color_loss"], parts["depth_loss"]])
+            else:
+                N.check(lib.dqo_map_loss_fwd_bwd(W, H, N.ptr(color), N.ptr(depth), N.ptr(hit_depth), N.ptr(gt_color), N.ptr(gt_depth),
+                                                 N.ptr(mask_u8), self.color_weight, self.depth_weight, self.add_depth_thres,
+                                                 N.ptr(self.loss), N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws),
+                                                 self.loss_ws.numel(), stream))
             ctx.sparse_grad_rows = True  # gradient rows of culled Gaussians stay unwritten; the Adam kernel gets radii instead
             grads = dgr._RasterizeGaussians.backward(ctx, self.dL_dcolor, self.dL_ddepth, None, None, None, None, None, None, None)
             g_means3D, g_sh, _, g_opacity, g_scales, g_rot = grads[0], grads[1], grads[2], grads[3], grads[4], grads[5]

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from diff_gaussian_rasterization_depth import GaussianRasterizationSettings, GaussianRasterizer
+from diff_gaussian_rasterization_depth import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_gated
 
 # configs/base.yaml:78-86
 COLOR_WEIGHT, DEPTH_WEIGHT, SSIM_WEIGHT = 0.8, 1.0, 0.2
@@ -73,7 +73,7 @@ def make_settings(cam, device, sh_degree=3, bg=(0.0, 0.0, 0.0), opaque_threshold
         cx=cam.cx, cy=cam.cy, T_threshold=0.0001)
 
 
-def render(settings, gaussian_data, tile_mask=None):
+def render(settings, gaussian_data, tile_mask=None, object_gate=None):
     """SLAM/render.py:134-272 (`Renderer.render`): default all-ones int32 tile mask (:178-185), the op's 9-tuple unpacked into the
     reference's dict keys (:213-222, 269-270), the per-pixel normal gathered through the depth hit index (:208-212; ids > -1, so
     pixels of never-rendered tiles alias Gaussian 0, quirk B7), and the optional second / third pass with `semantics_color` /
@@ -86,7 +86,12 @@ def render(settings, gaussian_data, tile_mask=None):
     normal = gaussian_data.get("normal")
     geo = dict(means3D=gaussian_data["xyz"], opacities=gaussian_data["opacity"], scales=gaussian_data["scales"],
                rotations=gaussian_data["rotations"], cov3D_precomp=None, normal_w=normal, tile_mask=tile_mask)
-    r = rasterizer(shs=gaussian_data["shs"], colors_precomp=None, **geo)
+    if object_gate is None:
+        r = rasterizer(shs=gaussian_data["shs"], colors_precomp=None, **geo)
+    else:
+        e = torch.Tensor([])
+        r = rasterize_gaussians_gated(gaussian_data["xyz"], gaussian_data["shs"], e, gaussian_data["opacity"], gaussian_data["scales"],
+                                      gaussian_data["rotations"], e, tile_mask, settings, object_gate[0], object_gate[1])
     out = {"render": r[0], "depth": r[1], "color_index_map": r[2], "depth_index_map": r[3], "color_hit_weight": r[4],
            "depth_hit_weight": r[5], "T_map": r[6], "n_touched": r[7], "radii": r[8]}
     if normal is not None:
@@ -164,6 +169,32 @@ def mapping_loss(out, gt_color, gt_depth, render_mask=None, add_depth_thres=0.1)
     total = DEPTH_WEIGHT * depth_loss + COLOR_WEIGHT * color_loss + SSIM_WEIGHT * ssim_loss
     return total, dict(total_loss=total.detach(), depth_loss=depth_loss.detach(), color_loss=color_loss.detach(),
                        ssim_loss=ssim_loss.detach())
+
+
+def per_object_loss(out, gt_color, gt_depth, pixel_object, render_mask=None, add_depth_thres=0.1, n_objects=64):
+    """The loss of the per-object job:  L = sum_k L_k,  L_k = mapping_loss's masked colour / depth terms evaluated on
+    object k's pixels alone (pixel_object == k, inside render_mask) and normalised by ITS OWN pixel counts — an object's loss and
+    gradients do not depend on which other objects are rendered with it, so shards of one map add up to the unsharded job.  Eager torch
+    statement of what DqoLossTap.per_object computes inside the blend kernels.  Returns (total, parts)."""
+    image, depth, depth_index = out["render"], out["depth"], out["depth_index_map"]
+    po = pixel_object.reshape(-1).long()
+    m = po >= 0
+    if render_mask is not None:
+        m = m & render_mask.reshape(-1).bool()
+    ids = po.clamp(min=0)
+    zeros = lambda: torch.zeros(n_objects, dtype=image.dtype, device=image.device)
+    e = torch.abs(image - gt_color).sum(0).reshape(-1) * m
+    s_c = zeros().index_add(0, ids, e)
+    n_c = zeros().index_add(0, ids, m.to(image.dtype))
+    color_loss = (s_c / (3.0 * n_c.clamp(min=1))).sum()
+    err = (depth - gt_depth).reshape(-1)
+    valid = m & (depth_index.reshape(-1) != -1) & (gt_depth.reshape(-1) > 0) & (err < add_depth_thres)
+    s_d = zeros().index_add(0, ids, torch.abs(err) * valid)
+    n_d = zeros().index_add(0, ids, valid.to(image.dtype))
+    depth_loss = (s_d / n_d.clamp(min=1)).sum()
+    total = DEPTH_WEIGHT * depth_loss + COLOR_WEIGHT * color_loss
+    return total, dict(total_loss=total.detach(), depth_loss=depth_loss.detach(), color_loss=color_loss.detach(),
+                       ssim_loss=image.new_zeros(()))
 
 
 def make_optimizer(params):

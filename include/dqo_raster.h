@@ -110,7 +110,25 @@ typedef struct DqoLossTap {
     float color_weight, depth_weight, add_depth_thres;
     float* loss_out;            /* [8] */
     float* grad_scale;          /* [2] */
+    /* ABI 3.  0: ONE masked loss over all mask pixels (the reference's loss_update with a render mask, mapper.py:836-875).
+     * non-zero, with DqoRastCtx.object_gate: the loss of the per-object job of SURVEY.md §8(e),  L = sum_k L_k,  L_k = the same masked
+     * loss evaluated on object k's pixels alone (pixel_object == k inside the mask), each term normalised by ITS OWN pixel counts — so
+     * that the loss (and every gradient) of an object does not depend on which other objects the caller renders with it: shards of one
+     * map add up to the unsharded job exactly.  loss_out[0..2] = sum_k of (total, colour, depth); [4..7] the raw sums over all objects;
+     * grad_scale is not written (the scales are per object).  Object ids must lie in [0, 64). */
+    int32_t per_object;
 } DqoLossTap;
+
+/* Optional object gate (ABI 3; not a feature of the reference, whose renders composite every Gaussian of a ray — F3).  With it a list
+ * entry acts on a pixel only if gaussian_object[id] == pixel_object[pixel] (a negative pixel id: no entry acts), in the forward and in
+ * the backward: every pixel sees the render of its own object alone, whatever other Gaussians the call holds.  This is what makes the
+ * per-object job of SURVEY.md §8(e) ONE function for every number of shards: a shard that owns some of the objects computes exactly its
+ * objects' pixels of the unsharded render.  List positions (n_contrib, the hit position) count gated entries like skipped ones.  Both
+ * arrays are device pointers and must stay valid from the forward to the backward. */
+typedef struct DqoObjectGate {
+    const int32_t* gaussian_object; /* [P] */
+    const int32_t* pixel_object;    /* [H*W] owner of every pixel, < 0 = none */
+} DqoObjectGate;
 
 typedef struct DqoRastCtx {
     void* geom;
@@ -135,6 +153,8 @@ typedef struct DqoRastCtx {
     int32_t keep_tile_order;
     /* NULL (default, the drop-in behaviour) or the loss tap described above; read by the forward and by the backward. */
     const DqoLossTap* loss_tap;
+    /* NULL (default: the reference's semantics) or the object gate described above; read by the forward and by the backward. */
+    const DqoObjectGate* object_gate;
 } DqoRastCtx;
 
 /* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206).  dL_dcolors, dL_dcov3D and
@@ -171,7 +191,7 @@ int dqo_abi_version(void);
 const char* dqo_last_error(void);
 /* sizeof() of the ABI structs as this library was compiled (a binding checks its own struct definitions against it):
  * 0 DqoRastParams, 1 DqoRastInputs, 2 DqoRastOutputs, 3 DqoRastCtx, 4 DqoRastGrads, 5 DqoRastHeader, 6 DqoProfileEntry,
- * 7 DqoAdamStep, 8 DqoLossTap; 0 for any other index. */
+ * 7 DqoAdamStep, 8 DqoLossTap, 9 DqoObjectGate; 0 for any other index. */
 size_t dqo_abi_sizeof(int32_t which);
 
 /* Optional per-kernel timing (measurement only; the reference has nothing comparable — it times whole frames with

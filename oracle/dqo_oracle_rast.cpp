@@ -73,6 +73,11 @@ struct RastCtx {
     // borrowed copies of the inputs needed by backward
     std::vector<R> means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp;
     std::vector<int32_t> tile_mask;
+    // Object gate (NOT a reference feature: SURVEY.md §8e's per-object render, test infrastructure for the sharded job).  Empty = off =
+    // the reference's semantics.  On: a list entry acts on a pixel only if the Gaussian's object id equals the pixel's owner id (a
+    // negative owner: no entry acts), i.e. every pixel sees the render of its own object alone; list positions (`contributor`) are
+    // counted as before.
+    std::vector<int32_t> gauss_obj, pix_obj;
     // GeometryState (rasterizer_impl.h:30-44)
     std::vector<R> depths, means2D, cov3D, conic_opacity, rgb;
     std::vector<uint8_t> clamped;
@@ -288,7 +293,8 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
                          const R* colors_precomp, const R* opacities, const R* scales, const R* rotations,
                          const R* cov3D_precomp, const R* view, const R* proj, const R* campos, const int32_t* tile_mask,
                          R* out_color, R* out_depth, int32_t* out_hit_color, int32_t* out_hit_depth, R* out_hit_color_w,
-                         R* out_hit_depth_w, R* out_T, int32_t* n_touched, int32_t* radii_out) {
+                         R* out_hit_depth_w, R* out_T, int32_t* n_touched, int32_t* radii_out, const int32_t* gauss_obj = nullptr,
+                         const int32_t* pix_obj = nullptr) {
     auto* c = new RastCtx<R>();
     const int P = c->P = ip[0];
     const int D = c->D = ip[1];
@@ -325,6 +331,8 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
     if (rotations) c->rotations.assign(rotations, rotations + 4 * (size_t)P);
     if (cov3D_precomp) c->cov3D_precomp.assign(cov3D_precomp, cov3D_precomp + 6 * (size_t)P);
     c->tile_mask.assign(tile_mask, tile_mask + T);
+    const bool gated = gauss_obj != nullptr && pix_obj != nullptr;
+    if (gated) c->gauss_obj.assign(gauss_obj, gauss_obj + P), c->pix_obj.assign(pix_obj, pix_obj + (size_t)H * W);
 
     // Initial fills: rasterize_points.cu:79-89 (ids are 0, not -1; T is 1) — quirk B7.
     const size_t HW = (size_t)H * W;
@@ -482,6 +490,7 @@ RastCtx<R>* rast_forward(const int* ip, const double* fp, const R* bg, const R* 
                 for (uint32_t k = r0; k < r1 && !done; k++) {
                     contributor++;
                     const int g = (int)c->point_list[k];
+                    if (gated && (c->pix_obj[pix_id] < 0 || c->gauss_obj[g] != c->pix_obj[pix_id])) continue;  // object gate (off = reference)
                     const R dx = c->means2D[2 * (size_t)g] - pixfx, dy = c->means2D[2 * (size_t)g + 1] - pixfy;
                     const R* co = &c->conic_opacity[4 * (size_t)g];
                     const R power = R(-0.5f) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
@@ -634,6 +643,7 @@ void rast_backward(RastCtx<R>* c, const R* dL_dpixels, const R* dL_dpixel_depths
                     contributor--;
                     const int g = (int)c->point_list[k];
                     if (contributor >= last_contributor) continue;
+                    if (!c->gauss_obj.empty() && (c->pix_obj[pix_id] < 0 || c->gauss_obj[g] != c->pix_obj[pix_id])) continue;  // object gate
                     const R dx = c->means2D[2 * (size_t)g] - pixfx, dy = c->means2D[2 * (size_t)g + 1] - pixfy;
                     const R* co = &c->conic_opacity[4 * (size_t)g];
                     const R power = R(-0.5f) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
@@ -951,6 +961,17 @@ void ctx_copy(RastCtx<R>* c, int which, void* dst) {
         return rast_forward<R>(ip, fp, bg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view,   \
                                proj, campos, tile_mask, out_color, out_depth, out_hit_color, out_hit_depth, out_hit_color_w,  \
                                out_hit_depth_w, out_T, n_touched, radii);                                                     \
+    }                                                                                                                         \
+    ORC_EXPORT void* orc_rast_forward_gated_##SUF(const int* ip, const double* fp, const R* bg, const R* means3D, const R* shs, \
+                                                  const R* colors_precomp, const R* opacities, const R* scales,               \
+                                                  const R* rotations, const R* cov3D_precomp, const R* view, const R* proj,   \
+                                                  const R* campos, const int32_t* tile_mask, R* out_color, R* out_depth,      \
+                                                  int32_t* out_hit_color, int32_t* out_hit_depth, R* out_hit_color_w,         \
+                                                  R* out_hit_depth_w, R* out_T, int32_t* n_touched, int32_t* radii,           \
+                                                  const int32_t* gauss_obj, const int32_t* pix_obj) {                         \
+        return rast_forward<R>(ip, fp, bg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view,   \
+                               proj, campos, tile_mask, out_color, out_depth, out_hit_color, out_hit_depth, out_hit_color_w,  \
+                               out_hit_depth_w, out_T, n_touched, radii, gauss_obj, pix_obj);                                 \
     }                                                                                                                         \
     ORC_EXPORT void orc_rast_backward_##SUF(void* h, const R* dL_dpix, const R* dL_ddepth, R* dmeans3D, R* dsh, R* dcolors,   \
                                             R* dopacity, R* dscales, R* drot, R* dcov3D, R* dmeans2D, R* dconic) {            \

@@ -28,6 +28,25 @@ def masked_loss(color, depth, depth_index, gt_color, gt_depth, render_mask, colo
     return total, color_loss, depth_loss, dL_dcolor, dL_ddepth
 
 
+def per_object_masked_loss(color, depth, depth_index, gt_color, gt_depth, pixel_object, render_mask=None, color_weight=0.8,
+                           depth_weight=1.0, add_depth_thres=0.1):
+    """The loss of the per-object job (DqoLossTap.per_object):  sum over the object ids k of masked_loss evaluated on
+    object k's pixels alone (pixel_object == k inside render_mask), each term with its own pixel counts.  Returns
+    (total, color_loss, depth_loss, dL_dcolor[3,H,W], dL_ddepth[1,H,W]) in float64."""
+    po = np.asarray(pixel_object).reshape(np.asarray(depth).shape[1:])
+    m = po >= 0
+    if render_mask is not None:
+        m = m & np.asarray(render_mask).astype(bool)
+    tot = col = dep = 0.0
+    dC, dD = np.zeros(np.asarray(color).shape, np.float64), np.zeros(np.asarray(depth).shape, np.float64)
+    for k in np.unique(po[m]):
+        t, c, d, gc, gd = masked_loss(color, depth, depth_index, gt_color, gt_depth, m & (po == k), color_weight, depth_weight, add_depth_thres)
+        tot, col, dep = tot + t, col + c, dep + d
+        dC += gc
+        dD += gd
+    return tot, col, dep, dC, dD
+
+
 def activate(opacity_raw, scaling_raw, rotation_raw):
     q = np.asarray(rotation_raw, np.float64)
     n = np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)

@@ -26,6 +26,7 @@ def _load(path):
     L = ctypes.CDLL(path)
     for suf in ("f32", "f64"):
         getattr(L, f"orc_rast_forward_{suf}").restype = ctypes.c_void_p
+        getattr(L, f"orc_rast_forward_gated_{suf}").restype = ctypes.c_void_p
     return L
 
 
@@ -91,7 +92,9 @@ class OracleRasterizer:
             self.h = None
 
     def forward(self, st, means3D, opacities, view, proj, campos, shs=None, colors_precomp=None, scales=None,
-                rotations=None, cov3D_precomp=None, tile_mask=None, pair_masks=False):
+                rotations=None, cov3D_precomp=None, tile_mask=None, pair_masks=False, gaussian_object=None, pixel_object=None):
+        """gaussian_object [P] / pixel_object [H, W] (int32, both or neither): the object gate of the sharded job's per-object
+        render — an entry acts on a pixel only if the ids agree (negative pixel id: nothing acts); default off = the reference."""
         self.free()
         dt = self.dt
         c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
@@ -123,10 +126,19 @@ class OracleRasterizer:
         r.radii = np.empty((P,), np.int32)
         self._keep = (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, tile_mask)
         self.P, self.M, self.W, self.H, self.gx, self.gy = P, M, W, H, gx, gy
-        self.h = getattr(self.lib, f"orc_rast_forward_{self.suf}")(
-            _p(ip), _p(fp), _p(bg), _p(means3D), _p(shs), _p(colors_precomp), _p(opacities), _p(scales), _p(rotations),
-            _p(cov3D_precomp), _p(view), _p(proj), _p(campos), _p(tile_mask), _p(r.color), _p(r.depth), _p(r.hit_color),
-            _p(r.hit_depth), _p(r.hit_color_weight), _p(r.hit_depth_weight), _p(r.T_map), _p(r.n_touched), _p(r.radii))
+        args = (_p(ip), _p(fp), _p(bg), _p(means3D), _p(shs), _p(colors_precomp), _p(opacities), _p(scales), _p(rotations),
+                _p(cov3D_precomp), _p(view), _p(proj), _p(campos), _p(tile_mask), _p(r.color), _p(r.depth), _p(r.hit_color),
+                _p(r.hit_depth), _p(r.hit_color_weight), _p(r.hit_depth_weight), _p(r.T_map), _p(r.n_touched), _p(r.radii))
+        if (gaussian_object is None) != (pixel_object is None):
+            raise ValueError("object gate: gaussian_object and pixel_object go together")
+        if gaussian_object is None:
+            self.h = getattr(self.lib, f"orc_rast_forward_{self.suf}")(*args)
+        else:
+            go = np.ascontiguousarray(gaussian_object, np.int32).reshape(-1)
+            po = np.ascontiguousarray(pixel_object, np.int32).reshape(-1)
+            assert go.size == P and po.size == W * H
+            self._keep = self._keep + (go, po)
+            self.h = getattr(self.lib, f"orc_rast_forward_gated_{self.suf}")(*args, _p(go), _p(po))
         info = np.zeros(4, np.int32)
         getattr(self.lib, f"orc_rast_ctx_info_{self.suf}")(ctypes.c_void_p(self.h), _p(info))
         r.num_rendered, r.num_tiles = int(info[0]), int(info[1])

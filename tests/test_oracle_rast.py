@@ -328,3 +328,36 @@ def test_openmp_build_equals_serial(oracle):
     for k in ("means3D", "sh", "opacity", "scales", "rotations", "colors"):
         a, b = getattr(res[0][1], k), getattr(res[1][1], k)
         assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max(), k
+
+
+def test_object_gate_of_the_oracle(oracle):
+    """The oracle's object gate (test infrastructure of the sharded job, off by default): with every Gaussian in ONE object, gating equals
+    masking — owned pixels render exactly as without the gate, pixels without an owner render nothing, and the backward equals the
+    ungated backward of the incoming gradient restricted to the owned pixels.  With two objects a pixel only sees its owner's Gaussians:
+    the gated render of the whole map equals, on object k's pixels, the ungated render of object k's Gaussians alone."""
+    from dqo_harness import scenes
+    import util_rast as U
+    cam, sc = scenes.make_config(1, P=1500)
+    P = 1500
+    o, r, _ = U.run_oracle(oracle, cam, sc)
+    owned = r["hit_depth"][0] >= 0
+    go, po = np.zeros(P, np.int32), np.where(owned, 0, -1).astype(np.int32)
+    og, rg, _ = U.run_oracle(oracle, cam, sc, object_gate=(go, po))
+    for k in ("color", "depth", "hit_depth", "hit_color", "T_map"):
+        assert np.array_equal(rg[k][..., owned], r[k][..., owned]), k
+    assert (rg["color"][:, ~owned] == 0).all() and (rg["T_map"][0][~owned] == 1).all() and (rg["hit_depth"][0][~owned] == -1).all()
+    rng = np.random.default_rng(1)
+    dL = (rng.normal(size=(3, cam.H, cam.W)).astype(np.float32), rng.normal(size=(1, cam.H, cam.W)).astype(np.float32))
+    gg, gu = U.oracle_backward(og, dL), U.oracle_backward(o, (dL[0] * owned, dL[1] * owned))
+    for k in gg:
+        assert np.array_equal(gg[k], gu[k]), k
+    # two objects
+    go2 = (np.arange(P) % 2).astype(np.int32)
+    po2 = np.where(owned, go2[np.clip(r["hit_depth"][0], 0, None)], -1).astype(np.int32)
+    _, r2, _ = U.run_oracle(oracle, cam, sc, object_gate=(go2, po2))
+    for k_obj in (0, 1):
+        m = go2 == k_obj
+        sub = {k: (v[m] if hasattr(v, "shape") and v.shape[:1] == (P,) else v) for k, v in sc.items()}
+        _, rk, _ = U.run_oracle(oracle, cam, sub)
+        px = po2 == k_obj
+        assert np.array_equal(r2["color"][:, px], rk["color"][:, px]) and np.array_equal(r2["depth"][:, px], rk["depth"][:, px])

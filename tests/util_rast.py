@@ -32,9 +32,11 @@ class HipRun:
 
     names = ("color", "depth", "hit_color", "hit_depth", "hit_color_weight", "hit_depth_weight", "T_map", "n_touched", "radii")
 
-    def __init__(self, cam, sc, device="cuda", tile_mask=None, colors_precomp=None, grad=True, sh_degree=3, bg=(0, 0, 0), **kw):
+    def __init__(self, cam, sc, device="cuda", tile_mask=None, colors_precomp=None, grad=True, sh_degree=3, bg=(0, 0, 0), object_gate=None,
+                 **kw):
+        """object_gate = (gaussian_object [P], pixel_object [H, W]) int arrays: the gated op (rasterize_gaussians_gated)."""
         import torch
-        from diff_gaussian_rasterization_depth import GaussianRasterizer
+        from diff_gaussian_rasterization_depth import GaussianRasterizer, rasterize_gaussians_gated
         self.torch, self.device = torch, device
         rs = raster_settings_torch(cam, device, sh_degree=sh_degree, bg=bg, **kw)
         rast = GaussianRasterizer(rs)
@@ -43,8 +45,15 @@ class HipRun:
         self.shs = t(sc["shs"]) if colors_precomp is None else None
         self.cp = t(colors_precomp) if colors_precomp is not None else None
         tm = None if tile_mask is None else torch.tensor(np.ascontiguousarray(tile_mask, np.int32), device=device)
-        self.out = rast(means3D=self.xyz, opacities=self.opac, shs=self.shs, colors_precomp=self.cp, scales=self.scales,
-                        rotations=self.rots, tile_mask=tm)
+        if object_gate is None:
+            self.out = rast(means3D=self.xyz, opacities=self.opac, shs=self.shs, colors_precomp=self.cp, scales=self.scales,
+                            rotations=self.rots, tile_mask=tm)
+        else:
+            e = torch.Tensor([])
+            go = torch.tensor(np.ascontiguousarray(object_gate[0], np.int32), device=device)
+            po = torch.tensor(np.ascontiguousarray(object_gate[1], np.int32), device=device)
+            self.out = rasterize_gaussians_gated(self.xyz, self.shs if self.shs is not None else e, self.cp if self.cp is not None else e,
+                                                 self.opac, self.scales, self.rots, e, tm, rs, go, po)
         self.res = {k: v.detach().cpu().numpy() for k, v in zip(self.names, self.out)}
 
     def _leaves(self):
@@ -72,12 +81,14 @@ def run_hip(cam, sc, device="cuda", tile_mask=None, colors_precomp=None, dL=None
     return r.res, (None if dL is None else r.backward(dL, retain=False))
 
 
-def run_oracle(ol, cam, sc, tile_mask=None, colors_precomp=None, dL=None, sh_degree=3, bg=(0, 0, 0), dtype=np.float32, **kw):
-    o = ol.OracleRasterizer(dtype)
+def run_oracle(ol, cam, sc, tile_mask=None, colors_precomp=None, dL=None, sh_degree=3, bg=(0, 0, 0), dtype=np.float32, object_gate=None,
+               omp=False, **kw):
+    o = ol.OracleRasterizer(dtype, omp=omp)
     st = oracle_settings(ol, cam, sh_degree=sh_degree, bg=bg, **kw)
     r = o.forward(st, sc["xyz"], sc["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
                   shs=None if colors_precomp is not None else sc["shs"], colors_precomp=colors_precomp, scales=sc["scales"],
-                  rotations=sc["rotations"], tile_mask=tile_mask)
+                  rotations=sc["rotations"], tile_mask=tile_mask,
+                  **({} if object_gate is None else dict(gaussian_object=object_gate[0], pixel_object=object_gate[1])))
     res = dict(color=r.color, depth=r.depth, hit_color=r.hit_color, hit_depth=r.hit_depth, hit_color_weight=r.hit_color_weight,
                hit_depth_weight=r.hit_depth_weight, T_map=r.T_map, n_touched=r.n_touched, radii=r.radii)
     grads = None if dL is None else oracle_backward(o, dL, colors_precomp is not None)
