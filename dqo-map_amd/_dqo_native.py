@@ -36,7 +36,7 @@ class DqoLossTap(ctypes.Structure):
 
 
 class DqoObjectGate(ctypes.Structure):
-    _fields_ = [("gaussian_object", c_vp), ("pixel_object", c_vp)]
+    _fields_ = [("gaussian_object", c_vp), ("pixel_object", c_vp), ("tile_objects", c_vp)]
 
 
 class DqoRastCtx(ctypes.Structure):

@@ -66,9 +66,12 @@ struct Cand {
     int gi, tile;
 };
 
+// tile_objects: DqoObjectGate.tile_objects or NULL — a candidate whose Gaussian's object (the spare word of its xy record) owns no pixel of
+// the tile is dropped like one whose footprint cannot reach the tile
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
                                                                 uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
-                                                                DqoBinLayout bin, int64_t capacity) {
+                                                                DqoBinLayout bin, int64_t capacity,
+                                                                const unsigned long long* __restrict__ tile_objects) {
     __shared__ uint32_t s_off[BIN_CHUNK + 1];  // exclusive prefix of the rect areas
     __shared__ uint2 s_rect[BIN_CHUNK];        // packed tile rects
     __shared__ float4 s_con[BIN_CHUNK];        // conic + opacity
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
     __shared__ uint32_t s_bits[BIN_WINDOW / 32];
     __shared__ uint32_t s_wave[BIN_THREADS / 64];
     __shared__ uint32_t s_base;
+    __shared__ int s_gobj[BIN_CHUNK];          // object id (object gate only)
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id(), wave = tid >> 6;
     const int chunk0 = blockIdx.x * BIN_CHUNK;
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
         if (area) {
             s_con[tid] = co;
             s_xyq[tid] = make_float4(xy.x, xy.y, dqo_q_threshold(co.w), xy.z);
+            s_gobj[tid] = __float_as_int(xy.w);
         }
         s_cnt[tid] = 0;
         s_prev[tid] = 0;
@@ -141,8 +146,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, c
             if (tile_mask != nullptr && !tile_mask[c.tile]) continue;
             const float4 co = s_con[c.gi], xyq = s_xyq[c.gi];
             const int x = c.tile % gx, y = c.tile / gx;
-            const bool live = dqo_splat_hits_rect(xyq.x, xyq.y, co.x, co.y, co.z, xyq.z, (float)(x * DQO_TILE), (float)(y * DQO_TILE),
-                                                  (float)(x * DQO_TILE + DQO_TILE - 1), (float)(y * DQO_TILE + DQO_TILE - 1));
+            bool live = dqo_splat_hits_rect(xyq.x, xyq.y, co.x, co.y, co.z, xyq.z, (float)(x * DQO_TILE), (float)(y * DQO_TILE),
+                                            (float)(x * DQO_TILE + DQO_TILE - 1), (float)(y * DQO_TILE + DQO_TILE - 1));
+            if (tile_objects != nullptr) live = live && ((tile_objects[c.tile] >> (s_gobj[c.gi] & 63)) & 1ull) != 0ull;
             if (live) {
                 atomicOr(&s_bits[(w - win) >> 5], 1u << ((w - win) & 31));
             } else if (flag_dead && tile_flag[c.tile] == 0u) {
@@ -254,9 +260,9 @@ __global__ __launch_bounds__(256) void bin_place_kernel(DqoGeomLayout g, DqoImag
 }  // namespace
 
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                         int64_t capacity, hipStream_t s) {
+                         int64_t capacity, const unsigned long long* tile_objects, hipStream_t s) {
     DQO_LAUNCH("bin_count_kernel", bin_count_kernel, dim3(dqo_spread_blocks(P)), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
-               img.tile_count, img.tile_flag, bin, capacity);
+               img.tile_count, img.tile_flag, bin, capacity, tile_objects);
     return DQO_OK;
 }
 

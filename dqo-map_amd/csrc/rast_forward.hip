@@ -822,7 +822,7 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                              const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate, hipStream_t s);
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                         int64_t capacity, hipStream_t s);
+                         int64_t capacity, const unsigned long long* tile_objects, hipStream_t s);
 int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
 
 int dqo_launch_zero_words(uint32_t* p, size_t n_words, hipStream_t s) {
@@ -868,7 +868,8 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     const int T = v.gx * v.gy;
     if (p->P > 0) {
         // footprint test, per-tile histogram + ranks, tiles_touched, gaussian-major slots (forward.cu:344-353, rasterizer_impl.cu:303)
-        int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap, s);
+        int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap,
+                                      ctx->object_gate ? reinterpret_cast<const unsigned long long*>(ctx->object_gate->tile_objects) : nullptr, s);
         if (rc) return rc;
     }
     // bucket mode with a tile_order kept from an earlier frame on the same image buffer: nothing of tile_scan_kernel is needed

@@ -53,6 +53,21 @@ def _checked_tile_mask(tm, device, H, W):
     return tm.to(device).contiguous()
 
 
+def tile_object_sets(pixel_object):
+    """DqoObjectGate.tile_objects of a pixel_object map (int32 [H, W], ids in [0, 64), < 0 = no owner): per 16x16 tile the 64-bit set of
+    the owners among its pixels, as an int64 tensor [ceil(H/16) * ceil(W/16)] (bit patterns; row-major tiles)."""
+    H, W = pixel_object.shape
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = torch.full((gy * 16, gx * 16), -1, dtype=torch.int64, device=pixel_object.device)
+    pad[:H, :W] = pixel_object
+    t = pad.reshape(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(gy * gx, 256)
+    bits = torch.where(t >= 0, torch.ones_like(t) << t.clamp(min=0), torch.zeros_like(t))
+    out = bits[:, 0].clone()
+    for j in range(1, 256):  # (bitwise OR over the tile's pixels; once per mapping call)
+        out |= bits[:, j]
+    return out.contiguous()
+
+
 class _Ctx:
     """Stand-in for the autograd ctx when the op's static forward/backward are driven directly."""
 
@@ -89,7 +104,7 @@ class FusedMapper:
         # must divide by the whole map's count for the shards to add up to the unsharded job: attach_count_reducer(local count) -> global
         # count (e.g. one all-reduce of one integer per mapping call — not per iteration); None = this mapper holds the whole map.
         self.attach_count_reducer = attach_count_reducer
-        self.gaussian_object = self.pixel_object = None  # set_object_gate()
+        self.gaussian_object = self.pixel_object = self.tile_objects = None  # set_object_gate()
         self.per_object_loss = False
         self.begin_mapping_call(reset_optimizer=False)
         P = self.P
@@ -113,7 +128,7 @@ class FusedMapper:
         ids in [0, 64)), so that what an object learns does not depend on which other objects this mapper holds: shards of one map add up
         to the unsharded job.  None, None switches the gate off (the reference's semantics).  A captured graph must be captured again."""
         if gaussian_object is None:
-            self.gaussian_object = self.pixel_object = None
+            self.gaussian_object = self.pixel_object = self.tile_objects = None
             self.per_object_loss = False
         else:
             H, W = int(self.settings.image_height), int(self.settings.image_width)
@@ -121,7 +136,10 @@ class FusedMapper:
             po = torch.as_tensor(pixel_object).to(self.device, torch.int32).contiguous().reshape(H, W)
             if go.numel() != self.P:
                 raise RuntimeError("set_object_gate: gaussian_object must have one id per Gaussian")
+            if int(go.min().item()) < 0 or int(go.max().item()) > 63 or int(po.max().item()) > 63:
+                raise RuntimeError("set_object_gate: object ids must lie in [0, 64)")
             self.gaussian_object, self.pixel_object, self.per_object_loss = go, po, bool(per_object_loss)
+            self.tile_objects = tile_object_sets(po)  # DqoObjectGate.tile_objects: which objects own a pixel of each 16x16 tile
         if getattr(self, "_g", None) is not None:
             self._g.stale = True
         return self
@@ -380,7 +398,8 @@ class FusedMapper:
                 g.cctx.loss_tap = ctypes.addressof(g.tap)
             g.gate = None
             if self.gaussian_object is not None:
-                g.gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(self.pixel_object))
+                g.gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(self.pixel_object),
+                                         tile_objects=N.ptr(self.tile_objects))
                 g.cctx.object_gate = ctypes.addressof(g.gate)
                 if self.per_object_loss and not loss_tap:
                     raise RuntimeError("FusedMapper.capture: the per-object loss is computed by the loss tap (loss_tap=True)")

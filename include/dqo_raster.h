@@ -126,8 +126,12 @@ typedef struct DqoLossTap {
  * objects' pixels of the unsharded render.  List positions (n_contrib, the hit position) count gated entries like skipped ones.  Both
  * arrays are device pointers and must stay valid from the forward to the backward. */
 typedef struct DqoObjectGate {
-    const int32_t* gaussian_object; /* [P] */
+    const int32_t* gaussian_object; /* [P], ids in [0, 64) */
     const int32_t* pixel_object;    /* [H*W] owner of every pixel, < 0 = none */
+    /* Optional (NULL = not used): per 16x16 tile the set of owners among its pixels, bit k = some pixel of the tile has owner k
+     * ([ceil(H/16) * ceil(W/16)] 64-bit words, derived from pixel_object by the caller — it only changes when pixel_object does).
+     * The binning then drops a (Gaussian, tile) instance whose object owns no pixel of the tile: it could act on none. */
+    const uint64_t* tile_objects;
 } DqoObjectGate;
 
 typedef struct DqoRastCtx {

@@ -70,6 +70,37 @@ def test_a_shard_renders_exactly_its_pixels_of_the_unsharded_map(env):
             assert np.abs(gfull[k][~mine]).max() == 0  # the other objects get nothing from these pixels
 
 
+def test_tile_object_sets_only_drop_entries_that_act_on_no_pixel(env):
+    """DqoObjectGate.tile_objects (instances whose object owns no pixel of the tile are dropped at binning time): fewer list entries,
+    and every output and the trained parameters bit for bit what the gate alone gives."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper, tile_object_sets
+    cam, sc, go, po, settings, gt_color, gt_depth, dev = _mapping_problem(torch)
+    ts = tile_object_sets(torch.tensor(po, device=dev))
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    want = np.zeros(gy * gx, np.uint64)
+    for ty in range(gy):
+        for tx in range(gx):
+            for k in np.unique(po[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]):
+                if k >= 0:
+                    want[ty * gx + tx] |= np.uint64(1) << np.uint64(k)
+    assert np.array_equal(ts.cpu().numpy().view(np.uint64), want)
+    mask = torch.tensor(po >= 0, device=dev)
+    a = FusedMapper(sc, settings, dev).set_object_gate(go, po)
+    b = FusedMapper(sc, settings, dev).set_object_gate(go, po)
+    b.tile_objects = None  # the gate alone
+    a.capture(gt_color, gt_depth, mask), b.capture(gt_color, gt_depth, mask)
+    for _ in range(3):
+        a.replay(), b.replay()
+    torch.cuda.synchronize()
+    assert 0 < a.header()["num_rendered"] < b.header()["num_rendered"]
+    for i in range(7):
+        assert torch.equal(a._g.out[i], b._g.out[i]), i
+    assert torch.equal(a.loss, b.loss)
+    for k, pa in a._params().items():
+        assert torch.equal(pa, b._params()[k]), k
+
+
 def _mapping_problem(torch, P=30000):
     from dqo_harness import mapping
     cam, sc, go, po = _scene(P=P)
