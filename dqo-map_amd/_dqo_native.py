@@ -71,7 +71,8 @@ class DqoAdamStep(ctypes.Structure):
 
 
 EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
-           "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_adam_step", "dqo_accumulate_gaussian_error", "dqo_accumulate_gaussian_confidence", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
+           "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_adam_step", "dqo_map_attach_workspace_bytes",
+           "dqo_map_attach_loss_fwd_bwd", "dqo_accumulate_gaussian_error", "dqo_accumulate_gaussian_confidence", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
            "dqo_rast_binning_bytes", "dqo_rast_binning_bytes_bucketed",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
            "dqo_rast_forward", "dqo_rast_backward", "dqo_rast_backward_adam", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
@@ -121,6 +122,9 @@ def lib():
         L.dqo_map_loss_workspace_bytes.argtypes = []
         L.dqo_map_loss_fwd_bwd.argtypes = [c_i32, c_i32] + [c_vp] * 6 + [c_f, c_f, c_f] + [c_vp] * 4 + [ctypes.c_size_t, c_vp]
         L.dqo_map_adam_step.argtypes = [P(DqoAdamStep), c_vp]
+        L.dqo_map_attach_workspace_bytes.restype = ctypes.c_size_t
+        L.dqo_map_attach_workspace_bytes.argtypes = [c_i32]
+        L.dqo_map_attach_loss_fwd_bwd.argtypes = [c_i32] + [c_vp] * 7 + [c_i32] + [c_vp] * 5 + [ctypes.c_size_t, c_vp]
         L.dqo_accumulate_gaussian_error.argtypes = [c_i32] * 3 + [c_vp] * 5 + [c_f] * 3 + [c_i32] + [c_vp] * 6
         L.dqo_accumulate_gaussian_confidence.argtypes = [c_i32] * 3 + [c_vp] * 7
         L.dqo_knn3_query_workspace_bytes.restype = ctypes.c_size_t

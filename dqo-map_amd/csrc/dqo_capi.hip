@@ -33,6 +33,10 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         const float* gt_depth, const uint8_t* render_mask, float color_weight, float depth_weight, float add_depth_thres,
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
+size_t dqo_map_attach_ws_bytes(int P);
+int dqo_launch_map_attach(int P, const float* scaling, const float* xyz, const float* rotation, const float* scaling0, const float* xyz0,
+                          const float* rotation0, const uint8_t* mask, int attach_count, float* loss, float* g_scaling, float* g_xyz,
+                          float* g_rotation, void* ws, hipStream_t s);
 int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                              const float* dL_ddepth, const DqoAdamStep* st, void* ws, hipStream_t s);
 size_t dqo_icp_ws_bytes(void);
@@ -362,6 +366,25 @@ DQO_API int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const
     }
     return dqo_launch_map_loss(W, H, color, depth, depth_index, gt_color, gt_depth, render_mask, color_weight, depth_weight,
                                add_depth_thres, loss_out, dL_dcolor, dL_ddepth, ws, (hipStream_t)stream);
+}
+
+DQO_API size_t dqo_map_attach_workspace_bytes(int32_t P) { return dqo_map_attach_ws_bytes(P < 0 ? 0 : P); }
+
+DQO_API int dqo_map_attach_loss_fwd_bwd(int32_t P, const float* scaling_raw, const float* xyz, const float* rotation_raw,
+                                        const float* init_scaling_raw, const float* init_xyz, const float* init_rotation_raw,
+                                        const uint8_t* attach_mask, int32_t attach_count, float* loss, float* g_scaling_raw, float* g_xyz,
+                                        float* g_rotation_raw, void* ws, size_t ws_bytes, void* stream) {
+    DQO_CHECK_ARG(P >= 0 && attach_count >= 0, "bad P / attach_count");
+    DQO_CHECK_ARG(loss, "null loss");
+    if (P == 0) return dqo_launch_zero_words(reinterpret_cast<uint32_t*>(loss), 1, (hipStream_t)stream);
+    DQO_CHECK_ARG(scaling_raw && xyz && rotation_raw && init_scaling_raw && init_xyz && init_rotation_raw && attach_mask && g_scaling_raw &&
+                      g_xyz && g_rotation_raw, "null pointer");
+    if (ws == nullptr || ws_bytes < dqo_map_attach_ws_bytes(P)) {
+        dqo_set_error("attach-loss workspace too small (%zu < %zu)", ws_bytes, dqo_map_attach_ws_bytes(P));
+        return DQO_ERR_WORKSPACE;
+    }
+    return dqo_launch_map_attach(P, scaling_raw, xyz, rotation_raw, init_scaling_raw, init_xyz, init_rotation_raw, attach_mask, attach_count,
+                                 loss, g_scaling_raw, g_xyz, g_rotation_raw, ws, (hipStream_t)stream);
 }
 
 DQO_API int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const float* ce, const float* de, const float* ne,

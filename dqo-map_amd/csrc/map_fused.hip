@@ -186,6 +186,53 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_grad_kernel(int HW, int n_p
     }
 }
 
+// ---------------------------------------------------------------- attach loss ----------------------------------------
+// dqo_map_attach_loss_fwd_bwd: the attach loss of Mapping.loss_update (mapper.py:812-829) and its gradient in one pass — for callers
+// that keep their own optimiser (the drop-in path): ~12 eager launches forward + ~25 backward as two.
+constexpr int ATT_THREADS = 256;
+__global__ __launch_bounds__(ATT_THREADS) void attach_loss_kernel(int P, const float* __restrict__ scaling, const float* __restrict__ xyz,
+                                                                  const float* __restrict__ rotation, const float* __restrict__ scaling0,
+                                                                  const float* __restrict__ xyz0, const float* __restrict__ rotation0,
+                                                                  const uint8_t* __restrict__ mask, float g3, float g4,
+                                                                  float* __restrict__ g_scaling, float* __restrict__ g_xyz,
+                                                                  float* __restrict__ g_rotation, double* __restrict__ partial) {
+    __shared__ double s_w[ATT_THREADS / 64];
+    const int i = blockIdx.x * ATT_THREADS + threadIdx.x;
+    double acc = 0.0;
+    if (i < P) {
+        const bool a = mask[i] != 0;
+        float ds[3], dx[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            ds[k] = a ? scaling[3 * i + k] - scaling0[3 * i + k] : 0.f;
+            dx[k] = a ? xyz[3 * i + k] - xyz0[3 * i + k] : 0.f;
+            g_scaling[3 * i + k] = g3 * ds[k];
+            g_xyz[3 * i + k] = g3 * dx[k];
+        }
+        const float4 q = reinterpret_cast<const float4*>(rotation)[i], q0 = reinterpret_cast<const float4*>(rotation0)[i];
+        const float4 d = a ? make_float4(q.x - q0.x, q.y - q0.y, q.z - q0.z, q.w - q0.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(g_rotation)[i] = make_float4(g4 * d.x, g4 * d.y, g4 * d.z, g4 * d.w);
+        acc = 0.5 * (double)g3 * ((double)ds[0] * ds[0] + (double)ds[1] * ds[1] + (double)ds[2] * ds[2] + (double)dx[0] * dx[0] +
+                                  (double)dx[1] * dx[1] + (double)dx[2] * dx[2]) +
+              0.5 * (double)g4 * ((double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+__global__ __launch_bounds__(ATT_THREADS) void attach_loss_sum_kernel(int n, const double* __restrict__ partial, float* __restrict__ loss) {
+    __shared__ double s_w[ATT_THREADS / 64];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < n; b += ATT_THREADS) acc += partial[b];  // fixed order: reproducible
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+
 // ---------------------------------------------------------------- Adam ------------------------------------------------
 // (AdamArgs, adam1, the per-group passes: dqo_adam.h — shared with the fused per-Gaussian tail, map_fused_tail.hip)
 __global__ void adam_advance_kernel(int32_t* step_dev, const DqoRastHeader* frame_header) {
@@ -347,5 +394,22 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     }
     if (st->step_dev != nullptr && !advance_inside)
         DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev, st->frame_header);
+    return DQO_OK;
+}
+
+size_t dqo_map_attach_ws_bytes(int P) { return sizeof(double) * (size_t)((P + ATT_THREADS - 1) / ATT_THREADS + 1); }
+
+int dqo_launch_map_attach(int P, const float* scaling, const float* xyz, const float* rotation, const float* scaling0, const float* xyz0,
+                          const float* rotation0, const uint8_t* mask, int attach_count, float* loss, float* g_scaling, float* g_xyz,
+                          float* g_rotation, void* ws, hipStream_t s) {
+    const int blocks = (P + ATT_THREADS - 1) / ATT_THREADS;
+    // d/dp of 1000 * mean((p - p0)^2) over |a| rows of 3 (scaling, xyz) / 4 (rotation) elements = 2000 (p - p0) / (len |a|); with an empty
+    // set the loss and its gradient are zero (mapper.py:813)
+    const float g3 = attach_count > 0 ? (float)(2000.0 / (3.0 * (double)attach_count)) : 0.f;
+    const float g4 = attach_count > 0 ? (float)(2000.0 / (4.0 * (double)attach_count)) : 0.f;
+    double* partial = (double*)ws;
+    DQO_LAUNCH("attach_loss_kernel", attach_loss_kernel, dim3(blocks), dim3(ATT_THREADS), s, P, scaling, xyz, rotation, scaling0, xyz0, rotation0,
+               mask, g3, g4, g_scaling, g_xyz, g_rotation, partial);
+    DQO_LAUNCH("attach_loss_sum_kernel", attach_loss_sum_kernel, dim3(1), dim3(ATT_THREADS), s, blocks, partial, loss);
     return DQO_OK;
 }

@@ -1,0 +1,98 @@
+"""Opt-in fused pieces for callers that stay on the reference's API (drop-in op + their own torch optimiser): two autograd Functions
+that replace eager torch op sequences of Mapping.loss_update (SLAM/multiprocess/mapper.py:799-905) by the HIP kernels of row f2 —
+
+    loss = masked_mapping_loss(out, gt_color, gt_depth, render_mask)[0]            # mapper.py:836-875 with a render mask
+    attach = fused_attach_loss(_scaling, _xyz, _rotation, init_stat)               # mapper.py:812-829
+    (loss + attach).backward(); optimizer.step()                                    # unchanged
+
+Each is a two-line change in mapper.py; values and gradients equal the eager statements (dqo_harness.mapping.mapping_loss /
+attach_loss) to float rounding (tests/test_gpu_fused_ops.py).  GPU only: there is no CPU path.
+"""
+import torch
+
+import _dqo_native as N
+from dqo_harness import mapping
+
+
+class _MaskedMappingLoss(torch.autograd.Function):
+    """dqo_map_loss_fwd_bwd as an autograd Function: loss values AND the gradient images come out of the forward's two launches; the
+    backward only scales them by the incoming gradient of the total."""
+
+    @staticmethod
+    def forward(ctx, render, depth, depth_index, gt_color, gt_depth, render_mask, color_weight, depth_weight, add_depth_thres):
+        lib = N.lib()
+        N.require_gpu(render, depth, depth_index, gt_color, gt_depth, render_mask)
+        if not render.is_cuda:
+            raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+        f = lambda t: t.detach().float().contiguous()
+        render, depth, gt_color, gt_depth = f(render), f(depth), f(gt_color), f(gt_depth)
+        depth_index = depth_index.to(torch.int32).contiguous()
+        mask = None if render_mask is None else render_mask.to(torch.uint8).contiguous()
+        H, W = render.shape[-2], render.shape[-1]
+        dev = render.device
+        loss = torch.empty(8, dtype=torch.float32, device=dev)
+        dC, dD = torch.empty_like(render), torch.empty_like(depth)
+        ws = torch.empty(lib.dqo_map_loss_workspace_bytes(), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.dqo_map_loss_fwd_bwd(W, H, N.ptr(render), N.ptr(depth), N.ptr(depth_index), N.ptr(gt_color), N.ptr(gt_depth),
+                                             N.ptr(mask), float(color_weight), float(depth_weight), float(add_depth_thres), N.ptr(loss),
+                                             N.ptr(dC), N.ptr(dD), N.ptr(ws), ws.numel(), N.current_stream()))
+        ctx.save_for_backward(dC, dD)
+        ctx.mark_non_differentiable(loss)
+        return loss[0].clone(), loss
+
+    @staticmethod
+    def backward(ctx, g_total, _g_loss):
+        dC, dD = ctx.saved_tensors
+        return g_total * dC, g_total * dD, None, None, None, None, None, None, None
+
+
+def masked_mapping_loss(out, gt_color, gt_depth, render_mask, add_depth_thres=0.1, color_weight=mapping.COLOR_WEIGHT,
+                        depth_weight=mapping.DEPTH_WEIGHT):
+    """mapping.mapping_loss for the masked case (mapper.py:836-875: 0.8 L1 colour + 1.0 depth L1; the SSIM term is skipped when a render
+    mask is given, B14) in two launches.  `out` = the dict of mapping.render / Renderer.render.  Returns (total, parts) like mapping_loss."""
+    total, loss = _MaskedMappingLoss.apply(out["render"], out["depth"], out["depth_index_map"], gt_color, gt_depth, render_mask,
+                                           color_weight, depth_weight, add_depth_thres)
+    return total, dict(total_loss=loss[0], color_loss=loss[1], depth_loss=loss[2], ssim_loss=loss[3])
+
+
+class _AttachLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, xyz, rotation, scaling0, xyz0, rotation0, attach_mask, attach_count):
+        lib = N.lib()
+        N.require_gpu(scaling, xyz, rotation, scaling0, xyz0, rotation0, attach_mask)
+        if not xyz.is_cuda:
+            raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+        f = lambda t: t.detach().float().contiguous()
+        s, x, q, s0, x0, q0 = f(scaling), f(xyz), f(rotation), f(scaling0), f(xyz0), f(rotation0)
+        P, dev = x.shape[0], x.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        gs, gx, gq = torch.empty_like(s), torch.empty_like(x), torch.empty_like(q)
+        ws = torch.empty(lib.dqo_map_attach_workspace_bytes(P), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.dqo_map_attach_loss_fwd_bwd(P, N.ptr(s), N.ptr(x), N.ptr(q), N.ptr(s0), N.ptr(x0), N.ptr(q0), N.ptr(attach_mask),
+                                                    int(attach_count), N.ptr(loss), N.ptr(gs), N.ptr(gx), N.ptr(gq), N.ptr(ws), ws.numel(),
+                                                    N.current_stream()))
+        ctx.save_for_backward(gs, gx, gq)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        gs, gx, gq = ctx.saved_tensors
+        return g * gs, g * gx, g * gq, None, None, None, None, None
+
+
+class AttachSet:
+    """The attach set of one mapping call (mapper.py:812-813: sigmoid(opacity at the start of the call) < 0.9), evaluated ONCE per call —
+    the reference re-derives it in every iteration from the same snapshot."""
+
+    def __init__(self, init_stat):
+        self.init_stat = init_stat
+        self.mask = (torch.sigmoid(init_stat["opacity"]) < 0.9).reshape(-1).to(torch.uint8).contiguous()
+        self.count = int(self.mask.sum().item())
+
+
+def fused_attach_loss(scaling, xyz, rotation, attach_set):
+    """mapping.attach_loss (mapper.py:812-829) in two launches; attach_set = AttachSet(params.init_stat())."""
+    st = attach_set.init_stat
+    return _AttachLoss.apply(scaling, xyz, rotation, st["scaling"], st["xyz"], st["rotation_raw"], attach_set.mask, attach_set.count)

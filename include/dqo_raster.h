@@ -283,6 +283,16 @@ int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const float* 
                          float depth_weight, float add_depth_thres, float* loss_out, float* dL_dcolor, float* dL_ddepth,
                          void* workspace, size_t workspace_bytes, void* hipStream);
 
+/* The attach loss of Mapping.loss_update (SLAM/multiprocess/mapper.py:812-829) with its gradient, for callers that keep their own
+ * optimiser (ABI 3):  loss[0] = 1000 * (mse(scaling[a], scaling0[a]) + mse(xyz[a], xyz0[a]) + mse(rotation[a], rotation0[a])),  a =
+ * attach_mask != 0 with |a| = attach_count (0: loss and gradients are zero), on the RAW parameters; g_* ([P,3], [P,3], [P,4]) are fully
+ * written (zeros outside a).  Two launches in place of the ~12 eager torch ops of the forward and the ~25 of their autograd backward. */
+size_t dqo_map_attach_workspace_bytes(int32_t P);
+int dqo_map_attach_loss_fwd_bwd(int32_t P, const float* scaling_raw, const float* xyz, const float* rotation_raw,
+                                const float* init_scaling_raw, const float* init_xyz, const float* init_rotation_raw,
+                                const uint8_t* attach_mask, int32_t attach_count, float* loss, float* g_scaling_raw, float* g_xyz,
+                                float* g_rotation_raw, void* workspace, size_t workspace_bytes, void* hipStream);
+
 /* dqo_accumulate_gaussian_error <- cuda_utils._C.accumulate_gaussian_error (submodules/cuda_utils/ext.cpp, cuda_utils.cu:17-62,
  * map_process.cu:33-245; caller SLAM/multiprocess/mapper.py:1034-1047).  Maps are [H*W]; outputs [P] are fully written
  * (zero-initialised inside).  check_max != 0: per-Gaussian maximum of the errors (the mode DQO-MAP uses); 0: mean, which needs

@@ -7,13 +7,13 @@ import argparse
 import torch
 import bench
 
-args = argparse.Namespace(cfg=3, P=None, view="room", scaling="strong", shard_by="work")
+args = argparse.Namespace(cfg=3, P=None, view="room", scaling="strong", shard_by="work", no_object_gate=True)
 dev = torch.device("cuda")
 import diff_gaussian_rasterization_depth as dgr
 dgr.set_sync_mode("lazy")
 prob = bench.build_problem(args, 0, 1, dev)
 from dqo_harness.sharding import PackedAllReduce
-step = bench.make_dropin_step(prob, dev, PackedAllReduce(bench.LOSS_SPEC, dev))
+step = bench.make_dropin_step(prob, dev, PackedAllReduce(bench.LOSS_SPEC, dev), optin=("optin" in sys.argv))
 for _ in range(10):
     step()
 torch.cuda.synchronize()
