@@ -886,6 +886,18 @@ def main():
                          "what": "the same loop with dqo_harness.fused_ops.masked_mapping_loss / fused_attach_loss in place of the eager "
                                  "loss and attach loss (two two-line changes in mapper.py); op and torch.optim.Adam untouched"}
             del sa, sb
+            # the op alone: forward + backward with a fixed incoming gradient (what share of the drop-in iteration is the operator)
+            pr_ = mapping.GaussianParams(prob["scene"], device)
+            gC, gD = torch.randn_like(prob["gt_color"]), torch.randn_like(prob["gt_depth"])
+
+            def op_only():
+                o_ = mapping.render(prob["settings"], {**pr_.activated(), "normal": None}, tile_mask=prob["tile_mask"])
+                torch.autograd.backward([o_["render"], o_["depth"]], [gC, gD])
+                for t_ in (pr_._xyz, pr_._features_dc, pr_._features_rest, pr_._opacity, pr_._scaling, pr_._rotation):
+                    t_.grad = None
+            alt["op_only_ms"] = round(time_path(op_only) * 1e3, 4)
+            alt["op_only_what"] = "drop-in op forward + backward (+ the six activation ops and their autograd), fixed incoming gradient"
+            del pr_
         else:
             other_runner = FusedRunner(prob, device, PackedAllReduce(LOSS_SPEC, device), 1, use_graph=not args.no_graph)
             d1 = time_path(other_runner.step)

@@ -25,18 +25,44 @@ import torch.nn as nn
 
 import _dqo_native as N
 
+# Operator state.  It lives at module level on purpose: the reference's caller builds a NEW GaussianRasterizer for every render call
+# (SLAM/render.py:163), so state hung off the module instance would not survive from one call to the next — and the lazy mode's capacity
+# hint has to.  One lock guards it (tracker and mapper threads of one process may render concurrently).
+import threading
+
+_lock = threading.RLock()
 _sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy": reuse / grow the previous capacity, no sync
 _cap_hint = {}
-_pending = []          # lazy mode: (event, pinned header tensor, key) of forwards not yet verified
-_last = {"num_rendered": None, "num_visible": None, "header": None}   # header: (event, pinned host copy of the 32-byte header)
+_pending = []          # lazy mode: (event, pinned header tensor, key, capacity) of forwards not yet verified
+_last = {"num_rendered": None, "num_visible": None, "header": None}   # header: (event, pinned host copy) or a weak reference to the geometry buffer
+_ring = []             # pinned 32-byte header buffers + their events, reused round robin (no pin_memory() / Event() per call)
+_ring_pos = [0]
+_RING = 64
+
+
+def _ring_slot():
+    """A pinned 8-int32 host buffer and an event from the ring (allocated on first use).  A slot is reused after _RING later forwards;
+    a pending lazy check older than that has long been verified (lazy mode verifies at every forward)."""
+    if len(_ring) < _RING:
+        _ring.append((torch.empty((8,), dtype=torch.int32).pin_memory(), torch.cuda.Event()))
+        return _ring[-1]
+    _ring_pos[0] = (_ring_pos[0] + 1) % _RING
+    slot = _ring[_ring_pos[0]]
+    if any(p[1] is slot[0] for p in _pending):  # (never in practice: the GPU would be _RING frames behind)
+        _verify_pending(block=True)
+    return slot
 
 
 def last_header():
     """Device header of the most recent forward (waits for its asynchronous 32-byte copy): dict with num_rendered = instances kept
     in the tile lists, num_candidates = the reference's num_rendered, num_tiles, max_tile_count, num_visible, overflow."""
-    if _last["header"] is None:
+    hd = _last["header"]
+    if hd is None:
         return None
-    ev, host = _last["header"]
+    if torch.is_tensor(hd):  # exact mode: read on demand from the forward's geometry buffer
+        h = hd[:32].view(torch.int32).cpu().tolist()
+        return dict(num_rendered=h[0], num_tiles=h[1], overflow=h[2], max_tile_count=h[3], num_visible=h[4], num_candidates=h[5])
+    ev, host = hd
     ev.synchronize()
     h = host.tolist()
     return dict(num_rendered=h[0], num_tiles=h[1], overflow=h[2], max_tile_count=h[3], num_visible=h[4], num_candidates=h[5])
@@ -199,14 +225,18 @@ class _RasterizeGaussians(torch.autograd.Function):
             cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
             N.check(lib.dqo_rast_forward_render(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
                                                 ctypes.byref(cctx), stream))
-            # asynchronous 32-byte copy of the device header (statistics; in lazy mode also the deferred capacity check)
-            host = torch.empty((8,), dtype=torch.int32).pin_memory()
-            host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
             if _sync_mode == "lazy":
-                _pending.append((ev, host, key, cap))
-        _last["header"] = (ev, host)  # (not the geometry buffer itself: that would pin ~160 B per Gaussian until the next call)
+                # asynchronous 32-byte copy of the device header into a pinned ring slot: the deferred capacity check (and statistics)
+                with _lock:
+                    host, ev = _ring_slot()
+                    host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
+                    ev.record()
+                    _pending.append((ev, host, key, cap))
+                    _last["header"] = (ev, host)
+            else:
+                # exact mode has read what it needs already: nothing per call; last_header() reads the rest on demand from the
+                # geometry buffer, which therefore stays referenced until the next forward (~160 B per Gaussian, one call longer)
+                _last["header"] = geomBuffer
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.inst_capacity = cap
