@@ -673,11 +673,10 @@ def eager_quadric_loop(axes, R, center, P34, obs, offs, sched):
 # ------------------------------------------------------------------------------------------------------------------
 # HBM traffic of the dominant kernel: rocprofv3 --pmc child passes over this same command (MI355X_MICROARCH.md, HBM section)
 # ------------------------------------------------------------------------------------------------------------------
-def pmc_traffic(args, kernel_name):
-    """Memory-side bytes per launch of `kernel_name` from two rocprofv3 --pmc passes (TCC read / write request counters: one
-    counter set per pass, --kernel-trace only beside them) over `python3 bench.py --inner` with this run's workload flags.
-    read = RDREQ x 64 B (the FETCH_SIZE convention; wide coalesced reads are 128-B requests tallied at 64 B and are NOT doubled here:
-    the blend kernels gather 16-B records), write = 64 B x WRREQ_64B + 32 B x the other write requests.  Returns dict or None."""
+def pmc_child(args, kernel_name, passes):
+    """Mean per-launch counter values of `kernel_name` from rocprofv3 --pmc child passes (one counter set per pass, --kernel-trace only
+    beside them) over `python3 bench.py --inner` with this run's workload flags.  passes = [(tag, [counters])].
+    Returns ({counter: mean per launch}, inner command line) or (None, reason)."""
     import csv
     import glob
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -697,7 +696,7 @@ def pmc_traffic(args, kernel_name):
     res = {}
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("WORLD_SIZE", None)
-    for tag, counters in (("rd", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]), ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])):
+    for tag, counters in passes:
         d = tempfile.mkdtemp(prefix="dqo_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--"] + inner
         # a session of its own: on a timeout the whole group goes (rocprofv3 AND the python it started — killing only the profiler would
@@ -732,10 +731,49 @@ def pmc_traffic(args, kernel_name):
             if c not in acc or acc[c][1] == 0:
                 return None, f"pmc pass {tag}: no samples of {kernel_name}"
             res[c] = acc[c][0] / acc[c][1]
+    return res, "bench.py " + " ".join(inner[2:])
+
+
+def pmc_traffic(args, kernel_name):
+    """Memory-side bytes per launch of `kernel_name`: read = RDREQ x 64 B (the FETCH_SIZE convention; wide coalesced reads are 128-B
+    requests tallied at 64 B and are NOT doubled here: the blend kernels gather 16-B records), write = 64 B x WRREQ_64B + 32 B x the
+    other write requests.  Returns (dict or None, source note)."""
+    res, note = pmc_child(args, kernel_name, (("rd", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]),
+                                              ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])))
+    if res is None:
+        return None, note
+    inner_cmd = note
     rd = res["TCC_EA0_RDREQ_sum"] * 64
     wr = res["TCC_EA0_WRREQ_64B_sum"] * 64 + (res["TCC_EA0_WRREQ_sum"] - res["TCC_EA0_WRREQ_64B_sum"]) * 32
-    return dict(read_bytes=int(rd), write_bytes=int(wr)), ("measured in this run: rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ child passes over `bench.py "
-                                                           + " ".join(inner[2:]) + "`")
+    return dict(read_bytes=int(rd), write_bytes=int(wr)), ("measured in this run: rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ child passes over `"
+                                                           + inner_cmd + "`")
+
+
+# one wave64 VALU instruction per 2.7 cycles and SIMD with 8 resident waves = 0.90 G wave-instructions / s / SIMD (tools/ubench_fma_peak.hip,
+# profiles/r02_ubench_fma_peak.txt: long runs of independent v_fma_f32, HIP events around the launch), 1024 SIMDs
+VALU_ROOF_GINST_PER_SIMD = 0.90
+N_SIMD = 1024
+
+
+def pmc_valu(args, kernel_name, avg_launch_us):
+    """roofline.valu of a VALU-bound kernel from one SQ --pmc child pass: wave-instructions per launch, the fraction of the measured issue
+    roof they amount to over the kernel's duration, the share of the SIMD cycles spent executing VALU, and the exec-mask lane utilisation
+    (the blend kernels predicate by arithmetic — alpha = 0 — so the USEFUL lane share is lower: tests/diag_pair_stats.py)."""
+    res, note = pmc_child(args, kernel_name, (("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
+                                                       "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES"]),))
+    if res is None:
+        return None, note
+    insts = res["SQ_INSTS_VALU"]
+    roof = VALU_ROOF_GINST_PER_SIMD * 1e9 * N_SIMD * avg_launch_us * 1e-6
+    wc = max(res["SQ_WAVE_CYCLES"], 1.0)
+    return dict(insts=int(insts), issue_frac_of_measured_roof=round(insts / roof, 4),
+                exec_lane_utilisation=round(res["SQ_THREAD_CYCLES_VALU"] / max(res["SQ_ACTIVE_INST_VALU"] * 64.0, 1.0), 4),
+                lane_utilisation=None,
+                lane_utilisation_note="useful lanes per wave step (pixels with alpha >= 1/255 among the 64): 37 % on cfg 3, from the oracle's "
+                                      "per-entry pixel masks (tests/diag_pair_stats.py, round 2); the exec mask is full: predication is arithmetic",
+                wave_cycles_waiting_frac=round(res["SQ_WAIT_ANY"] / wc, 4), wave_cycles_issue_stall_frac=round(res["SQ_WAIT_INST_ANY"] / wc, 4),
+                waves=int(res["SQ_WAVES"]), roof="0.90 G wave64 instr / s / SIMD x 1024 SIMDs (profiles/r02_ubench_fma_peak.txt)",
+                source="rocprofv3 --pmc SQ_* child pass over `" + note + "`"), note
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -985,26 +1023,31 @@ def main():
         contract = {"blend_backward_kernel": 40 * n_inst + 16 * HWa, "blend_forward_kernel": 28 * n_inst + 36 * HWa}
         bytes_dom = alg.get(dom_name, 0)
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic, traffic_note = None, "not collected"
+        traffic, traffic_note, valu = None, "not collected", None
         if rank == 0 and world == 1 and not args.no_pmc:
             tr, traffic_note = pmc_traffic(args, dom_name)
             if tr is not None:
                 traffic = tr["read_bytes"] + tr["write_bytes"]
                 stats["traffic_read_write"] = [tr["read_bytes"], tr["write_bytes"]]
+            if "blend" in dom_name:
+                valu, _ = pmc_valu(args, dom_name, dom_ms * 1e3)
         # whole iteration against HBM: the contract's B_iter (708 B / visible Gaussian + 4 B / Gaussian + 92 B / instance + 52 B / active
         # pixel + 1652 B / Gaussian Adam touches) over the measured time per iteration
         b_iter = 708 * n_vis + 4 * Pk + 92 * n_inst + 52 * HWa + 1652 * stats.get("adam_rows_touched", Pk)
         ms_step = dt / args.steps * 1e3
         roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_note,
+                        bound_measured=("valu" if "blend" in dom_name else "latency"), valu=valu,
                         avg_launch_us=round(dom_ms * 1e3, 2), algorithmic_bytes=int(bytes_dom),
                         contract_bytes=int(contract.get(dom_name, bytes_dom)),
                         contract_frac=round(contract.get(dom_name, bytes_dom) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom_ms > 0 else None,
                         iteration=dict(contract_bytes=int(b_iter), gbs=round(b_iter / (ms_step * 1e-3) / 1e9, 1),
                                        frac=round(b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
-                        note="algorithmic_bytes = DESIGN.md's per-launch model of the dominant kernel (120 B / instance + 32 B / active pixel for "
-                             "the backward blend); contract_bytes = SURVEY.md §8d's own share for it; the blend kernels are VALU-issue bound, "
-                             "not HBM bound (profiles/README.md); per-kernel GB/s of every kernel: kernel_gbs",
+                        note="`bound` / achieved / peak / frac price the dominant kernel against HBM as the bench contract asks (algorithmic_bytes = "
+                             "DESIGN.md's per-launch model: 120 B / instance + 32 B / active pixel for the backward blend; contract_bytes = "
+                             "SURVEY.md §8d's own share); what actually bounds it is `bound_measured`: the blend kernels are VALU-execution "
+                             "bound (`valu`: SQ counters of this run against the measured issue roof), the fused per-Gaussian tail by the "
+                             "latency of its dependent memory rounds; per-kernel GB/s of every kernel: kernel_gbs",
                         kernel_gbs={k: round(alg[k] / (us * 1e-6) / 1e9, 1) for k, us in kernels.items() if k in alg and us > 0})
 
     cpu = None
