@@ -75,6 +75,9 @@ def parse():
                     help="fused path: the two loss kernels between forward and backward instead of the loss tap inside the blend kernels (A/B)")
     ap.add_argument("--no-fused-tail", action="store_true",
                     help="fused path: record_sum + gaussian_backward + adam as three kernels instead of the one fused per-Gaussian tail (A/B)")
+    ap.add_argument("--list-split", default="auto",
+                    help="fused path: DqoRastCtx.list_split — 0 = one wave walks every tile list; n = lists longer than n entries are shared "
+                         "between eight waves in the forward blend; auto (default) = by the number of tiles the rank renders")
     ap.add_argument("--no-object-gate", action="store_true",
                     help="strong scaling: a shard's objects occlude each other (round 2's job definition) instead of the per-object gate that "
                          "makes every N compute the N = 1 function")
@@ -266,14 +269,14 @@ class FusedRunner:
     """The fused path of one rank: a FusedMapper on the rank's shard, one hipGraph replay per iteration, the packed all-reduce of
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
 
-    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True):
+    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True, list_split=0):
         from dqo_harness.fused_mapping import FusedMapper
         self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
         self.fm = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=attach_reducer(prob, world))
         if prob.get("gate") is not None:
             self.fm.set_object_gate(prob["gate"][0], prob["gate"][1])
         self.mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
-        self.use_graph, self.loss_tap, self.fused_tail = use_graph, loss_tap, fused_tail
+        self.use_graph, self.loss_tap, self.fused_tail, self.list_split = use_graph, loss_tap, fused_tail, list_split
         self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
         self.first_loss = None
         self.growth_pool = []  # the new points of every growth step: input data, resident in HBM before the timed region
@@ -283,7 +286,7 @@ class FusedRunner:
     def _capture(self, reuse_probe=False):
         p = self.prob
         self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap, reuse_probe=reuse_probe,
-                        fused_tail=self.fused_tail)
+                        fused_tail=self.fused_tail, list_split=self.list_split)
         if self.first_loss is None:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
 
@@ -422,7 +425,9 @@ def selfcheck(args, prob, runner, device, n_iters):
             twin.set_object_gate(gate[0], gate[1])
         mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
         if runner.use_graph:
-            twin.capture(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"])
+            # (the same order of arithmetic as the timed run: list_split regroups the transmittance products, and 1e-7 between two
+            # trajectories grows to 1e-3 of the loss within dozens of Adam steps)
+            twin.capture(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"], list_split=runner.list_split)
             for _ in range(n_iters):
                 twin.replay()
         else:
@@ -693,6 +698,7 @@ def pmc_child(args, kernel_name, passes):
             inner += [flag]
     if args.as_shard:
         inner += ["--as-shard", args.as_shard]
+    inner += ["--list-split", args.list_split]
     res = {}
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("WORLD_SIZE", None)
@@ -833,7 +839,8 @@ def main():
     runner = step_dropin = None
     if args.path == "fused":
         runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
-                             loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail)
+                             loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail,
+                             list_split=args.list_split if args.list_split == "auto" else int(args.list_split))
         step = runner.step
     else:
         step_dropin = make_dropin_step(prob, device, loss_buf)
@@ -1108,7 +1115,8 @@ def main():
                                    + ("" if args.path != "fused" or args.no_graph else " (one hipGraph replay per iteration)"),
                        "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
                        "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
-                       "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
+                       "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}),
+                       **({"list_split": int(runner.fm._g.cctx.list_split)} if (runner is not None and runner.fm._g is not None) else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
                                                                                    ("ok" if selfcheck_ok else "FAILED")), **stats},
             "loss": loss_now, "path": args.path,
         }

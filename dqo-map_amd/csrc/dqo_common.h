@@ -99,7 +99,7 @@ static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
 
 // DqoLossTap as the kernels get it (by value); scale == nullptr: no tap.  The per-frame sums live in the geometry buffer's spread
 // lines (words 8..15 of each of the DQO_SPREAD lines, as four 64-bit counters: colour error sum and depth error sum in 2^-32 fixed
-// point, the two pixel counts), the wave ticket in counters[2] — all zeroed with the header by the forward's zero fill.
+// point, the two pixel counts) — all zeroed with the header by the forward's zero fill.
 struct DqoTapDev {
     const float* gt_color;
     const float* gt_depth;
@@ -161,6 +161,9 @@ __device__ __forceinline__ unsigned long long dqo_tap_fixed(float s) {
 #endif
 
 // image buffer: per-tile tables + per-pixel forward->backward state.
+// DqoRastCtx.list_split as the kernels get it: 0 = off, otherwise the list length above which a list is shared between eight waves
+// (at least one chunk per wave makes no sense below 64 entries)
+static inline int dqo_list_split(const DqoRastCtx* ctx) { return ctx->list_split <= 0 ? 0 : (ctx->list_split < 64 ? 64 : ctx->list_split); }
 struct DqoImageLayout {
     uint32_t* tile_count;   // [T] instances per tile (atomic histogram, K1)
     uint32_t* tile_flag;    // [T] 1 = some Gaussian's reference rect covers the tile but all such instances were culled as dead
@@ -174,6 +177,8 @@ struct DqoImageLayout {
     uint32_t* hit_pos;      // [HW] bits 0..30: 1-based list position of the Gaussian that fixed the depth, 0 if none;
                             //      bit 31: the backward's ray/plane-depth branch applies to it (backward.cu:1016)
     uint32_t* long_tiles;   // [T] queue of the tiles whose lists are too long for tile_sort_wave_kernel (count: geom counters[1])
+    uint32_t* split_tiles;  // [T] DqoRastCtx.list_split: queue of the tiles whose lists the forward blend shares between eight waves (longer
+                            //     than list_split entries; count: geom counters[4], the blend's work ticket: counters[3])
     size_t total;
 };
 
@@ -197,6 +202,7 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
     L.n_contrib = (uint32_t*)take(4 * HW);
     L.hit_pos = (uint32_t*)take(4 * HW);
     L.long_tiles = (uint32_t*)take(4 * T);
+    L.split_tiles = (uint32_t*)take(4 * T);
     L.total = (size_t)(p - (char*)base);
     return L;
 }

@@ -595,7 +595,7 @@ constexpr int SORTW_THREADS = 128;
 // counter, and the frame statistics the header needs go to the spread lines (words 2..3), which tile_sort_kernel's first block
 // sums up (header_from_spread).
 __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g,
-                                                                       int64_t capacity, int keep_order) {
+                                                                       int64_t capacity, int keep_order, int list_split) {
     __shared__ uint64_t s_key[2 * SORTP_RUN];
     __shared__ uint32_t s_val[2 * SORTP_RUN];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -624,6 +624,8 @@ __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, Dq
     }
     const int n = (int)(rg.y - rg.x);
     if (n <= 0) return;
+    // DqoRastCtx.list_split: the forward blend's queue of lists to cut into runs (longest first, like the one below)
+    if (list_split > 0 && n > list_split && threadIdx.x == 0) img.split_tiles[atomicAdd(&g.counters[4], 1u)] = tile;
     if (n > SORTW_CAP) {  // tile_sort_kernel's: queued (the blocks run longest list first, so the queue is close to that order too)
         if (threadIdx.x == 0) img.long_tiles[atomicAdd(&g.counters[1], 1u)] = tile;
         return;
@@ -820,7 +822,7 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate, hipStream_t s);
+                             const DqoRastOutputs& out, int T, const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s);
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                          int64_t capacity, const unsigned long long* tile_objects, hipStream_t s);
 int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
@@ -882,11 +884,12 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
             if (rc) return rc;
         }
         const int slots = 8 * ((T + 7) / 8);  // tile_order is [8][T8]
-        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order);
+        DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order,
+                   dqo_list_split(ctx));
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
     }
-    return dqo_launch_blend_forward(v, g, img, bin, *out, T, (int64_t)ctx->inst_capacity, dqo_tap_dev(ctx->loss_tap),
-                                    dqo_gate_dev(ctx->object_gate), s);
+    return dqo_launch_blend_forward(v, g, img, bin, *out, T, dqo_tap_dev(ctx->loss_tap),
+                                    dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s);
 }
 
 int dqo_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s) {

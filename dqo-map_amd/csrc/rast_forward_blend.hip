@@ -104,24 +104,41 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
 // instantiation is held to 80 registers: left alone it takes 83-92 and loses two waves per SIMD, which is where its time goes — the
 // instruction counts of the two kernels are equal to 0.1 %; a duplicate of the entry loop without the owner comparison for the
 // one-owner quadrants measured nothing.)
-template <bool GATE>
-__global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
-                                                                    DqoBinLayout bin, DqoRastOutputs out, int64_t capacity,
-                                                                    const DqoTapDev tap, const DqoGateDev gate) {
-    __shared__ float4 s_co[FWD_THREADS];
-    __shared__ float4 s_xy[FWD_THREADS];
-    __shared__ float4 s_rgb[FWD_THREADS];
-    __shared__ int s_id[FWD_THREADS];
-    __shared__ int s_pos[FWD_THREADS];
-    __shared__ int s_half[FWD_THREADS];
+//
+// SEGS: waves per quadrant.  1 = the wave described at the top of the file.  8 = the list-splitting variant for launches that cannot
+// fill the chip (a strong-scaling shard: a few hundred tiles on 1024 SIMDs, where the time of the launch is the time of the ONE wave
+// with the longest walk).  The list is walked in rounds of SEGS chunks, chunk r * SEGS + w of round r by wave w:
+//   pass 1  every wave multiplies out, per pixel, the product of (1 - alpha) over the valid entries of its chunk and notes whether the
+//           chunk holds an opaque hit — both independent of the state the pixel arrives with, as long as it is unfinished;
+//   scan    transmittance and "depth already fixed" at the start of chunk w = the round's start state times the products / OR of the
+//           chunks before it; a pixel is finished before a chunk iff T_in < T_threshold and a hit lies before it (the reference
+//           finishes a pixel at the first valid entry at or behind BOTH the first entry that takes T below the threshold and the
+//           first hit, forward.cu:813-817);
+//   pass 2  the blend loop itself on the chunk, started from that state (a chunk entered finished ends at once);
+// one block barrier per round, and the block stops after the round that leaves no pixel unfinished — the early exit of the serial
+// walk at a granularity of SEGS chunks.  At the end wave 0 folds the waves' partial results by list position and writes the pixel.
+// The products are grouped by chunk instead of strictly front to back, so T differs from the serial order's in the last bits (and a
+// pixel sitting exactly on a threshold may fall on the other side): splitting is opt-in (DqoRastCtx.list_split), not a default.
+//
+// LDS: one block of FWD_BLK float4 per wave — the compaction buffers of its chunk; with SEGS > 1 the same block holds the wave's
+// merge record at the end (a wave only ever writes its own block), and SEGS * 64 more float4 behind the blocks the pass-1 results.
+constexpr int FWD_BLK = 4 * FWD_THREADS - FWD_THREADS / 4;  // 3 float4 tables + 3 int tables of 64 entries = 240 float4 = 3840 B
+constexpr int PART_STRIDE = FWD_BLK * 4;                    // floats per wave block
+constexpr int PART_WORDS = 14;                              // merge record of one (run, pixel): 13 x 64 floats <= PART_STRIDE
+static_assert(PART_WORDS * FWD_THREADS <= PART_STRIDE, "the merge record lives in the wave's own LDS block");
 
-    // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
-    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
-    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
-    const int lane = threadIdx.x;
-    if (tile_u == 0xffffffffu) return;  // unused slot
-    const int tile = (int)tile_u;
-    const int quad = jg & 3;
+template <bool GATE, int SEGS>
+__device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
+                                               const DqoRastOutputs& out, const DqoTapDev& tap, const DqoGateDev& gate, const int tile,
+                                               const int quad, const int wave, const int lane, float4* const lds, const int skip_over) {
+    float4* const s_co = lds + wave * FWD_BLK;
+    float4* const s_xy = s_co + FWD_THREADS;
+    float4* const s_rgb = s_xy + FWD_THREADS;
+    int* const s_id = reinterpret_cast<int*>(s_rgb + FWD_THREADS);
+    int* const s_pos = s_id + FWD_THREADS;
+    int* const s_half = s_pos + FWD_THREADS;
+    float* const s_part = reinterpret_cast<float*>(lds);  // run j, word k, lane l: s_part[j * PART_STRIDE + k * 64 + l]
+
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
     const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + (lane & 7);
     const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + (lane >> 3);
@@ -130,6 +147,7 @@ __global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kerne
     const size_t pix_id = (size_t)v.W * py + px;
     const uint2 range = img.ranges[tile];
     const int n = (int)(range.y - range.x);
+    if (n > skip_over) return;  // (SEGS == 1 beside a split launch: the long lists belong to the split blocks)
     // object gate: this pixel's owner, and the owners present in the quadrant as a 64-bit set of (id mod 64) — an entry whose object's
     // bit is not in the set matches no pixel of the quadrant and is culled with the entries that cannot reach it
     // (object ids lie in [0, 64), so the set is exact: in a quadrant with ONE owner — all but the object boundaries — the entries that
@@ -155,6 +173,7 @@ __global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kerne
         // active in the reference but whose instances were all culled as dead is rendered with an empty list instead:
         // colour = bg, ids = -1 (forward.cu:724-725, 852-860).
         const bool rendered = img.tile_flag[tile] != 0u;
+        if (SEGS > 1 && wave != 0) return;  // (block-uniform branch: no barrier is skipped)
         if (inside) {
             out.out_color[pix_id] = rendered ? v.bg[0] : 0.f;
             out.out_color[HW + pix_id] = rendered ? v.bg[1] : 0.f;
@@ -190,37 +209,89 @@ __global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kerne
     float color_weight_max = -1.f, hit_depth_weight = 0.f;
     uint8_t* live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;  // this quadrant's live bytes of this tile's segment
 
-    const int chunks = (n + FWD_THREADS - 1) / FWD_THREADS;
-    // prologue: loads of chunk 0
-    int id_nx = 0;
-    float4 co_nx = make_float4(0.f, 0.f, 0.f, 0.f), xy_nx = co_nx, cs_nx = co_nx;
-    if (lane < n) {
-        id_nx = (int)bin.point_list[range.x + lane];
-        co_nx = g.conic_opacity[id_nx];
-        xy_nx = g.xy_depth[id_nx];
-        cs_nx = g.rgb_smax[id_nx];
-    }
-    bool all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;  // wave-uniform
-    for (int c = 0; c < chunks && !all_done; c++) {  // a finished quadrant never looks at the entries further back
-        const int pos = c * FWD_THREADS + lane;
-        const int id = id_nx;
-        const float4 co = co_nx, xy = xy_nx, cs_me = cs_nx;
-        // issue the next chunk's loads now; they complete while this chunk is blended (all three records: a gather left for the
-        // compaction below would sit, unhidden, between the cull test and the first entry of every chunk)
-        {
-            const int pn = pos + FWD_THREADS;
-            if (pn < n) {
-                id_nx = (int)bin.point_list[range.x + pn];
-                co_nx = g.conic_opacity[id_nx];
-                xy_nx = g.xy_depth[id_nx];
-                cs_nx = g.rgb_smax[id_nx];
+    const int chunks_all = (n + FWD_THREADS - 1) / FWD_THREADS;
+    // the chunk in flight (written by the chunk loops below, read by entries())
+    int cnt = 0;                       // compacted entries of the chunk
+    unsigned long long live_m = 0ull;  // compacted entries of this chunk that were live (wave-uniform)
+    bool all_done = false;             // wave-uniform: none of the wave's pixels is unfinished
+    uint32_t wmax_pos = 0;             // SEGS > 1: list position of the entry that holds color_weight_max
+    // per-entry results of compacted entry k: was it live for this quadrant (bit k of live_m), and how many of the
+    // quadrant's pixels saw it with T' > 0.5 (s_half[k]; n_touched, forward.cu:833-835, quirk B8)
+    auto entries = [&]() {
+        for (int k = 0; k < cnt && !all_done; k++) {
+            const float4 xy_cur = s_xy[k], co_cur = s_co[k];
+            // ---- per-pixel update (forward.cu:750-842), arithmetic gating instead of per-lane control flow ----
+            // gate = 0 for a finished pixel, nohit = 0 once its depth is fixed: multiplying by them keeps the lane's
+            // predicates in VGPRs (a lane mask that lives across the loop costs scalar bookkeeping in every trip).  An
+            // entry that is not valid for a pixel acts on it with alpha = 0: T (1 - 0) = T, weight 0.
+            const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
+            const float power = dqo_power(co_cur.x, co_cur.y, co_cur.z, dx, dy);
+            const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
+            // (object gate, mixed quadrants only: the entry acts on the pixels of its own object)
+            const bool other = GATE && mixed && __float_as_int(xy_cur.w) != owner;
+            const float a_g = (power <= 0.0f && !other) ? alpha * pix_gate : 0.f;
+            const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
+            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+                const uint32_t contributor = (uint32_t)s_pos[k];
+                const float4 cs = s_rgb[k];
+                const int gid = s_id[k];
+                const float a_v = valid ? alpha : 0.f;
+                const bool newhit = a_v * nohit >= hit_thr;  // valid, no depth yet, alpha >= opaque_threshold
+                if (__builtin_amdgcn_ballot_w64(newhit) != 0ull) {
+                    // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
+                    const float4 n_np = g.normal_c[gid];
+                    const float raw_smax = g.point_c[gid].w;
+                    if (newhit) {
+                        const HitEval h = eval_hit(ray, n_np);
+                        hit_id = gid;
+                        hit_depth_weight = alpha * T;
+                        const float angle_distance = fabsf(h.den);
+                        const float depth_distance = fabsf(h.hit_z - xy_cur.z);
+                        depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
+                        // the backward repeats the test with the raw scales (backward.cu:1009-1016): decide it here once
+                        const bool plane_b = depth_distance <= v.depth_thr * raw_smax && angle_distance >= v.normal_thr;
+                        hit_pos = contributor | (plane_b ? 0x80000000u : 0u);
+                        nohit = 0.f;
+                    }
+                }
+                const float test_T = T * (1.f - a_v);  // == T when the entry is not valid for this pixel
+                const bool blend = valid && !(test_T < v.T_thr);       // forward.cu:818-840
+                const bool finish = valid && !blend && nohit == 0.f;   // forward.cu:813-817: done, T NOT updated
+                const float w = blend ? a_v * T : 0.f;
+                C0 += cs.x * w;
+                C1 += cs.y * w;
+                C2 += cs.z * w;
+                const bool newmax = blend && w > color_weight_max;
+                color_weight_max = newmax ? w : color_weight_max;
+                hit_color_id = newmax ? gid : hit_color_id;
+                if (SEGS > 1) wmax_pos = newmax ? contributor : wmax_pos;  // (the waves' maxima are merged by list position)
+                last_contributor = blend ? contributor : last_contributor;
+                end_T = blend ? test_T : end_T;
+                T = finish ? T : test_T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
+                pix_gate = finish ? 0.f : pix_gate;
+                // live for the backward: some pixel of the quadrant saw the entry with alpha >= 1/255 while unfinished — a
+                // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
+                // below T_threshold), so the backward never misses a pair it has work for.  The per-entry results are
+                // wave-uniform: the live flag goes into a scalar mask, the n_touched count into LDS (uniform store).
+                // (the compare writes its lane mask straight into a scalar pair: through __builtin_amdgcn_ballot_w64 the
+                // compiler materialises the predicate as 0/1 and compares it again)
+                const float t_half = blend ? test_T : 0.f;
+                unsigned long long half_m;
+                asm volatile("v_cmp_lt_f32 %0, 0.5, %1" : "=s"(half_m) : "v"(t_half));
+                s_half[k] = (int)__popcll(half_m);
+                live_m |= 1ull << k;
+                all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;
             }
         }
+    };
+
+    // the chunk's cull test and compaction into LDS; returns the lane's slot among the survivors (reach: this lane's entry survived)
+    auto compact = [&](int pos, int id, const float4& co, const float4& xy, const float4& cs_me, bool& reach) {
         // which entries of this chunk can reach this quadrant at all (conservative, dqo_cull.h); compact them into LDS
-        bool reach = pos < n && dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, dqo_q_threshold(co.w), qx0, qy0, qx0 + 7.f, qy0 + 7.f);
+        reach = pos < n && dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, dqo_q_threshold(co.w), qx0, qy0, qx0 + 7.f, qy0 + 7.f);
         if (GATE) reach = reach && ((present >> (__float_as_int(xy.w) & 63)) & 1ull) != 0ull;
         const unsigned long long rm = __builtin_amdgcn_ballot_w64(reach);
-        const int cnt = (int)__popcll(rm);
+        cnt = (int)__popcll(rm);
         const int myk = (int)__popcll(rm & ((1ull << lane) - 1ull));
         if (reach) {
             s_co[myk] = co;
@@ -229,83 +300,151 @@ __global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kerne
             s_id[myk] = id;
             s_pos[myk] = pos + 1;  // the reference's running counter `contributor` = list position + 1
         }
-        // per-entry results of compacted entry k: was it live for this quadrant (bit k of live_m), and how many of the
-        // quadrant's pixels saw it with T' > 0.5 (s_half[k]; n_touched, forward.cu:833-835, quirk B8)
-        unsigned long long live_m = 0ull;  // compacted entries of this chunk that were live (wave-uniform)
-        auto entries = [&]() {
-            for (int k = 0; k < cnt && !all_done; k++) {
+        return myk;
+    };
+    // what the chunk leaves behind: one scattered integer atomic per touched Gaussian, and the live byte of every list position
+    // (coalesced 64-byte store)
+    auto chunk_results = [&](int pos, bool reach, int myk) {
+        const int half_k = ((live_m >> lane) & 1ull) ? s_half[lane] : 0;
+        if (half_k > 0) atomicAdd(&out.n_touched[s_id[lane]], half_k);
+        if (pos < n) live[pos] = (reach && ((live_m >> myk) & 1ull)) ? (uint8_t)1 : (uint8_t)0;
+    };
+
+    // prologue: loads of the wave's first chunk (chunk `wave`; SEGS == 1: chunk 0)
+    int id_nx = 0;
+    float4 co_nx = make_float4(0.f, 0.f, 0.f, 0.f), xy_nx = co_nx, cs_nx = co_nx;
+    const int first = (SEGS > 1 ? wave : 0) * FWD_THREADS + lane;
+    if (first < n) {
+        id_nx = (int)bin.point_list[range.x + first];
+        co_nx = g.conic_opacity[id_nx];
+        xy_nx = g.xy_depth[id_nx];
+        cs_nx = g.rgb_smax[id_nx];
+    }
+    if (SEGS == 1) {
+        all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;
+        for (int c = 0; c < chunks_all && !all_done; c++) {  // a finished quadrant never looks at the entries further back
+            const int pos = c * FWD_THREADS + lane;
+            const int id = id_nx;
+            const float4 co = co_nx, xy = xy_nx, cs_me = cs_nx;
+            // issue the next chunk's loads now; they complete while this chunk is blended (all three records: a gather left for the
+            // compaction below would sit, unhidden, between the cull test and the first entry of every chunk)
+            {
+                const int pn = pos + FWD_THREADS;
+                if (pn < n) {
+                    id_nx = (int)bin.point_list[range.x + pn];
+                    co_nx = g.conic_opacity[id_nx];
+                    xy_nx = g.xy_depth[id_nx];
+                    cs_nx = g.rgb_smax[id_nx];
+                }
+            }
+            bool reach;
+            const int myk = compact(pos, id, co, xy, cs_me, reach);
+            live_m = 0ull;
+            if (cnt > 0) entries();
+            chunk_results(pos, reach, myk);
+        }
+    } else {
+        // ---- rounds of SEGS chunks, chunk r * SEGS + w to wave w ----
+        float* const s_ph = reinterpret_cast<float*>(lds + SEGS * FWD_BLK);  // [round parity][wave][P | H][lane]
+        const float static_gate = pix_gate;
+        float Tg = 1.f;     // transmittance at the start of the round (every wave computes the same bits)
+        bool hitg = false;  // the depth was fixed before the round
+        float T_last = 1.f; // running T behind the last chunk of this wave that the pixel entered unfinished
+        int last_alive = -1;
+        for (int r = 0; r * SEGS < chunks_all; r++) {
+            const int c = r * SEGS + wave;
+            const int pos = c * FWD_THREADS + lane;
+            const int id = id_nx;
+            const float4 co = co_nx, xy = xy_nx, cs_me = cs_nx;
+            {
+                const int pn = pos + SEGS * FWD_THREADS;  // the wave's chunk of the next round
+                if (pn < n) {
+                    id_nx = (int)bin.point_list[range.x + pn];
+                    co_nx = g.conic_opacity[id_nx];
+                    xy_nx = g.xy_depth[id_nx];
+                    cs_nx = g.rgb_smax[id_nx];
+                }
+            }
+            bool reach;
+            const int myk = compact(pos, id, co, xy, cs_me, reach);  // (a chunk past the end of the list: cnt = 0)
+            // pass 1: the chunk's product of (1 - alpha) and "holds an opaque hit", for a pixel that enters it unfinished
+            float P = 1.f;
+            bool H = false;
+#pragma unroll 2
+            for (int k = 0; k < cnt; k++) {
                 const float4 xy_cur = s_xy[k], co_cur = s_co[k];
-                // ---- per-pixel update (forward.cu:750-842), arithmetic gating instead of per-lane control flow ----
-                // gate = 0 for a finished pixel, nohit = 0 once its depth is fixed: multiplying by them keeps the lane's
-                // predicates in VGPRs (a lane mask that lives across the loop costs scalar bookkeeping in every trip).  An
-                // entry that is not valid for a pixel acts on it with alpha = 0: T (1 - 0) = T, weight 0.
                 const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
                 const float power = dqo_power(co_cur.x, co_cur.y, co_cur.z, dx, dy);
                 const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
-                // (object gate, mixed quadrants only: the entry acts on the pixels of its own object)
                 const bool other = GATE && mixed && __float_as_int(xy_cur.w) != owner;
-                const float a_g = (power <= 0.0f && !other) ? alpha * pix_gate : 0.f;
-                const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
-                if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                    const uint32_t contributor = (uint32_t)s_pos[k];
-                    const float4 cs = s_rgb[k];
-                    const int gid = s_id[k];
-                    const float a_v = valid ? alpha : 0.f;
-                    const bool newhit = a_v * nohit >= hit_thr;  // valid, no depth yet, alpha >= opaque_threshold
-                    if (__builtin_amdgcn_ballot_w64(newhit) != 0ull) {
-                        // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
-                        const float4 n_np = g.normal_c[gid];
-                        const float raw_smax = g.point_c[gid].w;
-                        if (newhit) {
-                            const HitEval h = eval_hit(ray, n_np);
-                            hit_id = gid;
-                            hit_depth_weight = alpha * T;
-                            const float angle_distance = fabsf(h.den);
-                            const float depth_distance = fabsf(h.hit_z - xy_cur.z);
-                            depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
-                            // the backward repeats the test with the raw scales (backward.cu:1009-1016): decide it here once
-                            const bool plane_b = depth_distance <= v.depth_thr * raw_smax && angle_distance >= v.normal_thr;
-                            hit_pos = contributor | (plane_b ? 0x80000000u : 0u);
-                            nohit = 0.f;
-                        }
-                    }
-                    const float test_T = T * (1.f - a_v);  // == T when the entry is not valid for this pixel
-                    const bool blend = valid && !(test_T < v.T_thr);       // forward.cu:818-840
-                    const bool finish = valid && !blend && nohit == 0.f;   // forward.cu:813-817: done, T NOT updated
-                    const float w = blend ? a_v * T : 0.f;
-                    C0 += cs.x * w;
-                    C1 += cs.y * w;
-                    C2 += cs.z * w;
-                    const bool newmax = blend && w > color_weight_max;
-                    color_weight_max = newmax ? w : color_weight_max;
-                    hit_color_id = newmax ? gid : hit_color_id;
-                    last_contributor = blend ? contributor : last_contributor;
-                    end_T = blend ? test_T : end_T;
-                    T = finish ? T : test_T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
-                    pix_gate = finish ? 0.f : pix_gate;
-                    // live for the backward: some pixel of the quadrant saw the entry with alpha >= 1/255 while unfinished — a
-                    // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
-                    // below T_threshold), so the backward never misses a pair it has work for.  The per-entry results are
-                    // wave-uniform: the live flag goes into a scalar mask, the n_touched count into LDS (uniform store).
-                    // (the compare writes its lane mask straight into a scalar pair: through __builtin_amdgcn_ballot_w64 the
-                    // compiler materialises the predicate as 0/1 and compares it again)
-                    const float t_half = blend ? test_T : 0.f;
-                    unsigned long long half_m;
-                    asm volatile("v_cmp_lt_f32 %0, 0.5, %1" : "=s"(half_m) : "v"(t_half));
-                    s_half[k] = (int)__popcll(half_m);
-                    live_m |= 1ull << k;
-                    all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;
-                }
+                const float a_g = (power <= 0.0f && !other) ? alpha * static_gate : 0.f;
+                const float a_v = a_g >= 1.0f / 255.0f ? alpha : 0.f;
+                P *= 1.f - a_v;
+                H = H || a_v >= hit_thr;
             }
-        };
-        if (cnt > 0) {
-            entries();
+            float* const ph = s_ph + (r & 1) * SEGS * 2 * FWD_THREADS;
+            ph[(wave * 2 + 0) * FWD_THREADS + lane] = P;
+            ph[(wave * 2 + 1) * FWD_THREADS + lane] = H ? 1.f : 0.f;
+            // (one barrier per round: the round after next writes this parity again, and the next round's barrier lies between)
+            __syncthreads();
+            // scan: the state this chunk starts from, and the state the next round starts from
+            float T_in = Tg, T_n = Tg;
+            bool h_in = hitg, h_n = hitg;
+#pragma unroll
+            for (int j = 0; j < SEGS; j++) {
+                if (j == wave) T_in = T_n, h_in = h_n;
+                T_n *= ph[(j * 2 + 0) * FWD_THREADS + lane];
+                h_n = h_n || ph[(j * 2 + 1) * FWD_THREADS + lane] != 0.f;
+            }
+            // pass 2: the blend of the chunk from that state.  A pixel is finished before the chunk iff T_in < T_threshold and a hit
+            // lies before it (forward.cu:813-817: it finishes at the first valid entry at or behind both)
+            T = T_in;
+            nohit = h_in ? 0.f : 1.f;
+            pix_gate = (h_in && T_in < v.T_thr) ? 0.f : static_gate;
+            const bool alive_in = pix_gate != 0.f;
+            all_done = __builtin_amdgcn_ballot_w64(alive_in) == 0ull;
+            live_m = 0ull;
+            if (cnt > 0) entries();
+            chunk_results(pos, reach, myk);
+            if (alive_in && c < chunks_all) T_last = T, last_alive = c;
+            Tg = T_n, hitg = h_n;
+            // every wave sees the same state: the block leaves together
+            if (__builtin_amdgcn_ballot_w64(static_gate != 0.f && !(hitg && Tg < v.T_thr)) == 0ull) break;
         }
-        // one scattered integer atomic per touched Gaussian of this chunk
-        const int half_k = ((live_m >> lane) & 1ull) ? s_half[lane] : 0;
-        if (half_k > 0) atomicAdd(&out.n_touched[s_id[lane]], half_k);
-        // live byte of every list position of this chunk (coalesced 64-byte store)
-        if (pos < n) live[pos] = (reach && ((live_m >> myk) & 1ull)) ? (uint8_t)1 : (uint8_t)0;
+        // ---- merge: the waves' results folded by wave 0 ----
+        float* rec = s_part + wave * PART_STRIDE + lane;
+        rec[0 * FWD_THREADS] = C0, rec[1 * FWD_THREADS] = C1, rec[2 * FWD_THREADS] = C2;
+        rec[3 * FWD_THREADS] = color_weight_max, rec[4 * FWD_THREADS] = __int_as_float(hit_color_id);
+        rec[5 * FWD_THREADS] = __uint_as_float(last_contributor), rec[6 * FWD_THREADS] = end_T;
+        rec[7 * FWD_THREADS] = __int_as_float(hit_id), rec[8 * FWD_THREADS] = __uint_as_float(hit_pos);
+        rec[9 * FWD_THREADS] = depth_, rec[10 * FWD_THREADS] = hit_depth_weight;
+        rec[11 * FWD_THREADS] = T_last, rec[12 * FWD_THREADS] = __int_as_float(last_alive);
+        rec[13 * FWD_THREADS] = __uint_as_float(wmax_pos);
+        __syncthreads();
+        if (wave != 0) return;
+        C0 = C1 = C2 = 0.f;
+        color_weight_max = -1.f, hit_color_id = -1, wmax_pos = 0;
+        last_contributor = 0, end_T = 1.f;
+        hit_id = -1, hit_pos = 0, depth_ = 0.f, hit_depth_weight = 0.f;
+        T = 1.f, last_alive = -1;
+        for (int j = 0; j < SEGS; j++) {
+            const float* q = s_part + j * PART_STRIDE + lane;
+            C0 += q[0 * FWD_THREADS], C1 += q[1 * FWD_THREADS], C2 += q[2 * FWD_THREADS];
+            const float wm = q[3 * FWD_THREADS];
+            const uint32_t wp = __float_as_uint(q[13 * FWD_THREADS]);
+            if (wm > color_weight_max || (wm == color_weight_max && wm >= 0.f && wp < wmax_pos))  // the first maximum in list order
+                color_weight_max = wm, hit_color_id = __float_as_int(q[4 * FWD_THREADS]), wmax_pos = wp;
+            const uint32_t lc = __float_as_uint(q[5 * FWD_THREADS]);
+            if (lc > last_contributor) last_contributor = lc, end_T = q[6 * FWD_THREADS];
+            const uint32_t hp = __float_as_uint(q[8 * FWD_THREADS]);
+            if (hp != 0u && (hit_pos == 0u || (hp & 0x7fffffffu) < (hit_pos & 0x7fffffffu))) {
+                // (one wave holds the hit: the chunks behind it start with the depth fixed)
+                hit_pos = hp, hit_id = __float_as_int(q[7 * FWD_THREADS]);
+                depth_ = q[9 * FWD_THREADS], hit_depth_weight = q[10 * FWD_THREADS];
+            }
+            const int la = __float_as_int(q[12 * FWD_THREADS]);
+            if (la > last_alive) last_alive = la, T = q[11 * FWD_THREADS];  // the running transmittance behind the last chunk entered
+        }
     }
     const float oc0 = C0 + T * v.bg[0], oc1 = C1 + T * v.bg[1], oc2 = C2 + T * v.bg[2];  // running T, not end_T (quirk B2, forward.cu:852)
     if (inside) {
@@ -330,15 +469,72 @@ __global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kerne
     if (tap.scale != nullptr) loss_tap_wave(tap, g, inside, pix_id, HW, oc0, oc1, oc2, depth_, hit_id, lane, owner);
 }
 
+// One wave64 per (tile, quadrant), block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item
+// j = b / 8 = (tile slot, quadrant).  (The gated instantiation is held to 80 registers, see above.)
+template <bool GATE>
+__global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+                                                                                  DqoBinLayout bin, DqoRastOutputs out, const DqoTapDev tap,
+                                                                                  const DqoGateDev gate) {
+    __shared__ float4 lds[FWD_BLK];
+    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
+    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
+    if (tile_u == 0xffffffffu) return;  // unused slot
+    blend_quadrant<GATE, 1>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, 0, (int)threadIdx.x, lds, 0x7fffffff);
+}
+
+// DqoRastCtx.list_split: blocks of SPLIT_RUNS waves.  The first SPLIT_GRID blocks take the long lists (longer than list_split entries: the
+// queue tile_sort_wave_kernel left in img.split_tiles, longest first) one (tile, quadrant) at a time, every wave one run of the list,
+// each block drawing its next item with a ticket; they are dispatched first, so the longest critical paths start first.  Every other
+// block is eight independent waves of the serial kind: two tiles of one XCD band, four quadrants each, skipping the long lists.
+constexpr int SPLIT_RUNS = 8;
+// (two blocks per CU at the gated kernel's 100 registers; held to 80 for three, it spills and measures the same)
+constexpr int SPLIT_GRID = 256;   // long-list blocks in front of the short-list blocks, and as many again behind them
+template <bool GATE>
+__global__ __launch_bounds__(FWD_THREADS * SPLIT_RUNS, 4) void blend_forward_split_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+                                                                                           DqoBinLayout bin, DqoRastOutputs out,
+                                                                                           const DqoTapDev tap, const DqoGateDev gate,
+                                                                                           const int list_split) {
+    __shared__ float4 lds[SPLIT_RUNS * (FWD_BLK + FWD_THREADS)];  // the waves' blocks, then the rounds' pass-1 results (two parities)
+    __shared__ uint32_t s_item;
+    // (readfirstlane: the compiler must know that everything derived from the wave index is wave-uniform, or every loop over a run's
+    // bounds is built as a divergent one)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    const int T = v.gx * v.gy, T8 = (T + 7) / 8;
+    const int short_blocks = 8 * ((T8 + 1) / 2);
+    // one long-list block per CU goes first and works beside the short-list blocks; the ones behind them take the slots those leave
+    if (blockIdx.x < SPLIT_GRID || (int)blockIdx.x >= SPLIT_GRID + short_blocks) {
+        const uint32_t items = 4u * min(g.counters[4], (uint32_t)T);
+        for (;;) {  // (ends for every wave of every block: the ticket only grows and `items` is fixed)
+            if (threadIdx.x == 0) s_item = atomicAdd(&g.counters[3], 1u);
+            __syncthreads();
+            const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
+            if (it >= items) return;
+            blend_quadrant<GATE, SPLIT_RUNS>(v, g, img, bin, out, tap, gate, (int)img.split_tiles[it >> 2], (int)(it & 3u), wave, lane, lds,
+                                             0x7fffffff);
+            __syncthreads();  // wave 0 has read the other waves' merge records (and everyone this trip's ticket)
+        }
+    }
+    const int b = (int)blockIdx.x - SPLIT_GRID;
+    const int slot = (b >> 3) * 2 + (wave >> 2);  // two tile slots of band b % 8 per block
+    if (slot >= T8) return;
+    const uint32_t tile_u = img.tile_order[(b & 7) * T8 + slot];
+    if (tile_u == 0xffffffffu) return;
+    blend_quadrant<GATE, 1>(v, g, img, bin, out, tap, gate, (int)tile_u, wave & 3, wave, lane, lds, list_split);
+}
+
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate, hipStream_t s) {
-    if (gate.gobj != nullptr)
-        DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<true>, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out,
-                   capacity, tap, gate);
-    else
-        DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<false>, dim3(8 * ((T + 7) / 8) * 4), dim3(FWD_THREADS), s, v, g, img, bin, out,
-                   capacity, tap, gate);
+                             const DqoRastOutputs& out, int T, const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s) {
+    const bool gt = gate.gobj != nullptr;
+    if (list_split > 0) {
+        const dim3 grid(2 * SPLIT_GRID + 8 * (((T + 7) / 8 + 1) / 2)), block(FWD_THREADS * SPLIT_RUNS);
+        if (gt) DQO_LAUNCH("blend_forward_kernel", blend_forward_split_kernel<true>, grid, block, s, v, g, img, bin, out, tap, gate, list_split);
+        else DQO_LAUNCH("blend_forward_kernel", blend_forward_split_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate, list_split);
+        return DQO_OK;
+    }
+    const dim3 grid(8 * ((T + 7) / 8) * 4), block(FWD_THREADS);
+    if (gt) DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<true>, grid, block, s, v, g, img, bin, out, tap, gate);
+    else DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate);
     return DQO_OK;
 }

@@ -31,6 +31,7 @@ import _dqo_native as N
 import threading
 
 _lock = threading.RLock()
+_list_split = 0         # DqoRastCtx.list_split of the forwards issued through this module (set_list_split)
 _sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy": reuse / grow the previous capacity, no sync
 _cap_hint = {}
 _pending = []          # lazy mode: (event, pinned header tensor, key, capacity) of forwards not yet verified
@@ -71,6 +72,16 @@ def last_header():
 def last_num_rendered():
     """Instance count N of the most recent forward that ran in 'exact' mode (statistics for benchmarks)."""
     return _last["num_rendered"]
+
+
+def set_list_split(longer_than):
+    """0 (default): the reference's front-to-back order of arithmetic in every tile list.  n > 0: the forward shares every list longer
+    than n entries between eight waves (DqoRastCtx.list_split, include/dqo_raster.h) — for renders of a few hundred tiles, a
+    strong-scaling shard, which cannot fill the GPU; results on those lists differ from the serial order in the last bits."""
+    global _list_split
+    if int(longer_than) < 0:
+        raise ValueError("list_split is 0 (off) or a list length")
+    _list_split = int(longer_than)
 
 
 def set_sync_mode(mode):
@@ -199,7 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        out_hit_depth_weight=hit_depth_weight.data_ptr(), out_T=T_map.data_ptr(),
                                        n_touched=N.ptr(n_touched), radii=N.ptr(radii))
             cctx = N.DqoRastCtx(geom=geomBuffer.data_ptr(), geom_bytes=geomBuffer.numel(), binning=None, binning_bytes=0,
-                                image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(), inst_capacity=0)
+                                image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(), inst_capacity=0, list_split=_list_split)
             if gate is not None:
                 cctx.object_gate = ctypes.addressof(gate)
             N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),

@@ -285,9 +285,22 @@ class FusedMapper:
         return dict(attach_mask=N.ptr(self.attach_mask), init_xyz=N.ptr(self.init_xyz), init_scaling_raw=N.ptr(self.init_scaling),
                     init_rotation_raw=N.ptr(self.init_rotation), attach_count=self.attach_count, attach_partial=N.ptr(self.attach_partial))
 
+    @staticmethod
+    def pick_list_split(list_split, tile_mask, st):
+        """DqoRastCtx.list_split of a capture: the list length given (0 = off), or for "auto" by the number of tiles the frame renders —
+        four waves per tile fill the 1024 SIMDs six deep at 1500 tiles; below that the forward's time is the time of its longest lists,
+        and the fewer tiles there are, the shorter the lists worth sharing between eight waves (measured on the shards of config 5,
+        DESIGN.md §6: 256 for an eighth of the frame, 1024 for a quarter; a full frame is faster with one wave per quadrant)."""
+        if list_split != "auto":
+            if int(list_split) < 0:
+                raise ValueError("list_split is 0 (off), a list length or 'auto'")
+            return int(list_split)
+        tiles = int((tile_mask != 0).sum().item()) if tile_mask is not None else ((st.image_width + 15) // 16) * ((st.image_height + 15) // 16)
+        return 256 if tiles <= 700 else 1024 if tiles <= 1800 else 0
+
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
-                loss_tap=True, reuse_probe=False, fused_tail=True):
+                loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
 
@@ -385,7 +398,8 @@ class FusedMapper:
                                          radii=o[8].data_ptr())
             g.cctx = N.DqoRastCtx(geom=g.geom.data_ptr(), geom_bytes=g.geom.numel(), binning=g.binning.data_ptr(),
                                   binning_bytes=g.binning.numel(), image=g.img.data_ptr(), image_bytes=g.img.numel(), inst_capacity=cap,
-                                  tile_bucket_capacity=g.bucket)
+                                  tile_bucket_capacity=g.bucket, list_split=self.pick_list_split(list_split, g.tile_mask, st))
+            g.list_split = list_split
             # DqoLossTap: the masked loss is summed by the forward's blend kernel and its gradient images are formed inside the
             # backward's (bit for bit what dqo_map_loss_fwd_bwd computes): no loss kernels, no passes over the full image
             g.tap = None
@@ -431,7 +445,7 @@ class FusedMapper:
                 self._last_probe = None
                 return self.capture(gt_color, gt_depth, render_mask, tile_mask=tile_mask, capacity_margin=capacity_margin,
                                     tile_buckets=tile_buckets, keep_tile_order=keep_tile_order, loss_tap=loss_tap, reuse_probe=False,
-                                    fused_tail=fused_tail)
+                                    fused_tail=fused_tail, list_split=list_split)
             if not self.graph_overflowed():  # (an invalid frame is a no-op for the optimiser and its step count)
                 self.step_count += 1
             # the eager iteration left its tile launch order in g.img; the replays keep it (DqoRastCtx.keep_tile_order: the order is
@@ -529,7 +543,7 @@ class FusedMapper:
                 # (capture() re-reads the device-side step count: the valid replays of this batch stay counted, the others do not)
                 self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
                              tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0, loss_tap=g.tap is not None,
-                             fused_tail=g.fused_tail)
+                             fused_tail=g.fused_tail, list_split=g.list_split)
                 recaptures += 1
         return recaptures
 

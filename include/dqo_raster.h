@@ -159,6 +159,14 @@ typedef struct DqoRastCtx {
     const DqoLossTap* loss_tap;
     /* NULL (default: the reference's semantics) or the object gate described above; read by the forward and by the backward. */
     const DqoObjectGate* object_gate;
+    /* 0 (default): every 8x8-pixel quadrant of a tile blends its list front to back in ONE wave, the reference's order of arithmetic.
+     * n > 0: lists longer than n entries (n < 64 counts as 64) are shared between eight waves in the forward — rounds of eight chunks of
+     * 64 entries: per chunk the product of (1 - alpha), a scan over the round, then the blend of every chunk from its scanned start
+     * state, and a merge by list position at the end — for launches that cannot fill the GPU, a strong-scaling shard of a few hundred
+     * tiles, whose time is the time of the one longest list.  The transmittance products are grouped by chunk, so results on those
+     * lists differ from the serial order in the last bits (1e-7 relative; a pixel exactly on T_threshold may finish one entry earlier
+     * or later); shorter lists are blended as with 0. */
+    int32_t list_split;
 } DqoRastCtx;
 
 /* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206).  dL_dcolors, dL_dcov3D and

@@ -38,3 +38,11 @@ print(f"cfg {cfg}: {T} tiles, {int(n.sum())} instances, mean {n.mean():.0f}, med
 for lo, hi in ((0, 64), (65, 256), (257, 512), (513, 1024), (1025, 2048), (2049, 4096), (4097, 8192), (8193, 1 << 30)):
     m = (n >= lo) & (n <= hi)
     print(f"  {lo:5d}..{hi if hi < 1 << 29 else 'inf':>5}: {int(m.sum()):5d} tiles, {int(n[m].sum()):9d} entries")
+# how far the blend actually walks the long lists (walk4: per quadrant, the last position any of its pixels used)
+w4 = img[off + al(8 * T):off + al(8 * T) + 16 * T].view(torch.int32).cpu().numpy().reshape(T, 4).astype(np.int64)
+for lo in (512, 1024, 2048):
+    m = n > lo
+    if m.any():
+        fr = w4[m] / n[m, None]
+        print(f"  lists > {lo}: {int(m.sum())} tiles; walked fraction per quadrant: mean {fr.mean():.2f}, median {np.median(fr):.2f}, "
+              f"p10 {np.quantile(fr, .1):.2f}, max {fr.max():.2f}; mean walked entries {w4[m].mean():.0f}, max {w4[m].max()}")
