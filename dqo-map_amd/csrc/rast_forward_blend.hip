@@ -127,7 +127,7 @@ constexpr int PART_STRIDE = FWD_BLK * 4;                    // floats per wave b
 constexpr int PART_WORDS = 14;                              // merge record of one (run, pixel): 13 x 64 floats <= PART_STRIDE
 static_assert(PART_WORDS * FWD_THREADS <= PART_STRIDE, "the merge record lives in the wave's own LDS block");
 
-template <bool GATE, int SEGS>
+template <bool GATE, int SEGS, bool PF>
 __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                                                const DqoRastOutputs& out, const DqoTapDev& tap, const DqoGateDev& gate, const int tile,
                                                const int quad, const int wave, const int lane, float4* const lds, const int skip_over) {
@@ -218,8 +218,16 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     // per-entry results of compacted entry k: was it live for this quadrant (bit k of live_m), and how many of the
     // quadrant's pixels saw it with T' > 0.5 (s_half[k]; n_touched, forward.cu:833-835, quirk B8)
     auto entries = [&]() {
+        // PF: the next entry's records are read from LDS while this one is blended (a read one past the chunk's last entry stays
+        // inside the wave's own block and is never used)
+        float4 xy_pf = make_float4(0.f, 0.f, 0.f, 0.f), co_pf = xy_pf, cs_pf = xy_pf;
+        int id_pf = 0, pos_pf = 0;
+        if (PF) xy_pf = s_xy[0], co_pf = s_co[0], cs_pf = s_rgb[0], id_pf = s_id[0], pos_pf = s_pos[0];
         for (int k = 0; k < cnt && !all_done; k++) {
-            const float4 xy_cur = s_xy[k], co_cur = s_co[k];
+            const float4 xy_cur = PF ? xy_pf : s_xy[k], co_cur = PF ? co_pf : s_co[k];
+            const float4 cs_now = cs_pf;
+            const int id_now = id_pf, pos_now = pos_pf;
+            if (PF) xy_pf = s_xy[k + 1], co_pf = s_co[k + 1], cs_pf = s_rgb[k + 1], id_pf = s_id[k + 1], pos_pf = s_pos[k + 1];
             // ---- per-pixel update (forward.cu:750-842), arithmetic gating instead of per-lane control flow ----
             // gate = 0 for a finished pixel, nohit = 0 once its depth is fixed: multiplying by them keeps the lane's
             // predicates in VGPRs (a lane mask that lives across the loop costs scalar bookkeeping in every trip).  An
@@ -232,9 +240,9 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             const float a_g = (power <= 0.0f && !other) ? alpha * pix_gate : 0.f;
             const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
             if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                const uint32_t contributor = (uint32_t)s_pos[k];
-                const float4 cs = s_rgb[k];
-                const int gid = s_id[k];
+                const uint32_t contributor = (uint32_t)(PF ? pos_now : s_pos[k]);
+                const float4 cs = PF ? cs_now : s_rgb[k];
+                const int gid = PF ? id_now : s_id[k];
                 const float a_v = valid ? alpha : 0.f;
                 const bool newhit = a_v * nohit >= hit_thr;  // valid, no depth yet, alpha >= opaque_threshold
                 if (__builtin_amdgcn_ballot_w64(newhit) != 0ull) {
@@ -479,13 +487,16 @@ __global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kerne
     const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
     if (tile_u == 0xffffffffu) return;  // unused slot
-    blend_quadrant<GATE, 1>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, 0, (int)threadIdx.x, lds, 0x7fffffff);
+    blend_quadrant<GATE, 1, false>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, 0, (int)threadIdx.x, lds, 0x7fffffff);
 }
 
 // DqoRastCtx.list_split: blocks of SPLIT_RUNS waves.  The first SPLIT_GRID blocks take the long lists (longer than list_split entries: the
 // queue tile_sort_wave_kernel left in img.split_tiles, longest first) one (tile, quadrant) at a time, every wave one run of the list,
 // each block drawing its next item with a ticket; they are dispatched first, so the longest critical paths start first.  Every other
 // block is eight independent waves of the serial kind: two tiles of one XCD band, four quadrants each, skipping the long lists.
+#ifndef SPLIT_PF
+#define SPLIT_PF true
+#endif
 constexpr int SPLIT_RUNS = 8;
 // (two blocks per CU at the gated kernel's 100 registers; held to 80 for three, it spills and measures the same)
 constexpr int SPLIT_GRID = 256;   // long-list blocks in front of the short-list blocks, and as many again behind them
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(FWD_THREADS * SPLIT_RUNS, 4) void blend_forward_spl
             __syncthreads();
             const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
             if (it >= items) return;
-            blend_quadrant<GATE, SPLIT_RUNS>(v, g, img, bin, out, tap, gate, (int)img.split_tiles[it >> 2], (int)(it & 3u), wave, lane, lds,
+            blend_quadrant<GATE, SPLIT_RUNS, SPLIT_PF>(v, g, img, bin, out, tap, gate, (int)img.split_tiles[it >> 2], (int)(it & 3u), wave, lane, lds,
                                              0x7fffffff);
             __syncthreads();  // wave 0 has read the other waves' merge records (and everyone this trip's ticket)
         }
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(FWD_THREADS * SPLIT_RUNS, 4) void blend_forward_spl
     if (slot >= T8) return;
     const uint32_t tile_u = img.tile_order[(b & 7) * T8 + slot];
     if (tile_u == 0xffffffffu) return;
-    blend_quadrant<GATE, 1>(v, g, img, bin, out, tap, gate, (int)tile_u, wave & 3, wave, lane, lds, list_split);
+    blend_quadrant<GATE, 1, SPLIT_PF>(v, g, img, bin, out, tap, gate, (int)tile_u, wave & 3, wave, lane, lds, list_split);
 }
 
 }  // namespace

@@ -286,17 +286,19 @@ class FusedMapper:
                     init_rotation_raw=N.ptr(self.init_rotation), attach_count=self.attach_count, attach_partial=N.ptr(self.attach_partial))
 
     @staticmethod
-    def pick_list_split(list_split, tile_mask, st):
+    def pick_list_split(list_split, tile_mask, st, longest=0):
         """DqoRastCtx.list_split of a capture: the list length given (0 = off), or for "auto" by the number of tiles the frame renders —
         four waves per tile fill the 1024 SIMDs six deep at 1500 tiles; below that the forward's time is the time of its longest lists,
         and the fewer tiles there are, the shorter the lists worth sharing between eight waves (measured on the shards of config 5,
-        DESIGN.md §6: 256 for an eighth of the frame, 1024 for a quarter; a full frame is faster with one wave per quadrant)."""
+        DESIGN.md §6: 256 for an eighth of the frame, 1024 for a quarter).  A frame that fills the GPU is faster with one wave per
+        quadrant unless a few of its lists (`longest`: the longest list of the state the capture is taken on) are several times as
+        long as the rest — then only those are shared."""
         if list_split != "auto":
             if int(list_split) < 0:
                 raise ValueError("list_split is 0 (off), a list length or 'auto'")
             return int(list_split)
         tiles = int((tile_mask != 0).sum().item()) if tile_mask is not None else ((st.image_width + 15) // 16) * ((st.image_height + 15) // 16)
-        return 256 if tiles <= 700 else 1024 if tiles <= 1800 else 0
+        return 256 if tiles <= 700 else 1024 if tiles <= 1800 else 2048 if longest > 4096 else 0
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
@@ -398,7 +400,7 @@ class FusedMapper:
                                          radii=o[8].data_ptr())
             g.cctx = N.DqoRastCtx(geom=g.geom.data_ptr(), geom_bytes=g.geom.numel(), binning=g.binning.data_ptr(),
                                   binning_bytes=g.binning.numel(), image=g.img.data_ptr(), image_bytes=g.img.numel(), inst_capacity=cap,
-                                  tile_bucket_capacity=g.bucket, list_split=self.pick_list_split(list_split, g.tile_mask, st))
+                                  tile_bucket_capacity=g.bucket, list_split=self.pick_list_split(list_split, g.tile_mask, st, longest))
             g.list_split = list_split
             # DqoLossTap: the masked loss is summed by the forward's blend kernel and its gradient images are formed inside the
             # backward's (bit for bit what dqo_map_loss_fwd_bwd computes): no loss kernels, no passes over the full image
