@@ -265,6 +265,9 @@ def attach_reducer(prob, world):
     return lambda n: prob["n_attach_full"]
 
 
+GROWTH_SPARE_ROWS = 32768  # FusedMapper.reserve: room for ~20 growth steps of cfg 5 (1 300 new Gaussians each) before a re-allocation
+
+
 class FusedRunner:
     """The fused path of one rank: a FusedMapper on the rank's shard, one hipGraph replay per iteration, the packed all-reduce of
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
@@ -275,6 +278,13 @@ class FusedRunner:
         self.fm = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=attach_reducer(prob, world))
         if prob.get("gate") is not None:
             self.fm.set_object_gate(prob["gate"][0], prob["gate"][1])
+        self.stable_mask = None
+        if growth_every:
+            # the reference's two clouds (mapper.py:1351-1466): the map the run starts from is the stable cloud, what the growth steps add
+            # is the unstable one.  Spare rows (FusedMapper.reserve) make the steps in place: no re-allocation, no re-capture.
+            P0 = self.fm.P
+            self.fm.reserve(GROWTH_SPARE_ROWS)
+            self.stable_mask = torch.arange(self.fm.P, device=device) < P0
         self.mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
         self.use_graph, self.loss_tap, self.fused_tail, self.list_split = use_graph, loss_tap, fused_tail, list_split
         self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
@@ -308,14 +318,28 @@ class FusedRunner:
             keep = mg.temp_points_filter_mask(b["xyz"], fm.xyz, fm.radius())
             sc = b["scales"]
             mg.update_geometry_scales(b["xyz"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(), 0.001, 0.05)
+            if self.stable_mask is not None:  # (on a thread and a stream of its own, as grow() runs it)
+                import threading
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream())
+
+                def warm():
+                    with torch.cuda.device(self.device), torch.cuda.stream(side), torch.no_grad():
+                        fm._temp_points_attach(b["xyz"], b["opacity"].reshape(-1, 1), self.stable_mask, 0.1)
+                th = threading.Thread(target=warm)
+                th.start()
+                th.join()
+                torch.cuda.current_stream().wait_stream(side)
             del keep
             torch.cuda.synchronize()
 
     def grow(self):
-        """cfg 5's growth step: 40 800 new surfel points -> temp_points_filter (dqo_knn3_query) -> update_geometry
-        (dqo_knn3) -> concat; delete = the per-Gaussian depth error of the last frame above 2 x add_depth_thres
-        (accumulate_gaussian_error, mapper.py:1034-1075); new mapping call (fresh Adam + init_stat, mapper.py:533-548) and graph
-        re-capture on the re-allocated buffers.  Everything on the GPU, no process restart."""
+        """cfg 5's growth step: 40 800 new surfel points -> temp_points_filter against the unstable cloud
+        (dqo_knn3_query) -> temp_points_attach against a render of the stable cloud -> update_geometry (dqo_knn3) -> the survivors take
+        spare rows of the map; delete = the per-Gaussian depth error of the last frame above 2 x add_depth_thres
+        (accumulate_gaussian_error, mapper.py:1034-1075), the deleted become spare rows; new mapping call (fresh Adam + init_stat + attach
+        set, mapper.py:533-548), all in place: the captured graph goes on.  (Out of spare rows: re-allocation + re-capture.)  Everything
+        on the GPU, no process restart."""
         from dqo_harness import scenes
         from cuda_utils._C import accumulate_gaussian_error
         fm, p = self.fm, self.prob
@@ -338,17 +362,25 @@ class FusedRunner:
             delete = (g_depth.reshape(-1) > 2 * 0.1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        st = fm.grow(new, delete_mask=delete, new_mapping_call=True)  # (fresh Adam + init_stat: mapper.py:533-548)
+        if self.use_graph and fm.graph_overflowed():
+            raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
+        st = fm.grow(new, delete_mask=delete, new_mapping_call=True, stable_mask=self.stable_mask)  # (fresh Adam + init_stat: mapper.py:533-548)
+        st.pop("rows", None)
+        kept = st.pop("kept_rows", None)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        if self.use_graph:
+        if not st.get("in_place", False):  # (the spare rows ran out: the map was compacted into new buffers)
+            old = self.stable_mask if kept is None else self.stable_mask[kept]
+            self.stable_mask = torch.cat([old, torch.zeros(fm.P - old.numel(), dtype=torch.bool, device=self.device)])
+        if self.use_graph and fm._g is None:
             self._capture(reuse_probe=True)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         st["ms"] = round((t3 - t0) * 1e3, 2)
-        st["ms_parts"] = dict(new_points_and_error_accumulation=round((t1 - t0) * 1e3, 2), filter_knn_scale_init_concat_new_mapping_call=round((t2 - t1) * 1e3, 2),
+        st["ms_parts"] = dict(new_points_and_error_accumulation=round((t1 - t0) * 1e3, 2), filter_attach_scale_init_new_mapping_call=round((t2 - t1) * 1e3, 2),
                               recapture=round((t3 - t2) * 1e3, 2))
-        st["P_after"] = fm.P
+        st["P_after"] = fm.n_alive
+        st["attach_set"] = fm.attach_count
         self.growth_log.append(st)
 
     def step(self):

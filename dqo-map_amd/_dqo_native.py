@@ -67,7 +67,7 @@ class DqoAdamStep(ctypes.Structure):
                                      "g_scales", "g_rotations", "m_xyz", "m_shs", "m_opacity", "m_scaling", "m_rotation", "v_xyz",
                                      "v_shs", "v_opacity", "v_scaling", "v_rotation", "act_opacity", "act_scales", "act_rotations", "radii", "step_dev", "moment_live",
                                      "attach_mask", "init_xyz", "init_scaling_raw", "init_rotation_raw")] +
-                [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp), ("block_ticket", c_vp), ("bias_table", c_vp)])
+                [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp), ("block_ticket", c_vp), ("bias_table", c_vp), ("attach_gains", c_vp)])
 
 
 EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",

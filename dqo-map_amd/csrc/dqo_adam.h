@@ -30,6 +30,7 @@ struct AdamArgs {
     int32_t* step_advance;                                                        // optional: the last block to finish adds 1 to it
     int32_t* block_ticket;                                                        // (with step_advance) blocks finished so far
     float* bias_table;                                                            // optional (with step_dev): DqoAdamStep.bias_table
+    const float* attach_gains;                                                    // optional: DqoAdamStep.attach_gains (replaces attach_g3/4)
 };
 
 // host side: DqoAdamStep -> AdamArgs (argument checks included); blocks = the launch's grid size (for the step-advance ticket)
@@ -100,6 +101,10 @@ __device__ __forceinline__ void adam_bias_to_lds(const AdamArgs& a, float* s_ss 
         return;
     }
     adam_bias_compute(a, step, s_ss);
+}
+// DqoAdamStep.attach_gains: the attach term's two factors from device memory (uniform loads)
+__device__ __forceinline__ void adam_attach_gains(AdamArgs& a) {
+    if (a.attach_gains != nullptr) a.attach_g3 = a.attach_gains[0], a.attach_g4 = a.attach_gains[1];
 }
 __device__ __forceinline__ void adam_bias_from_lds(AdamArgs& a, const float* s_ss) {
     a.bc2_sqrt = s_ss[0], a.step_xyz = s_ss[1], a.step_dc = s_ss[2], a.step_rest = s_ss[3], a.step_opacity = s_ss[4];

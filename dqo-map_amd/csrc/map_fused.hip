@@ -276,6 +276,7 @@ __device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ mom
     if (lane == 0) s_wave_n[wave] = (int)__popcll(am);
     __syncthreads();
     if (a.step_dev != nullptr) adam_bias_from_lds(a, s_ss);
+    if (ATTACH) adam_attach_gains(a);
     int before = 0, n_rows = 0;
 #pragma unroll
     for (int w = 0; w < ADAM_THREADS / 64; w++) {
@@ -361,12 +362,13 @@ int dqo_adam_args(const DqoAdamStep* st, int blocks, AdamArgs* out, bool* attach
     const bool advance_inside = st->step_dev != nullptr && st->block_ticket != nullptr && blocks > 0;
     a.step_advance = advance_inside ? st->step_dev : nullptr, a.block_ticket = st->block_ticket;
     a.bias_table = (advance_inside && st->step_dev != nullptr) ? st->bias_table : nullptr;
-    const bool attach = st->attach_mask != nullptr && st->attach_count > 0;
+    const bool attach = st->attach_mask != nullptr && (st->attach_count > 0 || st->attach_gains != nullptr);
+    a.attach_gains = attach ? st->attach_gains : nullptr;
     DQO_CHECK_ARG(!attach || (st->init_xyz && st->init_scaling_raw && st->init_rotation_raw), "attach_mask needs the three init_* tensors");
     DQO_CHECK_ARG(st->P < (1 << 30), "P must stay below 2^30");
     // d/dp of 1000 * mean((p - p0)^2) over |a| rows of 3 (scaling, xyz) / 4 (rotation) elements = 2000 (p - p0) / (len |a|)
-    a.attach_g3 = attach ? (float)(2000.0 / (3.0 * (double)st->attach_count)) : 0.f;
-    a.attach_g4 = attach ? (float)(2000.0 / (4.0 * (double)st->attach_count)) : 0.f;
+    a.attach_g3 = (attach && st->attach_count > 0) ? (float)(2000.0 / (3.0 * (double)st->attach_count)) : 0.f;
+    a.attach_g4 = (attach && st->attach_count > 0) ? (float)(2000.0 / (4.0 * (double)st->attach_count)) : 0.f;
     DQO_CHECK_ARG(st->M >= 0 && st->M * 3 < 256, "M out of range");
     a.row_magic = st->M > 0 ? ((1ull << 39) + (uint64_t)(3 * st->M) - 1) / (uint64_t)(3 * st->M) : 0ull;
     DQO_CHECK_ARG((int64_t)st->P * (st->M > 0 ? st->M : 1) * 3 < (int64_t)0x7fffffff, "P * M * 3 must stay below 2^31");

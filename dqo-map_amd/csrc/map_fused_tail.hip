@@ -88,6 +88,7 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
         adam_bias_to_lds(a, ss);
         adam_bias_from_lds(a, ss);
     }
+    if (ATTACH) adam_attach_gains(a);
     if (tid == 0) s_lohi[0] = 0xffffffffu, s_lohi[1] = 0u;
     const int idx = dqo_spread_index(blockIdx.x * TAIL_THREADS + tid, v.P);  // bin_count_kernel's thread -> Gaussian assignment
     const bool in_range = idx < v.P;

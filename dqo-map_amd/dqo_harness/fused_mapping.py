@@ -106,6 +106,10 @@ class FusedMapper:
         self.attach_count_reducer = attach_count_reducer
         self.gaussian_object = self.pixel_object = self.tile_objects = None  # set_object_gate()
         self.per_object_loss = False
+        self.alive = None  # reserve(): uint8 [P], 0 = a spare row (parked behind the camera, no Gaussian of the map)
+        # DqoAdamStep.attach_gains: the attach term's two factors in device memory, rewritten in place by begin_mapping_call — a captured
+        # graph survives a new mapping call
+        self.attach_gains = torch.zeros((2,), dtype=torch.float32, device=device)
         self.begin_mapping_call(reset_optimizer=False)
         P = self.P
         f = dict(dtype=torch.float32, device=device)
@@ -147,14 +151,23 @@ class FusedMapper:
     def begin_mapping_call(self, reset_optimizer=True):
         """Start of one `local_optimize` call (SLAM/multiprocess/mapper.py:531-548): snapshot `init_stat` (the raw parameters the
         attach loss pulls towards, :533-545, and the attach set `sigmoid(opacity) < 0.9`, :812-813) and — reset_optimizer — drop the
-        Adam moments, because the reference builds a fresh torch.optim.Adam per call (:548, B13)."""
-        self.init_xyz, self.init_scaling, self.init_rotation = self.xyz.clone(), self.scaling_raw.clone(), self.rotation_raw.clone()
-        self.attach_mask = (torch.sigmoid(self.opacity_raw) < 0.9).reshape(-1).to(torch.uint8).contiguous()
-        self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
-        if self.use_attach and self.attach_count_reducer is not None:
-            self.attach_count = int(self.attach_count_reducer(self.attach_count))
-        # (one partial sum per block of 256 Gaussians from dqo_map_adam_step, per wave of 64 from dqo_rast_backward_adam)
-        self.attach_partial = torch.zeros((4 * ((self.xyz.shape[0] + 255) // 256),), dtype=torch.float32, device=self.device)
+        Adam moments, because the reference builds a fresh torch.optim.Adam per call (:548, B13).  Everything is rewritten in place
+        when the map has kept its size (buffers, attach set and its size live in device memory: a captured graph stays valid)."""
+        P = self.xyz.shape[0]
+        mask = (torch.sigmoid(self.opacity_raw) < 0.9).reshape(-1)
+        if self.alive is not None:
+            mask &= self.alive.bool()  # (a spare row is no Gaussian of the map)
+        same = getattr(self, "init_xyz", None) is not None and self.init_xyz.shape[0] == P and self.attach_mask.shape[0] == P
+        if same:
+            self.init_xyz.copy_(self.xyz), self.init_scaling.copy_(self.scaling_raw), self.init_rotation.copy_(self.rotation_raw)
+            self.attach_mask.copy_(mask)
+            self.attach_partial.zero_()
+        else:
+            self.init_xyz, self.init_scaling, self.init_rotation = self.xyz.clone(), self.scaling_raw.clone(), self.rotation_raw.clone()
+            self.attach_mask = mask.to(torch.uint8).contiguous()
+            # (one partial sum per block of 256 Gaussians from dqo_map_adam_step, per wave of 64 from dqo_rast_backward_adam)
+            self.attach_partial = torch.zeros((4 * ((P + 255) // 256),), dtype=torch.float32, device=self.device)
+        self._count_attach_set()
         self._attach_n = 0
         if reset_optimizer:
             for m, v in self.state.values():
@@ -165,7 +178,17 @@ class FusedMapper:
             if getattr(self, "_g", None) is not None:
                 self._g.step_dev.fill_(1)
                 self._g.expected_step = 1
-                self._g.stale = True  # the captured kernel arguments (attach set, its size) were fixed at capture time
+        if getattr(self, "_g", None) is not None and not (same and getattr(self._g, "attach_in_place", False)):
+            self._g.stale = True  # the captured kernel arguments (attach set buffers) were fixed at capture time
+
+    def _count_attach_set(self):
+        self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
+        if self.use_attach and self.attach_count_reducer is not None:
+            self.attach_count = int(self.attach_count_reducer(self.attach_count))
+        n = self.attach_count
+        # the two factors exactly as the library derives them from attach_count: double arithmetic, rounded to float once
+        self.attach_gains.copy_(torch.tensor([2000.0 / (3.0 * n), 2000.0 / (4.0 * n)] if n > 0 else [0.0, 0.0], dtype=torch.float64)
+                                .to(torch.float32))
 
     # ------------------------------------------------------------------ map growth ---------------------------------------
     def radius(self):
@@ -173,9 +196,73 @@ class FusedMapper:
         sc = torch.exp(self.scaling_raw)
         return (sc.sum(dim=1) - sc.min(dim=1).values) / 2
 
+    def normals(self, rows=None):
+        """GaussianPointCloud.get_normal (SLAM/gaussian_pointcloud.py:780-791): the column of R(q / |q|) along the smallest scale,
+        normalised with the reference's + 1e-8 (utils/general_utils.py:108-137 build_rotation)."""
+        q = self.rotation_raw if rows is None else self.rotation_raw[rows]
+        sc = self.scaling_raw if rows is None else self.scaling_raw[rows]
+        q = q / torch.sqrt((q * q).sum(1, keepdim=True))
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        cols = (torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y + r * z), 2 * (x * z - r * y)], 1),
+                torch.stack([2 * (x * y - r * z), 1 - 2 * (x * x + z * z), 2 * (y * z + r * x)], 1),
+                torch.stack([2 * (x * z + r * y), 2 * (y * z - r * x), 1 - 2 * (x * x + y * y)], 1))
+        k = torch.argmin(sc, dim=1)  # (exp is monotone: the smallest raw scale is the smallest scale)
+        nrm = torch.where((k == 0)[:, None], cols[0], torch.where((k == 1)[:, None], cols[1], cols[2]))
+        return nrm / (torch.sqrt((nrm * nrm).sum(1, keepdim=True)) + 1e-8)
+
+    def _park_position(self):
+        """Where spare rows sit: 10^4 units behind the camera of this mapper's settings — culled by the frustum test (p_view.z <= 0.2,
+        forward.cu:258-262) like any Gaussian behind the camera, and far from every search box of the growth step."""
+        V = self.settings.viewmatrix  # world_view_transform as the reference passes it: p_view = p @ V[:3, :3] + V[3, :3]
+        return (self.settings.campos.reshape(3) - 1.0e4 * V[:3, 2]).to(torch.float32)
+
+    @torch.no_grad()
+    def reserve(self, spare_rows):
+        """Room for `spare_rows` more Gaussians in every per-Gaussian buffer, so that a growth step writes the new Gaussians into spare
+        rows and turns deleted ones into spare rows IN PLACE: no re-allocation, and a captured graph (whose kernel arguments are these
+        buffers and their length) stays valid across growth steps and mapping calls.  A spare row is parked behind the camera
+        (_park_position) with the raw parameters of a tiny transparent Gaussian: the preprocess stage culls it, it gets no gradient, the
+        sparse Adam never touches it, it is in no attach set — the map behaves as if the row did not exist, at the cost of the
+        per-Gaussian kernels looking at it.  `alive` [P] uint8 tells the rows apart.  Call before capture()."""
+        n = int(spare_rows)
+        if n <= 0:
+            return self
+        dev, P0 = self.device, self.xyz.shape[0]
+
+        def pad(a, fill):
+            tail = torch.empty((n,) + tuple(a.shape[1:]), dtype=a.dtype, device=dev)
+            tail[:] = fill if not torch.is_tensor(fill) else fill.to(a.dtype)
+            return torch.cat([a, tail]).contiguous()
+
+        park = self._park_position()
+        unit_q = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev)
+        self.alive = pad(self.alive if self.alive is not None else torch.ones((P0,), dtype=torch.uint8, device=dev), 0)
+        self.init_xyz, self.init_scaling, self.init_rotation = pad(self.init_xyz, park), pad(self.init_scaling, -10.0), pad(self.init_rotation, unit_q)
+        self.xyz, self.shs = pad(self.xyz, park), pad(self.shs, 0.0)
+        self.opacity_raw, self.scaling_raw, self.rotation_raw = pad(self.opacity_raw, -10.0), pad(self.scaling_raw, -10.0), pad(self.rotation_raw, unit_q)
+        self.state = {k: (pad(m, 0.0), pad(v, 0.0)) for k, (m, v) in self.state.items()}
+        if self.moment_live is not None:
+            self.moment_live = pad(self.moment_live, 0)
+        if self.gaussian_object is not None:
+            self.gaussian_object = pad(self.gaussian_object, 0)
+        self.attach_mask = pad(self.attach_mask, 0)
+        self._spare_rows = n
+        self.P = P = P0 + n
+        f = dict(dtype=torch.float32, device=dev)
+        self.opacity, self.scales, self.rotations = torch.empty((P, 1), **f), torch.empty((P, 3), **f), torch.empty((P, 4), **f)
+        self.attach_partial = torch.zeros((4 * ((P + 255) // 256),), **f)
+        self._attach_n = 0
+        self._act_valid = False
+        self._g = None
+        return self
+
+    @property
+    def n_alive(self):
+        return self.P if self.alive is None else int(self.alive.sum().item())
+
     @torch.no_grad()
     def grow(self, new, delete_mask=None, min_radius=0.001, max_radius=0.05, xyz_factor=(1.0, 1.0, 0.1), scale_factor=1.0,
-             new_mapping_call=False):
+             new_mapping_call=False, stable_mask=None, unstable_opacity_low=0.1):
         """The map-growth step between two mapping calls — Mapping.gaussians_add (SLAM/multiprocess/mapper.py:249-254) and the
         deletion half of error_gaussians_remove (:1086-1096) — on this mapper's map:
           1. temp_points_filter (:1351-1380): new points that fall inside an existing Gaussian (one of their 3 nearest existing
@@ -186,8 +273,17 @@ class FusedMapper:
           3. delete_mask [P] bool (optional): existing Gaussians to delete (the reference derives it from
              accumulate_gaussian_error's per-Gaussian depth error, cuda_utils._C);
           4. cat (:1466): the rest joins the map with zero Adam moments.
-        (temp_points_attach, :1384-1436, needs the stable / unstable split of the reference's two point clouds and is not part of
-        this mapper.)  `new`: dict(xyz [Q,3], scales [Q,3], rotations [Q,4], opacity [Q,1], shs [Q,M,3]) of numpy arrays or GPU
+        stable_mask [P] bool (optional) is the reference's split into its two clouds — 1 = a Gaussian of `stable_pointcloud`, 0 = of the
+        unstable `pointcloud` — and switches on the two steps that need it:
+          1'. the filter of step 1 looks at the UNSTABLE Gaussians only (:1356-1357, unstable_params);
+          1b. temp_points_attach (:1384-1436): the survivors of step 1 that project onto a pixel whose strongest contributor in a render
+             of the STABLE Gaussians alone exists and whose plane they lie within 0.5 x add_depth_thres of get opacity
+             `unstable_opacity_low` — which makes them members of the next mapping call's attach set (opacity < 0.9).  The stable-only
+             render is this mapper's map with the other Gaussians parked behind the camera (the index map is the stable cloud's, in
+             map rows).
+        With reserve()d spare rows and new_mapping_call=True the step is IN PLACE: deleted Gaussians become spare rows, new ones take
+        spare rows (row order then differs from the reference's cat; nothing depends on it), no buffer moves and a captured graph
+        stays valid; it falls back to re-allocation (with the same number of spare rows again) when the spare rows run out.  `new`: dict(xyz [Q,3], scales [Q,3], rotations [Q,4], opacity [Q,1], shs [Q,M,3]) of numpy arrays or GPU
         tensors.  Per-Gaussian buffers are re-allocated: a captured graph is dropped (capture() again), and the next mapping
         call starts with begin_mapping_call() — new_mapping_call=True does that here (fresh Adam, fresh init_stat, as the reference
         does after every growth step, mapper.py:533-548) and then neither gathers nor concatenates the old moments and snapshots,
@@ -203,20 +299,58 @@ class FusedMapper:
                 raise RuntimeError("FusedMapper.grow: with an object gate the new points need 'obj_id'")
             nobj = torch.as_tensor(new["obj_id"]).to(dev, torch.int32).reshape(-1)
         stats = dict(candidates=int(Q), inside_existing=0, invalid_scale=0, added=0, deleted=0)
-        exist_xyz, exist_radius = self.xyz, self.radius()
+        exist_xyz, exist_radius = self.xyz, self.radius()  # (spare rows sit 10^4 units away: outside every search box)
         keep = torch.ones((Q,), dtype=torch.bool, device=dev)
         if Q > 0:
-            inside = mg.temp_points_filter_mask(nx, exist_xyz, exist_radius)
+            if stable_mask is None:
+                inside = mg.temp_points_filter_mask(nx, exist_xyz, exist_radius)
+            else:  # the reference filters against its unstable cloud
+                un = ~stable_mask.to(dev).bool().reshape(-1)
+                if self.alive is not None:
+                    un &= self.alive.bool()
+                un = un.nonzero().reshape(-1)
+                inside = mg.temp_points_filter_mask(nx, exist_xyz[un], exist_radius[un])
             if inside is not None:
                 keep &= ~inside
                 stats["inside_existing"] = int(inside.sum().item())
         idx = keep.nonzero().reshape(-1)
         nx, nsc, nrot, nop, nsh = nx[idx], nsc[idx], nrot[idx], nop[idx], nsh[idx]
         nobj = None if nobj is None else nobj[idx]
+        attach_job = None
+        if stable_mask is not None and nx.shape[0] > 0:
+            # temp_points_attach only changes opacities, update_geometry only reads positions and radii: the two run side by side (the
+            # attach on a stream and a host thread of its own — both wait on the host for small results in between their kernels)
+            import threading
+            if not self._act_valid:
+                N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
+                                                 N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
+                self._act_valid = True
+            side, box = torch.cuda.Stream(device=dev), {}
+            side.wait_stream(torch.cuda.current_stream())
+
+            def attach_work(tx=nx, to=nop):
+                try:
+                    with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad():
+                        box["att"] = self._temp_points_attach(tx, to, stable_mask, unstable_opacity_low)
+                except BaseException as e:  # (re-raised by the caller's thread)
+                    box["err"] = e
+
+            attach_job = threading.Thread(target=attach_work)
+            attach_job.start()
         log_scales = None
         if nx.shape[0] > 0:
             nrad = (nsc.sum(dim=1) - nsc.min(dim=1).values) / 2
             scales, invalid = mg.update_geometry_scales(nx, nrad, exist_xyz, exist_radius, min_radius, max_radius)
+        if attach_job is not None:
+            attach_job.join()
+            torch.cuda.current_stream().wait_stream(side)
+            if "err" in box:
+                raise box["err"]
+            att = box["att"]
+            stats["attached"] = int(att.numel())
+            nop = nop.clone()
+            nop[att] = unstable_opacity_low
+        if nx.shape[0] > 0:
             stats["invalid_scale"] = int(invalid.sum().item())
             ok = (~invalid).nonzero().reshape(-1)
             if ok.numel() > 0:  # gaussian_pointcloud.py:558-568
@@ -228,13 +362,45 @@ class FusedMapper:
             nx, nrot, nop, nsh = nx[:0], nrot[:0], nop[:0], nsh[:0]
             nobj = None if nobj is None else nobj[:0]
             log_scales = torch.empty((0, 3), dtype=torch.float32, device=dev)
+        stats["added"] = n_add = int(nx.shape[0])
+        opc = nop.clamp(1e-4, 1 - 1e-4)
+        spare = 0 if self.alive is None else self.P - int(self.alive.sum().item())
+        if self.alive is not None:
+            dm = torch.zeros((self.P,), dtype=torch.bool, device=dev) if delete_mask is None else delete_mask.to(dev).bool().reshape(-1)
+            dm = dm & self.alive.bool()
+            stats["deleted"] = n_del = int(dm.sum().item())
+            if new_mapping_call and n_add <= spare + n_del:
+                # ---- in place: deleted Gaussians become spare rows, the new ones take spare rows ----
+                if n_del:
+                    self.alive[dm] = 0
+                    self.xyz[dm] = self._park_position()
+                    self.opacity_raw[dm], self.scaling_raw[dm] = -10.0, -10.0
+                if n_add:
+                    rows = (self.alive == 0).nonzero().reshape(-1)[:n_add]
+                    self.xyz[rows], self.shs[rows], self.rotation_raw[rows] = nx, nsh, nrot
+                    self.opacity_raw[rows], self.scaling_raw[rows] = torch.log(opc / (1 - opc)), log_scales
+                    if self.gaussian_object is not None:
+                        self.gaussian_object[rows] = nobj
+                    self.alive[rows] = 1
+                    stats["rows"] = rows
+                # (a captured iteration starts from the activations its previous Adam launch left: bring them up to date for the new rows)
+                N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
+                                                 N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
+                self._act_valid = True
+                self.begin_mapping_call(reset_optimizer=True)  # in place too: fresh moments, fresh init_stat, the new attach set
+                stats["in_place"] = True
+                return stats
+            # spare rows exhausted (or the mapping call goes on): compact — spare rows go with the deleted ones — and reserve again
+            delete_mask = dm | ~self.alive.bool()
+            self.alive = None
+            stats["in_place"] = False
         keep_old = None
         if delete_mask is not None:
             keep_old = (~delete_mask.to(dev).bool().reshape(-1)).nonzero().reshape(-1)
-            stats["deleted"] = int(self.P - keep_old.numel())
-        stats["added"] = int(nx.shape[0])
+            if "deleted" not in stats or stats.get("in_place") is None:
+                stats["deleted"] = int(self.P - keep_old.numel())
         sel = (lambda a: a) if keep_old is None else (lambda a: a[keep_old])
-        opc = nop.clamp(1e-4, 1 - 1e-4)
+        stats["kept_rows"] = keep_old  # (None = all of them, in place) the old rows that now lead the map, for per-row data of the caller's
         self.xyz = torch.cat([sel(self.xyz), nx]).contiguous()
         self.shs = torch.cat([sel(self.shs), nsh]).contiguous()
         self.opacity_raw = torch.cat([sel(self.opacity_raw), torch.log(opc / (1 - opc))]).contiguous()
@@ -259,8 +425,12 @@ class FusedMapper:
         self.opacity, self.scales, self.rotations = torch.empty((P, 1), **f), torch.empty((P, 3), **f), torch.empty((P, 4), **f)
         self._act_valid = False
         self._g = None
+        refill = stats.get("in_place") is False  # the map had spare rows and ran out of them: the same number again
         if new_mapping_call:
+            self.init_xyz = None  # (sizes changed: begin_mapping_call takes fresh snapshots)
             self.begin_mapping_call(reset_optimizer=True)
+            if refill:
+                self.reserve(self._spare_rows)
             return stats
         # init_stat / attach set: kept for the old Gaussians, the new ones start at their own values (they have not moved);
         # a new mapping call re-snapshots everything (begin_mapping_call)
@@ -268,22 +438,53 @@ class FusedMapper:
         self.init_scaling = torch.cat([sel(self.init_scaling), log_scales])
         self.init_rotation = torch.cat([sel(self.init_rotation), nrot])
         self.attach_mask = torch.cat([sel(self.attach_mask), (nop.reshape(-1) < 0.9).to(torch.uint8)]).contiguous()
-        self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
-        if self.use_attach and self.attach_count_reducer is not None:
-            self.attach_count = int(self.attach_count_reducer(self.attach_count))
+        self._count_attach_set()
         self.attach_partial = torch.zeros((4 * ((P + 255) // 256),), **f)
         self._attach_n = 0
+        if refill:
+            self.reserve(self._spare_rows)
         return stats
+
+    def _temp_points_attach(self, temp_xyz, temp_opacity, stable_mask, unstable_opacity_low):
+        """mapper.py:1384-1436 on this mapper's map: indices (into the temp points) that fall onto the stable cloud's surfaces."""
+        import dqo_mapgrowth as mg
+        from . import mapping
+        st, dev = self.settings, self.device
+        sm = stable_mask.to(dev).bool().reshape(-1)
+        if self.alive is not None:
+            sm = sm & self.alive.bool()
+        if not self._act_valid:
+            N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
+                                             N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
+            self._act_valid = True
+        # the stable cloud alone = the map with every other Gaussian parked behind the camera (culled before the binning, so the tile
+        # lists are the stable cloud's), indices in map rows.  One quirk to carry over: a tile that renders nothing keeps the op's
+        # zero fill, which the reference's `>= 0` test reads as a hit on Gaussian 0 OF THE STABLE CLOUD (F3 / rasterize_points.cu:79-89)
+        # — here that is the first stable row, and such a pixel is told from a real hit on row 0 by its zero weight.
+        if not bool(sm.any()):
+            return torch.empty((0,), dtype=torch.long, device=dev)
+        first = torch.argmax(sm.to(torch.uint8)).reshape(1)  # (the first stable row)
+        data = dict(xyz=torch.where(sm[:, None], self.xyz, self._park_position()[None, :]), opacity=self.opacity, scales=self.scales,
+                    rotations=self.rotations, shs=self.shs)
+        out = mapping.render(st, data)
+        cim = out["color_index_map"]
+        cim = torch.where((cim == 0) & (out["color_hit_weight"] == 0), first.to(cim.dtype).reshape(1, 1, 1), cim)
+        H, W = int(st.image_height), int(st.image_width)
+        K = torch.tensor([[W / (2.0 * st.tanfovx), 0.0, st.cx], [0.0, H / (2.0 * st.tanfovy), st.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+        return mg.temp_points_attach_indices(temp_xyz, temp_opacity, st.viewmatrix.T.contiguous(), K, W, H, cim, self.xyz,
+                                             lambda rows: self.normals(rows), self.add_depth_thres, unstable_opacity_low)
 
     def attach_loss(self):
         """The reference's reported "scale_loss" of the most recent iteration (attach loss at its pre-update parameters)."""
         return self.attach_partial[:self._attach_n].sum()
 
     def _attach_fields(self):
-        if not self.use_attach or self.attach_count == 0:
+        if not self.use_attach:
             return dict(attach_mask=None, init_xyz=None, init_scaling_raw=None, init_rotation_raw=None, attach_count=0, attach_partial=None)
+        # (attach_gains: the set's size is read from device memory when the launch runs — an empty set costs the mask read)
         return dict(attach_mask=N.ptr(self.attach_mask), init_xyz=N.ptr(self.init_xyz), init_scaling_raw=N.ptr(self.init_scaling),
-                    init_rotation_raw=N.ptr(self.init_rotation), attach_count=self.attach_count, attach_partial=N.ptr(self.attach_partial))
+                    init_rotation_raw=N.ptr(self.init_rotation), attach_count=self.attach_count, attach_partial=N.ptr(self.attach_partial),
+                    attach_gains=N.ptr(self.attach_gains))
 
     @staticmethod
     def pick_list_split(list_split, tile_mask, st, longest=0):
@@ -376,6 +577,7 @@ class FusedMapper:
             g.mask = None if render_mask is None else render_mask.to(torch.uint8).contiguous()
             g.tile_mask = tile_mask
             g.stale = False
+            g.attach_in_place = True  # attach set, init_stat and its size are read from device memory at every replay
             g.fused_tail = bool(fused_tail) and M <= 16
             g.out = (torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **i32), torch.empty((1, H, W), **i32),
                      torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **f), torch.empty((P,), **i32),
@@ -519,6 +721,7 @@ class FusedMapper:
         if g.expected_step != self.step_count + 1:  # eager step() calls in between: resynchronise the device-side step count
             g.step_dev.fill_(self.step_count + 1)
         g.graph.replay()
+        self._attach_n = ((self.P + 255) // 256) * (4 if g.fused_tail else 1)  # (a new mapping call in between had reset it)
         self.step_count += 1  # (assumes a valid frame; capture() re-reads the device-side count after an overflow)
         g.expected_step = self.step_count + 1
         return g.out

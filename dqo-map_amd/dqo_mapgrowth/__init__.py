@@ -135,6 +135,7 @@ def temp_points_attach_indices(temp_xyz, temp_opacity, w2c, intrinsic, image_wid
     hit = stable_index[puv[:, 1], puv[:, 0]] >= 0
     idx = idx[inside][hit[:, 0]]
     sidx = stable_index[uv[idx, 1], uv[idx, 0]].squeeze(-1).long()
-    d = ((stable_xyz[sidx] - temp_xyz[idx]) * stable_normal[sidx]).sum(dim=-1)  # (temp_xyz, not xyz: quirk B15)
+    nrm = stable_normal(sidx) if callable(stable_normal) else stable_normal[sidx]  # (a callable: normals of the rows asked for only)
+    d = ((stable_xyz[sidx] - temp_xyz[idx]) * nrm).sum(dim=-1)  # (temp_xyz, not xyz: quirk B15)
     idx = idx[d.abs() < 0.5 * add_depth_thres]
     return origin[keep][idx]

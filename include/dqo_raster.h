@@ -394,6 +394,11 @@ typedef struct DqoAdamStep {
      * step it advances to — instead of once per block of every launch; a launch whose step the table does not hold (the first one,
      * or after the caller rewrote *step_dev) computes them itself.  Same function either way: same bits. */
     float* bias_table;
+    /* Optional (ABI 3): two device floats { 2000 / (3 |a|), 2000 / (4 |a|) } (computed in double, rounded to float), read when the
+     * launch RUNS instead of deriving them from attach_count when it is issued — for a captured launch (hipGraph) whose attach set
+     * changes between replays: the caller rewrites attach_mask, init_* and these two numbers in place at the start of a mapping call
+     * and replays the same graph.  With it, the attach term is on whenever attach_mask is given (|a| = 0: write two zeros). */
+    const float* attach_gains;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
 

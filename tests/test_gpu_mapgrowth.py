@@ -204,3 +204,125 @@ def test_grow_into_a_new_mapping_call_and_recapture_with_reused_counts():
     c._last_probe = (10, 4, c.P)  # absurdly small
     c.capture(gt_color, gt_depth, mask, reuse_probe=True)
     assert not c.graph_overflowed() and c._last_probe[0] > 1000
+
+
+def _growth_problem(P=12000):
+    import torch
+    from dqo_harness import mapping, scenes
+    dev = torch.device("cuda")
+    cam, scene = scenes.make_config(3, P=P)
+    settings = mapping.make_settings(cam, dev)
+    with torch.no_grad():
+        tgt = mapping.render(settings, mapping.GaussianParams(scene, dev).activated())
+    return dev, cam, scene, settings, tgt["render"].clone(), tgt["depth"].clone(), (tgt["depth_index_map"][0] >= 0)
+
+
+def _rows_sorted(fm):
+    """The map's Gaussians in an order that does not depend on their rows (lexicographic by their centres at the start of the mapping
+    call, which training does not move)."""
+    import torch
+    rows = torch.arange(fm.P, device=fm.xyz.device) if fm.alive is None else fm.alive.nonzero().reshape(-1)
+    x = fm.init_xyz[rows].cpu().numpy()
+    o = np.lexsort((x[:, 2], x[:, 1], x[:, 0]))
+    return rows[torch.tensor(o, device=rows.device)]
+
+
+def test_growth_in_place_keeps_the_captured_graph_and_equals_the_reallocating_step():
+    """reserve() + grow(new_mapping_call=True): deleted Gaussians become spare rows, new ones take spare rows, the attach set / init_stat /
+    Adam state are rewritten in place — the graph captured BEFORE the growth step is replayed after it, and the map trains like the map
+    of the re-allocating step (same Gaussians in other rows).  Spare rows behave as if they did not exist."""
+    import torch
+    from dqo_harness import scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev, cam, scene, settings, gt_color, gt_depth, mask = _growth_problem()
+    new = scenes.surfel_room(79, 3000, n_objects=8)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, settings, dev).reserve(4000)
+    assert b.P == a.P + 4000 and b.n_alive == a.P
+    for fm in (a, b):
+        fm.capture(gt_color, gt_depth, mask)
+        for _ in range(3):
+            fm.replay()
+    torch.cuda.synchronize()
+    # spare rows: invisible to the render, the loss and the optimiser
+    assert torch.equal(a.loss, b.loss)
+    for k, v in a._params().items():
+        assert torch.equal(v, b._params()[k][: a.P]), k
+    assert int(b._g.out[8][a.P:].abs().max().item()) == 0 and float(b.state["xyz"][0][a.P:].abs().max().item()) == 0.0
+    delete = torch.zeros(a.P, dtype=torch.bool, device=dev)
+    delete[3::19] = True
+    sa = a.grow(new, delete_mask=delete, new_mapping_call=True)
+    graph_before = b._g
+    sb = b.grow(new, delete_mask=torch.cat([delete, torch.zeros(4000, dtype=torch.bool, device=dev)]), new_mapping_call=True)
+    assert sb["in_place"] and b._g is graph_before and not b._g.stale
+    assert (sa["added"], sa["deleted"], sa["inside_existing"], sa["invalid_scale"]) == (sb["added"], sb["deleted"], sb["inside_existing"], sb["invalid_scale"])
+    assert b.n_alive == a.P and b.attach_count == a.attach_count and sa["added"] > 0
+    a.capture(gt_color, gt_depth, mask)  # (one iteration of the new mapping call runs inside the capture)
+    for _ in range(3):
+        a.replay()
+    for _ in range(4):
+        b.replay()  # the graph captured before the growth step
+    torch.cuda.synchronize()
+    assert not a.graph_overflowed() and not b.graph_overflowed() and a.step_count == b.step_count
+    ra, rb = _rows_sorted(a), _rows_sorted(b)
+    # (Adam turns a gradient that changes sign near zero into a full step, and the two maps sum in different orders: compare in the
+    # norm and by the share of elements that went another way, not element by element)
+    for k, v in a._params().items():
+        d = (b._params()[k][rb] - v[ra]).abs()
+        assert float(d.mean()) < 2e-5 and float((d > 1e-4).float().mean()) < 0.02, (k, float(d.mean()), float((d > 1e-4).float().mean()))
+    np.testing.assert_allclose(b.loss[:3].cpu().numpy(), a.loss[:3].cpu().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(float(b.attach_loss()), float(a.attach_loss()), rtol=1e-4)
+
+
+def test_growth_runs_out_of_spare_rows_and_reserves_again():
+    import torch
+    from dqo_harness import scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev, cam, scene, settings, gt_color, gt_depth, mask = _growth_problem(8000)
+    fm = FusedMapper(scene, settings, dev).reserve(16)
+    fm.capture(gt_color, gt_depth, mask)
+    fm.replay()
+    st = fm.grow(scenes.surfel_room(80, 3000, n_objects=8), new_mapping_call=True)
+    assert st["added"] > 16 and st["in_place"] is False and fm._g is None
+    assert fm.n_alive == 8000 + st["added"] and fm.P == fm.n_alive + 16  # compacted, the same number of spare rows again
+    fm.capture(gt_color, gt_depth, mask)
+    for _ in range(2):
+        fm.replay()
+    torch.cuda.synchronize()
+    assert not fm.graph_overflowed() and torch.isfinite(fm.loss).all()
+    st2 = fm.grow(dict(xyz=np.zeros((0, 3), np.float32), scales=np.zeros((0, 3), np.float32), rotations=np.zeros((0, 4), np.float32),
+                       opacity=np.zeros((0, 1), np.float32), shs=np.zeros((0, 16, 3), np.float32)), new_mapping_call=True)
+    assert st2["added"] == 0 and st2["in_place"] and fm._g is not None
+
+
+def test_growth_attaches_new_points_that_fall_onto_the_stable_cloud(mg):
+    """grow(stable_mask=...) = the reference's two clouds (mapper.py:1351-1466): the filter looks at the unstable Gaussians, and
+    temp_points_attach gives the new points that lie on the stable cloud's surfaces opacity 0.1 — members of the next attach set.  The
+    stable-only render (unstable opacities at zero) is checked against a render of the stable Gaussians as a map of their own."""
+    torch, M = mg
+    from dqo_harness import mapping, scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev, cam, scene, settings, gt_color, gt_depth, mask = _growth_problem()
+    fm = FusedMapper(scene, settings, dev).reserve(4000)
+    stable = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+    stable[: 12000 : 2] = True
+    new = scenes.surfel_room(81, 3000, n_objects=8)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
+    nx, nop = t(new["xyz"]), t(new["opacity"]).reshape(-1, 1)
+    got = fm._temp_points_attach(nx, nop, stable, 0.1)
+    # reference route: the stable Gaussians as a map of their own (same activated values)
+    rows = stable.nonzero().reshape(-1)
+    sub = dict(xyz=fm.xyz[rows], opacity=fm.opacity[rows], scales=fm.scales[rows], rotations=fm.rotations[rows], shs=fm.shs[rows])
+    with torch.no_grad():
+        cim = mapping.render(settings, sub)["color_index_map"]
+    H, W = cam.H, cam.W
+    K = torch.tensor([[W / (2.0 * cam.tanfovx), 0.0, cam.cx], [0.0, H / (2.0 * cam.tanfovy), cam.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    want = M.temp_points_attach_indices(nx, nop, settings.viewmatrix.T.contiguous(), K, W, H, cim, fm.xyz[rows], fm.normals(rows), fm.add_depth_thres)
+    assert torch.equal(torch.sort(got).values, torch.sort(want).values) and 0 < got.numel() < nx.shape[0]
+    before = fm.attach_count
+    st = fm.grow(new, new_mapping_call=True, stable_mask=stable)
+    assert st["in_place"] and st["attached"] > 0 and st["added"] > 0
+    new_rows = st["rows"]
+    low = (torch.sigmoid(fm.opacity_raw[new_rows]) < 0.2).reshape(-1)
+    assert int(low.sum().item()) > 0 and bool(fm.attach_mask[new_rows][low].all())  # they are in the new call's attach set
+    assert fm.attach_count == before + int((torch.sigmoid(fm.opacity_raw[new_rows]) < 0.9).sum().item())

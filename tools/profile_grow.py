@@ -9,7 +9,7 @@ from dqo_harness import scenes
 from dqo_harness.fused_mapping import FusedMapper
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-args = argparse.Namespace(cfg=cfg, P=None, view="room", scaling="strong", shard_by="work")
+args = argparse.Namespace(cfg=cfg, P=None, view="room", scaling="strong", shard_by="work", no_object_gate=True, as_shard=None)
 dev = torch.device("cuda")
 prob = bench.build_problem(args, 0, 1, dev)
 mask = prob["render_mask"].to(torch.uint8).contiguous()
@@ -49,15 +49,24 @@ timed("update_geometry_scales", lambda: mg.update_geometry_scales(nx2, nrad, fm.
 keep_old = (~delete).nonzero().reshape(-1)
 timed("gather of the kept rows: params (5 arrays)", lambda: [a[keep_old] for a in fm._params().values()])
 timed("gather of the kept rows: moments (10 arrays)", lambda: [x[keep_old] for m, v in fm.state.values() for x in (m, v)])
-timed("whole grow()", lambda: None, reps=1)
-t0 = time.perf_counter()
-st = fm.grow(new, delete_mask=delete)
-torch.cuda.synchronize()
-t1 = time.perf_counter()
-fm.begin_mapping_call(reset_optimizer=True)
-torch.cuda.synchronize()
-t2 = time.perf_counter()
+print("pieces of the in-place step with the reference's two clouds (stable = the initial map):")
+P0 = fm.P
+fm.reserve(32768)
 fm.capture(prob["gt_color"], prob["gt_depth"], mask, tile_mask=prob["tile_mask"])
-torch.cuda.synchronize()
-t3 = time.perf_counter()
-print(f"grow {1e3 * (t1 - t0):.2f} ms, begin_mapping_call {1e3 * (t2 - t1):.2f} ms, capture {1e3 * (t3 - t2):.2f} ms; {st}")
+stable = torch.arange(fm.P, device=dev) < P0
+nop = new["opacity"].reshape(-1, 1)
+timed("_temp_points_attach (stable-only render + projection)", lambda: fm._temp_points_attach(nx, nop, stable, 0.1))
+timed("  of which the parked copy of xyz", lambda: torch.where(stable[:, None], fm.xyz, fm._park_position()[None, :]))
+from dqo_harness import mapping
+data = dict(xyz=fm.xyz, opacity=fm.opacity, scales=fm.scales, rotations=fm.rotations, shs=fm.shs)
+timed("  of which mapping.render of the whole map", lambda: mapping.render(fm.settings, data))
+nrad_all = (new["scales"].sum(1) - new["scales"].min(1).values) / 2
+timed("update_geometry_scales on all 40 800 candidates", lambda: mg.update_geometry_scales(nx, nrad_all, fm.xyz, fm.radius(), 0.001, 0.05))
+timed("begin_mapping_call (in place)", lambda: fm.begin_mapping_call(reset_optimizer=True))
+timed("radius() of the map", lambda: fm.radius())
+for i in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = fm.grow(new, delete_mask=torch.cat([delete, torch.zeros(fm.P - delete.numel(), dtype=torch.bool, device=dev)]), new_mapping_call=True, stable_mask=stable)
+    torch.cuda.synchronize()
+    print(f"in-place grow #{i}: {1e3 * (time.perf_counter() - t0):.2f} ms", {k: v for k, v in st.items() if k not in ("rows", "kept_rows")})
