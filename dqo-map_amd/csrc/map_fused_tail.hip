@@ -276,9 +276,8 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
 }  // namespace
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
-                              const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate,
-                              hipStream_t s);
+                              const float* dL_dcolor, const float* dL_ddepth, DqoGradRec* recs, uint8_t* valid, int64_t capacity,
+                              const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s);
 
 // blend backward + the fused per-Gaussian tail.  The caller (dqo_rast_backward_adam) has checked the arguments.
 int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
@@ -299,8 +298,8 @@ int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, co
     int rc = dqo_adam_args(st, blocks, &a, &attach);
     if (rc) return rc;
     a.frame_header = g.header;  // the frame whose gradients this step consumes is this context's
-    rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap,
-                                   dqo_tap_dev(ctx->loss_tap), dqo_gate_dev(ctx->object_gate), s);
+    rc = dqo_launch_blend_backward(v, g, img, bin, T, dL_dcolor, dL_ddepth, recs, valid, cap, dqo_tap_dev(ctx->loss_tap),
+                                   dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s);
     if (rc) return rc;
     const float4* partial = reinterpret_cast<const float4*>(recs);
     const uint32_t* vw = reinterpret_cast<const uint32_t*>(valid);

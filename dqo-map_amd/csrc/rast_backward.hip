@@ -235,9 +235,8 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
 }  // namespace
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
-                              const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate,
-                              hipStream_t s);
+                              const float* dL_dcolor, const float* dL_ddepth, DqoGradRec* recs, uint8_t* valid, int64_t capacity,
+                              const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s);
 
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                         const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* gr, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -253,8 +252,8 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     const int64_t cap = (int64_t)ctx->inst_capacity;
     DqoGradRec* recs = (DqoGradRec*)ws;
     uint8_t* valid = reinterpret_cast<uint8_t*>(bin.rec_valid);  // zeroed by the forward (bin_place_kernel)
-    int rc = dqo_launch_blend_backward(v, g, img, bin, T, in->scales, in->rotations, dL_dcolor, dL_ddepth, recs, valid, cap,
-                                       dqo_tap_dev(ctx->loss_tap), dqo_gate_dev(ctx->object_gate), s);
+    int rc = dqo_launch_blend_backward(v, g, img, bin, T, dL_dcolor, dL_ddepth, recs, valid, cap, dqo_tap_dev(ctx->loss_tap),
+                                       dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s);
     if (rc) return rc;
     DqoGradRec* sums = reinterpret_cast<DqoGradRec*>(g.grad_sum);  // [P], lives in the forward's geometry buffer
     DQO_LAUNCH("record_sum_kernel", record_sum_kernel, dim3(dqo_spread_blocks(p->P)), dim3(256), s, p->P, g, reinterpret_cast<const float4*>(recs),

@@ -187,59 +187,65 @@ __device__ __forceinline__ void tap_report_per_object(const DqoGeomLayout& g, co
 }
 
 constexpr int BWD_THREADS = 64;
+// LDS of one wave: the gathered records of its chunk's live entries (three float4 tables, three word tables) and the depth-hit sums
+constexpr int BWD_BLK = 3 * BWD_THREADS * 4 + 3 * BWD_THREADS + 5 * BWD_THREADS;  // words: 1280 = 5120 B
+constexpr int BWD_XCH = 5 * BWD_THREADS;                                            // words of one wave's pass-1 result (SEGS > 1)
+struct BwdTap {  // DqoLossTap, backward half: the two gradient scales of the frame
+    float gc, gdw;
+};
+// ... from the frame totals in the spread lines (one whole wave; report: lane 0 also writes the loss and the scales out)
+__device__ __forceinline__ BwdTap tap_frame_scales(const DqoGeomLayout& g, const DqoTapDev& tap, int lane, bool report) {
+    double tot[4];
+    dqo_tap_totals(g.spread, lane, tot);
+    const float n_col = fmaxf((float)tot[1], 1.f), n_dep = fmaxf((float)tot[3], 1.f);
+    BwdTap t;
+    t.gc = tap.color_weight / (3.f * n_col), t.gdw = tap.depth_weight / n_dep;  // = loss_grad_kernel's gc / gdw
+    if (report && lane == 0) {
+        const float color_loss = (float)(tot[0] / (3.0 * (double)n_col)), depth_loss = (float)(tot[2] / (double)n_dep);
+        tap.loss_out[0] = tap.depth_weight * depth_loss + tap.color_weight * color_loss;  // mapper.py:870-875
+        tap.loss_out[1] = color_loss, tap.loss_out[2] = depth_loss, tap.loss_out[3] = 0.f;
+        tap.loss_out[4] = (float)tot[0], tap.loss_out[5] = (float)tot[1], tap.loss_out[6] = (float)tot[2], tap.loss_out[7] = (float)tot[3];
+        tap.scale[0] = t.gc, tap.scale[1] = t.gdw;
+    }
+    return t;
+}
 // live entries per reduction batch: BWD_NB x 9 values go through one butterfly — 7 x 9 = 63 of 64 values (wave_reduce64), or
 // 3 x 9 = 27 of 32 (wave_reduce32: fewer registers -> more waves per SIMD)
 // GATE: DqoObjectGate (an entry acts on a pixel only if the Gaussian's object id equals the pixel's owner id) — a template parameter,
 // so that the ungated kernel keeps its instruction stream.
-template <int BWD_NB, bool GATE>
-__global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
-                                                                     DqoBinLayout bin, const float* __restrict__ scales,
-                                                                     const float* __restrict__ rotations,
-                                                                     const float* __restrict__ dL_dpixels,
-                                                                     const float* __restrict__ dL_ddepths,
-                                                                     float* __restrict__ recs, uint8_t* __restrict__ valid,
-                                                                     int64_t capacity, const DqoTapDev tap, const DqoGateDev gate) {
-    __shared__ float4 s_co[BWD_THREADS];
-    __shared__ float4 s_xy[BWD_THREADS];
-    __shared__ float4 s_rgb[BWD_THREADS];
-    __shared__ int s_id[BWD_THREADS];
-    __shared__ uint32_t s_slot[BWD_THREADS];
-    __shared__ int s_pos[BWD_THREADS];
-    __shared__ float s_hit[BWD_THREADS * 5];
-
-    // DqoLossTap, backward half: every wave that has work derives the two gradient scales from the frame totals the forward left in
-    // the spread lines (one load per lane + a wave sum); the first block also reports the loss
-    float tap_gc = 0.f, tap_gdw = 0.f;
-    auto tap_scales = [&](bool report) {
-        double tot[4];
-        dqo_tap_totals(g.spread, (int)threadIdx.x, tot);
-        const float n_col = fmaxf((float)tot[1], 1.f), n_dep = fmaxf((float)tot[3], 1.f);
-        tap_gc = tap.color_weight / (3.f * n_col), tap_gdw = tap.depth_weight / n_dep;  // = loss_grad_kernel's gc / gdw
-        if (report && threadIdx.x == 0) {
-            const float color_loss = (float)(tot[0] / (3.0 * (double)n_col)), depth_loss = (float)(tot[2] / (double)n_dep);
-            tap.loss_out[0] = tap.depth_weight * depth_loss + tap.color_weight * color_loss;  // mapper.py:870-875
-            tap.loss_out[1] = color_loss, tap.loss_out[2] = depth_loss, tap.loss_out[3] = 0.f;
-            tap.loss_out[4] = (float)tot[0], tap.loss_out[5] = (float)tot[1], tap.loss_out[6] = (float)tot[2], tap.loss_out[7] = (float)tot[3];
-            tap.scale[0] = tap_gc, tap.scale[1] = tap_gdw;
-        }
-    };
-    if (tap.scale != nullptr && blockIdx.x == 0) {  // (before the early exits below: block 0 may have no list)
-        if (GATE && tap.per_object) tap_report_per_object(g, tap);
-        else tap_scales(true);
-    }
-    // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
-    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
-    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
-    if (tile_u == 0xffffffffu) return;  // unused slot
-    const int tile = (int)tile_u;
-    const int quad = jg & 3;
+// SEGS: waves per quadrant.  1 = the wave described at the top of the file.  8 = DqoRastCtx.list_split, the counterpart of the
+// forward's split (rast_forward_blend.hip): the walk goes in rounds of SEGS chunks, chunk r * SEGS + w of round r by wave w.  Walking
+// an entry maps the pixel's state (T, S) to (T / (1 - alpha), S + alpha (c - S)) — T is scaled, S goes through an affine map — so
+//   pass 1  every wave composes its chunk's maps per pixel: Q = prod 1 / (1 - alpha), and (A, B) with S_out = A + B S_in;
+//   scan    the state its chunk starts from = the round's start state sent through the chunks before it (one block barrier per round);
+//   pass 2  the walk itself on the chunk from that state: the gradient sums and records exactly as the single wave forms them.
+// The backward has no early exit, so unlike the forward nothing is evaluated that the single wave would have skipped; pass 1 costs
+// a quarter of pass 2.  T and S are grouped by chunk instead of strictly back to front: last-bit differences, like the forward's.
+template <int BWD_NB, bool GATE, int SEGS>
+__device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
+                                                   const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths,
+                                                   float* __restrict__ recs, uint8_t* __restrict__ valid, const int64_t capacity,
+                                                   const DqoTapDev& tap, const DqoGateDev& gate, const int tile, const int quad, const int wave, const int lane, uint32_t* const lds, const int skip_over) {
+    uint32_t* const blk = lds + wave * BWD_BLK;
+    float4* const s_co = reinterpret_cast<float4*>(blk);
+    float4* const s_xy = s_co + BWD_THREADS;
+    float4* const s_rgb = s_xy + BWD_THREADS;
+    int* const s_id = reinterpret_cast<int*>(s_rgb + BWD_THREADS);
+    uint32_t* const s_slot = reinterpret_cast<uint32_t*>(s_id + BWD_THREADS);
+    int* const s_pos = reinterpret_cast<int*>(s_slot + BWD_THREADS);
+    float* const s_hit = reinterpret_cast<float*>(s_pos + BWD_THREADS);
     const uint2 range = img.ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n == 0) return;
+    if (n == 0 || n > skip_over) return;  // (n > skip_over: SEGS == 1 beside the split blocks, which own the long lists)
     const int L = min((int)img.walk4[tile * 4 + quad], n);  // list positions [0, L) matter to this quadrant
     if (L == 0) return;
-    if (tap.scale != nullptr && blockIdx.x != 0 && !(GATE && tap.per_object)) tap_scales(false);
-    const int lane = threadIdx.x;
+    // DqoLossTap, backward half: every wave that has work derives the two gradient scales from the frame totals the forward left in
+    // the spread lines (one load per lane + a wave sum)
+    float tap_gc = 0.f, tap_gdw = 0.f;
+    if (tap.scale != nullptr && !(GATE && tap.per_object)) {
+        const BwdTap t = tap_frame_scales(g, tap, lane, false);
+        tap_gc = t.gc, tap_gdw = t.gdw;
+    }
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
     const size_t HW = (size_t)v.W * v.H;
 
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     // previous call's records (the workspace is the caller's and changes between calls) — the backward is a function of its
     // arguments only, like the reference's.
     if (__builtin_amdgcn_ballot_w64(dp0 != 0.f || dp1 != 0.f || dp2 != 0.f || ddep != 0.f) == 0ull) {
+        if (SEGS > 1 && wave != 0) return;  // (every wave of the quadrant sees the same pixels: a block-uniform branch)
         const uint8_t* live0 = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;
         for (int p0 = 0; p0 < L; p0 += BWD_THREADS) {
             const int pos = p0 + lane;
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     {
         const bool has_hit = hit_pos > 0;  // implies inside
         const unsigned long long hm = __builtin_amdgcn_ballot_w64(has_hit);
-        if (hm != 0ull) {
+        if (hm != 0ull && (SEGS == 1 || wave == 0)) {
             float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             uint32_t slot_h = 0xffffffffu;
             if (has_hit) {
@@ -384,18 +391,85 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
     const uint8_t* live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;
 
     const int chunks = (L + BWD_THREADS - 1) / BWD_THREADS;
-    // chunk c covers list positions L-1-c*64 ... descending; lane l looks at position L-1-(c*64+l): lane order == walk order
-    uint8_t lv_nx = (L - 1 - lane >= 0) ? live[L - 1 - lane] : (uint8_t)0;
-    for (int c = 0; c < chunks; c++) {
-        const int pos = L - 1 - (c * BWD_THREADS + lane);
-        const bool is_live = lv_nx != 0;
-        {
-            const int pn = pos - BWD_THREADS;
-            lv_nx = pn >= 0 ? live[pn] : (uint8_t)0;  // next chunk's live bytes, in flight while this chunk is processed
+    int cnt = 0;  // live entries of the chunk in flight (compacted in LDS)
+    // The live entries of the chunk are processed BWD_NB at a time: their 9 colour-path sums each go through ONE reduce-scatter
+    // butterfly, after which lane l = 9 b + f holds float f of entry b's record.  A batch whose BWD_NB entries all exist runs as
+    // one straight-line block (FULL): no wave-uniform branch sits between two entries, so the scheduler interleaves the parts of
+    // neighbouring entries that do not depend on each other (footprint, exp, alpha — everything but the T / S recurrences).  A
+    // wave issues a dependent VALU instruction only every ~10 cycles (tools/ubench_valu.hip), so the loop is paced by the length
+    // of its dependency chains, not by the number of instructions: with a branch per entry the chain was one whole entry long.
+    auto batch = [&](const int k0, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int NV = BWD_NB == 7 ? 64 : 32;
+        float v64[NV];
+#pragma unroll
+        for (int i = 9 * BWD_NB; i < NV; i++) v64[i] = 0.f;
+        uint32_t hitmask = 0u;  // entries of this batch that also carry depth-hit sums (wave-uniform)
+#pragma unroll
+        for (int b = 0; b < BWD_NB; b++) {
+            const int k = k0 + b;
+            float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
+            if (FULL || k < cnt) {  // wave-uniform
+                const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
+                const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
+                // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
+                // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
+                // and S + 0 * (c - S) = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
+                const float dx = xy.x - pixfx, dy = xy.y - pixfy;
+                const float power = dqo_power(co.x, co.y, co.z, dx, dy);
+                const float Gx = dqo_gauss(power);
+                const float alpha_x = fminf(0.99f, co.w * Gx);
+                const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f && (!GATE || __float_as_int(xy.w) == owner);
+                const float alpha = did_color ? alpha_x : 0.f;
+                const float G = did_color ? Gx : 0.f;
+                const float inv_1ma = dqo_rcp(1.f - alpha);
+                T = T * inv_1ma;  // T / (1 - alpha), backward.cu:948
+                const float e0 = cs.x - S0, e1 = cs.y - S1, e2 = cs.z - S2;
+                float dL_dalpha = (e0 * dp0 + e1 * dp1 + e2 * dp2) * T;
+                dL_dalpha += bg_term * inv_1ma;
+                const float dchannel_dcolor = alpha * T;
+                S0 += alpha * e0;  // = alpha c + (1 - alpha) S: one fma on the difference that is needed anyway
+                S1 += alpha * e1;
+                S2 += alpha * e2;
+                // Everything downstream of dL/dalpha * G is linear in per-Gaussian constants (opacity, conic, W/2, H/2):
+                // the wave only sums the pixel moments of q = G * dL/dalpha — q, q dx, q dy, q dx^2, q dx dy, q dy^2 — and
+                // gaussian_backward_kernel applies those constants once per Gaussian (backward.cu:964-994 does it per pair).
+                const float q = G * dL_dalpha;
+                const float qx = q * dx, qy = q * dy;
+                r_c0 = dchannel_dcolor * dp0;
+                r_c1 = dchannel_dcolor * dp1;
+                r_c2 = dchannel_dcolor * dp2;
+                r_mx = qx, r_my = qy;
+                r_ka = qx * dx;
+                r_kb = qx * dy;
+                r_kc = qy * dy;
+                r_op = q;
+
+                // the entry fixed some pixel's depth: its record also carries the depth-hit sums written before the loop
+                if (__builtin_amdgcn_ballot_w64(hit_c0 == c0) != 0ull) hitmask |= 1u << b;
+            }
+            v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
+            v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;
         }
+        float tot;
+        if constexpr (BWD_NB == 7) tot = wave_reduce64(v64, lane);
+        else tot = wave_reduce32(v64, lane);
+        // lane 9 b + f stores float f (0..8) of entry b's 64-byte partial record; lanes 0..BWD_NB-1 mark the records valid
+        // (1 = colour-path floats, 3 = depth-hit floats 9..13 present as well)
+        const int kb = k0 + lane_b;
+        if (lane < 9 * BWD_NB && (FULL || kb < cnt)) {
+            const uint32_t slot = s_slot[kb];
+            if ((int64_t)slot < capacity) recs[((size_t)slot * 4 + quad) * 16 + lane_f] = tot;
+        }
+        if (lane < BWD_NB && (FULL || k0 + lane < cnt)) {
+            const uint32_t slot = s_slot[k0 + lane];
+            if ((int64_t)slot < capacity) valid[(size_t)slot * 4 + quad] = ((hitmask >> lane) & 1u) ? (uint8_t)3 : (uint8_t)1;
+        }
+    };
+    // the chunk's live entries gathered into LDS (lane order == walk order); sets cnt
+    auto gather = [&](int pos, bool is_live) {
         const unsigned long long lm = __builtin_amdgcn_ballot_w64(is_live);
-        const int cnt = (int)__popcll(lm);
-        if (cnt == 0) continue;
+        cnt = (int)__popcll(lm);
         const int myk = (int)__popcll(lm & ((1ull << lane) - 1ull));
         if (is_live) {
             // only live entries are gathered at all
@@ -407,84 +481,137 @@ __global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backwa
             s_xy[myk] = g.xy_depth[id];
             s_rgb[myk] = g.rgb_smax[id];
         }
-        // The live entries of the chunk are processed BWD_NB at a time: their 9 colour-path sums each go through ONE reduce-scatter
-        // butterfly, after which lane l = 9 b + f holds float f of entry b's record.  A batch whose BWD_NB entries all exist runs as
-        // one straight-line block (FULL): no wave-uniform branch sits between two entries, so the scheduler interleaves the parts of
-        // neighbouring entries that do not depend on each other (footprint, exp, alpha — everything but the T / S recurrences).  A
-        // wave issues a dependent VALU instruction only every ~10 cycles (tools/ubench_valu.hip), so the loop is paced by the length
-        // of its dependency chains, not by the number of instructions: with a branch per entry the chain was one whole entry long.
-        auto batch = [&](const int k0, auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            constexpr int NV = BWD_NB == 7 ? 64 : 32;
-            float v64[NV];
-#pragma unroll
-            for (int i = 9 * BWD_NB; i < NV; i++) v64[i] = 0.f;
-            uint32_t hitmask = 0u;  // entries of this batch that also carry depth-hit sums (wave-uniform)
-#pragma unroll
-            for (int b = 0; b < BWD_NB; b++) {
-                const int k = k0 + b;
-                float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
-                if (FULL || k < cnt) {  // wave-uniform
-                    const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
-                    const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
-                    // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
-                    // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
-                    // and S + 0 * (c - S) = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
-                    const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-                    const float power = dqo_power(co.x, co.y, co.z, dx, dy);
-                    const float Gx = dqo_gauss(power);
-                    const float alpha_x = fminf(0.99f, co.w * Gx);
-                    const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f && (!GATE || __float_as_int(xy.w) == owner);
-                    const float alpha = did_color ? alpha_x : 0.f;
-                    const float G = did_color ? Gx : 0.f;
-                    const float inv_1ma = dqo_rcp(1.f - alpha);
-                    T = T * inv_1ma;  // T / (1 - alpha), backward.cu:948
-                    const float e0 = cs.x - S0, e1 = cs.y - S1, e2 = cs.z - S2;
-                    float dL_dalpha = (e0 * dp0 + e1 * dp1 + e2 * dp2) * T;
-                    dL_dalpha += bg_term * inv_1ma;
-                    const float dchannel_dcolor = alpha * T;
-                    S0 += alpha * e0;  // = alpha c + (1 - alpha) S: one fma on the difference that is needed anyway
-                    S1 += alpha * e1;
-                    S2 += alpha * e2;
-                    // Everything downstream of dL/dalpha * G is linear in per-Gaussian constants (opacity, conic, W/2, H/2):
-                    // the wave only sums the pixel moments of q = G * dL/dalpha — q, q dx, q dy, q dx^2, q dx dy, q dy^2 — and
-                    // gaussian_backward_kernel applies those constants once per Gaussian (backward.cu:964-994 does it per pair).
-                    const float q = G * dL_dalpha;
-                    const float qx = q * dx, qy = q * dy;
-                    r_c0 = dchannel_dcolor * dp0;
-                    r_c1 = dchannel_dcolor * dp1;
-                    r_c2 = dchannel_dcolor * dp2;
-                    r_mx = qx, r_my = qy;
-                    r_ka = qx * dx;
-                    r_kb = qx * dy;
-                    r_kc = qy * dy;
-                    r_op = q;
-
-                    // the entry fixed some pixel's depth: its record also carries the depth-hit sums written before the loop
-                    if (__builtin_amdgcn_ballot_w64(hit_c0 == c0) != 0ull) hitmask |= 1u << b;
-                }
-                v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
-                v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;
-            }
-            float tot;
-            if constexpr (BWD_NB == 7) tot = wave_reduce64(v64, lane);
-            else tot = wave_reduce32(v64, lane);
-            // lane 9 b + f stores float f (0..8) of entry b's 64-byte partial record; lanes 0..BWD_NB-1 mark the records valid
-            // (1 = colour-path floats, 3 = depth-hit floats 9..13 present as well)
-            const int kb = k0 + lane_b;
-            if (lane < 9 * BWD_NB && (FULL || kb < cnt)) {
-                const uint32_t slot = s_slot[kb];
-                if ((int64_t)slot < capacity) recs[((size_t)slot * 4 + quad) * 16 + lane_f] = tot;
-            }
-            if (lane < BWD_NB && (FULL || k0 + lane < cnt)) {
-                const uint32_t slot = s_slot[k0 + lane];
-                if ((int64_t)slot < capacity) valid[(size_t)slot * 4 + quad] = ((hitmask >> lane) & 1u) ? (uint8_t)3 : (uint8_t)1;
-            }
-        };
+    };
+    auto walk_chunk = [&]() {
         int k0 = 0;
         for (; k0 + BWD_NB <= cnt; k0 += BWD_NB) batch(k0, std::true_type{});
         if (k0 < cnt) batch(k0, std::false_type{});
+    };
+    if (SEGS == 1) {
+        // chunk c covers list positions L-1-c*64 ... descending; lane l looks at position L-1-(c*64+l): lane order == walk order
+        uint8_t lv_nx = (L - 1 - lane >= 0) ? live[L - 1 - lane] : (uint8_t)0;
+        for (int c = 0; c < chunks; c++) {
+            const int pos = L - 1 - (c * BWD_THREADS + lane);
+            const bool is_live = lv_nx != 0;
+            {
+                const int pn = pos - BWD_THREADS;
+                lv_nx = pn >= 0 ? live[pn] : (uint8_t)0;  // next chunk's live bytes, in flight while this chunk is processed
+            }
+            if (__builtin_amdgcn_ballot_w64(is_live) == 0ull) continue;
+            gather(pos, is_live);
+            walk_chunk();
+        }
+    } else {
+        // ---- rounds of SEGS chunks, chunk r * SEGS + w (in walk order) to wave w ----
+        float* const s_x = reinterpret_cast<float*>(lds + SEGS * BWD_BLK);  // [round parity][wave][Q, B, A0, A1, A2][lane]
+        float T_round = T_final, R0 = 0.f, R1 = 0.f, R2 = 0.f;              // the state at the start of the round (same bits in every wave)
+        int p_nx = L - 1 - (wave * BWD_THREADS + lane);
+        uint8_t lv_nx = p_nx >= 0 ? live[p_nx] : (uint8_t)0;
+        for (int r = 0; r * SEGS < chunks; r++) {
+            const int pos = L - 1 - ((r * SEGS + wave) * BWD_THREADS + lane);
+            const bool is_live = lv_nx != 0;
+            {
+                const int pn = pos - SEGS * BWD_THREADS;
+                lv_nx = pn >= 0 ? live[pn] : (uint8_t)0;
+            }
+            gather(pos, is_live);  // (no live entry, or a chunk past the front of the list: cnt = 0, the identity map)
+            // pass 1: the chunk's map of the pixel's state
+            float Q = 1.f, B = 1.f, A0 = 0.f, A1 = 0.f, A2 = 0.f;
+#pragma unroll 2
+            for (int k = 0; k < cnt; k++) {
+                const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
+                const int c0 = s_pos[k];
+                const float dx = xy.x - pixfx, dy = xy.y - pixfy;
+                const float power = dqo_power(co.x, co.y, co.z, dx, dy);
+                const float alpha_x = fminf(0.99f, co.w * dqo_gauss(power));
+                const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f && (!GATE || __float_as_int(xy.w) == owner);
+                const float alpha = did_color ? alpha_x : 0.f;
+                Q *= dqo_rcp(1.f - alpha);
+                A0 += alpha * (cs.x - A0), A1 += alpha * (cs.y - A1), A2 += alpha * (cs.z - A2);
+                B *= 1.f - alpha;
+            }
+            float* const xw = s_x + ((r & 1) * SEGS + wave) * BWD_XCH + lane;
+            xw[0 * BWD_THREADS] = Q, xw[1 * BWD_THREADS] = B, xw[2 * BWD_THREADS] = A0, xw[3 * BWD_THREADS] = A1, xw[4 * BWD_THREADS] = A2;
+            // (one barrier per round: the round after next writes this parity again, and the next round's barrier lies between)
+            __syncthreads();
+            // scan: the state this chunk starts from, and the state the next round starts from
+            float Tn = T_round, N0 = R0, N1 = R1, N2 = R2;
+#pragma unroll
+            for (int j = 0; j < SEGS; j++) {
+                if (j == wave) T = Tn, S0 = N0, S1 = N1, S2 = N2;
+                const float* xj = s_x + ((r & 1) * SEGS + j) * BWD_XCH + lane;
+                const float Bj = xj[1 * BWD_THREADS];
+                Tn *= xj[0 * BWD_THREADS];
+                N0 = xj[2 * BWD_THREADS] + Bj * N0, N1 = xj[3 * BWD_THREADS] + Bj * N1, N2 = xj[4 * BWD_THREADS] + Bj * N2;
+            }
+            T_round = Tn, R0 = N0, R1 = N1, R2 = N2;
+            // pass 2: the walk of the chunk from that state
+            walk_chunk();
+        }
     }
+}
+
+// block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
+template <int BWD_NB, bool GATE>
+__global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+                                                                     DqoBinLayout bin, const float* __restrict__ dL_dpixels,
+                                                                     const float* __restrict__ dL_ddepths,
+                                                                     float* __restrict__ recs, uint8_t* __restrict__ valid,
+                                                                     int64_t capacity, const DqoTapDev tap, const DqoGateDev gate) {
+    __shared__ uint32_t lds[BWD_BLK];
+    // DqoLossTap: the first block also reports the loss (before the early exits below: block 0 may have no list)
+    if (tap.scale != nullptr && blockIdx.x == 0) {
+        if (GATE && tap.per_object) tap_report_per_object(g, tap);
+        else tap_frame_scales(g, tap, (int)threadIdx.x, true);
+    }
+    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
+    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
+    if (tile_u == 0xffffffffu) return;  // unused slot
+    blend_quadrant_bwd<BWD_NB, GATE, 1>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, jg & 3, 0,
+                                         (int)threadIdx.x, lds, 0x7fffffff);
+}
+
+// DqoRastCtx.list_split, the backward's half (the layout of blend_forward_split_kernel): blocks of eight waves; the first BSPLIT_GRID and
+// the last BSPLIT_GRID blocks take the long lists from img.split_tiles one (tile, quadrant) at a time by ticket, every wave one chunk per
+// round; the blocks in between are eight independent single-wave walks, two tiles of one XCD band, skipping the long lists.
+constexpr int BSPLIT_RUNS = 8;
+constexpr int BSPLIT_GRID = 256;
+template <bool GATE>
+__global__ __launch_bounds__(BWD_THREADS * BSPLIT_RUNS, 4) void blend_backward_split_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+                                                                     DqoBinLayout bin, const float* __restrict__ dL_dpixels,
+                                                                     const float* __restrict__ dL_ddepths,
+                                                                     float* __restrict__ recs, uint8_t* __restrict__ valid,
+                                                                     int64_t capacity, const DqoTapDev tap, const DqoGateDev gate) {
+    __shared__ uint32_t lds[BSPLIT_RUNS * BWD_BLK + 2 * BSPLIT_RUNS * BWD_XCH];  // the waves' blocks, then the pass-1 results (two parities)
+    __shared__ uint32_t s_item;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    if (tap.scale != nullptr && blockIdx.x == 0 && wave == 0) {
+        if (GATE && tap.per_object) tap_report_per_object(g, tap);
+        else tap_frame_scales(g, tap, lane, true);
+    }
+    const int T = v.gx * v.gy, T8 = (T + 7) / 8;
+    const int short_blocks = 8 * ((T8 + 1) / 2);
+    if (blockIdx.x < BSPLIT_GRID || (int)blockIdx.x >= BSPLIT_GRID + short_blocks) {
+        const uint32_t items = 4u * min(g.counters[4], (uint32_t)T);
+        for (;;) {  // (ends for every wave of every block: the ticket only grows and `items` is fixed)
+            if (threadIdx.x == 0) s_item = atomicAdd(&g.counters[5], 1u);
+            __syncthreads();
+            const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
+            if (it >= items) return;
+            blend_quadrant_bwd<7, GATE, BSPLIT_RUNS>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate,
+                                                     (int)img.split_tiles[it >> 2], (int)(it & 3u), wave, lane, lds, 0x7fffffff);
+            __syncthreads();  // (everyone has read this trip's ticket and the last round's pass-1 results)
+        }
+    }
+    // the lists in the queue are the ones longer than the FORWARD's threshold (0: it built no queue, every list is walked here)
+    const int fwd_split = (int)g.counters[6];
+    const int b = (int)blockIdx.x - BSPLIT_GRID;
+    const int slot = (b >> 3) * 2 + (wave >> 2);  // two tile slots of band b % 8 per block
+    if (slot >= T8) return;
+    const uint32_t tile_u = img.tile_order[(b & 7) * T8 + slot];
+    if (tile_u == 0xffffffffu) return;
+    blend_quadrant_bwd<7, GATE, 1>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, wave & 3, wave, lane,
+                                   lds, fwd_split > 0 ? fwd_split : 0x7fffffff);
 }
 
 }  // namespace
@@ -515,25 +642,34 @@ int dqo_launch_tap_report(const DqoGeomLayout& g, const DqoTapDev& tap, hipStrea
 }
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
-                              const float* scales, const float* rotations, const float* dL_dcolor, const float* dL_ddepth,
-                              DqoGradRec* recs, uint8_t* valid, int64_t capacity, const DqoTapDev& tap, const DqoGateDev& gate,
-                              hipStream_t s) {
+                              const float* dL_dcolor, const float* dL_ddepth, DqoGradRec* recs, uint8_t* valid, int64_t capacity,
+                              const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s) {
     // DQO_BWD_NB=3 (measurement only) selects the 32-value butterfly: 55 instead of 81 VGPRs, 5.4 instead of 3.7 waves resident
     // per SIMD — and 5 % SLOWER (round 2, profiles/README.md): the kernel is bound by VALU execution, not by latency
     static const int nb = [] {
         const char* e = getenv("DQO_BWD_NB");
         return e ? atoi(e) : 7;
     }();
-    const dim3 grid(8 * ((T + 7) / 8) * 4);
     float* r = reinterpret_cast<float*>(recs);
+    if (list_split > 0) {
+        const dim3 grid(2 * BSPLIT_GRID + 8 * (((T + 7) / 8 + 1) / 2)), block(BWD_THREADS * BSPLIT_RUNS);
+        if (gate.gobj != nullptr)
+            DQO_LAUNCH("blend_backward_kernel", blend_backward_split_kernel<true>, grid, block, s, v, g, img, bin, dL_dcolor, dL_ddepth, r, valid,
+                       capacity, tap, gate);
+        else
+            DQO_LAUNCH("blend_backward_kernel", blend_backward_split_kernel<false>, grid, block, s, v, g, img, bin, dL_dcolor, dL_ddepth, r, valid,
+                       capacity, tap, gate);
+        return DQO_OK;
+    }
+    const dim3 grid(8 * ((T + 7) / 8) * 4);
     if (gate.gobj != nullptr)
-        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true>), grid, dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
-                   dL_dcolor, dL_ddepth, r, valid, capacity, tap, gate);
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true>), grid, dim3(BWD_THREADS), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
+                   valid, capacity, tap, gate);
     else if (nb == 7)
-        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
-                   dL_dcolor, dL_ddepth, r, valid, capacity, tap, gate);
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
+                   valid, capacity, tap, gate);
     else
-        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<3, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, scales, rotations,
-                   dL_dcolor, dL_ddepth, r, valid, capacity, tap, gate);
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<3, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
+                   valid, capacity, tap, gate);
     return DQO_OK;
 }

@@ -600,6 +600,9 @@ __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, Dq
     __shared__ uint32_t s_val[2 * SORTP_RUN];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ti = blockIdx.x;
+    // the threshold the queue is built with, for the backward: its split kernel leaves to the queue exactly the lists that are in it
+    // (whatever the caller's backward context says)
+    if (ti == 0 && threadIdx.x == 0) g.counters[6] = (uint32_t)list_split;
     const uint32_t tile = img.tile_order[ti];  // [8][T8] slots, unused ones hold ~0
     if (tile >= (uint32_t)T) return;
     uint2 rg;
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, Dq
     }
     const int n = (int)(rg.y - rg.x);
     if (n <= 0) return;
-    // DqoRastCtx.list_split: the forward blend's queue of lists to cut into runs (longest first, like the one below)
+    // DqoRastCtx.list_split: the blend kernels' queue of lists shared between eight waves (longest first, like the one below)
     if (list_split > 0 && n > list_split && threadIdx.x == 0) img.split_tiles[atomicAdd(&g.counters[4], 1u)] = tile;
     if (n > SORTW_CAP) {  // tile_sort_kernel's: queued (the blocks run longest list first, so the queue is close to that order too)
         if (threadIdx.x == 0) img.long_tiles[atomicAdd(&g.counters[1], 1u)] = tile;

@@ -251,6 +251,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.inst_capacity = cap
+        ctx.list_split = _list_split  # (the backward shares the same lists between eight waves: the queue is the forward's)
         ctx.M = M
         ctx.object_gate = None if gate is None else (gaussian_object, pixel_object)
         ctx.save_for_backward(colors_precomp, hit_depth, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -296,7 +297,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 inputs = _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask)
                 cctx = N.DqoRastCtx(geom=geomBuffer.data_ptr(), geom_bytes=geomBuffer.numel(), binning=binningBuffer.data_ptr(),
                                     binning_bytes=binningBuffer.numel(), image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(),
-                                    inst_capacity=cap)
+                                    inst_capacity=cap, list_split=getattr(ctx, "list_split", 0))
                 if getattr(ctx, "object_gate", None) is not None:
                     gate = N.DqoObjectGate(gaussian_object=N.ptr(ctx.object_gate[0]), pixel_object=N.ptr(ctx.object_gate[1]))
                     cctx.object_gate = ctypes.addressof(gate)

@@ -133,11 +133,12 @@ def test_auto_list_split_follows_the_number_of_rendered_tiles(env):
     st = mapping.make_settings(cam, torch.device("cuda"))
     gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
     full = torch.ones(gy * gx, dtype=torch.int32)
-    assert FusedMapper.pick_list_split("auto", None, st) == FusedMapper.pick_list_split("auto", full, st)
+    pick = FusedMapper.pick_list_split
+    assert pick("auto", None, st, 5000) == pick("auto", full, st, 5000)
     part = full.clone()
     part[200:] = 0
-    few = FusedMapper.pick_list_split("auto", part, st)
-    assert 0 < few <= 1024 and FusedMapper.pick_list_split("auto", torch.ones(4000, dtype=torch.int32), st) == 0  # a full frame: off
-    assert FusedMapper.pick_list_split(300, None, st) == 300 and FusedMapper.pick_list_split(0, None, st) == 0
+    assert pick("auto", part, st, 5000) == 256 and pick("auto", part, st, 800) == 0  # no list worth cutting: one wave per quadrant
+    assert pick("auto", full, st, 5000) == 1024 and pick("auto", torch.ones(4000, dtype=torch.int32), st, 6000) == 0
+    assert pick(300, None, st) == 300 and pick(0, None, st) == 0
     with pytest.raises(ValueError):
-        FusedMapper.pick_list_split(-1, None, st)
+        pick(-1, None, st)
