@@ -491,16 +491,17 @@ class FusedMapper:
         """DqoRastCtx.list_split of a capture: the list length given (0 = off), or for "auto" by the number of tiles the frame renders and
         the longest list of the state the capture is taken on.  Four waves per tile fill the 1024 SIMDs six deep at 1500 tiles; below
         that the blend kernels' time is the time of their longest lists, and the fewer tiles there are, the shorter the lists worth
-        sharing between eight waves (measured on the shards of config 5, DESIGN.md §6: 256 for an eighth of the frame, 1024 for a
-        quarter).  The eight-wave blocks cost the short lists occupancy (config 3's shards, whose lists all stay below 1 k, lose 10 %),
-        so the split is only taken when some list is at least four times the threshold: a tail worth cutting."""
+        sharing between eight waves (measured on the shards of configs 4 and 5).  The eight-wave blocks cost the short
+        lists occupancy (config 3's shards, whose lists all stay below 600 entries, lose 10 %, and so does a frame that fills the GPU),
+        so the split is only taken when some list holds a thousand entries: a tail worth cutting."""
         if list_split != "auto":
             if int(list_split) < 0:
                 raise ValueError("list_split is 0 (off), a list length or 'auto'")
             return int(list_split)
         tiles = int((tile_mask != 0).sum().item()) if tile_mask is not None else ((st.image_width + 15) // 16) * ((st.image_height + 15) // 16)
-        t = 256 if tiles <= 700 else 1024 if tiles <= 1800 else 2048
-        return t if longest >= 4 * t else 0
+        if tiles > 1800 or longest < 1024:
+            return 0
+        return 256 if tiles <= 400 else 512 if tiles <= 800 else 1024
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,

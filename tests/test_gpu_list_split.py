@@ -131,14 +131,13 @@ def test_auto_list_split_follows_the_number_of_rendered_tiles(env):
     from dqo_harness.fused_mapping import FusedMapper
     cam, _ = scenes.make_config(3, P=1000)
     st = mapping.make_settings(cam, torch.device("cuda"))
-    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
-    full = torch.ones(gy * gx, dtype=torch.int32)
     pick = FusedMapper.pick_list_split
-    assert pick("auto", None, st, 5000) == pick("auto", full, st, 5000)
-    part = full.clone()
-    part[200:] = 0
-    assert pick("auto", part, st, 5000) == 256 and pick("auto", part, st, 800) == 0  # no list worth cutting: one wave per quadrant
-    assert pick("auto", full, st, 5000) == 1024 and pick("auto", torch.ones(4000, dtype=torch.int32), st, 6000) == 0
+    tiles = lambda n: torch.ones(n, dtype=torch.int32)
+    gy, gx = (cam.H + 15) // 16, (cam.W + 15) // 16
+    assert pick("auto", None, st, 5000) == pick("auto", tiles(gy * gx), st, 5000)
+    assert pick("auto", tiles(200), st, 5000) == 256 and pick("auto", tiles(200), st, 800) == 0  # no list worth cutting
+    assert pick("auto", tiles(600), st, 1500) == 512
+    assert pick("auto", tiles(1200), st, 5000) == 1024 and pick("auto", tiles(4000), st, 6000) == 0  # a frame that fills the GPU
     assert pick(300, None, st) == 300 and pick(0, None, st) == 0
     with pytest.raises(ValueError):
         pick(-1, None, st)
