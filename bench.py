@@ -826,6 +826,9 @@ def main():
     backend = os.environ.get("DQO_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if backend == "gloo":  # code-path rehearsal of the N-rank run on fewer GPUs (not a measurement)
         local = local % torch.cuda.device_count()
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but this node shows {torch.cuda.device_count()} device(s) — one process per GPU "
+                         "(RCCL); to rehearse the N-rank job on fewer GPUs set DQO_BENCH_BACKEND=gloo (ranks then share the devices)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:

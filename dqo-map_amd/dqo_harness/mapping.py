@@ -105,6 +105,19 @@ def render(settings, gaussian_data, tile_mask=None, object_gate=None):
     return out
 
 
+def render_obj(settings, gaussian_data, tile_mask=None):
+    """SLAM/render.py:61-132 (`Renderer.render_obj`, the per-object ellipsoid view; dead under the shipped MODE = 1, F3): the same
+    rasteriser call as render() with `obj_color` [P, 3] as precomputed colours — no SH, no normals — the default all-ones int32 tile
+    mask (:105-112), and only the colour image of the op's 9-tuple handed back, as `render_obj` (:126-130)."""
+    dev = gaussian_data["xyz"].device
+    if tile_mask is None:
+        tile_mask = torch.ones(((settings.image_height + 15) // 16, (settings.image_width + 15) // 16), dtype=torch.int32, device=dev)
+    rasterizer = GaussianRasterizer(raster_settings=settings)
+    r = rasterizer(means3D=gaussian_data["xyz"], opacities=gaussian_data["opacity"], shs=None, colors_precomp=gaussian_data["obj_color"],
+                   scales=gaussian_data["scales"], rotations=gaussian_data["rotations"], cov3D_precomp=None, normal_w=None, tile_mask=tile_mask)
+    return {"render_obj": r[0]}
+
+
 def _gaussian_window(window_size=11, sigma=1.5, channel=3, device="cpu"):
     # utils/loss_utils.py:41-58
     g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / float(2 * sigma ** 2)) for x in range(window_size)])

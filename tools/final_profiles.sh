@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round measurements on one MI355X (run through gpurun): default bench, rocprofv3 kernel stats of the same command, the other
-# BASELINE maps, the SQ counters of the blend kernels.  Results under gpurun_out/final/ (copied to profiles/r02_b_* afterwards).
+# BASELINE maps, the SQ counters of the blend kernels.  Results under gpurun_out/final/ (copied to profiles/r<round>_* afterwards).
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 out=gpurun_out/final; mkdir -p $out
 timeout -k 10 500 python bench.py > $out/bench_cfg3.json 2> $out/bench_cfg3.err || exit 1
@@ -14,4 +14,7 @@ for c in 2 4 5; do
   echo "cfg$c done"
 done
 timeout -k 10 300 python bench.py --cfg 5 --growth-every 0 --no-cpu-baseline --no-pmc --no-aux > $out/bench_cfg5_nogrowth.json 2> $out/bench_cfg5_nogrowth.err || exit 1
+# two ranks on the one GPU of the box (gloo: RCCL wants one device per rank): a rehearsal of the launcher, the sharded job and its
+# self-checks, not a scaling number
+DQO_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 50 --warmup 10 > $out/bench_cfg3_2ranks_one_gpu.json 2> $out/bench_cfg3_2ranks_one_gpu.err || echo "2-rank rehearsal failed"
 echo "all done"
