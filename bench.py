@@ -77,7 +77,8 @@ def parse():
                     help="fused path: record_sum + gaussian_backward + adam as three kernels instead of the one fused per-Gaussian tail (A/B)")
     ap.add_argument("--list-split", default="auto",
                     help="fused path: DqoRastCtx.list_split — 0 = one wave walks every tile list; n = lists longer than n entries are shared "
-                         "between eight waves in the forward blend; auto (default) = by the number of tiles the rank renders")
+                         "between eight waves in both blend kernels; f,b = forward / backward thresholds (b = 0: forward only); auto (default) = "
+                         "by the number of tiles the rank renders and its longest list")
     ap.add_argument("--no-object-gate", action="store_true",
                     help="strong scaling: a shard's objects occlude each other (round 2's job definition) instead of the per-object gate that "
                          "makes every N compute the N = 1 function")
@@ -92,6 +93,16 @@ def parse():
 # ------------------------------------------------------------------------------------------------------------------
 # N ranks from a plain `python bench.py --gpus N`
 # ------------------------------------------------------------------------------------------------------------------
+def parse_list_split(v):
+    """--list-split: "auto", a list length, or "f,b" (forward threshold, backward threshold: 0 or the same)."""
+    if v == "auto":
+        return v
+    if "," in v:
+        f, b = v.split(",")
+        return int(f), int(b)
+    return int(v)
+
+
 def launch_ranks(args):
     """`--gpus N` (N > 1) without a launcher's environment: start the N ranks as a child job — python -m torch.distributed.run, one
     process per GPU, rendezvous on 127.0.0.1 — forward its output (rank 0's ONE JSON line) and return its exit code.  Called before
@@ -875,7 +886,7 @@ def main():
     if args.path == "fused":
         runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
                              loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail,
-                             list_split=args.list_split if args.list_split == "auto" else int(args.list_split))
+                             list_split=parse_list_split(args.list_split))
         step = runner.step
     else:
         step_dropin = make_dropin_step(prob, device, loss_buf)
@@ -1151,7 +1162,7 @@ def main():
                        "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
                        "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
                        "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}),
-                       **({"list_split": int(runner.fm._g.cctx.list_split)} if (runner is not None and runner.fm._g is not None) else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
+                       **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
                                                                                    ("ok" if selfcheck_ok else "FAILED")), **stats},
             "loss": loss_now, "path": args.path,
         }

@@ -487,21 +487,37 @@ class FusedMapper:
                     attach_gains=N.ptr(self.attach_gains))
 
     @staticmethod
-    def pick_list_split(list_split, tile_mask, st, longest=0):
-        """DqoRastCtx.list_split of a capture: the list length given (0 = off), or for "auto" by the number of tiles the frame renders and
-        the longest list of the state the capture is taken on.  Four waves per tile fill the 1024 SIMDs six deep at 1500 tiles; below
-        that the blend kernels' time is the time of their longest lists, and the fewer tiles there are, the shorter the lists worth
-        sharing between eight waves (measured on the shards of configs 4 and 5).  The eight-wave blocks cost the short
-        lists occupancy (config 3's shards, whose lists all stay below 600 entries, lose 10 %, and so does a frame that fills the GPU),
-        so the split is only taken when some list holds a thousand entries: a tail worth cutting."""
+    def pick_list_split_pair(list_split, tile_mask, st, longest=0):
+        """(forward, backward) values of DqoRastCtx.list_split for a capture: an int for both kernels, a pair (f, b) as given (b must be
+        0 or f: the backward walks the forward's queue), or "auto" by the number of tiles the frame renders and the longest list of the
+        state the capture is taken on.  Four waves per tile fill the 1024 SIMDs six deep at 1500 tiles; below that the blend kernels'
+        time is the time of their longest lists, and the fewer tiles there are, the shorter the lists worth sharing between eight waves
+        (measured on the shards of configs 4 and 5).  The eight-wave blocks cost the short lists occupancy (config 3's
+        shards, whose lists all stay below 600 entries, lose 10 %), so a split is only taken when some list is long enough to be a tail
+        worth cutting; and the fuller the GPU, the less the BACKWARD gains — it has no early exit, so its tail is the whole list's
+        work, not a handful of quadrants' — so frames of more than 1300 tiles share lists in the forward only (config 5: half the
+        frame 1.12 -> 0.96 ms, the full frame 1.69 -> 1.66 ms)."""
+        if isinstance(list_split, (tuple, list)):
+            f, b = int(list_split[0]), int(list_split[1])
+            if f < 0 or b not in (0, f):
+                raise ValueError("list_split pair: (forward threshold, 0 or the same threshold)")
+            return f, b
         if list_split != "auto":
             if int(list_split) < 0:
-                raise ValueError("list_split is 0 (off), a list length or 'auto'")
-            return int(list_split)
+                raise ValueError("list_split is 0 (off), a list length, a pair or 'auto'")
+            return int(list_split), int(list_split)
         tiles = int((tile_mask != 0).sum().item()) if tile_mask is not None else ((st.image_width + 15) // 16) * ((st.image_height + 15) // 16)
-        if tiles > 1800 or longest < 1024:
-            return 0
-        return 256 if tiles <= 400 else 512 if tiles <= 800 else 1024
+        if tiles <= 1300:
+            t = 256 if tiles <= 400 else 512 if tiles <= 800 else 1024
+            return (t, t) if longest >= 1024 else (0, 0)
+        if tiles <= 2600:
+            return (1024, 0) if longest >= 2048 else (0, 0)
+        return (2048, 0) if longest >= 4096 else (0, 0)
+
+    @staticmethod
+    def pick_list_split(list_split, tile_mask, st, longest=0):
+        """The threshold BOTH blend kernels share under pick_list_split_pair's rule (0 when only the forward splits)."""
+        return FusedMapper.pick_list_split_pair(list_split, tile_mask, st, longest)[1]
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
@@ -604,7 +620,10 @@ class FusedMapper:
                                          radii=o[8].data_ptr())
             g.cctx = N.DqoRastCtx(geom=g.geom.data_ptr(), geom_bytes=g.geom.numel(), binning=g.binning.data_ptr(),
                                   binning_bytes=g.binning.numel(), image=g.img.data_ptr(), image_bytes=g.img.numel(), inst_capacity=cap,
-                                  tile_bucket_capacity=g.bucket, list_split=self.pick_list_split(list_split, g.tile_mask, st, longest))
+                                  tile_bucket_capacity=g.bucket)
+            # (DqoRastCtx.list_split is read by the forward and by the backward call: _static_iteration sets it before each)
+            g.ls_fwd, g.ls_bwd = self.pick_list_split_pair(list_split, g.tile_mask, st, longest)
+            g.cctx.list_split = g.ls_fwd
             g.list_split = list_split
             # DqoLossTap: the masked loss is summed by the forward's blend kernel and its gradient images are formed inside the
             # backward's (bit for bit what dqo_map_loss_fwd_bwd computes): no loss kernels, no passes over the full image
@@ -699,7 +718,9 @@ class FusedMapper:
         st = self.settings
         H, W = int(st.image_height), int(st.image_width)
         stream = N.current_stream()
+        g.cctx.list_split = g.ls_fwd
         N.check(lib.dqo_rast_forward(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.outputs), ctypes.byref(g.cctx), stream))
+        g.cctx.list_split = g.ls_bwd  # (0 with a split forward: the single-wave backward walks every list, the queue is ignored)
         o = g.out
         if g.tap is None:
             N.check(lib.dqo_map_loss_fwd_bwd(W, H, o[0].data_ptr(), o[1].data_ptr(), o[3].data_ptr(), N.ptr(g.gt_color), N.ptr(g.gt_depth),

@@ -111,10 +111,10 @@ def test_fused_mapper_with_split_lists_trains_like_the_serial_one(env):
     gt_d = (r["depth"] * 1.01).contiguous()
     mask = torch.ones((cam.H, cam.W), dtype=torch.uint8, device=dev)
     outs = []
-    for runs in (0, 128):
+    for runs in (0, 128, (128, 0)):  # (forward only: the single-wave backward walks every list and ignores the forward's queue)
         fm = FusedMapper(sc, st, dev)
         fm.capture(gt_c, gt_d, mask, list_split=runs)
-        assert int(fm._g.cctx.list_split) == runs
+        assert (int(fm._g.ls_fwd), int(fm._g.ls_bwd)) == (runs if isinstance(runs, tuple) else (runs, runs))
         for _ in range(5):
             fm.replay()
         torch.cuda.synchronize()
@@ -139,5 +139,11 @@ def test_auto_list_split_follows_the_number_of_rendered_tiles(env):
     assert pick("auto", tiles(600), st, 1500) == 512
     assert pick("auto", tiles(1200), st, 5000) == 1024 and pick("auto", tiles(4000), st, 6000) == 0  # a frame that fills the GPU
     assert pick(300, None, st) == 300 and pick(0, None, st) == 0
+    pair = FusedMapper.pick_list_split_pair
+    assert pair("auto", tiles(4000), st, 6000) == (2048, 0) and pair("auto", tiles(4000), st, 3000) == (0, 0)  # forward only on a full frame
+    assert pair("auto", tiles(2000), st, 3000) == (1024, 0)  # half a frame
+    assert pair("auto", tiles(200), st, 5000) == (256, 256) and pair(300, None, st) == (300, 300) and pair((512, 0), None, st) == (512, 0)
+    with pytest.raises(ValueError):
+        pair((512, 256), None, st)
     with pytest.raises(ValueError):
         pick(-1, None, st)

@@ -31,7 +31,7 @@ for rep in range(2):
     st.update({k + "_m": m.clone() for k, (m, v) in fm.state.items()})
     st["loss"] = fm.loss.clone()
     ends.append(st)
-    print(f"cfg {cfg} list_split {int(fm._g.cctx.list_split)} run {rep}: {n} iterations in {dt:.2f} s ({n / dt:.0f} iter/s incl. {recaps} re-captures), loss {fm.loss[:3].tolist()}, "
+    print(f"cfg {cfg} list_split {int(fm._g.ls_fwd)} run {rep}: {n} iterations in {dt:.2f} s ({n / dt:.0f} iter/s incl. {recaps} re-captures), loss {fm.loss[:3].tolist()}, "
           f"header {fm.header()}")
     assert all(torch.isfinite(v).all() for v in st.values()), "non-finite state"
 same = all(torch.equal(ends[0][k], ends[1][k]) for k in ends[0])
