@@ -597,7 +597,12 @@ __global__ __launch_bounds__(BWD_THREADS * BSPLIT_RUNS, 4) void blend_backward_s
             if (threadIdx.x == 0) s_item = atomicAdd(&g.counters[5], 1u);
             __syncthreads();
             const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
-            if (it >= items) return;
+            if (it >= items) {
+                // every long-list block draws exactly one ticket beyond the queue: the block that draws the last of them puts the ticket
+                // back to zero, for a second backward over the same forward (the forward's zero fill only runs once per frame)
+                if (threadIdx.x == 0 && it == items + 2u * BSPLIT_GRID - 1u) g.counters[5] = 0u;
+                return;
+            }
             blend_quadrant_bwd<7, GATE, BSPLIT_RUNS>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate,
                                                      (int)img.split_tiles[it >> 2], (int)(it & 3u), wave, lane, lds, 0x7fffffff);
             __syncthreads();  // (everyone has read this trip's ticket and the last round's pass-1 results)

@@ -147,3 +147,65 @@ def test_auto_list_split_follows_the_number_of_rendered_tiles(env):
         pair((512, 256), None, st)
     with pytest.raises(ValueError):
         pick(-1, None, st)
+
+
+def test_split_backward_with_quadrants_that_get_no_gradient(env):
+    """Half of the image carries no incoming gradient: those quadrants take the backward's early exit (in the eight-wave blocks: wave 0
+    takes back the validity marks, the others leave), and a second backward over the same forward with a full gradient must not see
+    anything of the first — the split backward is a function of its arguments only, like the single-wave one."""
+    dgr = env
+    cam, sc = scenes.make_config(5, P=120000)
+    dL = _dL(cam, 12)
+    half = np.zeros((cam.H, cam.W), np.float32)
+    half[:, : cam.W // 2] = 1
+    dLh = (dL[0] * half, dL[1] * half)
+    runs_ = {}
+    for runs in (0, 128):
+        dgr.set_list_split(runs)
+        runs_[runs] = U.HipRun(cam, sc)
+    dgr.set_list_split(0)
+    a, b = runs_[0], runs_[128]
+    # (a pixel on a threshold may fall on the other side with the split on: no gradient comes in there, on either side)
+    same = ((np.abs(a.res["color"] - b.res["color"]).max(0) < 1e-4) & (a.res["hit_depth"][0] == b.res["hit_depth"][0])).astype(np.float32)
+    assert same.mean() > 0.999
+    dL, dLh = (dL[0] * same, dL[1] * same), (dLh[0] * same, dLh[1] * same)
+    res = {}
+    for runs, r in runs_.items():
+        g_half = r.backward(dLh)
+        g_full = r.backward(dL)       # records of the first call must not leak into this one
+        g_half2 = r.backward(dLh, retain=False)
+        for k in g_half:
+            assert np.array_equal(g_half[k], g_half2[k]), (runs, k)  # bitwise: a function of its arguments
+        res[runs] = (g_half, g_full)
+    for ga, gb in zip(res[0], res[128]):
+        for k in ga:
+            den = np.abs(ga[k]).max() + 1e-30
+            assert np.abs(ga[k] - gb[k]).max() / den < 1e-3, (k, np.abs(ga[k] - gb[k]).max() / den)
+
+
+def test_fused_mapper_with_split_lists_and_a_partial_render_mask(env):
+    """The loss tap with a render mask that covers a third of the frame, long lists shared between eight waves: trains like the
+    single-wave kernels (quadrants outside the mask have no gradient: the early exit of the split backward)."""
+    import torch
+    from dqo_harness import mapping
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, sc = scenes.make_config(5, P=100000)
+    dev = torch.device("cuda")
+    st = mapping.make_settings(cam, dev)
+    with torch.no_grad():
+        r = mapping.render(st, mapping.GaussianParams(sc, dev).activated())
+    gt_c = (r["render"] * 0.9 + 0.05).contiguous()
+    gt_d = (r["depth"] * 1.01).contiguous()
+    mask = torch.zeros((cam.H, cam.W), dtype=torch.uint8, device=dev)
+    mask[cam.H // 3: 2 * cam.H // 3, 100:900] = 1
+    outs = []
+    for runs in (0, 128):
+        fm = FusedMapper(sc, st, dev)
+        fm.capture(gt_c, gt_d, mask, list_split=runs)
+        for _ in range(4):
+            fm.replay()
+        torch.cuda.synchronize()
+        assert not fm.graph_overflowed()
+        outs.append((fm.xyz.detach().cpu().numpy().copy(), fm.shs.detach().cpu().numpy().copy(), float(fm.loss[0].item())))
+    assert abs(outs[1][2] - outs[0][2]) <= 1e-5 * abs(outs[0][2])
+    assert np.abs(outs[1][0] - outs[0][0]).mean() < 1e-6 and np.abs(outs[1][1] - outs[0][1]).mean() < 1e-6

@@ -7,7 +7,7 @@ import argparse
 import torch
 import bench
 
-args = argparse.Namespace(cfg=3, P=None, view="room", scaling="strong", shard_by="work", no_object_gate=True)
+args = argparse.Namespace(cfg=3, P=None, view="room", scaling="strong", shard_by="work", no_object_gate=True, as_shard=None)
 dev = torch.device("cuda")
 import diff_gaussian_rasterization_depth as dgr
 dgr.set_sync_mode("lazy")
