@@ -552,23 +552,29 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
 }
 
 // block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item j = b / 8 = (tile slot, quadrant)
+#ifndef BWD_WPB
+#define BWD_WPB 1  // waves (= quadrants of ONE tile) per workgroup; independent of each other either way
+#endif
 template <int BWD_NB, bool GATE>
-__global__ __launch_bounds__(BWD_THREADS, BWD_NB == 7 ? 5 : 8) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+__global__ __launch_bounds__(BWD_THREADS * BWD_WPB, BWD_NB == 7 ? 5 : 8) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                      DqoBinLayout bin, const float* __restrict__ dL_dpixels,
                                                                      const float* __restrict__ dL_ddepths,
                                                                      float* __restrict__ recs, uint8_t* __restrict__ valid,
                                                                      int64_t capacity, const DqoTapDev tap, const DqoGateDev gate) {
-    __shared__ uint32_t lds[BWD_BLK];
+    __shared__ uint32_t lds[BWD_BLK * BWD_WPB];
+    const int wave = BWD_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int lane = (int)(threadIdx.x & 63);
     // DqoLossTap: the first block also reports the loss (before the early exits below: block 0 may have no list)
-    if (tap.scale != nullptr && blockIdx.x == 0) {
+    if (tap.scale != nullptr && blockIdx.x == 0 && wave == 0) {
         if (GATE && tap.per_object) tap_report_per_object(g, tap);
-        else tap_frame_scales(g, tap, (int)threadIdx.x, true);
+        else tap_frame_scales(g, tap, lane, true);
     }
-    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
+    const int xg = blockIdx.x & 7, jg = BWD_WPB > 1 ? ((int)(blockIdx.x >> 3) * BWD_WPB + wave) : (int)(blockIdx.x >> 3);
+    const int T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
     if (tile_u == 0xffffffffu) return;  // unused slot
-    blend_quadrant_bwd<BWD_NB, GATE, 1>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, jg & 3, 0,
-                                         (int)threadIdx.x, lds, 0x7fffffff);
+    blend_quadrant_bwd<BWD_NB, GATE, 1>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, jg & 3, wave, lane,
+                                         lds, 0x7fffffff);
 }
 
 // DqoRastCtx.list_split, the backward's half (the layout of blend_forward_split_kernel): blocks of eight waves; the first BSPLIT_GRID and
@@ -666,15 +672,15 @@ int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const Dq
                        capacity, tap, gate);
         return DQO_OK;
     }
-    const dim3 grid(8 * ((T + 7) / 8) * 4);
+    const dim3 grid(8 * ((T + 7) / 8) * 4 / BWD_WPB);
     if (gate.gobj != nullptr)
-        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true>), grid, dim3(BWD_THREADS), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true>), grid, dim3(BWD_THREADS * BWD_WPB), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
                    valid, capacity, tap, gate);
     else if (nb == 7)
-        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, false>), grid, dim3(BWD_THREADS * BWD_WPB), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
                    valid, capacity, tap, gate);
     else
-        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<3, false>), grid, dim3(BWD_THREADS), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
+        DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<3, false>), grid, dim3(BWD_THREADS * BWD_WPB), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
                    valid, capacity, tap, gate);
     return DQO_OK;
 }

@@ -479,15 +479,20 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 
 // One wave64 per (tile, quadrant), block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item
 // j = b / 8 = (tile slot, quadrant).  (The gated instantiation is held to 80 registers, see above.)
+#ifndef FWD_WPB
+#define FWD_WPB 1  // waves (= quadrants of ONE tile) per workgroup; independent of each other either way
+#endif
 template <bool GATE>
-__global__ __launch_bounds__(FWD_THREADS, GATE ? 6 : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
-                                                                                  DqoBinLayout bin, DqoRastOutputs out, const DqoTapDev tap,
-                                                                                  const DqoGateDev gate) {
-    __shared__ float4 lds[FWD_BLK];
-    const int xg = blockIdx.x & 7, jg = blockIdx.x >> 3, T8 = (v.gx * v.gy + 7) / 8;
+__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? 6 : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+                                                                                            DqoBinLayout bin, DqoRastOutputs out,
+                                                                                            const DqoTapDev tap, const DqoGateDev gate) {
+    __shared__ float4 lds[FWD_BLK * FWD_WPB];
+    const int wave = FWD_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int xg = blockIdx.x & 7, jg = FWD_WPB > 1 ? ((int)(blockIdx.x >> 3) * FWD_WPB + wave) : (int)(blockIdx.x >> 3);
+    const int T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
     if (tile_u == 0xffffffffu) return;  // unused slot
-    blend_quadrant<GATE, 1, false>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, 0, (int)threadIdx.x, lds, 0x7fffffff);
+    blend_quadrant<GATE, 1, false>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, wave, (int)(threadIdx.x & 63), lds, 0x7fffffff);
 }
 
 // DqoRastCtx.list_split: blocks of SPLIT_RUNS waves.  The first SPLIT_GRID blocks take the long lists (longer than list_split entries: the
@@ -544,7 +549,7 @@ int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const Dqo
         else DQO_LAUNCH("blend_forward_kernel", blend_forward_split_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate, list_split);
         return DQO_OK;
     }
-    const dim3 grid(8 * ((T + 7) / 8) * 4), block(FWD_THREADS);
+    const dim3 grid(8 * ((T + 7) / 8) * 4 / FWD_WPB), block(FWD_THREADS * FWD_WPB);
     if (gt) DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<true>, grid, block, s, v, g, img, bin, out, tap, gate);
     else DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate);
     return DQO_OK;
