@@ -195,7 +195,10 @@ def build_problem(args, rank, world, device):
         obj_id = torch.tensor(full["obj_id"], device=device)
         pix_obj = obj_id[hit.long().clamp(min=0)]
         pix_obj[hit < 0] = -1
-        work = sharding.view_work(tgt["radii"].cpu().numpy())  # tiles every Gaussian covers in this view
+        # tiles every Gaussian covers in this view, plus what a Gaussian costs whether it is in view or not (preprocess, binning and the
+        # per-Gaussian tail look at every row of the shard: 0.11 ns per Gaussian against 0.75 ns per candidate tile, measured on the
+        # shards of config 5 — a shard holding a third of the map out of view was the slowest of eight)
+        work = sharding.view_work(tgt["radii"].cpu().numpy()) + GAUSSIAN_COST_IN_TILES
         del tgt
     if strong and world > 1:
         # objects -> ranks by the instances they put on screen (LPT); the same deterministic assignment on every rank
@@ -276,6 +279,7 @@ def attach_reducer(prob, world):
     return lambda n: prob["n_attach_full"]
 
 
+GAUSSIAN_COST_IN_TILES = 0.15  # --shard-by work: the fixed cost of a Gaussian in units of one candidate (Gaussian, tile) pair
 GROWTH_SPARE_ROWS = 32768  # FusedMapper.reserve: room for ~20 growth steps of cfg 5 (1 300 new Gaussians each) before a re-allocation
 
 

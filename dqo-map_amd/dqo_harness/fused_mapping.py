@@ -508,7 +508,7 @@ class FusedMapper:
             return int(list_split), int(list_split)
         tiles = int((tile_mask != 0).sum().item()) if tile_mask is not None else ((st.image_width + 15) // 16) * ((st.image_height + 15) // 16)
         if tiles <= 1300:
-            t = 256 if tiles <= 400 else 512 if tiles <= 800 else 1024
+            t = 256 if tiles <= 500 else 512 if tiles <= 800 else 1024
             return (t, t) if longest >= 1024 else (0, 0)
         if tiles <= 2600:
             return (1024, 0) if longest >= 2048 else (0, 0)
