@@ -13,8 +13,9 @@ is one rank; started plainly as `python bench.py --gpus N`, the script launches 
 touches the GPU (launch_ranks) and exits with the child's code.  Default `--scaling strong`: ONE map is
 built, sharded by object id (dqo_harness.sharding.shard_scene), every rank owns its objects' Gaussians + Adam state and renders
 only the tiles its objects' masks touch; one iteration of the job = every shard stepped once, so value = steps / time whatever N
-is.  The only exchange is one packed all-reduce per iteration of the shards' loss sums (started asynchronously, off the compute
-stream's critical path).  `--scaling weak` keeps round 1's mode (an independent map of P Gaussians per rank).  After the timed
+is.  The job is defined per object (object gate + per-object masked loss), so N shards compute exactly what N = 1
+computes — asserted on every N > 1 run (config.n1_equivalence).  The only exchange is one packed all-reduce per iteration of the
+shards' loss sums (started asynchronously, off the compute stream's critical path).  `--scaling weak` keeps round 1's mode (an independent map of P Gaussians per rank).  After the timed
 loop every rank checks its result against the same shard run alone and the job exits non-zero on a mismatch.
 Rank 0 prints ONE JSON line.
 """

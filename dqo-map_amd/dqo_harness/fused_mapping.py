@@ -7,9 +7,12 @@ the autograd graph and the ~110 eager launches per iteration: activation kernel 
 forward+backward -> rasteriser backward -> fused (activation-Jacobian + Adam) kernel.  The rasteriser is called through the
 same operator code (`_RasterizeGaussians.forward / .backward`), so it is the same C-ABI path the drop-in op uses.
 
-`capture()` records one whole iteration (13 kernel launches + one 16 KB memset, no host synchronisation, the Adam step count
-kept on the device) into a hipGraph over persistent buffers; `replay()` re-issues it with a single launch call — at ~0.78 ms
-of GPU work per iteration on config 3 the per-launch host work of the eager path is otherwise as long as the GPU work.
+`capture()` records one whole iteration (eight kernel launches since round 3: zero fill, preprocess, binning, two sort kernels, forward
+blend with the loss tap, backward blend, and ONE per-Gaussian tail — record sums, the per-Gaussian chain and Adam; no memset node, no
+host synchronisation, the Adam step count, the attach set and its size kept on the device) into a hipGraph over persistent buffers;
+`replay()` re-issues it with a single launch call — at ~0.53 ms of GPU work per iteration on config 3 the per-launch host work of the
+eager path is otherwise longer than the GPU work.  `reserve()` + `grow()` + `begin_mapping_call()` keep the captured graph valid across
+map-growth steps and mapping calls (everything they change is rewritten in place).
 
 Only the masked-loss case is fused (SSIM needs an 11x11 convolution and is skipped by the reference when a render mask is
 given, B14); without a mask use the autograd path of dqo_harness/mapping.py.  GPU only.
