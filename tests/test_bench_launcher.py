@@ -48,7 +48,9 @@ def test_plain_gpus_n_starts_n_ranks_and_relays_the_exit_code():
     if torch.cuda.is_available():
         pytest.skip("GPU box: covered by test_two_rank_rehearsal_on_one_gpu")
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    # (the launcher ends the other rank as soon as the first one fails: at least one rank has said why, and its failure summary lists two)
+    assert r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-2000:]
+    assert "local_rank: 0" in r.stderr and "local_rank: 1" in r.stderr, r.stderr[-2000:]
 
 
 def test_world_size_mismatch_exits_nonzero():
