@@ -935,6 +935,24 @@ def main():
         fails = selfcheck(args, prob, runner, device, n_iters)
         for f in fails:
             print(f"[bench] SELF-CHECK FAILED on rank {rank}: {f}", file=sys.stderr, flush=True)
+    # the collective's own cost ("the all-reduce time share"): the packed all-reduce of the iteration — the same payload,
+    # the same staging path — issued back to back with nothing else in flight, max over the ranks.  In the timed loop it runs
+    # asynchronously beside the next iteration's graph, so this is what it would add if it were on the critical path, not what it adds.
+    allreduce = None
+    if world > 1:
+        n_ops = 50
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_ops):
+            loss_buf.reduce_async(src=(runner.fm.loss if runner is not None else None))
+        loss_buf.finish()
+        torch.cuda.synchronize()
+        t_ar = torch.tensor([(time.perf_counter() - t0) / n_ops], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t_ar, op=torch.distributed.ReduceOp.MAX)
+        allreduce = dict(payload_bytes=int(loss_buf.buf.numel() * 4), ms_per_op=round(float(t_ar.item()) * 1e3, 4),
+                         share_of_iteration=round(float(t_ar.item()) / (dt / args.steps), 4),
+                         mode="asynchronous on a ring of staging buffers, off the compute stream's critical path")
     # the sharded per-object job computes the N = 1 function: the shards' losses of the initial state, all-reduced, against the unsharded
     # job's loss of the same state (every rank has the full map on the host: it rendered the target from it)
     n1_check = None
@@ -1165,6 +1183,7 @@ def main():
                                    + " + attach loss, raster fwd+bwd + Adam (6 groups); path=" + args.path
                                    + ("" if args.path != "fused" or args.no_graph else " (one hipGraph replay per iteration)"),
                        "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
+                       **({"allreduce": allreduce} if allreduce is not None else {}),
                        "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
                        "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}),
                        **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else

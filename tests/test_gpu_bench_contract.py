@@ -48,6 +48,8 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shards"] == 2 and d["config"]["selfcheck"] == "ok"
+    ar = d["config"]["allreduce"]  # the all-reduce time share
+    assert ar["payload_bytes"] == 32 and ar["ms_per_op"] > 0 and 0 < ar["share_of_iteration"] < 10
     assert d["config"]["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo" and d["config"]["devices"] == [0, 0]
     assert "sharded by object id over 2 ranks" in d["config"]["workload"]
     assert 0 < d["config"]["P_shard"] < d["config"]["P"] and d["loss"][0] > 0
