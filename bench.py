@@ -230,13 +230,14 @@ def build_problem(args, rank, world, device):
 LOSS_SPEC = [("total", 1), ("color", 1), ("depth", 1), ("pad", 1), ("sum_color", 1), ("n_color", 1), ("sum_depth", 1), ("n_depth", 1)]
 
 
-def make_dropin_step(prob, device, loss_buf, optin=False):
+def make_dropin_step(prob, device, loss_buf, optin=False, dqo_adam=False):
     """What unchanged DQO-MAP code executes: autograd through the drop-in op, eager torch loss, torch.optim.Adam.  optin: the same loop
     with the two opt-in Functions of dqo_harness.fused_ops in place of the eager masked loss and attach loss (two two-line changes in
-    mapper.py's loss_update); op and optimiser untouched."""
+    mapper.py's loss_update); op and optimiser untouched.  dqo_adam: fused_ops.DqoAdam in place of torch.optim.Adam (one more line:
+    the optimiser's constructor, gaussian_pointcloud.py:378) — same groups, same arithmetic, one launch per step."""
     from dqo_harness import mapping, fused_ops
     params = mapping.GaussianParams(prob["scene"], device)
-    opt = mapping.make_optimizer(params)
+    opt = fused_ops.DqoAdam(params.param_groups(), lr=0.0, eps=1e-15) if dqo_adam else mapping.make_optimizer(params)
     init_stat = params.init_stat()
     st, gtc, gtd, rm, tm = prob["settings"], prob["gt_color"], prob["gt_depth"], prob["render_mask"], prob["tile_mask"]
 
@@ -989,17 +990,21 @@ def main():
             # both loops are host-bound (the GPU drains 0.4 ms after the last launch call of an iteration): three alternations, median
             sa = make_dropin_step(prob, device, PackedAllReduce(LOSS_SPEC, device))
             sb = make_dropin_step(prob, device, PackedAllReduce(LOSS_SPEC, device), optin=True)
-            da, db = [], []
+            sc = make_dropin_step(prob, device, PackedAllReduce(LOSS_SPEC, device), optin=True, dqo_adam=True)
+            da, db, dc = [], [], []
             for _ in range(3):
-                da.append(time_path(sa)), db.append(time_path(sb))
-            d1, d2 = sorted(da)[1], sorted(db)[1]
+                da.append(time_path(sa)), db.append(time_path(sb)), dc.append(time_path(sc))
+            d1, d2, d3 = sorted(da)[1], sorted(db)[1], sorted(dc)[1]
             alt = {"path": "dropin", "value": round(1.0 / d1, 3), "unit": "iter/s", "ms_per_step": round(d1 * 1e3, 4),
                    "what": "unchanged DQO-MAP code: autograd through the drop-in op, the reference's eager loss / attach loss (its job: no "
                            "object gate, one masked loss), torch.optim.Adam"}
             alt_optin = {"path": "dropin + opt-in loss Functions", "value": round(1.0 / d2, 3), "unit": "iter/s", "ms_per_step": round(d2 * 1e3, 4),
                          "what": "the same loop with dqo_harness.fused_ops.masked_mapping_loss / fused_attach_loss in place of the eager "
-                                 "loss and attach loss (two two-line changes in mapper.py); op and torch.optim.Adam untouched"}
-            del sa, sb
+                                 "loss and attach loss (two two-line changes in mapper.py); op and torch.optim.Adam untouched",
+                         "with_dqo_adam": {"value": round(1.0 / d3, 3), "unit": "iter/s", "ms_per_step": round(d3 * 1e3, 4),
+                                           "what": "and dqo_harness.fused_ops.DqoAdam in place of torch.optim.Adam (same groups, same "
+                                                   "arithmetic, one launch per step)"}}
+            del sa, sb, sc
             # the op alone: forward + backward with a fixed incoming gradient (what share of the drop-in iteration is the operator)
             pr_ = mapping.GaussianParams(prob["scene"], device)
             gC, gD = torch.randn_like(prob["gt_color"]), torch.randn_like(prob["gt_depth"])

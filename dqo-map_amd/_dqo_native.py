@@ -70,9 +70,13 @@ class DqoAdamStep(ctypes.Structure):
                 [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp), ("block_ticket", c_vp), ("bias_table", c_vp), ("attach_gains", c_vp)])
 
 
+class DqoAdamTensor(ctypes.Structure):
+    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("n", ctypes.c_int64), ("lr", c_f)]
+
+
 EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
            "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_adam_step", "dqo_map_attach_workspace_bytes",
-           "dqo_map_attach_loss_fwd_bwd", "dqo_accumulate_gaussian_error", "dqo_accumulate_gaussian_confidence", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
+           "dqo_map_attach_loss_fwd_bwd", "dqo_adam_multi", "dqo_accumulate_gaussian_error", "dqo_accumulate_gaussian_confidence", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
            "dqo_rast_binning_bytes", "dqo_rast_binning_bytes_bucketed",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
            "dqo_rast_forward", "dqo_rast_backward", "dqo_rast_backward_adam", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
@@ -124,6 +128,7 @@ def lib():
         L.dqo_map_adam_step.argtypes = [P(DqoAdamStep), c_vp]
         L.dqo_map_attach_workspace_bytes.restype = ctypes.c_size_t
         L.dqo_map_attach_workspace_bytes.argtypes = [c_i32]
+        L.dqo_adam_multi.argtypes = [c_vp, c_i32, c_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp]
         L.dqo_map_attach_loss_fwd_bwd.argtypes = [c_i32] + [c_vp] * 7 + [c_i32] + [c_vp] * 5 + [ctypes.c_size_t, c_vp]
         L.dqo_accumulate_gaussian_error.argtypes = [c_i32] * 3 + [c_vp] * 5 + [c_f] * 3 + [c_i32] + [c_vp] * 6
         L.dqo_accumulate_gaussian_confidence.argtypes = [c_i32] * 3 + [c_vp] * 7
@@ -143,7 +148,7 @@ def lib():
         L.dqo_abi_sizeof.restype = ctypes.c_size_t
         L.dqo_abi_sizeof.argtypes = [c_i32]
         for k, st in enumerate((DqoRastParams, DqoRastInputs, DqoRastOutputs, DqoRastCtx, DqoRastGrads, DqoRastHeader, DqoProfileEntry,
-                                DqoAdamStep, DqoLossTap, DqoObjectGate)):
+                                DqoAdamStep, DqoLossTap, DqoObjectGate, DqoAdamTensor)):
             if L.dqo_abi_sizeof(k) != ctypes.sizeof(st):
                 raise RuntimeError(f"libdqoraster.so: struct {st.__name__} is {L.dqo_abi_sizeof(k)} bytes in the library, "
                                    f"{ctypes.sizeof(st)} in the binding")

@@ -10,6 +10,11 @@
 struct AdamArgs {
     int P, M;
     float beta1, beta2, eps, bc2_sqrt;
+    // torch forms 1 - beta and beta^t from python floats (double) and rounds the RESULT to float: 1 - 0.999 is 0.001f there, while
+    // 1.f - 0.999f is 0.00099998713 (1.3e-5 off, and with it exp_avg_sq and the bias correction).  The ABI carries the betas as floats:
+    // dqo_beta_double() takes them back to the decimal they were written as.
+    float omb1, omb2;          // (float)(1 - beta1), (float)(1 - beta2)
+    double beta1_d, beta2_d;
     float step_xyz, step_dc, step_rest, step_opacity, step_scaling, step_rotation;
     float *xyz, *shs, *opacity_raw, *scaling_raw, *rotation_raw;                 // parameters (raw), updated in place
     const float *g_xyz, *g_shs, *g_opacity, *g_scales, *g_rot;                    // gradients w.r.t. the ACTIVATED parameters
@@ -32,6 +37,9 @@ struct AdamArgs {
     float* bias_table;                                                            // optional (with step_dev): DqoAdamStep.bias_table
     const float* attach_gains;                                                    // optional: DqoAdamStep.attach_gains (replaces attach_g3/4)
 };
+
+// a float beta as the double it was most likely written as: rounded to seven decimals (0.999f = 0.99900001287... -> 0.999)
+static inline double dqo_beta_double(float b) { return (double)(long long)((double)b * 1e7 + 0.5) / 1e7; }
 
 // host side: DqoAdamStep -> AdamArgs (argument checks included); blocks = the launch's grid size (for the step-advance ticket)
 int dqo_adam_args(const DqoAdamStep* st, int blocks, AdamArgs* out, bool* attach);
@@ -62,8 +70,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
     // Separate IEEE operations (no FMA contraction): every instantiation of the kernel then produces the same bits, which the
     // exact sparse mode's equivalence to the dense update is tested against.
 #pragma clang fp contract(off)
-    m = m + (g - m) * (1.f - a.beta1);
-    v = v * a.beta2 + (1.f - a.beta2) * g * g;
+    m = m + (g - m) * a.omb1;
+    v = v * a.beta2 + a.omb2 * g * g;
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
     p = p - step_size * (m / denom);
 }
@@ -85,7 +93,7 @@ struct AdamGradGlobal {
 // learning rates / (1 - beta1^t).  Two double-precision pow() calls, a square root and six divisions: several hundred instructions.
 __device__ __forceinline__ void adam_bias_compute(const AdamArgs& a, const int step, float* out /*[7]*/) {
     const double t = (double)step;
-    const double bc1 = 1.0 - pow((double)a.beta1, t), bc2 = 1.0 - pow((double)a.beta2, t);
+    const double bc1 = 1.0 - pow(a.beta1_d, t), bc2 = 1.0 - pow(a.beta2_d, t);
     out[0] = (float)sqrt(bc2);
     out[1] = (float)((double)a.lr_xyz / bc1), out[2] = (float)((double)a.lr_dc / bc1), out[3] = (float)((double)a.lr_rest / bc1);
     out[4] = (float)((double)a.lr_opacity / bc1), out[5] = (float)((double)a.lr_scaling / bc1);

@@ -34,6 +34,7 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
 size_t dqo_map_attach_ws_bytes(int P);
+int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s);
 int dqo_launch_map_attach(int P, const float* scaling, const float* xyz, const float* rotation, const float* scaling0, const float* xyz0,
                           const float* rotation0, const uint8_t* mask, int attach_count, float* loss, float* g_scaling, float* g_xyz,
                           float* g_rotation, void* ws, hipStream_t s);
@@ -135,7 +136,8 @@ DQO_API int dqo_profile_collect(DqoProfileEntry* out, int max_entries, int reset
 DQO_API int dqo_abi_version(void) { return DQO_ABI_VERSION; }
 DQO_API size_t dqo_abi_sizeof(int32_t which) {
     static const size_t sz[] = {sizeof(DqoRastParams), sizeof(DqoRastInputs), sizeof(DqoRastOutputs), sizeof(DqoRastCtx), sizeof(DqoRastGrads),
-                                sizeof(DqoRastHeader), sizeof(DqoProfileEntry), sizeof(DqoAdamStep), sizeof(DqoLossTap), sizeof(DqoObjectGate)};
+                                sizeof(DqoRastHeader), sizeof(DqoProfileEntry), sizeof(DqoAdamStep), sizeof(DqoLossTap), sizeof(DqoObjectGate),
+                                sizeof(DqoAdamTensor)};
     return (which >= 0 && which < (int32_t)(sizeof(sz) / sizeof(sz[0]))) ? sz[which] : 0;
 }
 DQO_API const char* dqo_last_error(void) { return g_err; }
@@ -385,6 +387,21 @@ DQO_API int dqo_map_attach_loss_fwd_bwd(int32_t P, const float* scaling_raw, con
     }
     return dqo_launch_map_attach(P, scaling_raw, xyz, rotation_raw, init_scaling_raw, init_xyz, init_rotation_raw, attach_mask, attach_count,
                                  loss, g_scaling_raw, g_xyz, g_rotation_raw, ws, (hipStream_t)stream);
+}
+
+DQO_API int dqo_adam_multi(const DqoAdamTensor* ts, int32_t n_tensors, int32_t step, double beta1, double beta2, double eps, void* stream) {
+    DQO_CHECK_ARG(n_tensors >= 0 && n_tensors <= DQO_ADAM_MULTI_MAX, "n_tensors out of range");
+    DQO_CHECK_ARG(n_tensors == 0 || ts != nullptr, "null tensor list");
+    DQO_CHECK_ARG(step >= 1, "step is the 1-based count of this update");
+    DQO_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "bad betas / eps");
+    int64_t total = 0;
+    for (int t = 0; t < n_tensors; t++) {
+        DQO_CHECK_ARG(ts[t].n >= 0, "negative element count");
+        DQO_CHECK_ARG(ts[t].n == 0 || (ts[t].p && ts[t].g && ts[t].m && ts[t].v), "null pointer in the tensor list");
+        total += ts[t].n;
+    }
+    DQO_CHECK_ARG(total < ((int64_t)1 << 40), "too many elements");
+    return dqo_launch_adam_multi(ts, n_tensors, step, beta1, beta2, eps, (hipStream_t)stream);
 }
 
 DQO_API int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const float* ce, const float* de, const float* ne,

@@ -338,9 +338,11 @@ int dqo_adam_args(const DqoAdamStep* st, int blocks, AdamArgs* out, bool* attach
     AdamArgs a;
     a.P = st->P, a.M = st->M;
     a.beta1 = st->beta1, a.beta2 = st->beta2, a.eps = st->eps;
+    a.beta1_d = dqo_beta_double(st->beta1), a.beta2_d = dqo_beta_double(st->beta2);
+    a.omb1 = (float)(1.0 - a.beta1_d), a.omb2 = (float)(1.0 - a.beta2_d);
     // bias corrections in double like torch (python floats), then cast
     const double tstep = st->step >= 1 ? (double)st->step : 1.0;  // (ignored by the kernel when step_dev is given)
-    const double bc1 = 1.0 - pow((double)st->beta1, tstep), bc2 = 1.0 - pow((double)st->beta2, tstep);
+    const double bc1 = 1.0 - pow(a.beta1_d, tstep), bc2 = 1.0 - pow(a.beta2_d, tstep);
     a.bc2_sqrt = (float)sqrt(bc2);
     a.step_xyz = (float)((double)st->lr_xyz / bc1);
     a.step_dc = (float)((double)st->lr_f_dc / bc1);
@@ -396,6 +398,70 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s) {
     }
     if (st->step_dev != nullptr && !advance_inside)
         DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, st->step_dev, st->frame_header);
+    return DQO_OK;
+}
+
+// ---- dqo_adam_multi: torch.optim.Adam.step() over a handful of dense tensors in one launch ----
+namespace {
+constexpr int ADAMM_THREADS = 256, ADAMM_PER_THREAD = 4;
+struct AdamMultiArgs {
+    float* p[DQO_ADAM_MULTI_MAX];
+    const float* g[DQO_ADAM_MULTI_MAX];
+    float* m[DQO_ADAM_MULTI_MAX];
+    float* v[DQO_ADAM_MULTI_MAX];
+    int64_t n[DQO_ADAM_MULTI_MAX];
+    float step_size[DQO_ADAM_MULTI_MAX];      // lr / (1 - beta1^t)
+    uint32_t first_block[DQO_ADAM_MULTI_MAX + 1];  // tensor t owns blocks [first_block[t], first_block[t + 1])
+    int n_tensors;
+    float beta1, beta2, omb1, omb2, eps, bc2_sqrt;
+};
+__global__ __launch_bounds__(ADAMM_THREADS) void adam_multi_kernel(const AdamMultiArgs q) {
+    int t = 0;  // (block-uniform: at most 16 trips)
+    while (t + 1 < q.n_tensors && blockIdx.x >= q.first_block[t + 1]) t++;
+    AdamArgs a;  // (adam1 reads these fields only)
+    a.beta2 = q.beta2, a.omb1 = q.omb1, a.omb2 = q.omb2, a.eps = q.eps, a.bc2_sqrt = q.bc2_sqrt;
+    const float ss = q.step_size[t];
+    float* const p = q.p[t];
+    const float* const g = q.g[t];
+    float* const m = q.m[t];
+    float* const v = q.v[t];
+    const int64_t n = q.n[t];
+    const int64_t base = ((int64_t)(blockIdx.x - q.first_block[t]) * ADAMM_THREADS + threadIdx.x) * ADAMM_PER_THREAD;
+    if (base + ADAMM_PER_THREAD <= n && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0u) {
+        float4 pp = *reinterpret_cast<const float4*>(p + base), mm = *reinterpret_cast<const float4*>(m + base);
+        float4 vv = *reinterpret_cast<const float4*>(v + base);
+        const float4 gg = *reinterpret_cast<const float4*>(g + base);
+        adam1(pp.x, gg.x, mm.x, vv.x, a, ss), adam1(pp.y, gg.y, mm.y, vv.y, a, ss);
+        adam1(pp.z, gg.z, mm.z, vv.z, a, ss), adam1(pp.w, gg.w, mm.w, vv.w, a, ss);
+        *reinterpret_cast<float4*>(p + base) = pp, *reinterpret_cast<float4*>(m + base) = mm, *reinterpret_cast<float4*>(v + base) = vv;
+    } else {
+        for (int64_t i = base; i < base + ADAMM_PER_THREAD && i < n; i++) {
+            float pi = p[i], mi = m[i], vi = v[i];
+            adam1(pi, g[i], mi, vi, a, ss);
+            p[i] = pi, m[i] = mi, v[i] = vi;
+        }
+    }
+}
+}  // namespace
+
+int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s) {
+    AdamMultiArgs q;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    q.n_tensors = n_tensors, q.beta1 = (float)beta1, q.beta2 = (float)beta2, q.eps = (float)eps, q.bc2_sqrt = (float)sqrt(bc2);
+    q.omb1 = (float)(1.0 - beta1), q.omb2 = (float)(1.0 - beta2);
+    uint32_t blocks = 0;
+    for (int t = 0; t < DQO_ADAM_MULTI_MAX; t++) {
+        const bool in = t < n_tensors;
+        q.p[t] = in ? ts[t].p : nullptr, q.g[t] = in ? ts[t].g : nullptr, q.m[t] = in ? ts[t].m : nullptr, q.v[t] = in ? ts[t].v : nullptr;
+        q.n[t] = in ? ts[t].n : 0;
+        q.step_size[t] = in ? (float)((double)ts[t].lr / bc1) : 0.f;
+        q.first_block[t] = blocks;
+        if (in) blocks += (uint32_t)((ts[t].n + ADAMM_THREADS * ADAMM_PER_THREAD - 1) / (ADAMM_THREADS * ADAMM_PER_THREAD));
+    }
+    q.first_block[DQO_ADAM_MULTI_MAX] = blocks;
+    for (int t = n_tensors; t <= DQO_ADAM_MULTI_MAX; t++) q.first_block[t] = blocks;
+    if (blocks == 0) return DQO_OK;
+    DQO_LAUNCH("adam_multi_kernel", adam_multi_kernel, dim3(blocks), dim3(ADAMM_THREADS), s, q);
     return DQO_OK;
 }
 

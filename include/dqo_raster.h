@@ -301,6 +301,25 @@ int dqo_map_attach_loss_fwd_bwd(int32_t P, const float* scaling_raw, const float
                                 const uint8_t* attach_mask, int32_t attach_count, float* loss, float* g_scaling_raw, float* g_xyz,
                                 float* g_rotation_raw, void* workspace, size_t workspace_bytes, void* hipStream);
 
+/* torch.optim.Adam's step (weight_decay = 0, amsgrad = False, maximize = False) over up to DQO_ADAM_MULTI_MAX dense fp32 tensors in
+ * ONE launch, for callers that keep the reference's parameter tensors and autograd (ABI 3): per tensor p, its gradient g (w.r.t. p
+ * itself — no activation Jacobian is applied here, unlike dqo_map_adam_step), exp_avg m, exp_avg_sq v, element count n and the
+ * group's learning rate; `step` is the 1-based step count of THIS update, common to the tensors of the call (gaussian_pointcloud.py:
+ * 331-378 builds ONE Adam over six groups with eps = 1e-15, so they share it).  The element update is the library's adam1 — the
+ * statement order of torch's single- / multi-tensor paths; betas and eps arrive as doubles and 1 - beta, beta^t, lr / (1 - beta1^t) are
+ * formed in double and rounded once, as torch forms them from python floats.  In place
+ * of torch.optim.Adam.step()'s per-group launches (and their host time: six groups = 0.28 ms per iteration on the drop-in path). */
+#define DQO_ADAM_MULTI_MAX 16
+typedef struct DqoAdamTensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    float lr;
+} DqoAdamTensor;
+int dqo_adam_multi(const DqoAdamTensor* tensors, int32_t n_tensors, int32_t step, double beta1, double beta2, double eps, void* hipStream);
+
 /* dqo_accumulate_gaussian_error <- cuda_utils._C.accumulate_gaussian_error (submodules/cuda_utils/ext.cpp, cuda_utils.cu:17-62,
  * map_process.cu:33-245; caller SLAM/multiprocess/mapper.py:1034-1047).  Maps are [H*W]; outputs [P] are fully written
  * (zero-initialised inside).  check_max != 0: per-Gaussian maximum of the errors (the mode DQO-MAP uses); 0: mean, which needs

@@ -68,3 +68,52 @@ def test_fused_attach_loss_function_matches_the_eager_loss(env):
     z = fused_ops.fused_attach_loss(params._scaling, params._xyz, params._rotation, e)
     gz = torch.autograd.grad(z, [params._scaling, params._xyz, params._rotation])
     assert z.item() == 0.0 and all(float(t.abs().max()) == 0.0 for t in gz)
+
+
+def test_dqo_adam_is_torch_adam(env):
+    """DqoAdam against torch.optim.Adam on the reference's six parameter groups (gaussian_pointcloud.py:331-378: per-group lr, eps =
+    1e-15), ten steps with fresh random gradients, one group without a gradient in some steps (torch skips it and its step count):
+    parameters and both moments within float rounding of torch's (whose foreach / fused paths do not agree with each other bit for
+    bit either), and the state keys are torch's."""
+    torch = env
+    from dqo_harness.fused_ops import DqoAdam
+    dev = torch.device("cuda")
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    P = 20011
+    shapes = dict(xyz=(P, 3), f_dc=(P, 1, 3), f_rest=(P, 15, 3), opacity=(P, 1), scaling=(P, 3), rotation=(P, 4))
+    lrs = dict(xyz=1e-3, f_dc=2.5e-3, f_rest=1.25e-4, opacity=5e-2, scaling=5e-3, rotation=1e-3)
+
+    def build(cls):
+        ps = {k: torch.nn.Parameter(torch.randn(s, device=dev, generator=torch.Generator(device="cuda").manual_seed(hash(k) % 1000))) for k, s in shapes.items()}
+        opt = cls([dict(params=[ps[k]], lr=lrs[k], name=k) for k in shapes], lr=0.0, eps=1e-15)
+        return ps, opt
+
+    pa, oa = build(torch.optim.Adam)
+    pb, ob = build(DqoAdam)
+    for k in shapes:
+        assert torch.equal(pa[k], pb[k])
+    for it in range(10):
+        for k in shapes:
+            g = torch.randn(shapes[k], device=dev, generator=gen) * (10.0 ** (it % 4 - 2))
+            if k == "opacity" and it in (3, 4):
+                pa[k].grad = pb[k].grad = None  # no gradient this step: skipped by both, its step count does not advance
+                continue
+            pa[k].grad, pb[k].grad = g.clone(), g.clone()
+        oa.step(), ob.step()
+    for k in shapes:
+        assert torch.allclose(pa[k], pb[k], rtol=2e-6, atol=1e-7), (k, (pa[k] - pb[k]).abs().max().item())
+        sa, sb = oa.state[pa[k]], ob.state[pb[k]]
+        assert int(sa["step"]) == int(sb["step"]) == (8 if k == "opacity" else 10)
+        # (an exp_avg element near zero is a cancelled sum: an absolute bar of a few ulps of the gradients' size)
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=2e-6, atol=1e-6) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    # a non-contiguous gradient, an odd size (scalar tail of the float4 path) and a learning-rate change between steps
+    q = torch.nn.Parameter(torch.randn(1001, 3, device=dev))
+    r = torch.nn.Parameter(q.detach().clone())
+    o1, o2 = torch.optim.Adam([q], lr=1e-2), DqoAdam([r], lr=1e-2)
+    for it in range(3):
+        g = torch.randn(3, 1001, device=dev).t()
+        q.grad, r.grad = g, g
+        for o in (o1, o2):
+            o.param_groups[0]["lr"] = 1e-2 / (it + 1)
+        o1.step(), o2.step()
+    assert torch.allclose(q, r, rtol=2e-6, atol=1e-7)
