@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cfg", type=int, default=3)
     ap.add_argument("--P", type=int, default=None)
-    ap.add_argument("--sync-mode", default="lazy", choices=("lazy", "exact"))
+    ap.add_argument("--sync-mode", default="lazy", choices=("lazy", "exact", "deferred"),
+                    help="drop-in op (diff_gaussian_rasterization_depth.set_sync_mode): exact = one D2H read per forward; lazy (default) = none in "
+                         "the forward, the backward waits for its forward's header; deferred = the host never waits")
     ap.add_argument("--path", default="fused", choices=("fused", "dropin"),
                     help="fused: dqo_harness.FusedMapper (activation / loss / Adam kernels of row f2 around the op); "
                          "dropin: autograd through the drop-in op + torch.optim.Adam, exactly what unchanged DQO-MAP code runs")
@@ -995,6 +997,11 @@ def main():
             for _ in range(3):
                 da.append(time_path(sa)), db.append(time_path(sb)), dc.append(time_path(sc))
             d1, d2, d3 = sorted(da)[1], sorted(db)[1], sorted(dc)[1]
+            # ... and with the op's 'deferred' mode (the backward no longer waits on the host for its forward's header)
+            dgr.set_sync_mode("deferred")
+            d4 = sorted(time_path(sc) for _ in range(3))[1]
+            d5 = sorted(time_path(sa) for _ in range(3))[1]
+            dgr.set_sync_mode(args.sync_mode)
             alt = {"path": "dropin", "value": round(1.0 / d1, 3), "unit": "iter/s", "ms_per_step": round(d1 * 1e3, 4),
                    "what": "unchanged DQO-MAP code: autograd through the drop-in op, the reference's eager loss / attach loss (its job: no "
                            "object gate, one masked loss), torch.optim.Adam"}
@@ -1003,7 +1010,12 @@ def main():
                                  "loss and attach loss (two two-line changes in mapper.py); op and torch.optim.Adam untouched",
                          "with_dqo_adam": {"value": round(1.0 / d3, 3), "unit": "iter/s", "ms_per_step": round(d3 * 1e3, 4),
                                            "what": "and dqo_harness.fused_ops.DqoAdam in place of torch.optim.Adam (same groups, same "
-                                                   "arithmetic, one launch per step)"}}
+                                                   "arithmetic, one launch per step)"},
+                         "with_dqo_adam_and_deferred_sync": {"value": round(1.0 / d4, 3), "unit": "iter/s", "ms_per_step": round(d4 * 1e3, 4),
+                                                             "what": "and set_sync_mode('deferred'): the op's backward does not wait on the host for "
+                                                                     "its forward's header (an overflow raises one call later)"}}
+            alt["deferred_sync"] = {"value": round(1.0 / d5, 3), "unit": "iter/s", "ms_per_step": round(d5 * 1e3, 4),
+                                    "what": "unchanged caller code after one line: diff_gaussian_rasterization_depth.set_sync_mode('deferred')"}
             del sa, sb, sc
             # the op alone: forward + backward with a fixed incoming gradient (what share of the drop-in iteration is the operator)
             pr_ = mapping.GaussianParams(prob["scene"], device)

@@ -13,7 +13,9 @@ Differences that are not visible to callers:
   * the forward does ONE 4-byte device->host read (the instance count N, to size the binning buffer exactly as the
     reference does at rasterizer_impl.cu:307) instead of the reference's two reads plus a host loop over all tiles;
     `set_sync_mode("lazy")` removes even that one (capacity carried over from the previous call, overflow detected
-    and raised at the next synchronisation point — never silent);
+    and raised at the next synchronisation point — never silent; the backward waits for its forward's header so that no gradient of
+    an invalid frame is ever produced), `set_sync_mode("deferred")` also drops that wait (an overflow is then raised by a later call,
+    after at most a few iterations whose gradients were zero: see set_sync_mode);
   * `tile_mask=None` is accepted and means "all tiles" (the reference requires a tensor).
 There is no CPU path: tensors must live on the GPU and the HIP library must be built.
 """
@@ -32,7 +34,7 @@ import threading
 
 _lock = threading.RLock()
 _list_split = 0         # DqoRastCtx.list_split of the forwards issued through this module (set_list_split)
-_sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy": reuse / grow the previous capacity, no sync
+_sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy" / "deferred": reuse / grow the previous capacity, no sync
 _cap_hint = {}
 _pending = []          # lazy mode: (event, pinned header tensor, key, capacity) of forwards not yet verified
 _last = {"num_rendered": None, "num_visible": None, "header": None}   # header: (event, pinned host copy) or a weak reference to the geometry buffer
@@ -85,13 +87,24 @@ def set_list_split(longer_than):
 
 
 def set_sync_mode(mode):
-    """'exact' (default, one 4-byte D2H read per forward) or 'lazy' (no host synchronisation in the forward)."""
+    """'exact' (default): one 4-byte D2H read per forward.  'lazy': no host synchronisation in the forward — the instance capacity is
+    carried over from earlier calls, the device header of every forward is copied back asynchronously and checked later; the BACKWARD
+    waits for its own forward's header first (the host then idles until the forward has run: 0.3 ms per iteration on config 3), so a
+    frame that outgrew the capacity raises before any gradient of it exists.  'deferred': like 'lazy' without that wait — the host
+    never blocks; an overflowed frame (empty lists: its outputs are background, its gradients exact zeros, nothing is written out of
+    bounds) raises at a later forward / backward / verify_pending() call, typically one iteration later, and the optimiser steps taken
+    in between saw zero gradients.  For loops that can tolerate that (or call verify_pending() where it matters)."""
     global _sync_mode
-    if mode not in ("exact", "lazy"):
+    if mode not in ("exact", "lazy", "deferred"):
         raise ValueError(mode)
     if _pending:
         _verify_pending(block=True)  # forwards issued in lazy mode are still checked (raises if one of them overflowed)
     _sync_mode = mode
+
+
+def verify_pending():
+    """Wait for the headers of every forward issued in 'lazy' / 'deferred' mode and raise if one of them overflowed its capacity."""
+    _verify_pending(block=True)
 
 
 def _verify_pending(block):
@@ -236,7 +249,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
             N.check(lib.dqo_rast_forward_render(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
                                                 ctypes.byref(cctx), stream))
-            if _sync_mode == "lazy":
+            if _sync_mode != "exact":
                 # asynchronous 32-byte copy of the device header into a pinned ring slot: the deferred capacity check (and statistics)
                 with _lock:
                     host, ev = _ring_slot()
@@ -269,8 +282,8 @@ class _RasterizeGaussians(torch.autograd.Function):
          opacities, tile_mask) = ctx.saved_tensors
         if tile_mask.numel() == 0:
             tile_mask = None
-        if _sync_mode == "lazy":
-            _verify_pending(block=True)
+        if _sync_mode != "exact":
+            _verify_pending(block=(_sync_mode == "lazy"))  # (lazy: no gradient of an invalid frame; deferred: never wait, see set_sync_mode)
         P, M = means3D.size(0), ctx.M
         H, W = int(rs.image_height), int(rs.image_width)
         dev = means3D.device

@@ -106,6 +106,37 @@ def test_lazy_mode_overflow_is_detected_and_recovers(torch_cuda, oracle):
     U.compare_forward(h3, r)
 
 
+def test_deferred_mode_never_waits_and_raises_an_overflow_later(torch_cuda, oracle):
+    """set_sync_mode('deferred'): the backward does not wait for its forward's header.  A frame that outgrew the capacity renders
+    background (lists emptied, nothing out of bounds) and the error comes from a later call — verify_pending() at the latest; a frame
+    that fits gives the gradients of the exact mode bit for bit."""
+    import torch
+    import diff_gaussian_rasterization_depth as dgr
+    cam, sc = scenes.make_config(1, P=3000)
+    dL = _dL(cam, 4)
+    h0, g0 = U.run_hip(cam, sc, dL=dL)  # exact mode
+    try:
+        dgr.set_sync_mode("deferred")
+        h1, g1 = U.run_hip(cam, sc, dL=dL)
+        dgr.verify_pending()
+        for k in g0:
+            assert np.array_equal(g0[k], g1[k]), k
+        key = (0, 3000, cam.W, cam.H)
+        dgr._cap_hint[key] = 64  # far too small on purpose
+        r = U.HipRun(cam, sc)  # the forward goes through without an exception: its header has not been looked at ...
+        assert (r.res["hit_depth"] <= 0).all() and (r.res["T_map"] == 1).all()  # ... the invalid frame is background (lists emptied)
+        with pytest.raises(RuntimeError, match="only 64 fitted"):
+            r.backward(dL)         # ... and a LATER call raises (here the backward: reading the outputs back has let the header arrive;
+            dgr.verify_pending()   # in a loop that never reads anything back, the next forward or verify_pending() does)
+        assert dgr._cap_hint[key] > 64
+        h3, g3 = U.run_hip(cam, sc, dL=dL)
+        dgr.verify_pending()
+        for k in g0:
+            assert np.array_equal(g0[k], g3[k]), k
+    finally:
+        dgr.set_sync_mode("exact")
+
+
 @pytest.mark.parametrize("n", [64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193])
 def test_sort_paths_at_their_boundaries(torch_cuda, oracle, n):
     """A tile list of EXACTLY n entries — the lengths at which the per-tile sort changes path (one wave with 1..8 keys per lane,
