@@ -159,13 +159,16 @@ typedef struct DqoRastCtx {
     const DqoLossTap* loss_tap;
     /* NULL (default: the reference's semantics) or the object gate described above; read by the forward and by the backward. */
     const DqoObjectGate* object_gate;
-    /* 0 (default): every 8x8-pixel quadrant of a tile blends its list front to back in ONE wave, the reference's order of arithmetic.
-     * n > 0: lists longer than n entries (n < 64 counts as 64) are shared between eight waves in the forward — rounds of eight chunks of
-     * 64 entries: per chunk the product of (1 - alpha), a scan over the round, then the blend of every chunk from its scanned start
-     * state, and a merge by list position at the end — for launches that cannot fill the GPU, a strong-scaling shard of a few hundred
-     * tiles, whose time is the time of the one longest list.  The transmittance products are grouped by chunk, so results on those
-     * lists differ from the serial order in the last bits (1e-7 relative; a pixel exactly on T_threshold may finish one entry earlier
-     * or later); shorter lists are blended as with 0. */
+    /* 0 (default): every 8x8-pixel quadrant of a tile blends its list front to back (and walks it back to front) in ONE wave, the
+     * reference's order of arithmetic.  n > 0: lists longer than n entries (n < 64 counts as 64) are shared between eight waves — rounds
+     * of eight chunks of 64 entries: per chunk the composed map of the per-pixel state (forward: the product of (1 - alpha) and "holds an
+     * opaque hit"; backward: the scale of T and the affine map of the colour blended behind), a scan over the round, then the blend /
+     * walk of every chunk from its scanned start state — for launches that cannot fill the GPU, a strong-scaling shard of a few hundred
+     * tiles, whose time is the time of the one longest list.  Read by the forward AND by the backward call: the forward builds the
+     * queue of long lists, the backward (given n > 0 too) walks that queue with eight waves per quadrant; a backward given 0 walks every
+     * list in one wave whatever the forward did.  The state is grouped by chunk, so results on those lists differ from the serial order
+     * in the last bits (1e-7 relative; a pixel exactly on T_threshold may finish one entry earlier or later); shorter lists are treated
+     * as with 0. */
     int32_t list_split;
 } DqoRastCtx;
 
