@@ -320,11 +320,18 @@ class FusedRunner:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
 
     def make_growth_batch(self, k):
+        """The candidate points of growth step k.  Strong scaling: ONE batch for the job — every rank draws the same 40 800 points and
+        keeps the candidates of the objects it owns (an object's Gaussians never live on two ranks); the decisions of the step
+        (inside an existing Gaussian? neighbours for the scale?) are then taken against the rank's own Gaussians, so with growth the
+        N-rank map is not the N = 1 map to the last Gaussian (a candidate next to ANOTHER rank's object is judged without it)."""
         from dqo_harness import scenes
         p = self.prob
-        sc = scenes.surfel_room(9000 + 17 * k + self.growth_seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])
-        b = {n: torch.tensor(np.ascontiguousarray(sc[n], np.float32), device=self.device) for n in ("xyz", "scales", "rotations", "opacity", "shs")}
-        b["obj_id"] = torch.tensor(np.asarray(sc["obj_id"], np.int32), device=self.device)
+        seed = 9000 + 17 * k + (0 if p.get("sharded") else self.growth_seed)
+        sc = scenes.surfel_room(seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])
+        keep = np.ones(len(sc["obj_id"]), bool) if not p.get("sharded") else np.isin(np.asarray(sc["obj_id"]), np.asarray(p["objects"]))
+        b = {n: torch.tensor(np.ascontiguousarray(np.asarray(sc[n], np.float32)[keep]), device=self.device)
+             for n in ("xyz", "scales", "rotations", "opacity", "shs")}
+        b["obj_id"] = torch.tensor(np.asarray(sc["obj_id"], np.int32)[keep], device=self.device)
         return b
 
     def prepare_growth(self, n_iters):
