@@ -58,3 +58,29 @@ def test_world_size_mismatch_exits_nonzero():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, cwd=ROOT,
                        env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 8" in r.stderr
+
+
+def test_list_split_choices_are_host_logic():
+    """FusedMapper.pick_list_split_pair (which lists the blend kernels share between eight waves: by tile count and longest list) and
+    bench.parse_list_split — pure host logic, no GPU needed."""
+    import types
+    sys.path[:0] = [os.path.join(ROOT, "dqo-map_amd")]
+    import torch
+    from dqo_harness.fused_mapping import FusedMapper
+    import bench
+    st = types.SimpleNamespace(image_width=1200, image_height=680)  # 75 x 43 = 3225 tiles
+    pair = FusedMapper.pick_list_split_pair
+    tiles = lambda n: torch.ones(n, dtype=torch.int32)
+    assert pair("auto", None, st, 7000) == (2048, 0) and pair("auto", None, st, 3000) == (0, 0)      # a full frame: forward only, long tail only
+    assert pair("auto", tiles(2000), st, 3000) == (1024, 0) and pair("auto", tiles(2000), st, 1500) == (0, 0)  # half a frame
+    assert pair("auto", tiles(1000), st, 1500) == (1024, 1024) and pair("auto", tiles(700), st, 1500) == (512, 512)
+    assert pair("auto", tiles(300), st, 1500) == (256, 256) and pair("auto", tiles(300), st, 900) == (0, 0)   # no list worth cutting
+    mask = tiles(3225)
+    mask[500:] = 0
+    assert pair("auto", mask, st, 5000) == (256, 256)  # masked-out tiles do not count
+    assert pair(300, None, st) == (300, 300) and pair(0, None, st) == (0, 0) and pair((512, 0), None, st) == (512, 0)
+    for bad in ((512, 256), -1):
+        with pytest.raises(ValueError):
+            pair(bad, None, st)
+    assert FusedMapper.pick_list_split("auto", tiles(300), st, 1500) == 256 and FusedMapper.pick_list_split("auto", None, st, 7000) == 0
+    assert bench.parse_list_split("auto") == "auto" and bench.parse_list_split("512") == 512 and bench.parse_list_split("2048,0") == (2048, 0)
