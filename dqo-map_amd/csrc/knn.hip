@@ -8,7 +8,11 @@
 // reads for the bounding box and allocates five temporaries per call): one caller-owned workspace, everything on the
 // caller's stream.  Points are gathered ONCE into Morton order as float4 (xyz + original index), so the candidate scan
 // reads contiguous, wave-uniform addresses (broadcast loads) instead of chasing an index indirection per candidate.
-// The sort is a 64-bit (code << 32 | index) bitonic network: 4096-key runs in LDS, merge steps >= 4096 in global memory.
+// The sort is a stable LSD radix sort of the 30-bit codes (index as payload: equal codes keep index order = the reference's stable
+// sort), four 8-bit passes of histogram -> scan -> scatter; the rank of a key among the equal digits of its block comes from wave
+// ballots (eight ballots match the lanes with the same digit) + per-wave counts in LDS.  12 launches for any size; the first
+// version — a 64-bit bitonic network, 4096-key runs in LDS, merge steps >= 4096 in global memory — needed 55 launches and 0.73 ms
+// for 2 M keys (`make EXTRA=-DKNN_BITONIC_SORT` keeps it for comparison).
 #include <float.h>
 #include <limits.h>
 
@@ -22,6 +26,7 @@ constexpr int KNN_BOX = 1024;  // simple_knn.cu:16 BOX_SIZE (part of the pruning
 constexpr int KNN_SUB = 64;    // second pruning level of the query search: one wave-load of sorted points
 constexpr int SORT_RUN = 4096;
 constexpr int SORT_T = 256;
+constexpr int RDX_T = 256, RDX_KPT = 8, RDX_BLK = RDX_T * RDX_KPT;  // radix sort: keys per block
 
 struct KnnWs {
     float* bbox;        // [8] min xyz, max xyz
@@ -29,6 +34,7 @@ struct KnnWs {
     float4* sorted;     // [P] (x, y, z, bits(original index)) in Morton order
     float* boxes;       // [nb][8] min xyz, max xyz of each run of 1024 sorted points
     float* sub;         // [ceil(P / 64)][8] ... of each run of 64 sorted points (query search only)
+    uint32_t* hist;     // [256][ceil(P / RDX_BLK)] digit histograms / scatter offsets of one radix pass
     size_t total;
 };
 
@@ -52,6 +58,7 @@ inline KnnWs knn_ws(void* base, int P) {
     w.sorted = (float4*)take(16 * (size_t)P);
     w.boxes = (float*)take(32 * (size_t)((P + KNN_BOX - 1) / KNN_BOX));
     w.sub = (float*)take(32 * (size_t)((P + KNN_SUB - 1) / KNN_SUB));
+    w.hist = (uint32_t*)take(4 * 256 * ((size_t)((P + RDX_BLK - 1) / RDX_BLK) + 1));  // + the 256 row totals behind the table
     w.total = (size_t)(p - (char*)base);
     return w;
 }
@@ -162,6 +169,105 @@ __global__ void bitonic_global_kernel(uint64_t* __restrict__ keys, int n_half, i
     if ((a > b) == up) {
         keys[i] = b;
         keys[p] = a;
+    }
+}
+
+// ---- stable LSD radix sort, one 8-bit pass = three kernels ----
+// (1) digit histogram of every block of RDX_BLK keys, stored digit-major: hist[digit][block]
+__global__ __launch_bounds__(RDX_T) void radix_hist_kernel(int n, const uint64_t* __restrict__ keys, int shift, uint32_t* __restrict__ hist,
+                                                            int nblk) {
+    __shared__ uint32_t s[256];
+    s[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RDX_BLK;
+#pragma unroll
+    for (int r = 0; r < RDX_KPT; r++) {
+        const int i = base + r * RDX_T + threadIdx.x;
+        if (i < n) atomicAdd(&s[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s[threadIdx.x];
+}
+// (2) one block per digit: exclusive prefix over that digit's row (its count in block 0, 1, ...) in place, the row's total to tot[digit]
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ hist, int nblk, uint32_t* __restrict__ tot) {
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    const int per = (nblk + 255) / 256, a = tid * per, b = min(nblk, a + per);
+    uint32_t sum = 0;
+    for (int i = a; i < b; i++) sum += row[i];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum;
+    for (int w = 0; w < wave; w++) pre += s_w[w];
+    for (int i = a; i < b; i++) {
+        const uint32_t h = row[i];
+        row[i] = pre;
+        pre += h;
+    }
+    if (tid == 255) tot[blockIdx.x] = pre;  // (the last thread's running sum is the row total)
+}
+// (3) scatter: key -> offs[digit][block] + its rank among the block's keys of the same digit, in block order (stable)
+__global__ __launch_bounds__(RDX_T) void radix_scatter_kernel(int n, const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int shift,
+                                                               const uint32_t* __restrict__ offs, int nblk,
+                                                               const uint32_t* __restrict__ tot) {
+    __shared__ uint32_t s_run[256];              // next free position of every digit (earlier rounds of this block included)
+    __shared__ uint32_t s_wc[RDX_T / 64][256];   // this round's keys per (wave, digit)
+    __shared__ uint32_t s_t[RDX_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // where digit `tid` starts in the output = the keys of all smaller digits: exclusive prefix over the 256 row totals
+        const uint32_t t = tot[tid];
+        uint32_t incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_t[wave] = incl;
+        __syncthreads();
+        uint32_t pre = incl - t;
+        for (int w = 0; w < wave; w++) pre += s_t[w];
+        s_run[tid] = pre + offs[(size_t)tid * nblk + blockIdx.x];
+    }
+#pragma unroll
+    for (int w = 0; w < RDX_T / 64; w++) s_wc[w][tid] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RDX_BLK;
+    for (int r = 0; r < RDX_KPT; r++) {
+        const int i = base + r * RDX_T + tid;
+        const bool valid = i < n;
+        const uint64_t key = valid ? in[i] : 0ull;
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        // the lanes of this wave that hold the same digit: eight ballots
+        unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const bool one = ((d >> bit) & 1u) != 0u;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
+            peers &= one ? bal : ~bal;
+        }
+        const uint32_t rank_w = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank_w == 0u) s_wc[wave][d] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = s_run[d] + rank_w;
+            for (int w = 0; w < wave; w++) pos += s_wc[w][d];
+            out[pos] = key;
+        }
+        __syncthreads();
+        {   // digit `tid`: advance its position by this round's keys, clear the round's counts
+            uint32_t c = 0;
+#pragma unroll
+            for (int w = 0; w < RDX_T / 64; w++) c += s_wc[w][tid], s_wc[w][tid] = 0;
+            s_run[tid] += c;
+        }
+        __syncthreads();
     }
 }
 
@@ -417,6 +523,7 @@ static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, h
         DQO_LAUNCH("bbox_fold_kernel", bbox_fold_kernel, dim3(1), dim3(512), s, nb, partial, w.bbox);
     }
     DQO_LAUNCH("morton_kernel", morton_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
+#ifdef KNN_BITONIC_SORT
     const int runs = P2 / SORT_RUN;
     DQO_LAUNCH("bitonic_lds_kernel", bitonic_lds_kernel, dim3(runs), dim3(SORT_T), s, w.keys, SORT_RUN, 1);
     for (int k = SORT_RUN * 2; k <= P2; k <<= 1) {
@@ -425,6 +532,22 @@ static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, h
         }
         DQO_LAUNCH("bitonic_lds_kernel", bitonic_lds_kernel, dim3(runs), dim3(SORT_T), s, w.keys, k, 0);
     }
+#else
+    {   // the Morton code sits in bits 32..61 of the key: four stable 8-bit passes; the second key buffer is `sorted` (16 B per point,
+        // written by the gather only after the sort); an even number of passes leaves the result in w.keys
+        const int nblk = (P + RDX_BLK - 1) / RDX_BLK;
+        uint64_t* a = w.keys;
+        uint64_t* b = reinterpret_cast<uint64_t*>(w.sorted);
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 32 + 8 * pass;
+            DQO_LAUNCH("radix_hist_kernel", radix_hist_kernel, dim3(nblk), dim3(RDX_T), s, P, a, shift, w.hist, nblk);
+            DQO_LAUNCH("radix_scan_kernel", radix_scan_kernel, dim3(256), dim3(256), s, w.hist, nblk, w.hist + (size_t)256 * nblk);
+            DQO_LAUNCH("radix_scatter_kernel", radix_scatter_kernel, dim3(nblk), dim3(RDX_T), s, P, a, b, shift, w.hist, nblk,
+                       w.hist + (size_t)256 * nblk);
+            std::swap(a, b);
+        }
+    }
+#endif
     DQO_LAUNCH("gather_sorted_kernel", gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), s, P, xyz, w.keys, w.sorted);
     if (with_boxes) {
         const int nb = (P + KNN_BOX - 1) / KNN_BOX;
