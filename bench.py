@@ -390,7 +390,8 @@ class FusedRunner:
         t1 = time.perf_counter()
         if self.use_graph and fm.graph_overflowed():
             raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
-        st = fm.grow(new, delete_mask=delete, new_mapping_call=True, stable_mask=self.stable_mask)  # (fresh Adam + init_stat: mapper.py:533-548)
+        st = fm.grow(new, delete_mask=delete, new_mapping_call=True, stable_mask=self.stable_mask,
+                     attach_async=os.environ.get("DQO_GROW_ASYNC", "1") == "1")  # (0: the attach step in line, for A/B)  # (fresh Adam + init_stat: mapper.py:533-548)
         st.pop("rows", None)
         kept = st.pop("kept_rows", None)
         torch.cuda.synchronize()
@@ -916,6 +917,12 @@ def main():
         runner.prepare_growth(args.warmup + args.steps)
     for _ in range(args.warmup):
         step()
+    # the interpreter's cyclic collector off the timed region: a full collection over the set-up's objects (the synthetic maps, the
+    # oracle's arrays) is a 40-80 ms pause, and the growth steps' temporaries trigger one now and then (nothing here builds cycles)
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -932,6 +939,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     per_object = prob.get("gate") is not None
+    gc.enable()
     loss_now = reduced_losses(loss_buf.buf, world, per_object)
     dbg("timed loop done: dt", dt, "rank loss", runner.fm.loss[:3].tolist() if runner else None, "reduced", loss_now)
     if args.inner:

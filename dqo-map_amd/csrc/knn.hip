@@ -35,6 +35,7 @@ struct KnnWs {
     float* boxes;       // [nb][8] min xyz, max xyz of each run of 1024 sorted points
     float* sub;         // [ceil(P / 64)][8] ... of each run of 64 sorted points (query search only)
     uint32_t* hist;     // [256][ceil(P / RDX_BLK)] digit histograms / scatter offsets of one radix pass
+    float* groups;      // [ceil(nb / 64)][8] min / max of each run of 64 level-1 boxes = 65 536 sorted points (query search only)
     size_t total;
 };
 
@@ -59,6 +60,7 @@ inline KnnWs knn_ws(void* base, int P) {
     w.boxes = (float*)take(32 * (size_t)((P + KNN_BOX - 1) / KNN_BOX));
     w.sub = (float*)take(32 * (size_t)((P + KNN_SUB - 1) / KNN_SUB));
     w.hist = (uint32_t*)take(4 * 256 * ((size_t)((P + RDX_BLK - 1) / RDX_BLK) + 1));  // + the 256 row totals behind the table
+    w.groups = (float*)take(32 * (size_t)(((P + KNN_BOX - 1) / KNN_BOX + 63) / 64));
     w.total = (size_t)(p - (char*)base);
     return w;
 }
@@ -405,6 +407,22 @@ __global__ __launch_bounds__(256) void sub_minmax_kernel(int P, const float4* __
     else if (lane < 6) sub[8 * w + lane] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
 }
 
+// third pruning level of the query search: min / max over runs of 64 level-1 boxes (one wave per group)
+__global__ __launch_bounds__(256) void group_minmax_kernel(int nb, const float* __restrict__ boxes, float* __restrict__ groups) {
+    const int gidx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int ng = (nb + 63) / 64;
+    if (gidx >= ng) return;
+    const float* bx = boxes + 8 * (size_t)min(gidx * 64 + lane, nb - 1);  // (the last box again for the padding lanes)
+    float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
+    for (int a = 0; a < 3; a++)
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    if (lane < 3) groups[8 * gidx + lane] = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
+    else if (lane < 6) groups[8 * gidx + lane] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
+}
+
 // wave64 minimum, result wave-uniform.  DPP lanes that are not written keep `v` itself (old = v), so the minimum is unaffected.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_self(float v) {
@@ -431,8 +449,8 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // 2 M Gaussians — a wave's queries lie far apart and it scanned ~45 boxes of 1024 points each: 39 ms, now 1 ms.)
 __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float* __restrict__ q_xyz, int R,
                                                              const float4* __restrict__ sorted_r, const float* __restrict__ boxes,
-                                                             const float* __restrict__ sub, float* __restrict__ dist2,
-                                                             int32_t* __restrict__ idx3) {
+                                                             const float* __restrict__ sub, const float* __restrict__ groups,
+                                                             float* __restrict__ dist2, int32_t* __restrict__ idx3) {
     const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (q >= Q) return;
     const float4 me = make_float4(q_xyz[3 * q], q_xyz[3 * q + 1], q_xyz[3 * q + 2], 0.f);
@@ -489,18 +507,29 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
         bmin = __builtin_amdgcn_readlane(bl, owner);
     }
     scan_box(bmin);
-    // pass 2: every other box that cannot be excluded
-    for (int bb = 0; bb < nb; bb += 64) {
-        const int b = bb + lane;
-        const bool in = b < nb && b != bmin;
-        const float d = in ? dist_box_point(boxes + 8 * (size_t)b, me) : FLT_MAX;
-        unsigned long long m1 = __builtin_amdgcn_ballot_w64(in && !(d > b2));
-        while (m1 != 0ull) {
-            const int l = (int)__builtin_ctzll(m1);
-            m1 &= m1 - 1ull;
-            const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
-            if (dl > b2) continue;
-            scan_box(bb + l);
+    // pass 2: every other box that cannot be excluded, group by group (runs of 64 boxes = 65 536 sorted points: a group that cannot hold
+    // a better candidate is skipped whole — 31 group tests instead of 1954 box tests against a 2 M-point map)
+    const int ng = (nb + 63) / 64;
+    for (int gg = 0; gg < ng; gg += 64) {
+        const int gr = gg + lane;
+        const float dg = gr < ng ? dist_box_point(groups + 8 * (size_t)gr, me) : FLT_MAX;
+        unsigned long long mg = __builtin_amdgcn_ballot_w64(gr < ng && !(dg > b2));
+        while (mg != 0ull) {
+            const int lg = (int)__builtin_ctzll(mg);
+            mg &= mg - 1ull;
+            const float dgl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dg), lg));
+            if (dgl > b2) continue;  // the bound has tightened since the ballot
+            const int b = (gg + lg) * 64 + lane;
+            const bool in = b < nb && b != bmin;
+            const float d = in ? dist_box_point(boxes + 8 * (size_t)b, me) : FLT_MAX;
+            unsigned long long m1 = __builtin_amdgcn_ballot_w64(in && !(d > b2));
+            while (m1 != 0ull) {
+                const int l = (int)__builtin_ctzll(m1);
+                m1 &= m1 - 1ull;
+                const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
+                if (dl > b2) continue;
+                scan_box((gg + lg) * 64 + l);
+            }
         }
     }
     if (lane == 0) {
@@ -577,7 +606,9 @@ int dqo_launch_knn3_query(int Q, const float* q_xyz, int R, const float* r_xyz, 
     if (rc) return rc;
     const int ns = (R + KNN_SUB - 1) / KNN_SUB;
     DQO_LAUNCH("sub_minmax_kernel", sub_minmax_kernel, dim3((ns * 64 + 255) / 256), dim3(256), s, R, wr.sorted, wr.sub);
+    const int nb = (R + KNN_BOX - 1) / KNN_BOX, ng = (nb + 63) / 64;
+    DQO_LAUNCH("group_minmax_kernel", group_minmax_kernel, dim3((ng * 64 + 255) / 256), dim3(256), s, nb, wr.boxes, wr.groups);
     DQO_LAUNCH("knn_query_wave_kernel", knn_query_wave_kernel, dim3(((size_t)Q * 64 + 255) / 256), dim3(256), s, Q, q_xyz, R, wr.sorted,
-               wr.boxes, wr.sub, dist2, idx3);
+               wr.boxes, wr.sub, wr.groups, dist2, idx3);
     return DQO_OK;
 }

@@ -265,7 +265,7 @@ class FusedMapper:
 
     @torch.no_grad()
     def grow(self, new, delete_mask=None, min_radius=0.001, max_radius=0.05, xyz_factor=(1.0, 1.0, 0.1), scale_factor=1.0,
-             new_mapping_call=False, stable_mask=None, unstable_opacity_low=0.1):
+             new_mapping_call=False, stable_mask=None, unstable_opacity_low=0.1, attach_async=True):
         """The map-growth step between two mapping calls — Mapping.gaussians_add (SLAM/multiprocess/mapper.py:249-254) and the
         deletion half of error_gaussians_remove (:1086-1096) — on this mapper's map:
           1. temp_points_filter (:1351-1380): new points that fall inside an existing Gaussian (one of their 3 nearest existing
@@ -328,7 +328,9 @@ class FusedMapper:
                 N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
                                                  N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
                 self._act_valid = True
-            side, box = torch.cuda.Stream(device=dev), {}
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=dev)  # (made once: creating a stream costs a growth step ~1 ms)
+            side, box = self._side_stream, {}
             side.wait_stream(torch.cuda.current_stream())
 
             def attach_work(tx=nx, to=nop):
@@ -338,8 +340,13 @@ class FusedMapper:
                 except BaseException as e:  # (re-raised by the caller's thread)
                     box["err"] = e
 
-            attach_job = threading.Thread(target=attach_work)
-            attach_job.start()
+            if attach_async:
+                attach_job = threading.Thread(target=attach_work)
+                attach_job.start()
+            else:  # (A/B of the overlap: the same work in line)
+                attach_work()
+                attach_job = threading.Thread(target=lambda: None)
+                attach_job.start()
         log_scales = None
         if nx.shape[0] > 0:
             nrad = (nsc.sum(dim=1) - nsc.min(dim=1).values) / 2

@@ -64,9 +64,10 @@ nrad_all = (new["scales"].sum(1) - new["scales"].min(1).values) / 2
 timed("update_geometry_scales on all 40 800 candidates", lambda: mg.update_geometry_scales(nx, nrad_all, fm.xyz, fm.radius(), 0.001, 0.05))
 timed("begin_mapping_call (in place)", lambda: fm.begin_mapping_call(reset_optimizer=True))
 timed("radius() of the map", lambda: fm.radius())
-for i in range(3):
+for i in range(8):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    st = fm.grow(new, delete_mask=torch.cat([delete, torch.zeros(fm.P - delete.numel(), dtype=torch.bool, device=dev)]), new_mapping_call=True, stable_mask=stable)
+    st = fm.grow(new, delete_mask=torch.cat([delete, torch.zeros(fm.P - delete.numel(), dtype=torch.bool, device=dev)]), new_mapping_call=True, stable_mask=stable,
+                 attach_async=(i % 2 == 0))
     torch.cuda.synchronize()
-    print(f"in-place grow #{i}: {1e3 * (time.perf_counter() - t0):.2f} ms", {k: v for k, v in st.items() if k not in ("rows", "kept_rows")})
+    print(f"in-place grow #{i} ({'attach on its own thread' if i % 2 == 0 else 'in line'}): {1e3 * (time.perf_counter() - t0):.2f} ms", {k: v for k, v in st.items() if k not in ("rows", "kept_rows")})
