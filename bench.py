@@ -993,6 +993,8 @@ def main():
         def time_path(step_other):
             for _ in range(max(2, args.warmup // 2)):
                 step_other()
+            gc.collect()
+            gc.disable()  # (as in the main timed region: no collector pause inside the measurement)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             k = min(args.steps, 50)
@@ -1000,6 +1002,7 @@ def main():
                 step_other()
             torch.cuda.synchronize()
             d = (time.perf_counter() - t1) / k
+            gc.enable()
             if args.sync_mode == "lazy":
                 dgr._verify_pending(block=True)
             return d
