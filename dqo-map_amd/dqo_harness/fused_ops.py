@@ -126,7 +126,7 @@ class DqoAdam(torch.optim.Optimizer):
         lib = N.lib()
         by_step = {}  # tensors that take the same step number go into one launch (normally: all of them)
         keep = []
-        betas = eps = None
+        betas = eps = dev = None
         for group in self.param_groups:
             if betas is None:
                 betas, eps = tuple(group["betas"]), float(group["eps"])
@@ -137,6 +137,10 @@ class DqoAdam(torch.optim.Optimizer):
                     continue
                 if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise RuntimeError("DqoAdam: dense contiguous float32 GPU parameters only; there is no CPU path")
+                if dev is None:
+                    dev = p.device
+                elif p.device != dev:
+                    raise RuntimeError("DqoAdam: all parameters must live on one GPU (one launch on that device's current stream)")
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = 0
@@ -149,7 +153,6 @@ class DqoAdam(torch.optim.Optimizer):
                     N.DqoAdamTensor(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(), v=st["exp_avg_sq"].data_ptr(), n=p.numel(),
                                     lr=float(group["lr"])))
         for step, ts in by_step.items():
-            dev = self.param_groups[0]["params"][0].device
             with torch.cuda.device(dev):
                 for i in range(0, len(ts), 16):
                     chunk = ts[i:i + 16]
