@@ -26,6 +26,9 @@ constexpr int BIN_THREADS = 256;
 constexpr int BIN_CHUNK = BIN_THREADS;  // Gaussians per block, one per thread
 constexpr int BIN_WINDOW = 16384;       // candidate pairs whose live bits fit the LDS bit array at once
 constexpr int BIN_FLIGHT = 4;           // returning atomics in flight per thread
+#ifndef BIN_WAVES
+#define BIN_WAVES 8  // waves per SIMD the register allocation leaves room for (8: at most 64 VGPRs)
+#endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -68,7 +71,7 @@ struct Cand {
 
 // tile_objects: DqoObjectGate.tile_objects or NULL — a candidate whose Gaussian's object (the spare word of its xy record) owns no pixel of
 // the tile is dropped like one whose footprint cannot reach the tile
-__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
+__global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
                                                                 uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
                                                                 DqoBinLayout bin, int64_t capacity,
                                                                 const unsigned long long* __restrict__ tile_objects) {
