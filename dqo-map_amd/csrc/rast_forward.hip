@@ -17,6 +17,12 @@
 #include "dqo_common.h"
 #include "dqo_cull.h"
 
+#ifndef K1_WAVES
+#define K1_WAVES 4     // preprocess_kernel: waves per SIMD the register allocation leaves room for
+#endif
+#ifndef SORTW_WAVES
+#define SORTW_WAVES 7  // tile_sort_wave_kernel
+#endif
 namespace {
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -52,7 +58,7 @@ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315
 __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
 
-__global__ __launch_bounds__(K1_THREADS, 4) void preprocess_kernel(const DqoView v, const float* __restrict__ means3D,
+__global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const DqoView v, const float* __restrict__ means3D,
                                                                 const float* __restrict__ scales,
                                                                 const float* __restrict__ rotations,
                                                                 const float* __restrict__ opacities,
@@ -594,7 +600,7 @@ constexpr int SORTW_THREADS = 128;
 // frame left in the image buffer (any permutation of the tiles gives the same results), a list's range follows from its own
 // counter, and the frame statistics the header needs go to the spread lines (words 2..3), which tile_sort_kernel's first block
 // sums up (header_from_spread).
-__global__ __launch_bounds__(SORTW_THREADS) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g,
+__global__ __launch_bounds__(SORTW_THREADS, SORTW_WAVES) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g,
                                                                        int64_t capacity, int keep_order, int list_split) {
     __shared__ uint64_t s_key[2 * SORTP_RUN];
     __shared__ uint32_t s_val[2 * SORTP_RUN];
