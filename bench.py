@@ -185,24 +185,14 @@ def build_problem(args, rank, world, device):
     settings = mapping.make_settings(cam, device)
     # target = render of a perturbed copy of the FULL map, so the gradients are non-trivial; every rank renders
     # it once (same camera, target image and mask set on every GPU, §8e)
-    rng = np.random.default_rng(cfgd["seed"] + 7)
-    pert = dict(full)
-    pert["xyz"] = (full["xyz"] + rng.normal(0, 0.004, full["xyz"].shape)).astype(np.float32)
-    pert["shs"] = full["shs"].copy()
-    pert["shs"][:, 0, :] += rng.normal(0, 0.15, (P, 3)).astype(np.float32)
-    with torch.no_grad():
-        tgt = mapping.render(settings, mapping.GaussianParams(pert, device).activated())
-        gt_color, gt_depth = tgt["render"].clone(), tgt["depth"].clone()
-        # per-object screen masks: a pixel belongs to the object of the Gaussian that fixes its depth in the target render
-        hit = tgt["depth_index_map"][0]
-        obj_id = torch.tensor(full["obj_id"], device=device)
-        pix_obj = obj_id[hit.long().clamp(min=0)]
-        pix_obj[hit < 0] = -1
-        # tiles every Gaussian covers in this view, plus what a Gaussian costs whether it is in view or not (preprocess, binning and the
-        # per-Gaussian tail look at every row of the shard: 0.11 ns per Gaussian against 0.75 ns per candidate tile, measured on the
-        # shards of config 5 — a shard holding a third of the map out of view was the slowest of eight)
-        work = sharding.view_work(tgt["radii"].cpu().numpy()) + GAUSSIAN_COST_IN_TILES
-        del tgt
+    tgt = mapping.perturbed_target(full, settings, device, cfgd["seed"] + 7)
+    gt_color, gt_depth, pix_obj = tgt["gt_color"], tgt["gt_depth"], tgt["pix_obj"]
+    obj_id = torch.tensor(full["obj_id"], device=device)
+    # tiles every Gaussian covers in this view, plus what a Gaussian costs whether it is in view or not (preprocess, binning and the
+    # per-Gaussian tail look at every row of the shard: 0.11 ns per Gaussian against 0.75 ns per candidate tile, measured on the
+    # shards of config 5 — a shard holding a third of the map out of view was the slowest of eight)
+    work = sharding.view_work(tgt["radii"].cpu().numpy()) + GAUSSIAN_COST_IN_TILES
+    del tgt
     if strong and world > 1:
         # objects -> ranks by the instances they put on screen (LPT); the same deterministic assignment on every rank
         mine, assignment = sharding.shard_scene(full, rank, world, work=None if args.shard_by == "count" else work)
@@ -392,7 +382,8 @@ class FusedRunner:
             raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
         st = fm.grow(new, delete_mask=delete, new_mapping_call=True, stable_mask=self.stable_mask,
                      attach_async=os.environ.get("DQO_GROW_ASYNC", "1") == "1")  # (0: the attach step in line, for A/B)  # (fresh Adam + init_stat: mapper.py:533-548)
-        st.pop("rows", None)
+        st.pop("rows", None)  # (an in-place step has cleared self.stable_mask on these rows: what growth adds is unstable, also in a
+        # row that a deleted stable Gaussian freed)
         kept = st.pop("kept_rows", None)
         torch.cuda.synchronize()
         t2 = time.perf_counter()

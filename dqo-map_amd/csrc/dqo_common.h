@@ -63,6 +63,8 @@ struct DqoGeomLayout {
     float4* rgb_smax;        // [P] (r, g, b, max(scale)*scale_mod)                 forward.cu:333-335, 73
     float4* normal_c;        // [P] (n_c.xyz, n_c . p_c)   surfel normal in camera space, hoisted out of the blend loop
     float4* point_c;         // [P] (p_c.xyz, max raw scale)   forward.cu:782-783, backward.cu:1009
+    float4* drgb_dir;        // [P][3] d(SH colour)/d(view direction) (dqo_sh_dir_grad, backward.cu:168-258): (dRGBdx[3], -), (dRGBdy[3], -),
+                             //        (dRGBdz[3], -) — evaluated by the forward, read by the backward's per-Gaussian chain
     uint2* rect16;           // [P] (minx | maxx<<16, miny | maxy<<16)
     uint32_t* tiles_touched; // [P]
     uint32_t* slot_base;     // [P] first gaussian-major instance slot of this Gaussian
@@ -88,6 +90,7 @@ static inline DqoGeomLayout dqo_geom_layout(void* base, int64_t P) {
     L.rgb_smax = (float4*)take(sizeof(float4) * P);
     L.normal_c = (float4*)take(sizeof(float4) * P);
     L.point_c = (float4*)take(sizeof(float4) * P);
+    L.drgb_dir = (float4*)take(sizeof(float4) * 3 * P);
     L.rect16 = (uint2*)take(sizeof(uint2) * P);
     L.tiles_touched = (uint32_t*)take(sizeof(uint32_t) * P);
     L.slot_base = (uint32_t*)take(sizeof(uint32_t) * P);

@@ -12,6 +12,60 @@
 #pragma once
 #include "dqo_common.h"
 
+// d(SH colour)/d(view direction) of one Gaussian, before the clamp mask and the incoming gradient are applied: out[0..2] = dRGBdx,
+// out[3..5] = dRGBdy, out[6..8] = dRGBdz (per channel) — the sums of backward.cu:168-258 in the reference's statement order.  They
+// depend on the SH coefficients and the direction only, not on any gradient, so the FORWARD's preprocess_kernel — which holds the 48
+// coefficients and the direction anyway — evaluates them and leaves 9 floats per visible Gaussian (DqoGeomLayout::drgb_dir); the
+// backward chain reads those instead of the 48-float SH row (45 registers less across its whole length, 192 B less to gather per
+// Gaussian).  Same statements, same operands, contraction off on both sides: the later dot products of backward.cu:259-261 round where
+// they rounded when the chain evaluated this itself.
+__device__ __forceinline__ void dqo_sh_dir_grad(const int D, const float* sh, const float dx, const float dy, const float dz, float (&out)[9]) {
+#pragma clang fp contract(off)
+    constexpr float bSH_C1 = 0.4886025119029199f;
+    constexpr float bSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                 0.5462742152960396f};
+    constexpr float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+    float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+    if (D > 0) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            dRGBdx[ch] = -bSH_C1 * sh[9 + ch];
+            dRGBdy[ch] = -bSH_C1 * sh[3 + ch];
+            dRGBdz[ch] = bSH_C1 * sh[6 + ch];
+        }
+        if (D > 1) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                dRGBdx[ch] += bSH_C2[0] * dy * sh[12 + ch] + bSH_C2[2] * 2.f * -dx * sh[18 + ch] + bSH_C2[3] * dz * sh[21 + ch] +
+                              bSH_C2[4] * 2.f * dx * sh[24 + ch];
+                dRGBdy[ch] += bSH_C2[0] * dx * sh[12 + ch] + bSH_C2[1] * dz * sh[15 + ch] + bSH_C2[2] * 2.f * -dy * sh[18 + ch] +
+                              bSH_C2[4] * 2.f * -dy * sh[24 + ch];
+                dRGBdz[ch] += bSH_C2[1] * dy * sh[15 + ch] + bSH_C2[2] * 2.f * 2.f * dz * sh[18 + ch] + bSH_C2[3] * dx * sh[21 + ch];
+            }
+            if (D > 2) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    dRGBdx[ch] += (bSH_C3[0] * sh[27 + ch] * 3.f * 2.f * xy + bSH_C3[1] * sh[30 + ch] * yz +
+                                   bSH_C3[2] * sh[33 + ch] * -2.f * xy + bSH_C3[3] * sh[36 + ch] * -3.f * 2.f * xz +
+                                   bSH_C3[4] * sh[39 + ch] * (-3.f * xx + 4.f * zz - yy) + bSH_C3[5] * sh[42 + ch] * 2.f * xz +
+                                   bSH_C3[6] * sh[45 + ch] * 3.f * (xx - yy));
+                    dRGBdy[ch] += (bSH_C3[0] * sh[27 + ch] * 3.f * (xx - yy) + bSH_C3[1] * sh[30 + ch] * xz +
+                                   bSH_C3[2] * sh[33 + ch] * (-3.f * yy + 4.f * zz - xx) + bSH_C3[3] * sh[36 + ch] * -3.f * 2.f * yz +
+                                   bSH_C3[4] * sh[39 + ch] * -2.f * xy + bSH_C3[5] * sh[42 + ch] * -2.f * yz +
+                                   bSH_C3[6] * sh[45 + ch] * -3.f * 2.f * xy);
+                    dRGBdz[ch] += (bSH_C3[1] * sh[30 + ch] * xy + bSH_C3[2] * sh[33 + ch] * 4.f * 2.f * yz +
+                                   bSH_C3[3] * sh[36 + ch] * 3.f * (2.f * zz - xx - yy) + bSH_C3[4] * sh[39 + ch] * 4.f * 2.f * xz +
+                                   bSH_C3[5] * sh[42 + ch] * (xx - yy));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) out[ch] = dRGBdx[ch], out[3 + ch] = dRGBdy[ch], out[6 + ch] = dRGBdz[ch];
+}
+
 // what the chain needs of one visible Gaussian: its summed gradient record and its parameters / forward tables
 struct DqoChainIn {
     float a[16];           // DqoGradRec, summed over the Gaussian's instances
@@ -19,7 +73,7 @@ struct DqoChainIn {
     float mx, my, mz;      // mean
     float sx, sy, sz;      // activated scales
     float4 qt;             // activated rotation (r, x, y, z)
-    float sh[48];          // SH coefficients; [3 ..) of the active degree are read (coefficient 0 has no direction gradient)
+    float dd[9];           // dqo_sh_dir_grad of the forward (DqoGeomLayout::drgb_dir): dRGBdx[3], dRGBdy[3], dRGBdz[3]
     float4 n_np, pc;       // surfel normal in camera space (+ n . p_c), camera-space point (+ max raw scale)
     uint32_t cl;           // SH colour clamp bits
 };
@@ -53,7 +107,6 @@ __device__ __forceinline__ void dqo_gauss_chain(const DqoView& v, const float (&
     const float* a = in.a;
     const float4 cop = in.cop, qt = in.qt, n_np = in.n_np, pc = in.pc;
     const float mx = in.mx, my = in.my, mz = in.mz, sx = in.sx, sy = in.sy, sz = in.sz;
-    const float* sh = in.sh;
     const int D = DEG >= 0 ? DEG : v.D;
     const float dcolr[3] = {a[0], a[1], a[2]};
     // pixel moments of q = G * dL/dalpha summed by the blend kernel (DqoGradRec) -> gradients w.r.t. the 2D mean, the conic and
@@ -223,7 +276,8 @@ __device__ __forceinline__ void dqo_gauss_chain(const DqoView& v, const float (&
         const float dx = dox / len, dy = doy / len, dz = doz / len;
         const float dRGB[3] = {dcolr[0] * ((cl & 1u) ? 0.f : 1.f), dcolr[1] * ((cl & 2u) ? 0.f : 1.f), dcolr[2] * ((cl & 4u) ? 0.f : 1.f)};
         o.dRGB[0] = dRGB[0], o.dRGB[1] = dRGB[1], o.dRGB[2] = dRGB[2];
-        float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+        // d(colour)/d(direction): evaluated by the forward (dqo_sh_dir_grad above), 9 floats
+        const float dRGBdx[3] = {in.dd[0], in.dd[1], in.dd[2]}, dRGBdy[3] = {in.dd[3], in.dd[4], in.dd[5]}, dRGBdz[3] = {in.dd[6], in.dd[7], in.dd[8]};
         // dL/dsh[k][c] = w * dRGB[c]: the caller forms the product (one IEEE multiply, as the reference's per-coefficient statement)
 #define DQO_SETD(k, wv) o.w[k] = (wv)
         const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
@@ -232,26 +286,12 @@ __device__ __forceinline__ void dqo_gauss_chain(const DqoView& v, const float (&
             DQO_SETD(1, -bSH_C1 * dy);
             DQO_SETD(2, bSH_C1 * dz);
             DQO_SETD(3, -bSH_C1 * dx);
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                dRGBdx[ch] = -bSH_C1 * sh[9 + ch];
-                dRGBdy[ch] = -bSH_C1 * sh[3 + ch];
-                dRGBdz[ch] = bSH_C1 * sh[6 + ch];
-            }
             if (D > 1) {
                 DQO_SETD(4, bSH_C2[0] * xy);
                 DQO_SETD(5, bSH_C2[1] * yz);
                 DQO_SETD(6, bSH_C2[2] * (2.f * zz - xx - yy));
                 DQO_SETD(7, bSH_C2[3] * xz);
                 DQO_SETD(8, bSH_C2[4] * (xx - yy));
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    dRGBdx[ch] += bSH_C2[0] * dy * sh[12 + ch] + bSH_C2[2] * 2.f * -dx * sh[18 + ch] + bSH_C2[3] * dz * sh[21 + ch] +
-                                  bSH_C2[4] * 2.f * dx * sh[24 + ch];
-                    dRGBdy[ch] += bSH_C2[0] * dx * sh[12 + ch] + bSH_C2[1] * dz * sh[15 + ch] + bSH_C2[2] * 2.f * -dy * sh[18 + ch] +
-                                  bSH_C2[4] * 2.f * -dy * sh[24 + ch];
-                    dRGBdz[ch] += bSH_C2[1] * dy * sh[15 + ch] + bSH_C2[2] * 2.f * 2.f * dz * sh[18 + ch] + bSH_C2[3] * dx * sh[21 + ch];
-                }
                 if (D > 2) {
                     DQO_SETD(9, bSH_C3[0] * dy * (3.f * xx - yy));
                     DQO_SETD(10, bSH_C3[1] * xy * dz);
@@ -260,20 +300,6 @@ __device__ __forceinline__ void dqo_gauss_chain(const DqoView& v, const float (&
                     DQO_SETD(13, bSH_C3[4] * dx * (4.f * zz - xx - yy));
                     DQO_SETD(14, bSH_C3[5] * dz * (xx - yy));
                     DQO_SETD(15, bSH_C3[6] * dx * (xx - 3.f * yy));
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        dRGBdx[ch] += (bSH_C3[0] * sh[27 + ch] * 3.f * 2.f * xy + bSH_C3[1] * sh[30 + ch] * yz +
-                                       bSH_C3[2] * sh[33 + ch] * -2.f * xy + bSH_C3[3] * sh[36 + ch] * -3.f * 2.f * xz +
-                                       bSH_C3[4] * sh[39 + ch] * (-3.f * xx + 4.f * zz - yy) + bSH_C3[5] * sh[42 + ch] * 2.f * xz +
-                                       bSH_C3[6] * sh[45 + ch] * 3.f * (xx - yy));
-                        dRGBdy[ch] += (bSH_C3[0] * sh[27 + ch] * 3.f * (xx - yy) + bSH_C3[1] * sh[30 + ch] * xz +
-                                       bSH_C3[2] * sh[33 + ch] * (-3.f * yy + 4.f * zz - xx) + bSH_C3[3] * sh[36 + ch] * -3.f * 2.f * yz +
-                                       bSH_C3[4] * sh[39 + ch] * -2.f * xy + bSH_C3[5] * sh[42 + ch] * -2.f * yz +
-                                       bSH_C3[6] * sh[45 + ch] * -3.f * 2.f * xy);
-                        dRGBdz[ch] += (bSH_C3[1] * sh[30 + ch] * xy + bSH_C3[2] * sh[33 + ch] * 4.f * 2.f * yz +
-                                       bSH_C3[3] * sh[36 + ch] * 3.f * (2.f * zz - xx - yy) + bSH_C3[4] * sh[39 + ch] * 4.f * 2.f * xz +
-                                       bSH_C3[5] * sh[42 + ch] * (xx - yy));
-                    }
                 }
             }
         }

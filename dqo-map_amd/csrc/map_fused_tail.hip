@@ -62,7 +62,7 @@ struct AdamGradLds {
 };
 
 #ifndef DQO_TAIL_WAVES
-#define DQO_TAIL_WAVES 3  // waves per SIMD the register allocation leaves room for
+#define DQO_TAIL_WAVES 4  // waves per SIMD the register allocation leaves room for (128 VGPRs since the SH row left the chain)
 #endif
 template <bool SPARSE, bool ATTACH>
 __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_kernel(const DqoView v, DqoGeomLayout g, const float* means3D,
@@ -138,8 +138,9 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
     //      same round structure as gaussian_backward_kernel; in flight while phase B runs).  (Compacting the visible Gaussians of a
     //      256-thread block into as few waves as they fill — cfg 3: 39 % are visible — was built and measured: no gain; the chain is a
     //      long dependent instruction sequence whose duration does not depend on how many lanes run it.) ----
-    const bool sh_vec4 = v.M == 16 && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0u;
     DqoChainIn ci;
+#pragma unroll
+    for (int i = 0; i < 9; i++) ci.dd[i] = 0.f;
     ci.cop = make_float4(0.f, 0.f, 0.f, 0.f);
     ci.mx = ci.my = ci.mz = ci.sx = ci.sy = ci.sz = 0.f;
     ci.qt = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -151,27 +152,12 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
         ci.sx = scales[3 * idx], ci.sy = scales[3 * idx + 1], ci.sz = scales[3 * idx + 2];
         ci.qt = reinterpret_cast<const float4*>(rotations)[idx];
         ci.n_np = g.normal_c[idx], ci.pc = g.point_c[idx], ci.cl = g.clamped[idx];
-        // the SH coefficients of the active degree (the view-direction gradient at the end of the chain reads them).  Issued here, with
-        // the other inputs, their latency overlaps the record gather; fetched behind the gather instead (where they would not compete
-        // with its sixteen 16-byte records for registers) the kernel measured 6 % slower.
-        const float* shp = shs + (size_t)idx * v.M * 3;
-        if (v.D >= 3 && sh_vec4) {  // rows of 48 floats as twelve 16-byte pieces
-            const float4* shp4 = reinterpret_cast<const float4*>(shp);
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const float4 t = shp4[i];
-                ci.sh[4 * i] = t.x, ci.sh[4 * i + 1] = t.y, ci.sh[4 * i + 2] = t.z, ci.sh[4 * i + 3] = t.w;
-            }
-        } else if (v.D >= 3) {
-#pragma unroll
-            for (int i = 3; i < 48; i++) ci.sh[i] = shp[i];
-        } else if (v.D == 2) {
-#pragma unroll
-            for (int i = 3; i < 27; i++) ci.sh[i] = shp[i];
-        } else if (v.D == 1) {
-#pragma unroll
-            for (int i = 3; i < 12; i++) ci.sh[i] = shp[i];
-        }
+        // d(SH colour)/d(direction), left by the forward's preprocess_kernel (dqo_sh_dir_grad): 9 floats in place of the 48-float SH
+        // row the chain held in registers across its whole length until round 4 (168 VGPRs -> three waves per SIMD)
+        const float4* ddp = g.drgb_dir + 3 * (size_t)idx;
+        const float4 d0 = ddp[0], d1 = ddp[1], d2 = ddp[2];
+        ci.dd[0] = d0.x, ci.dd[1] = d0.y, ci.dd[2] = d0.z, ci.dd[3] = d1.x, ci.dd[4] = d1.y, ci.dd[5] = d1.z;
+        ci.dd[6] = d2.x, ci.dd[7] = d2.y, ci.dd[8] = d2.z;
     }
 
     // ---- B: fixed-order sum of this lane's Gaussian's partial gradient records (record_sum_kernel's statements; one slot per thread and trip) ----

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
     float4& cop = ci.cop;  // (conic, opacity) of the forward
     float &mx = ci.mx, &my = ci.my, &mz = ci.mz, &sx = ci.sx, &sy = ci.sy, &sz = ci.sz;
     float4& qt = ci.qt;
-    float(&sh)[48] = ci.sh;  // SH coefficients 1.. of the active degree (coefficient 0 has no direction gradient)
+#pragma unroll
+    for (int i = 0; i < 9; i++) ci.dd[i] = 0.f;
     float4 &n_np = ci.n_np, &pc = ci.pc;
     uint32_t& cl = ci.cl;
     cop = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -160,19 +161,11 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
         qt = reinterpret_cast<const float4*>(rotations)[idx];
         n_np = g.normal_c[idx], pc = g.point_c[idx], cl = g.clamped[idx];  // (depth-hit chain / SH clamp flags: same round)
         if (shs != nullptr && gr.dL_dsh != nullptr) {
-            // the SH coefficients of the active degree in the same round (they are only needed at the end of the chain; fetched
-            // there, inside the per-degree blocks, they would arrive in three waited-for groups)
-            const float* shp = shs + (size_t)idx * v.M * 3;
-            if (v.D >= 3) {
-#pragma unroll
-                for (int i = 3; i < 48; i++) sh[i] = shp[i];
-            } else if (v.D == 2) {
-#pragma unroll
-                for (int i = 3; i < 27; i++) sh[i] = shp[i];
-            } else if (v.D == 1) {
-#pragma unroll
-                for (int i = 3; i < 12; i++) sh[i] = shp[i];
-            }
+            // d(SH colour)/d(direction) of the forward (dqo_sh_dir_grad): 9 floats in place of the 48-float SH row
+            const float4* ddp = g.drgb_dir + 3 * (size_t)idx;
+            const float4 d0 = ddp[0], d1 = ddp[1], d2 = ddp[2];
+            ci.dd[0] = d0.x, ci.dd[1] = d0.y, ci.dd[2] = d0.z, ci.dd[3] = d1.x, ci.dd[4] = d1.y, ci.dd[5] = d1.z;
+            ci.dd[6] = d2.x, ci.dd[7] = d2.y, ci.dd[8] = d2.z;
         }
         a[0] = r0.x, a[1] = r0.y, a[2] = r0.z, a[3] = r0.w;
         a[4] = r1.x, a[5] = r1.y, a[6] = r1.z, a[7] = r1.w;

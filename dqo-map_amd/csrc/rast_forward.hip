@@ -16,6 +16,7 @@
 
 #include "dqo_common.h"
 #include "dqo_cull.h"
+#include "dqo_gauss_chain.h"
 
 #ifndef K1_WAVES
 #define K1_WAVES 4     // preprocess_kernel: waves per SIMD the register allocation leaves room for
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const 
             if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
             // colour: computeColorFromSH, forward.cu:104-155
             float rgb[3];
+            float dd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             uint32_t clampbits = 0;
             if (colors_precomp == nullptr) {
                 const float dxx = px - cam0, dyy = py - cam1, dzz = pz - cam2;
@@ -215,6 +217,9 @@ __global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const 
                     if (result < 0.f) clampbits |= 1u << ch;
                     rgb[ch] = fmaxf(result, 0.0f);
                 }
+                // d(colour)/d(direction) for the backward's view-direction gradient (backward.cu:168-258): a function of the coefficients
+                // and the direction alone, both in registers here — 9 floats instead of the backward gathering the 48-float row again
+                dqo_sh_dir_grad(v.D, sh, x, y, z, dd);
             } else {
                 rgb[0] = colors_precomp[3 * idx], rgb[1] = colors_precomp[3 * idx + 1], rgb[2] = colors_precomp[3 * idx + 2];
             }
@@ -235,6 +240,11 @@ __global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const 
             // .w = max of the RAW scales: the backward's depth test uses it without scale_modifier (backward.cu:1009, quirk B6)
             g.point_c[idx] = make_float4(tvx, tvy, tvz, maxis == 0 ? sx : (maxis == 1 ? sy : sz));
             g.clamped[idx] = (uint8_t)clampbits;
+            if (colors_precomp == nullptr) {
+                float4* const ddp = g.drgb_dir + 3 * (size_t)idx;
+                ddp[0] = make_float4(dd[0], dd[1], dd[2], 0.f), ddp[1] = make_float4(dd[3], dd[4], dd[5], 0.f);
+                ddp[2] = make_float4(dd[6], dd[7], dd[8], 0.f);
+            }
         } while (false);
         radii_out[idx] = radius;
         n_touched_out[idx] = 0;

@@ -108,22 +108,29 @@ def verify_pending():
 
 
 def _verify_pending(block):
-    """Lazy mode: check the headers of earlier forwards; raise if one of them overflowed its instance capacity."""
-    keep = []
-    for ev, host, key, cap in _pending:
-        if not block and not ev.query():
-            keep.append((ev, host, key, cap))
-            continue
-        ev.synchronize()
-        n, overflow = int(host[0]), int(host[2])
-        # the hint only grows: one key serves calls with different tile masks / camera poses, whose N differ
-        _cap_hint[key] = max(_cap_hint.get(key, 0), int(n * 1.25) + 4096)
-        if overflow:
-            _pending[:] = keep
-            raise RuntimeError(f"diff_gaussian_rasterization_depth (lazy mode): a previous forward produced {n} Gaussian-tile "
-                               f"instances but only {cap} fitted its binning buffer; its outputs are invalid. The capacity has "
-                               "been raised — re-run that iteration (or use set_sync_mode('exact')).")
-    _pending[:] = keep
+    """Lazy mode: check the headers of earlier forwards; raise if one of them overflowed its instance capacity.  The whole pass runs
+    under the module lock (forwards of other threads append to `_pending` and read `_cap_hint`; the autograd engine calls this from
+    its own thread); the error is raised after the lock is released."""
+    err = None
+    with _lock:
+        keep = []
+        for i, (ev, host, key, cap) in enumerate(_pending):
+            if not block and not ev.query():
+                keep.append((ev, host, key, cap))
+                continue
+            ev.synchronize()
+            n, overflow = int(host[0]), int(host[2])
+            # the hint only grows: one key serves calls with different tile masks / camera poses, whose N differ
+            _cap_hint[key] = max(_cap_hint.get(key, 0), int(n * 1.25) + 4096)
+            if overflow:
+                keep.extend(_pending[i + 1:])  # (the later forwards stay pending: they are checked by the next call)
+                err = (n, cap)
+                break
+        _pending[:] = keep
+    if err is not None:
+        raise RuntimeError(f"diff_gaussian_rasterization_depth (lazy mode): a previous forward produced {err[0]} Gaussian-tile "
+                           f"instances but only {err[1]} fitted its binning buffer; its outputs are invalid. The capacity has "
+                           "been raised — re-run that iteration (or use set_sync_mode('exact')).")
 
 
 def _f32(t, name):

@@ -181,6 +181,7 @@ class FusedMapper:
             if getattr(self, "_g", None) is not None:
                 self._g.step_dev.fill_(1)
                 self._g.expected_step = 1
+                self._g.unsettled = False
         if getattr(self, "_g", None) is not None and not (same and getattr(self._g, "attach_in_place", False)):
             self._g.stale = True  # the captured kernel arguments (attach set buffers) were fixed at capture time
 
@@ -192,6 +193,17 @@ class FusedMapper:
         # the two factors exactly as the library derives them from attach_count: double arithmetic, rounded to float once
         self.attach_gains.copy_(torch.tensor([2000.0 / (3.0 * n), 2000.0 / (4.0 * n)] if n > 0 else [0.0, 0.0], dtype=torch.float64)
                                 .to(torch.float32))
+
+    def activate(self):
+        """(opacity [P,1], scales [P,3], rotations [P,4]): the activations of the current raw parameters (SLAM/gaussian_pointcloud.py:
+        732-733, 746-747), i.e. what the rasteriser sees in the next iteration — computed if they are not up to date.  The tensors are
+        this mapper's own buffers: the next Adam step overwrites them."""
+        if not self._act_valid:
+            with torch.cuda.device(self.device):
+                N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
+                                                 N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
+            self._act_valid = True
+        return self.opacity, self.scales, self.rotations
 
     # ------------------------------------------------------------------ map growth ---------------------------------------
     def radius(self):
@@ -276,8 +288,9 @@ class FusedMapper:
           3. delete_mask [P] bool (optional): existing Gaussians to delete (the reference derives it from
              accumulate_gaussian_error's per-Gaussian depth error, cuda_utils._C);
           4. cat (:1466): the rest joins the map with zero Adam moments.
-        stable_mask [P] bool (optional) is the reference's split into its two clouds — 1 = a Gaussian of `stable_pointcloud`, 0 = of the
-        unstable `pointcloud` — and switches on the two steps that need it:
+        stable_mask [P] bool GPU tensor (optional) is the reference's split into its two clouds — 1 = a Gaussian of `stable_pointcloud`, 0 =
+        of the unstable `pointcloud`; an in-place step clears it IN PLACE on the rows the new Gaussians take — and switches on the two
+        steps that need it:
           1'. the filter of step 1 looks at the UNSTABLE Gaussians only (:1356-1357, unstable_params);
           1b. temp_points_attach (:1384-1436): the survivors of step 1 that project onto a pixel whose strongest contributor in a render
              of the STABLE Gaussians alone exists and whose plane they lie within 0.5 x add_depth_thres of get opacity
@@ -393,6 +406,11 @@ class FusedMapper:
                         self.gaussian_object[rows] = nobj
                     self.alive[rows] = 1
                     stats["rows"] = rows
+                    if stable_mask is not None:
+                        # what growth adds belongs to the UNSTABLE cloud (mapper.py:1438-1466) — also when it lands in a row a deleted
+                        # stable Gaussian just freed (spare rows are handed out lowest index first): the caller's mask is updated in
+                        # place, so the next step's filter / stable-only render see the row as unstable
+                        stable_mask[rows] = False
                 # (a captured iteration starts from the activations its previous Adam launch left: bring them up to date for the new rows)
                 N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
                                                  N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
@@ -561,13 +579,9 @@ class FusedMapper:
         with torch.cuda.device(dev):
             if getattr(self, "_g", None) is not None:
                 # re-capture (e.g. after an overflow): replays of invalid frames did not advance the device-side step count
-                # (DqoAdamStep.frame_header), the host count assumed they did.  After the last replay the device count was expected to
-                # be g.expected_step; what it falls short of that is the number of invalid replays, and only those are taken back —
-                # eager step() calls since then advanced the host count alone (they never touch g.step_dev) and stay counted.
-                g_old = self._g
-                invalid = int(g_old.expected_step) - int(g_old.step_dev.item())
-                if invalid > 0:
-                    self.step_count -= invalid
+                # (DqoAdamStep.frame_header), the host count assumed they did — _settle_replays takes exactly those back; eager step()
+                # calls since then advanced the host count alone (they never touch g.step_dev) and stay counted
+                self._settle_replays()
                 self._g = None
             if not self._act_valid:
                 N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
@@ -752,12 +766,36 @@ class FusedMapper:
         if g.stale:
             raise RuntimeError("FusedMapper: begin_mapping_call() changed the attach set since capture(); capture again")
         if g.expected_step != self.step_count + 1:  # eager step() calls in between: resynchronise the device-side step count
-            g.step_dev.fill_(self.step_count + 1)
+            self._resync_step_count()
         g.graph.replay()
+        g.unsettled = True
         self._attach_n = ((self.P + 255) // 256) * (4 if g.fused_tail else 1)  # (a new mapping call in between had reset it)
         self.step_count += 1  # (assumes a valid frame; capture() re-reads the device-side count after an overflow)
         g.expected_step = self.step_count + 1
         return g.out
+
+    def _settle_replays(self):
+        """Make the host step count agree with what the device counted.  replay() assumes a valid frame; the device count only advances
+        on valid ones (DqoAdamStep.frame_header: an overflowed frame is a no-op for the optimiser), so what it falls short of the count
+        expected after the last replay is the number of invalid replays — taken back here, BEFORE anything else (an eager step(), a
+        re-capture, a resynchronisation) builds on the host count or overwrites the device count.  One 4-byte read, and only when
+        replays happened since the last time."""
+        g = getattr(self, "_g", None)
+        if g is None or not getattr(g, "unsettled", False):
+            return
+        dev_step = int(g.step_dev.item())
+        invalid = int(g.expected_step) - dev_step
+        if invalid > 0:
+            self.step_count -= invalid
+        g.expected_step = dev_step
+        g.unsettled = False
+
+    def _resync_step_count(self):
+        """Eager step() calls between two replays advanced the host count alone: bring the device count up to it."""
+        self._settle_replays()
+        g = self._g
+        g.step_dev.fill_(self.step_count + 1)
+        g.expected_step = self.step_count + 1
 
     def run(self, n_iters, check_every=64, capacity_margin=1.5):
         """`n_iters` VALID mapping iterations on the captured graph: replays in batches of `check_every`, one small D2H read per batch
@@ -790,9 +828,10 @@ class FusedMapper:
         profiling: events cannot be recorded inside a replay)."""
         g = self._g
         if g.expected_step != self.step_count + 1:
-            g.step_dev.fill_(self.step_count + 1)
+            self._resync_step_count()
         with torch.cuda.device(self.device):
             self._static_iteration()
+        g.unsettled = True
         self.step_count += 1
         g.expected_step = self.step_count + 1
         return g.out
@@ -814,6 +853,7 @@ class FusedMapper:
         """One mapping iteration; returns the op's 9-tuple (views of this iteration's outputs) — losses are in self.loss."""
         lib = N.lib()
         P, M = self.P, self.M
+        self._settle_replays()  # (replays of invalid frames since the last check do not count: this step's bias corrections depend on it)
         with torch.cuda.device(self.device):
             stream = N.current_stream()
             if not self._act_valid:  # later iterations get the activations from the previous Adam step

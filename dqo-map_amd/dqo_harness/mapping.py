@@ -105,6 +105,28 @@ def render(settings, gaussian_data, tile_mask=None, object_gate=None):
     return out
 
 
+def perturbed_target(full, settings, device, seed):
+    """The synthetic ground truth of a BASELINE configuration ("target image = render of a perturbed copy, so gradients
+    are non-trivial") and the per-object screen masks of the per-object job (§8e): render of the map with its centres moved by
+    N(0, 4 mm) and its DC colours by N(0, 0.15) (numpy default_rng(seed)); a pixel belongs to the object of the Gaussian that fixes
+    its depth in that render, -1 where nothing does.  bench.py and the full-size parity tests build their problem with this ONE
+    function.  Returns dict(gt_color [3,H,W], gt_depth [1,H,W], pix_obj int32 [H,W], radii int32 [P]) of GPU tensors."""
+    P = full["xyz"].shape[0]
+    rng = np.random.default_rng(seed)
+    pert = dict(full)
+    pert["xyz"] = (full["xyz"] + rng.normal(0, 0.004, full["xyz"].shape)).astype(np.float32)
+    pert["shs"] = full["shs"].copy()
+    pert["shs"][:, 0, :] += rng.normal(0, 0.15, (P, 3)).astype(np.float32)
+    with torch.no_grad():
+        tgt = render(settings, GaussianParams(pert, device).activated())
+        hit = tgt["depth_index_map"][0]
+        obj_id = torch.tensor(np.asarray(full["obj_id"]), device=device)
+        pix_obj = obj_id[hit.long().clamp(min=0)]
+        pix_obj[hit < 0] = -1
+        return dict(gt_color=tgt["render"].clone(), gt_depth=tgt["depth"].clone(), pix_obj=pix_obj.to(torch.int32).contiguous(),
+                    radii=tgt["radii"].clone())
+
+
 def render_obj(settings, gaussian_data, tile_mask=None):
     """SLAM/render.py:61-132 (`Renderer.render_obj`, the per-object ellipsoid view; dead under the shipped MODE = 1, F3): the same
     rasteriser call as render() with `obj_color` [P, 3] as precomputed colours — no SH, no normals — the default all-ones int32 tile

@@ -517,6 +517,38 @@ def test_graph_capacity_overflow_is_flagged(env):
         assert ((v - twin._params()[k]).abs() > 0.01 * lr + 1e-7).float().mean().item() < 1e-3, k
 
 
+def test_step_count_survives_invalid_replays_followed_by_eager_steps(env):
+    """Overflowed replays (no-ops for the optimiser, not counted by the device) -> an eager step() -> replay() -> capture(): the host
+    count must drop the invalid replays BEFORE the eager step builds on it and before the resynchronising replay overwrites the device
+    count — otherwise every later Adam step runs with the bias corrections of a later step than it is."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    fm = FusedMapper(scene, settings, dev)
+    for _ in range(2):
+        fm.step(gt_color, gt_depth, mask)                        # valid steps 1, 2
+    fm.capture(gt_color, gt_depth, mask, capacity_margin=0.05)   # overflows: not counted
+    for _ in range(3):
+        fm.replay()                                              # three invalid replays (the host count runs ahead: 5)
+    assert fm.step_count == 5
+    fm.step(gt_color, gt_depth, mask)                            # eager (exact capacity): valid step 3
+    assert fm.step_count == 3
+    fm.replay()                                                  # invalid again (same small capacity); device count rewritten to 4 first
+    torch.cuda.synchronize()
+    assert fm.graph_overflowed() and int(fm._g.step_dev.item()) == 4
+    fm.capture(gt_color, gt_depth, mask)                         # valid step 4
+    assert fm.step_count == 4 and int(fm._g.step_dev.item()) == 5
+    fm.replay()                                                  # valid step 5
+    torch.cuda.synchronize()
+    assert not fm.graph_overflowed() and fm.step_count == 5 and int(fm._g.step_dev.item()) == 6
+    twin = FusedMapper(scene, settings, dev)
+    for _ in range(5):
+        twin.step(gt_color, gt_depth, mask)
+    for k, v in fm._params().items():
+        lr = dict(xyz=0.001, shs=0.0005, opacity=1.0, scaling=0.004, rotation=0.001)[k]
+        assert ((v - twin._params()[k]).abs() > 0.01 * lr + 1e-7).float().mean().item() < 1e-3, k
+
+
 def test_run_recaptures_after_an_overflow_and_delivers_valid_iterations(env):
     """FusedMapper.run(n): n VALID iterations whatever happens to the capacities — here the graph is captured with room for 5 % of the
     candidate pairs, so every replay of the first batch is an invalid frame (a no-op for the optimiser); run() notices from the

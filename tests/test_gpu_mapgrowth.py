@@ -326,3 +326,28 @@ def test_growth_attaches_new_points_that_fall_onto_the_stable_cloud(mg):
     low = (torch.sigmoid(fm.opacity_raw[new_rows]) < 0.2).reshape(-1)
     assert int(low.sum().item()) > 0 and bool(fm.attach_mask[new_rows][low].all())  # they are in the new call's attach set
     assert fm.attach_count == before + int((torch.sigmoid(fm.opacity_raw[new_rows]) < 0.9).sum().item())
+
+
+def test_a_new_gaussian_in_a_row_freed_by_a_stable_one_is_unstable(mg):
+    """In-place growth hands out spare rows lowest index first — including the row a deleted STABLE Gaussian just freed.  What growth
+    adds belongs to the unstable cloud (mapper.py:1438-1466): grow() clears the caller's stable mask on the rows it fills, so the next
+    step filters against them and keeps them out of the stable-only render."""
+    torch, M = mg
+    from dqo_harness import scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev, cam, scene, settings, gt_color, gt_depth, mask = _growth_problem()
+    P0 = 12000
+    fm = FusedMapper(scene, settings, dev).reserve(4000)
+    stable = torch.arange(fm.P, device=dev) < P0     # bench.py's split: the map the run starts from is the stable cloud
+    delete = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+    delete[5:200:7] = True                           # stable rows, all below every spare row
+    st = fm.grow(scenes.surfel_room(83, 3000, n_objects=8), delete_mask=delete, new_mapping_call=True, stable_mask=stable)
+    rows = st["rows"]
+    reused = rows[rows < P0]
+    assert st["in_place"] and reused.numel() == int(delete.sum().item()) and st["added"] > reused.numel()
+    assert not bool(stable[rows].any())              # every new Gaussian is unstable, the reused rows included
+    assert bool(stable[:P0][~delete[:P0]].all())     # the surviving stable Gaussians stay stable
+    # the next step's filter (mapper.py:1356-1357: against the unstable cloud) sees them: the same points again all fall inside
+    st2 = fm.grow(dict(xyz=fm.xyz[rows].clone(), scales=torch.exp(fm.scaling_raw[rows]), rotations=fm.rotation_raw[rows].clone(),
+                       opacity=torch.sigmoid(fm.opacity_raw[rows]), shs=fm.shs[rows].clone()), new_mapping_call=True, stable_mask=stable)
+    assert st2["inside_existing"] == rows.numel() and st2["added"] == 0
