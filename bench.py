@@ -982,7 +982,10 @@ def main():
     alt = alt_optin = None
     if world == 1:
         def time_path(step_other):
-            for _ in range(max(2, args.warmup // 2)):
+            # (host-bound loops: the allocator's block cache, the op's capacity hint and header ring, torch's kernel modules all settle
+            # over the first iterations — at least ten of them, whatever --warmup says; a driver-style `--warmup 5` run used to time
+            # these loops cold)
+            for _ in range(max(10, args.warmup // 2)):
                 step_other()
             gc.collect()
             gc.disable()  # (as in the main timed region: no collector pause inside the measurement)

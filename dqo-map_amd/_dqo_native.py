@@ -71,7 +71,7 @@ class DqoAdamStep(ctypes.Structure):
 
 
 class DqoAdamTensor(ctypes.Structure):
-    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("n", ctypes.c_int64), ("lr", c_f)]
+    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("n", ctypes.c_int64), ("lr", ctypes.c_double)]
 
 
 EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
@@ -79,7 +79,7 @@ EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_e
            "dqo_map_attach_loss_fwd_bwd", "dqo_adam_multi", "dqo_accumulate_gaussian_error", "dqo_accumulate_gaussian_confidence", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
            "dqo_rast_binning_bytes", "dqo_rast_binning_bytes_bucketed",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
-           "dqo_rast_forward", "dqo_rast_backward", "dqo_rast_backward_adam", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
+           "dqo_rast_forward", "dqo_rast_forward_async", "dqo_rast_backward", "dqo_rast_backward_adam", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
            "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam", "dqo_tile_count_mask", "dqo_transmission_mask", "dqo_tile_color_error", "dqo_knn3_query_workspace_bytes",
            "dqo_knn3_query", "dqo_icp_workspace_bytes", "dqo_icp_normal_equations")
 
@@ -112,6 +112,7 @@ def lib():
         L.dqo_rast_forward_prepare.argtypes = [P(DqoRastParams), P(DqoRastInputs), P(DqoRastOutputs), P(DqoRastCtx), c_vp]
         L.dqo_rast_forward_render.argtypes = L.dqo_rast_forward_prepare.argtypes
         L.dqo_rast_forward.argtypes = L.dqo_rast_forward_prepare.argtypes
+        L.dqo_rast_forward_async.argtypes = L.dqo_rast_forward_prepare.argtypes[:4] + [c_vp, c_vp, c_vp]
         L.dqo_rast_read_header.argtypes = [P(DqoRastCtx), P(DqoRastHeader), c_vp]
         L.dqo_rast_backward.argtypes = [P(DqoRastParams), P(DqoRastInputs), P(DqoRastCtx), c_vp, c_vp, c_vp, P(DqoRastGrads), c_vp,
                                         ctypes.c_size_t, c_vp]
@@ -143,7 +144,7 @@ def lib():
         L.dqo_tile_color_error.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         L.dqo_profile_enable.argtypes = [ctypes.c_int]
         L.dqo_profile_collect.argtypes = [P(DqoProfileEntry), ctypes.c_int, ctypes.c_int]
-        if L.dqo_abi_version() != 3:
+        if L.dqo_abi_version() != 4:
             raise RuntimeError("libdqoraster.so ABI version mismatch")
         L.dqo_abi_sizeof.restype = ctypes.c_size_t
         L.dqo_abi_sizeof.argtypes = [c_i32]

@@ -216,7 +216,7 @@ DQO_API int dqo_rast_read_header(const DqoRastCtx* ctx, DqoRastHeader* host_out,
     return host_out->overflow ? DQO_ERR_OVERFLOW : DQO_OK;
 }
 
-DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, void* stream) {
+static int check_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx) {
     int rc = check_common(p, in, ctx);
     if (rc) return rc;
     rc = check_outputs(p, out);
@@ -234,6 +234,12 @@ DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs*
                       dqo_rast_binning_bytes_bucketed(ctx->inst_capacity, p->W, p->H, ctx->tile_bucket_capacity));
         return DQO_ERR_WORKSPACE;
     }
+    return DQO_OK;
+}
+
+DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, void* stream) {
+    const int rc = check_render(p, in, out, ctx);
+    if (rc) return rc;
     return dqo_launch_forward_render(p, in, out, ctx, (hipStream_t)stream);
 }
 
@@ -241,6 +247,15 @@ DQO_API int dqo_rast_forward(const DqoRastParams* p, const DqoRastInputs* in, Dq
     int rc = dqo_rast_forward_prepare(p, in, out, ctx, stream);
     if (rc) return rc;
     return dqo_rast_forward_render(p, in, out, ctx, stream);
+}
+
+DQO_API int dqo_rast_forward_async(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx,
+                                   DqoRastHeader* header_host, void* header_event, void* stream) {
+    int rc = check_render(p, in, out, ctx);  // (covers the checks of the first stage)
+    if (rc) return rc;
+    rc = dqo_launch_forward_prepare(p, in, out, ctx, (hipStream_t)stream);
+    if (rc) return rc;
+    return dqo_launch_forward_render(p, in, out, ctx, (hipStream_t)stream, header_host, (hipEvent_t)header_event);
 }
 
 DQO_API int dqo_rast_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,

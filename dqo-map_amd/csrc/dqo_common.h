@@ -344,6 +344,7 @@ int dqo_launch_zero_words(uint32_t* p, size_t n_words, hipStream_t s);
 
 // launchers (defined in the .hip files)
 int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);
-int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);
+int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s,
+                              DqoRastHeader* header_host = nullptr, hipEvent_t header_event = nullptr);
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                         const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* g, void* ws, size_t ws_bytes, hipStream_t s);

@@ -454,7 +454,7 @@ int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, doub
         const bool in = t < n_tensors;
         q.p[t] = in ? ts[t].p : nullptr, q.g[t] = in ? ts[t].g : nullptr, q.m[t] = in ? ts[t].m : nullptr, q.v[t] = in ? ts[t].v : nullptr;
         q.n[t] = in ? ts[t].n : 0;
-        q.step_size[t] = in ? (float)((double)ts[t].lr / bc1) : 0.f;
+        q.step_size[t] = in ? (float)(ts[t].lr / bc1) : 0.f;
         q.first_block[t] = blocks;
         if (in) blocks += (uint32_t)((ts[t].n + ADAMM_THREADS * ADAMM_PER_THREAD - 1) / (ADAMM_THREADS * ADAMM_PER_THREAD));
     }

@@ -400,6 +400,9 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     // of its dependency chains, not by the number of instructions: with a branch per entry the chain was one whole entry long.
     auto batch = [&](const int k0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
+#ifdef DQO_EXP_FREE_FETCH
+        const float4 exp_co = s_co[0], exp_xy = s_xy[0], exp_cs = s_rgb[0];
+#endif
         constexpr int NV = BWD_NB == 7 ? 64 : 32;
         float v64[NV];
 #pragma unroll
@@ -410,8 +413,15 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
             const int k = k0 + b;
             float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
             if (FULL || k < cnt) {  // wave-uniform
+#ifdef DQO_EXP_FREE_FETCH  // (timing experiment, results invalid: what would the walk cost if an entry's record were already in registers?
+                // every entry reuses the chunk's first record, opaque to the optimiser — no LDS read of the records in the loop)
+                float4 co = exp_co, xy = exp_xy, cs = exp_cs;
+                asm volatile("" : "+v"(co.x), "+v"(co.y), "+v"(co.z), "+v"(co.w), "+v"(xy.x), "+v"(xy.y), "+v"(xy.w), "+v"(cs.x), "+v"(cs.y), "+v"(cs.z));
+                const int c0 = s_pos[k];
+#else
                 const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
                 const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
+#endif
                 // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
                 // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
                 // and S + 0 * (c - S) = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.

@@ -879,7 +879,12 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
     return DQO_OK;
 }
 
-int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s) {
+// header_host / header_event (both optional): once the frame's device header is final — behind the sort kernels, BEFORE the blend kernel
+// — its 32 bytes are copied to (pinned) host memory on the launch stream and the event is recorded: a caller that carries its instance
+// capacity over from earlier frames (no host synchronisation in the forward) learns whether the capacity was enough a whole blend
+// kernel earlier than from a copy issued behind the forward.
+int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s,
+                              DqoRastHeader* header_host, hipEvent_t header_event) {
     const DqoView v = dqo_make_view(p, in);
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
@@ -907,6 +912,8 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
                    dqo_list_split(ctx));
         DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
     }
+    if (header_host != nullptr) DQO_CHECK_HIP(hipMemcpyAsync(header_host, g.header, sizeof(DqoRastHeader), hipMemcpyDeviceToHost, s));
+    if (header_event != nullptr) DQO_CHECK_HIP(hipEventRecord(header_event, s));
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, dqo_tap_dev(ctx->loss_tap),
                                     dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s);
 }

@@ -38,19 +38,24 @@ _sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy" / "
 _cap_hint = {}
 _pending = []          # lazy mode: (event, pinned header tensor, key, capacity) of forwards not yet verified
 _last = {"num_rendered": None, "num_visible": None, "header": None}   # header: (event, pinned host copy) or a weak reference to the geometry buffer
-_ring = []             # pinned 32-byte header buffers + their events, reused round robin (no pin_memory() / Event() per call)
-_ring_pos = [0]
+_ring = {}             # per device: pinned 32-byte header buffers + their events, reused round robin (no pin_memory() / Event() per call)
 _RING = 64
 
 
-def _ring_slot():
-    """A pinned 8-int32 host buffer and an event from the ring (allocated on first use).  A slot is reused after _RING later forwards;
-    a pending lazy check older than that has long been verified (lazy mode verifies at every forward)."""
-    if len(_ring) < _RING:
-        _ring.append((torch.empty((8,), dtype=torch.int32).pin_memory(), torch.cuda.Event()))
-        return _ring[-1]
-    _ring_pos[0] = (_ring_pos[0] + 1) % _RING
-    slot = _ring[_ring_pos[0]]
+def _ring_slot(dev_index):
+    """(pinned 8-int32 host buffer, event, host pointer, raw event handle) from the device's ring (allocated on first use; the event is
+    recorded once at creation — on the device it will serve — so that its handle exists: dqo_rast_forward_async records it from C).
+    A slot is reused after _RING later forwards; a pending lazy check older than that has long been verified (lazy mode verifies at
+    every forward).  Called under the module lock."""
+    ring, pos = _ring.setdefault(dev_index, ([], [0]))
+    if len(ring) < _RING:
+        host, ev = torch.empty((8,), dtype=torch.int32).pin_memory(), torch.cuda.Event()
+        host.zero_()
+        ev.record()
+        ring.append((host, ev, host.data_ptr(), ev.cuda_event))
+        return ring[-1]
+    pos[0] = (pos[0] + 1) % _RING
+    slot = ring[pos[0]]
     if any(p[1] is slot[0] for p in _pending):  # (never in practice: the GPU would be _RING frames behind)
         _verify_pending(block=True)
     return slot
@@ -133,6 +138,27 @@ def _verify_pending(block):
                            "been raised — re-run that iteration (or use set_sync_mode('exact')).")
 
 
+_gate_checked = {}  # (data_ptr, numel, version) of object-id tensors whose value range has been checked (one reduction per new tensor)
+
+
+def _check_gate_ids(gaussian_object, pixel_object):
+    """The object gate's ids must lie in [0, 64) (pixel ids: < 64, negative = no owner): the kernels keep a quadrant's owners as a
+    64-bit set and skip the exact id comparison where a quadrant has one owner, so an id of 69 would act on the pixels of object 5
+    (DqoObjectGate, include/dqo_raster.h).  Checked once per tensor (and again when it is modified in place)."""
+    for t, lo_ok in ((gaussian_object, False), (pixel_object, True)):
+        key = (t.data_ptr(), t.numel(), t._version)
+        if _gate_checked.get(key):
+            continue
+        if t.numel():
+            mn, mx = int(t.min().item()), int(t.max().item())
+            if mx > 63 or (mn < 0 and not lo_ok):
+                raise RuntimeError("object gate: object ids must lie in [0, 64) (negative pixel ids = no owner); got "
+                                   f"[{mn}, {mx}] in {'pixel_object' if lo_ok else 'gaussian_object'}")
+        if len(_gate_checked) > 64:
+            _gate_checked.clear()
+        _gate_checked[key] = True
+
+
 def _f32(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError(f"expected scalar type Float but found {t.dtype} ({name})")
@@ -206,6 +232,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if gaussian_object.numel() != P or pixel_object.numel() != H * W:
                 raise RuntimeError("object gate: gaussian_object must have num_points elements, pixel_object H x W")
             gaussian_object, pixel_object = gaussian_object.contiguous(), pixel_object.contiguous()
+            _check_gate_ids(gaussian_object, pixel_object)
             gate = N.DqoObjectGate(gaussian_object=N.ptr(gaussian_object), pixel_object=N.ptr(pixel_object))
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -233,41 +260,57 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(), inst_capacity=0, list_split=_list_split)
             if gate is not None:
                 cctx.object_gate = ctypes.addressof(gate)
-            N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
-                                                 ctypes.byref(cctx), stream))
             key = (dev.index, P, W, H)
-            if _sync_mode == "exact":
+            cap = None
+            if _sync_mode != "exact":
+                _verify_pending(block=False)
+                with _lock:
+                    cap = _cap_hint.get(key)
+            if cap is None:
+                # 'exact', or the first call for this shape in 'lazy' / 'deferred' (measure once): stage 1, the one D2H read, stage 2
+                N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
+                                                     ctypes.byref(cctx), stream))
                 hdr = N.DqoRastHeader()
-                N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))  # the one D2H read
+                N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))
                 # (Gaussian, tile) pairs in the tile rects: the reference's num_rendered, and an upper bound of the instances
                 # the binning keeps after its footprint test — a capacity that always fits
                 num_rendered = int(hdr.num_candidates)
                 cap = max(num_rendered, 1)
-                _last["num_rendered"], _last["num_visible"] = num_rendered, int(hdr.num_visible)
+                if _sync_mode == "exact":
+                    _last["num_rendered"], _last["num_visible"] = num_rendered, int(hdr.num_visible)
+                else:
+                    cap = num_rendered + 4096  # later calls keep max(this, 1.25 N)
+                    with _lock:
+                        cap = _cap_hint[key] = max(_cap_hint.get(key, 0), cap)
+                    num_rendered = -1
+                binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
+                cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
+                N.check(lib.dqo_rast_forward_render(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
+                                                    ctypes.byref(cctx), stream))
+                if _sync_mode == "exact":
+                    # exact mode has read what it needs already: nothing per call; last_header() reads the rest on demand from the
+                    # geometry buffer, which therefore stays referenced until the next forward (~160 B per Gaussian, one call longer)
+                    _last["header"] = geomBuffer
+                else:
+                    with _lock:
+                        host, ev, _, _ = _ring_slot(dev.index)
+                        host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
+                        ev.record()
+                        _pending.append((ev, host, key, cap))
+                        _last["header"] = (ev, host)
             else:
-                _verify_pending(block=False)
-                cap = _cap_hint.get(key)
-                if cap is None:  # first call for this shape: measure once
-                    hdr = N.DqoRastHeader()
-                    N.check(lib.dqo_rast_read_header(ctypes.byref(cctx), ctypes.byref(hdr), stream))
-                    cap = _cap_hint[key] = int(hdr.num_candidates) + 4096  # an upper bound of N; later calls keep max(this, 1.25 N)
+                # 'lazy' / 'deferred' with a carried-over capacity: ONE call — both stages, and between the sort and the blend kernel
+                # (where the frame's header is final) its asynchronous copy into a pinned ring slot + the slot's event: the deferred
+                # capacity check, available a blend kernel before the forward's end
                 num_rendered = -1
-            binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
-            cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
-            N.check(lib.dqo_rast_forward_render(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
-                                                ctypes.byref(cctx), stream))
-            if _sync_mode != "exact":
-                # asynchronous 32-byte copy of the device header into a pinned ring slot: the deferred capacity check (and statistics)
+                binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
+                cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
                 with _lock:
-                    host, ev = _ring_slot()
-                    host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
-                    ev.record()
+                    host, ev, host_ptr, ev_handle = _ring_slot(dev.index)
+                    N.check(lib.dqo_rast_forward_async(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
+                                                       ctypes.byref(cctx), host_ptr, ev_handle, stream))
                     _pending.append((ev, host, key, cap))
                     _last["header"] = (ev, host)
-            else:
-                # exact mode has read what it needs already: nothing per call; last_header() reads the rest on demand from the
-                # geometry buffer, which therefore stays referenced until the next forward (~160 B per Gaussian, one call longer)
-                _last["header"] = geomBuffer
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.inst_capacity = cap

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DQO_ABI_VERSION 3
+#define DQO_ABI_VERSION 4
 
 typedef enum DqoStatus {
     DQO_OK = 0,
@@ -206,7 +206,7 @@ int dqo_abi_version(void);
 const char* dqo_last_error(void);
 /* sizeof() of the ABI structs as this library was compiled (a binding checks its own struct definitions against it):
  * 0 DqoRastParams, 1 DqoRastInputs, 2 DqoRastOutputs, 3 DqoRastCtx, 4 DqoRastGrads, 5 DqoRastHeader, 6 DqoProfileEntry,
- * 7 DqoAdamStep, 8 DqoLossTap, 9 DqoObjectGate; 0 for any other index. */
+ * 7 DqoAdamStep, 8 DqoLossTap, 9 DqoObjectGate, 10 DqoAdamTensor; 0 for any other index. */
 size_t dqo_abi_sizeof(int32_t which);
 
 /* Optional per-kernel timing (measurement only; the reference has nothing comparable — it times whole frames with
@@ -237,6 +237,16 @@ int dqo_rast_read_header(const DqoRastCtx*, DqoRastHeader* host_out, void* hipSt
 int dqo_rast_forward_render(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
 /* Both stages back to back, no host synchronisation (caller guarantees / later checks capacity). */
 int dqo_rast_forward(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
+
+/* Both stages in ONE call for a caller that carries its instance capacity over from earlier frames and checks it afterwards (ABI 4; the
+ * drop-in op's 'lazy' / 'deferred' modes): as dqo_rast_forward, plus — where the frame's header is final, behind the sort kernels and
+ * BEFORE the blend kernel — an asynchronous copy of the 32-byte device header to `header_host` (pinned host memory; NULL: no copy) and
+ * hipEventRecord(header_event) on the launch stream (a hipEvent_t; NULL: none).  When the event has completed, header_host->overflow says
+ * whether ctx.inst_capacity held the frame (num_rendered, num_tiles, max_tile_count, num_visible and num_candidates are final
+ * too) — about one blend kernel earlier than a copy issued behind the call would.  Replaces the reference's blocking
+ * cudaMemcpy of rasterizer_impl.cu:307 like dqo_rast_read_header does, without the host wait. */
+int dqo_rast_forward_async(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, DqoRastHeader* header_host,
+                           void* header_event, void* hipStream);
 
 /* rasterizer_impl.cu:445-564 (K7-K9).  `hit_image` is out_hit_depth of the forward ([H*W]); workspace holds the
  * per-instance gradient records. */
@@ -319,7 +329,7 @@ typedef struct DqoAdamTensor {
     float* m;
     float* v;
     int64_t n;
-    float lr;
+    double lr;  /* the group's learning rate as the python float it is: lr / (1 - beta1^t) is formed in double and rounded once, as torch does */
 } DqoAdamTensor;
 int dqo_adam_multi(const DqoAdamTensor* tensors, int32_t n_tensors, int32_t step, double beta1, double beta2, double eps, void* hipStream);
 
@@ -368,6 +378,9 @@ int dqo_icp_normal_equations(int32_t H, int32_t W, const float* vertex0, const f
 typedef struct DqoAdamStep {
     int32_t P, M;      /* Gaussians, SH coefficients per Gaussian (f_dc = coefficient 0, f_rest = the others) */
     int32_t step;      /* 1-based Adam step count */
+    /* betas travel as floats; 1 - beta and beta^t are formed in double from the decimal the float was written as (rounded to seven
+     * decimals: 0.9, 0.999 and every other short decimal come back exactly; a beta that is not a short decimal is used to seven
+     * decimals — dqo_adam_multi takes doubles and has no such limit) */
     float beta1, beta2, eps;
     float lr_xyz, lr_f_dc, lr_f_rest, lr_opacity, lr_scaling, lr_rotation;
     float *xyz, *shs, *opacity_raw, *scaling_raw, *rotation_raw;            /* raw parameters, updated in place */
