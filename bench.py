@@ -287,6 +287,7 @@ class FusedRunner:
         self.fm = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=attach_reducer(prob, world))
         if prob.get("gate") is not None:
             self.fm.set_object_gate(prob["gate"][0], prob["gate"][1])
+            self.fm.object_cell = (8.0, 4.0, 8.0)  # the synthetic rooms are 6 x 3 x 4 m (dqo_harness.scenes.surfel_room)
         self.stable_mask = None
         if growth_every:
             # the reference's two clouds (mapper.py:1351-1466): the map the run starts from is the stable cloud, what the growth steps add
@@ -311,12 +312,13 @@ class FusedRunner:
 
     def make_growth_batch(self, k):
         """The candidate points of growth step k.  Strong scaling: ONE batch for the job — every rank draws the same 40 800 points and
-        keeps the candidates of the objects it owns (an object's Gaussians never live on two ranks); the decisions of the step
-        (inside an existing Gaussian? neighbours for the scale?) are then taken against the rank's own Gaussians, so with growth the
-        N-rank map is not the N = 1 map to the last Gaussian (a candidate next to ANOTHER rank's object is judged without it)."""
+        keeps the candidates of the objects it owns (an object's Gaussians never live on two ranks).  With the object gate every
+        decision of the step judges a candidate against the Gaussians of its own object (FusedMapper.grow -> dqo_mapgrowth.*_per_object),
+        so the N-rank map grows exactly like the N = 1 map (selfcheck compares the rank's end state with the unsharded job's)."""
         from dqo_harness import scenes
         p = self.prob
-        seed = 9000 + 17 * k + (0 if p.get("sharded") else self.growth_seed)
+        job_wide = p.get("sharded") or p.get("job_wide_growth")
+        seed = 9000 + 17 * k + (0 if job_wide else self.growth_seed)
         sc = scenes.surfel_room(seed, 40_800, n_objects=p["cfgd"]["n_objects"], rest_sigma=p["cfgd"]["rest_sigma"])
         keep = np.ones(len(sc["obj_id"]), bool) if not p.get("sharded") else np.isin(np.asarray(sc["obj_id"]), np.asarray(p["objects"]))
         b = {n: torch.tensor(np.ascontiguousarray(np.asarray(sc[n], np.float32)[keep]), device=self.device)
@@ -331,9 +333,14 @@ class FusedRunner:
             # warm-up iterations of the step itself: one discarded pass through the growth step's searches
             import dqo_mapgrowth as mg
             fm, b = self.fm, self.growth_pool[0]
-            keep = mg.temp_points_filter_mask(b["xyz"], fm.xyz, fm.radius())
             sc = b["scales"]
-            mg.update_geometry_scales(b["xyz"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(), 0.001, 0.05)
+            if fm.gaussian_object is not None:  # (the per-object forms of the two decisions: what grow() runs with an object gate)
+                keep = mg.temp_points_filter_mask_per_object(b["xyz"], b["obj_id"], fm.xyz, fm.radius(), fm.gaussian_object, cell=fm.object_cell)
+                mg.update_geometry_scales_per_object(b["xyz"], b["obj_id"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(),
+                                                     fm.gaussian_object, 0.001, 0.05, cell=fm.object_cell)
+            else:
+                keep = mg.temp_points_filter_mask(b["xyz"], fm.xyz, fm.radius())
+                mg.update_geometry_scales(b["xyz"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(), 0.001, 0.05)
             if self.stable_mask is not None:  # (on a thread and a stream of its own, as grow() runs it)
                 import threading
                 side = torch.cuda.Stream(device=self.device)
@@ -341,7 +348,8 @@ class FusedRunner:
 
                 def warm():
                     with torch.cuda.device(self.device), torch.cuda.stream(side), torch.no_grad():
-                        fm._temp_points_attach(b["xyz"], b["opacity"].reshape(-1, 1), self.stable_mask, 0.1)
+                        fm._temp_points_attach(b["xyz"], b["opacity"].reshape(-1, 1), self.stable_mask, 0.1,
+                                               temp_obj=b["obj_id"] if fm.gaussian_object is not None else None)
                 th = threading.Thread(target=warm)
                 th.start()
                 th.join()
@@ -368,10 +376,12 @@ class FusedRunner:
         if out is not None:
             H, W = p["cam"].H, p["cam"].W
             depth_err = (p["gt_depth"] - out[1]).clamp(min=0)  # mapper.py:1016-1017
-            invalid = (p["gt_depth"] == 0) | (out[3] == -1)
+            # (... and only on the pixels of this rank's objects: a tile the rank does not render keeps the op's initial fills — depth 0
+            # and hit id 0, quirk B7 — which would charge the whole ground-truth depth of those pixels to the rank's Gaussian 0)
+            invalid = (p["gt_depth"] == 0) | (out[3] == -1) | ~p["render_mask"][None]
             depth_err[invalid] = 0
             color_err = (p["gt_color"] - out[0]).abs().sum(0, keepdim=True)
-            color_err[p["gt_depth"] == 0] = 0
+            color_err[(p["gt_depth"] == 0) | ~p["render_mask"][None]] = 0
             zero = torch.zeros_like(depth_err)
             _, g_depth, _, _ = accumulate_gaussian_error(H, W, fm.P, color_err.reshape(-1), depth_err.reshape(-1), zero.reshape(-1),
                                                          out[2].reshape(-1), out[3].reshape(-1), 0.1, 0.1, 0.1, True)
@@ -399,6 +409,11 @@ class FusedRunner:
                               recapture=round((t3 - t2) * 1e3, 2))
         st["P_after"] = fm.n_alive
         st["attach_set"] = fm.attach_count
+        if not self.growth_log and fm.gaussian_object is not None and (p.get("sharded") or p.get("job_wide_growth")) and torch.distributed.is_initialized():
+            # the map right after the FIRST growth step, per owned object (selfcheck: grown_shard_vs_unsharded) — outside `ms`
+            g = getattr(fm, "_g", None)
+            self.first_growth_snapshot = dict(rows={k: object_rows(fm, k) for k in p["objects"]}, added=st["added"], deleted=st["deleted"],
+                                              list_split=(int(g.ls_fwd), int(g.ls_bwd)) if g is not None else self.list_split)
         self.growth_log.append(st)
 
     def step(self):
@@ -467,7 +482,10 @@ def selfcheck(args, prob, runner, device, n_iters):
     if in_view and int((out["depth_index_map"] >= 0).sum().item()) == 0:
         fails.append("the shard renders no depth hit at all (blank frame)")
     del out, params
-    if not runner.growth_log:  # (a grown map has no stand-alone twin to compare with)
+    if runner.growth_log and prob.get("sharded") and gate is not None and torch.distributed.is_initialized():
+        # (a shard run alone, --as-shard, cannot know the attach counts of the shards it has no partner for)
+        fails += grown_shard_vs_unsharded(prob, runner, device)
+    if not runner.growth_log:  # (a grown shard is compared with the unsharded job instead: grown_shard_vs_unsharded)
         end = runner.fm.loss.clone()
         twin = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=(None if not prob.get("sharded") else
                                                                                           (lambda n: prob["n_attach_full"])))
@@ -496,6 +514,68 @@ def selfcheck(args, prob, runner, device, n_iters):
         if in_view and a[0] == got0[0]:
             fails.append(f"the loss did not move in {n_iters} iterations ({a[0]}): no optimiser step took effect")
         del twin
+    torch.cuda.empty_cache()
+    return fails
+
+
+def object_rows(fm, k):
+    """The Gaussians of object k in a FusedMapper as rows (xyz | scaling | rotation | opacity | SH) in lexicographic order of their centres."""
+    m = fm.gaussian_object == k
+    if fm.alive is not None:
+        m = m & fm.alive.bool()
+    n = int(m.sum().item())
+    r = torch.cat([fm.xyz[m], fm.scaling_raw[m], fm.rotation_raw[m], fm.opacity_raw[m], fm.shs[m].reshape(n, -1)], 1).cpu().numpy()
+    return r[np.lexsort((r[:, 2], r[:, 1], r[:, 0]))]
+
+
+def grown_shard_vs_unsharded(prob, runner, device):
+    """Growth under sharding computes the N = 1 function: the UNSHARDED job — the full map, the same candidate batches, the same growth
+    schedule, the same list-split thresholds as this rank (so that every list is blended in the same grouping) — is run beside on this
+    rank up to and including its FIRST growth step, and the Gaussians of every object the rank owns are compared, as sets, with the
+    snapshot the rank took right after its own first growth step: bit for bit the same rows (rows matched in lexicographic order of
+    their centres) — the iterations before the step trained every owned Gaussian identically, and the step deleted, kept, attached
+    and sized the same candidates.  (Compared right after the step, not at the end of the run: from then on new Gaussians sit in
+    different rows on different shard layouts, two list entries of bit-equal depth may blend in the other order — the sort's tie break is
+    the row index — and Adam turns such last-bit differences into visible ones within tens of iterations.)"""
+    snap = getattr(runner, "first_growth_snapshot", None)
+    if snap is None:
+        return []
+    twin_prob = dict(prob, scene=prob["full"], sharded=False, job_wide_growth=True, P_shard=prob["P"],
+                     gate=(torch.tensor(np.asarray(prob["full"]["obj_id"], np.int32), device=device), prob["pix_obj"]),
+                     render_mask=prob["pix_obj"] >= 0)
+    from dqo_harness import sharding
+    from dqo_harness.sharding import PackedAllReduce
+    twin_prob["tile_mask"] = torch.tensor(sharding.tile_mask_from_pixel_mask(twin_prob["render_mask"].cpu().numpy()), device=device)
+    twin = FusedRunner(twin_prob, device, PackedAllReduce(LOSS_SPEC, device), 1, use_graph=runner.use_graph, growth_every=runner.growth_every,
+                       loss_tap=runner.loss_tap, fused_tail=runner.fused_tail, list_split=snap["list_split"])
+    twin.prepare_growth(runner.growth_every)
+    while not twin.growth_log:  # (the iterations before the step, then the step itself — at the top of the next call)
+        twin.step()
+    torch.cuda.synchronize()
+    fails, n_rows, n_diff, n_count_diff = [], 0, 0, 0
+    tw = twin.first_growth_snapshot
+    # Exact only in the serial order of arithmetic (list_split 0 / 0): with lists shared between eight waves the transmittance products
+    # are grouped by chunks of 64 LIST POSITIONS, and a tile's list holds other objects' entries in the unsharded job that it does not
+    # hold on a shard — last-bit differences that Adam amplifies, so a handful of threshold decisions of the step may fall the other
+    # way; then the per-object counts are bounded (0.1 %) instead of asserted equal.
+    exact = tuple(snap["list_split"]) == (0, 0)
+    for k in prob["objects"]:
+        a, b = snap["rows"][k], tw["rows"][k]
+        if a.shape != b.shape:
+            n_count_diff += abs(a.shape[0] - b.shape[0])
+            if exact or abs(a.shape[0] - b.shape[0]) > max(2, 1e-3 * b.shape[0]):
+                fails.append(f"object {k}: {a.shape[0]} Gaussians on this rank after the first growth step, {b.shape[0]} in the unsharded job")
+            continue
+        n_rows += a.shape[0]
+        n_diff += int((a != b).any(1).sum()) if a.size else 0
+    runner.growth_vs_unsharded = dict(compared="the rank's objects right after the first growth step, as sets" + (", bitwise" if exact else
+                                               " (lists shared between eight waves: grouping differs between shard layouts, counts bounded at 0.1 %)"),
+                                      exact_order_of_arithmetic=exact, objects=len(prob["objects"]), rows=n_rows, rows_differing=n_diff,
+                                      gaussians_more_or_fewer=n_count_diff, added=snap["added"], deleted=snap["deleted"],
+                                      unsharded_added=tw["added"], unsharded_deleted=tw["deleted"])
+    if exact and n_diff:
+        fails.append(f"{n_diff} of {n_rows} Gaussians of this rank's objects differ from the unsharded job's right after the first growth step")
+    del twin
     torch.cuda.empty_cache()
     return fails
 
@@ -1067,6 +1147,8 @@ def main():
             stats["n1_equivalence"] = n1_check
         if runner.first_loss is not None:  # [total, colour, depth] of the initial state and after the last iteration (this rank's shard)
             stats["loss_first_last"] = [[round(x, 6) for x in runner.first_loss[:3].tolist()], [round(x, 6) for x in fm_.loss[:3].tolist()]]
+    if runner is not None and getattr(runner, "growth_vs_unsharded", None) is not None:
+        stats["growth_n1_equivalence"] = runner.growth_vs_unsharded  # (rank 0's objects; every rank checks its own)
     if runner is not None and runner.growth_log:
         stats["growth_every"] = args.growth_every
         stats["growth_steps"] = runner.growth_log

@@ -111,6 +111,7 @@ class FusedMapper:
         # count (e.g. one all-reduce of one integer per mapping call — not per iteration); None = this mapper holds the whole map.
         self.attach_count_reducer = attach_count_reducer
         self.gaussian_object = self.pixel_object = self.tile_objects = None  # set_object_gate()
+        self.object_cell = None  # per-object growth decisions: cell size of dqo_mapgrowth.object_offsets (None = its 16 m default)
         self.per_object_loss = False
         self.alive = None  # reserve(): uint8 [P], 0 = a spare row (parked behind the camera, no Gaussian of the map)
         # DqoAdamStep.attach_gains: the attach term's two factors in device memory, rewritten in place by begin_mapping_call — a captured
@@ -320,15 +321,24 @@ class FusedMapper:
         stats = dict(candidates=int(Q), inside_existing=0, invalid_scale=0, added=0, deleted=0)
         exist_xyz, exist_radius = self.xyz, self.radius()  # (spare rows sit 10^4 units away: outside every search box)
         keep = torch.ones((Q,), dtype=torch.bool, device=dev)
+        # The per-object job (set_object_gate): every decision of the step judges a candidate against the Gaussians of its OWN object
+        # only (dqo_mapgrowth.*_per_object), so a shard — which holds whole objects — takes exactly the decisions the unsharded map
+        # takes for its objects: the N-rank map grows like the N = 1 map.  Without a gate: the reference's decisions.
+        per_obj = nobj is not None
+        live_rows = None if self.alive is None else self.alive.bool()
         if Q > 0:
-            if stable_mask is None:
+            if stable_mask is None and not per_obj:
                 inside = mg.temp_points_filter_mask(nx, exist_xyz, exist_radius)
             else:  # the reference filters against its unstable cloud
-                un = ~stable_mask.to(dev).bool().reshape(-1)
-                if self.alive is not None:
-                    un &= self.alive.bool()
+                un = torch.ones((self.P,), dtype=torch.bool, device=dev) if stable_mask is None else ~stable_mask.to(dev).bool().reshape(-1)
+                if live_rows is not None:
+                    un = un & live_rows  # (spare rows are no Gaussians of the map)
                 un = un.nonzero().reshape(-1)
-                inside = mg.temp_points_filter_mask(nx, exist_xyz[un], exist_radius[un])
+                if per_obj:
+                    inside = mg.temp_points_filter_mask_per_object(nx, nobj, exist_xyz[un], exist_radius[un], self.gaussian_object[un],
+                                                                   cell=self.object_cell)
+                else:
+                    inside = mg.temp_points_filter_mask(nx, exist_xyz[un], exist_radius[un])
             if inside is not None:
                 keep &= ~inside
                 stats["inside_existing"] = int(inside.sum().item())
@@ -349,10 +359,10 @@ class FusedMapper:
             side, box = self._side_stream, {}
             side.wait_stream(torch.cuda.current_stream())
 
-            def attach_work(tx=nx, to=nop):
+            def attach_work(tx=nx, to=nop, tobj=nobj):
                 try:
                     with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad():
-                        box["att"] = self._temp_points_attach(tx, to, stable_mask, unstable_opacity_low)
+                        box["att"] = self._temp_points_attach(tx, to, stable_mask, unstable_opacity_low, temp_obj=tobj)
                 except BaseException as e:  # (re-raised by the caller's thread)
                     box["err"] = e
 
@@ -366,7 +376,12 @@ class FusedMapper:
         log_scales = None
         if nx.shape[0] > 0:
             nrad = (nsc.sum(dim=1) - nsc.min(dim=1).values) / 2
-            scales, invalid = mg.update_geometry_scales(nx, nrad, exist_xyz, exist_radius, min_radius, max_radius)
+            if per_obj:
+                rows_all = torch.arange(self.P, device=dev) if live_rows is None else live_rows.nonzero().reshape(-1)
+                scales, invalid = mg.update_geometry_scales_per_object(nx, nobj, nrad, exist_xyz[rows_all], exist_radius[rows_all],
+                                                                       self.gaussian_object[rows_all], min_radius, max_radius, cell=self.object_cell)
+            else:
+                scales, invalid = mg.update_geometry_scales(nx, nrad, exist_xyz, exist_radius, min_radius, max_radius)
         if attach_job is not None:
             attach_job.join()
             torch.cuda.current_stream().wait_stream(side)
@@ -476,8 +491,12 @@ class FusedMapper:
             self.reserve(self._spare_rows)
         return stats
 
-    def _temp_points_attach(self, temp_xyz, temp_opacity, stable_mask, unstable_opacity_low):
-        """mapper.py:1384-1436 on this mapper's map: indices (into the temp points) that fall onto the stable cloud's surfaces."""
+    def _temp_points_attach(self, temp_xyz, temp_opacity, stable_mask, unstable_opacity_low, temp_obj=None):
+        """mapper.py:1384-1436 on this mapper's map: indices (into the temp points) that fall onto the stable cloud's surfaces.
+        temp_obj (the per-object job): the stable cloud is rendered through the object gate — every pixel shows its owner object's
+        stable Gaussians, exactly what a shard that owns the object renders there — and a candidate only attaches to a stable Gaussian of
+        its own object; the zero fill of never-rendered tiles counts as no hit (the reference's alias of such a pixel to "Gaussian 0"
+        would name a different Gaussian on every shard layout)."""
         import dqo_mapgrowth as mg
         from . import mapping
         st, dev = self.settings, self.device
@@ -497,13 +516,16 @@ class FusedMapper:
         first = torch.argmax(sm.to(torch.uint8)).reshape(1)  # (the first stable row)
         data = dict(xyz=torch.where(sm[:, None], self.xyz, self._park_position()[None, :]), opacity=self.opacity, scales=self.scales,
                     rotations=self.rotations, shs=self.shs)
-        out = mapping.render(st, data)
+        gated = temp_obj is not None and self.gaussian_object is not None
+        out = mapping.render(st, data, object_gate=(self.gaussian_object, self.pixel_object.reshape(-1)) if gated else None)
         cim = out["color_index_map"]
-        cim = torch.where((cim == 0) & (out["color_hit_weight"] == 0), first.to(cim.dtype).reshape(1, 1, 1), cim)
+        zero_fill = (cim == 0) & (out["color_hit_weight"] == 0)
+        cim = torch.where(zero_fill, torch.full_like(cim, -1) if gated else first.to(cim.dtype).reshape(1, 1, 1), cim)
         H, W = int(st.image_height), int(st.image_width)
         K = torch.tensor([[W / (2.0 * st.tanfovx), 0.0, st.cx], [0.0, H / (2.0 * st.tanfovy), st.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
         return mg.temp_points_attach_indices(temp_xyz, temp_opacity, st.viewmatrix.T.contiguous(), K, W, H, cim, self.xyz,
-                                             lambda rows: self.normals(rows), self.add_depth_thres, unstable_opacity_low)
+                                             lambda rows: self.normals(rows), self.add_depth_thres, unstable_opacity_low,
+                                             temp_obj=temp_obj if gated else None, stable_obj=self.gaussian_object if gated else None)
 
     def attach_loss(self):
         """The reference's reported "scale_loss" of the most recent iteration (attach loss at its pre-update parameters)."""

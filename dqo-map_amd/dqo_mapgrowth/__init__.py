@@ -8,6 +8,9 @@
     update_geometry_scales    the scale initialisation of GaussianPointCloud.update_geometry
                          (SLAM/gaussian_pointcloud.py:519-570) on top of simple_knn's distCUDA2
 
+    *_per_object         the same two decisions for the per-object job: a candidate is judged against the Gaussians of ITS
+                         OWN object only, so that a sharded map grows exactly like the unsharded one (not a reference feature)
+
     temp_points_attach_indices   the decision of Mapping.temp_points_attach (mapper.py:1384-1430): which new points lie on a stable
                          Gaussian's plane in the current frame (they get opacity 0.1 and thereby become the members of the attach
                          loss, mapper.py:812-829) — gathers over the stable render's color_index_map, no kernel of its own
@@ -109,14 +112,99 @@ def update_geometry_scales(xyz, radius, extra_xyz, extra_radius, min_radius, max
     return torch.clip(scales, min=min_radius, max=max_radius), invalid
 
 
+# ---- the per-object job (SURVEY.md §8e): every growth decision of a candidate looks at the Gaussians of the candidate's own object only ----
+# A shard of the map holds whole objects, so a decision that only looks at the candidate's object is the same on every shard layout:
+# the N-rank map grows exactly like the N = 1 map.  One search per step, as in the reference's form: every object is moved to a cell
+# of its own on a grid (ids in [0, 64): 4 x 4 x 4 cells of `cell` metres per axis, powers of two so that the shift is exact for most
+# coordinates), so a point's nearest neighbours are its own object's whenever that object has three nearby — checked explicitly, never
+# assumed — and the distances the decisions use are recomputed from the unshifted coordinates of the pairs found (the shift only selects
+# neighbours, it never enters a value).  The cells must keep two objects apart by more than the distance at which a neighbour still
+# matters: a neighbour beyond 0.087 m + 3 x its radius saturates the scale at max_radius (0.05) exactly like a missing one, and the
+# filter only looks at distances below 0.6 x radius — so a gap of a metre is ample; the default of 16 m cells holds any room below 15 m
+# across, a caller that knows its scene (bench.py: 6 x 3 x 4 m rooms) passes tighter cells, which keeps the search's Morton grid fine.
+OBJECT_CELL = (16.0, 16.0, 16.0)
+
+
+def object_offsets(obj, cell=None):
+    """[n, 3] float32 translation of every point's object cell (ids in [0, 64))."""
+    o = obj.long()
+    c = torch.tensor(OBJECT_CELL if cell is None else cell, dtype=torch.float32, device=obj.device)
+    return torch.stack([o % 4, (o // 4) % 4, o // 16], dim=1).to(torch.float32) * c
+
+
+def _per_object_bbox_mask(query_xyz, query_obj, ref_xyz, ref_obj, padding=0.05, n_objects=64):
+    """bbox_filter per object: a reference point passes iff it lies strictly inside the padded bounding box of the QUERY points of its
+    own object (no query of that object: it does not pass)."""
+    inf = float("inf")
+    idx = query_obj.long()[:, None].expand(-1, 3)
+    lo = torch.full((n_objects, 3), inf, device=query_xyz.device).scatter_reduce(0, idx, query_xyz, "amin", include_self=True)
+    hi = torch.full((n_objects, 3), -inf, device=query_xyz.device).scatter_reduce(0, idx, query_xyz, "amax", include_self=True)
+    ro = ref_obj.long()
+    return (ref_xyz > lo[ro] - padding).all(dim=-1) & (ref_xyz < hi[ro] + padding).all(dim=-1)
+
+
+def temp_points_filter_mask_per_object(temp_xyz, temp_obj, exist_xyz, exist_radius, exist_obj, cell=None):
+    """temp_points_filter_mask with every candidate judged against the existing Gaussians of its own object: True for the temp points
+    that lie within 0.6 x radius of one of the (up to) 3 nearest existing centres of their object.  None: nothing to test against."""
+    if torch.numel(exist_xyz) == 0 or torch.numel(temp_xyz) == 0:
+        return None
+    inbbox = _per_object_bbox_mask(temp_xyz, temp_obj, exist_xyz, exist_obj)
+    exist_xyz, exist_radius, exist_obj = exist_xyz[inbbox], exist_radius[inbbox], exist_obj[inbbox]
+    if torch.numel(exist_xyz) == 0:
+        return None
+    _, nn_idx = knn_points_k3(temp_xyz + object_offsets(temp_obj, cell), exist_xyz + object_offsets(exist_obj, cell))
+    j = nn_idx.clamp(min=0)
+    valid = (nn_idx >= 0) & (exist_obj[j] == temp_obj[:, None])
+    nn_dist = torch.sqrt((temp_xyz[:, None, :] - exist_xyz[j]).pow(2).sum(-1))  # (of the pairs found, unshifted)
+    return ((nn_dist < exist_radius.reshape(-1)[j] * 0.6) & valid).any(dim=-1)
+
+
+def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius, extra_obj, min_radius, max_radius, cell=None):
+    """update_geometry_scales with every new point's three neighbours taken from its own object (the other new points of the object and
+    the object's existing points inside the bounding box of the object's new points).  A point whose object offers fewer than three
+    neighbours keeps `inf` in the missing slots: its scale is clipped to max_radius, on every shard layout alike."""
+    n = xyz.shape[0]
+    xyz = xyz.float().contiguous()
+    radius, extra_radius = radius.reshape(-1), extra_radius.reshape(-1)
+    if torch.numel(extra_xyz) > 0:
+        inbbox = _per_object_bbox_mask(xyz, obj, extra_xyz, extra_obj)
+        extra_xyz, extra_radius, extra_obj = extra_xyz[inbbox], extra_radius[inbbox], extra_obj[inbbox]
+    inf = torch.full((n, 3), float("inf"), device=xyz.device)
+    shifted = (xyz + object_offsets(obj, cell)).contiguous()
+    cand_d, cand_r = [inf], [torch.zeros_like(inf)]
+    if n > 1:
+        _, i_new = distCUDA2(shifted)
+        j = i_new.long().clamp(max=n - 1)
+        ok = (i_new < n) & (obj[j] == obj[:, None])
+        cand_d.append(torch.where(ok, (xyz[:, None, :] - xyz[j]).pow(2).sum(-1), inf))
+        cand_r.append(radius[j])
+    if torch.numel(extra_xyz) > 0:
+        _, i_old = knn_points_k3(shifted, extra_xyz + object_offsets(extra_obj, cell))
+        j = i_old.clamp(min=0)
+        ok = (i_old >= 0) & (extra_obj[j] == obj[:, None])
+        cand_d.append(torch.where(ok, (xyz[:, None, :] - extra_xyz[j]).pow(2).sum(-1), inf))
+        cand_r.append(extra_radius[j])
+    cd, cr = torch.cat(cand_d, 1), torch.cat(cand_r, 1)
+    top = torch.topk(cd, 3, dim=1, largest=False)
+    dist = torch.sqrt(top.values)
+    rr = torch.gather(cr, 1, top.indices)
+    d = [dist[:, k] - 3 * rr[:, k] for k in range(3)]
+    invalid = (d[0] < 0) | (d[1] < 0) | (d[2] < 0)
+    scales = torch.sqrt((d[0] ** 2 + d[1] ** 2 + d[2] ** 2) / 3)
+    return torch.clip(scales, min=min_radius, max=max_radius), invalid
+
+
 def temp_points_attach_indices(temp_xyz, temp_opacity, w2c, intrinsic, image_width, image_height, stable_color_index_map, stable_xyz,
-                               stable_normal, add_depth_thres, unstable_opacity_low=0.1):
+                               stable_normal, add_depth_thres, unstable_opacity_low=0.1, temp_obj=None, stable_obj=None):
     """mapper.py:1384-1430: indices (into the temp cloud) of the points whose opacity the reference sets to `unstable_opacity_low`.
 
     temp_xyz [N,3], temp_opacity [N,1] (activated); w2c [4,4], intrinsic [3,3] (scene/cameras.py:207-214 get_uv: pixel =
     trunc(K (R x + t) / z), truncation toward zero, so a point up to one pixel left of / above the image still counts as inside);
     stable_color_index_map int [1,H,W] = the op's hit_color of a render of the STABLE Gaussians only (-1 / 0-fill rules as the op has
     them: `>= 0` is the reference's test); stable_xyz [S,3], stable_normal [S,3] (gaussian_pointcloud.py:780-791).
+
+    temp_obj / stable_obj (optional, both): object ids of the temp points and of the map rows; a candidate then only attaches to a stable
+    Gaussian of its own object.
 
     Quirk kept (B15): after the opacity filter the reference indexes the UNFILTERED temp cloud with positions of the FILTERED one when
     it fetches the points for the point-to-plane test (mapper.py:1419); the two agree whenever no temp point has been attached yet
@@ -136,6 +224,13 @@ def temp_points_attach_indices(temp_xyz, temp_opacity, w2c, intrinsic, image_wid
     idx = idx[inside][hit[:, 0]]
     sidx = stable_index[uv[idx, 1], uv[idx, 0]].squeeze(-1).long()
     nrm = stable_normal(sidx) if callable(stable_normal) else stable_normal[sidx]  # (a callable: normals of the rows asked for only)
-    d = ((stable_xyz[sidx] - temp_xyz[idx]) * nrm).sum(dim=-1)  # (temp_xyz, not xyz: quirk B15)
-    idx = idx[d.abs() < 0.5 * add_depth_thres]
+    # (temp_xyz, not xyz: quirk B15 — position idx of the UNFILTERED cloud.  The per-object job takes the candidate's own point instead:
+    # which point sits at that position depends on the other candidates of the batch, i.e. on the shard layout)
+    d = ((stable_xyz[sidx] - (temp_xyz if temp_obj is None else xyz)[idx]) * nrm).sum(dim=-1)
+    on_plane = d.abs() < 0.5 * add_depth_thres
+    if temp_obj is not None:
+        # the per-object job: a candidate attaches to a stable Gaussian of its OWN object only (temp_obj [N], stable_obj [S]) — on a
+        # shard the other objects' Gaussians are not there to attach to
+        on_plane &= stable_obj[sidx] == temp_obj[keep][idx]
+    idx = idx[on_plane]
     return origin[keep][idx]

@@ -351,3 +351,54 @@ def test_a_new_gaussian_in_a_row_freed_by_a_stable_one_is_unstable(mg):
     st2 = fm.grow(dict(xyz=fm.xyz[rows].clone(), scales=torch.exp(fm.scaling_raw[rows]), rotations=fm.rotation_raw[rows].clone(),
                        opacity=torch.sigmoid(fm.opacity_raw[rows]), shs=fm.shs[rows].clone()), new_mapping_call=True, stable_mask=stable)
     assert st2["inside_existing"] == rows.numel() and st2["added"] == 0
+
+
+def test_a_sharded_map_grows_exactly_like_the_unsharded_map(mg):
+    """The per-object job's growth step (FusedMapper.grow with an object gate): every decision — inside an existing Gaussian? on a
+    stable surfel's plane? which neighbours set the scale? — judges a candidate against the Gaussians of its OWN object, so two shards
+    that hold disjoint object sets take, for their objects, exactly the decisions the map that holds every object takes: the same
+    Gaussians are added (bit for bit: position, scale, opacity, rotation) and the same ones deleted, whatever the shard layout."""
+    torch, M = mg
+    from dqo_harness import mapping, scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev, cam, scene, settings, gt_color, gt_depth, mask = _growth_problem()
+    P = 12000
+    go = np.asarray(scene["obj_id"], np.int32)
+    with torch.no_grad():
+        hit = mapping.render(settings, mapping.GaussianParams(scene, dev).activated())["depth_index_map"][0].cpu().numpy()
+    po = np.where(hit >= 0, go[np.clip(hit, 0, None)], -1).astype(np.int32)
+    new = scenes.surfel_room(84, 6000, n_objects=8)
+    objs_a = [0, 2, 5, 7]
+    in_a = np.isin(go, objs_a)
+    sub = lambda m: {k: (v[m] if hasattr(v, "shape") and v.shape[:1] == (P,) else v) for k, v in scene.items()}
+    nsub = lambda m: {k: (np.asarray(v)[m] if hasattr(v, "shape") and v.shape[:1] == (6000,) else v) for k, v in new.items()}
+    new_in_a = np.isin(np.asarray(new["obj_id"]), objs_a)
+    rng = np.random.default_rng(5)
+    delete = rng.uniform(size=P) < 0.01
+    half_stable = (np.arange(P) % 3) != 0  # a third of the map is the unstable cloud the filter looks at
+
+    def run(sc, gobj, nw, keep):
+        fm = FusedMapper(sc, settings, dev).set_object_gate(gobj, po).reserve(3000)
+        n0 = len(gobj)
+        stable = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+        stable[:n0] = torch.tensor(half_stable[keep], device=dev)
+        dm = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+        dm[:n0] = torch.tensor(delete[keep], device=dev)
+        st = fm.grow(nw, delete_mask=dm, new_mapping_call=True, stable_mask=stable)
+        assert st["in_place"]
+        alive = fm.alive.bool()
+        f = lambda a: a[alive].cpu().numpy()
+        rows = np.concatenate([f(fm.xyz), f(fm.scaling_raw), f(fm.opacity_raw), f(fm.rotation_raw), f(fm.shs).reshape(int(alive.sum()), -1)], 1)
+        return st, f(fm.gaussian_object), rows
+
+    st_w, obj_w, rows_w = run(scene, go, new, np.ones(P, bool))
+    st_a, obj_a, rows_a = run(sub(in_a), go[in_a], nsub(new_in_a), in_a)
+    st_b, obj_b, rows_b = run(sub(~in_a), go[~in_a], nsub(~new_in_a), ~in_a)
+    assert st_w["added"] > 100 and st_w["inside_existing"] > 0 and st_w.get("attached", 0) > 0
+    for k in ("added", "deleted", "inside_existing", "invalid_scale", "attached"):
+        assert st_a[k] + st_b[k] == st_w[k], (k, st_a[k], st_b[k], st_w[k])
+    canon = lambda r: r[np.lexsort(r.T[::-1])]
+    for k in np.unique(obj_w):
+        want = canon(rows_w[obj_w == k])
+        got = canon(rows_a[obj_a == k]) if k in objs_a else canon(rows_b[obj_b == k])
+        assert want.shape == got.shape and np.array_equal(want, got), (int(k), want.shape, got.shape)
