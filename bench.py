@@ -118,7 +118,14 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this stack
+    # The ranks run in the caller's environment as it stands.  One variable is filled in ONLY when the caller left it unset: this
+    # image's hosts support dmabuf IPC only, and the pool's own environment exports HSA_ENABLE_IPC_MODE_LEGACY=0 for multi-process GPU
+    # work (without it RCCL's buffer exchange fails with hipIpcGetMemHandle: invalid argument); a caller's own value is never
+    # overridden.  Whether the collective layer came up is not assumed: every rank checks it (init_collectives) and the job reports the
+    # environment it tried in config.backend_note, exiting non-zero on a failure.
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in env:
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        env["DQO_BENCH_IPC_MODE_SET_BY_LAUNCHER"] = "1"
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.run(cmd, env=env).returncode
 
@@ -929,17 +936,32 @@ def main():
                          "(RCCL); to rehearse the N-rank job on fewer GPUs set DQO_BENCH_BACKEND=gloo (ranks then share the devices)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    ipc = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    backend_note = (f"backend {backend}; HSA_ENABLE_IPC_MODE_LEGACY=" + ("unset" if ipc is None else ipc)
+                    + (" (filled in by bench.py's launcher because the caller left it unset)" if os.environ.get("DQO_BENCH_IPC_MODE_SET_BY_LAUNCHER") else
+                       " (the caller's environment)") + f"; MASTER_ADDR={os.environ.get('MASTER_ADDR')}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # one process per GPU; device_id binds the communicator to this rank's GPU up front (no guessing at the first barrier)
-        torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
-        if torch.distributed.get_world_size() != args.gpus:
-            raise SystemExit(f"bench.py: the process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
-        # every rank's device index, for config.devices (which GPU each rank of the job ran on)
-        dv = torch.zeros(world, dtype=torch.int32, device=device)
-        dv[rank] = local
-        torch.distributed.all_reduce(dv)
-        rank_devices = [int(x) for x in dv.tolist()]
+        try:
+            # one process per GPU; device_id binds the communicator to this rank's GPU up front (no guessing at the first barrier)
+            torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+            if torch.distributed.get_world_size() != args.gpus:
+                raise SystemExit(f"bench.py: the process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
+            # the first collective (it is what brings RCCL's transports up): every rank's device index, for config.devices
+            dv = torch.zeros(world, dtype=torch.int32, device=device)
+            dv[rank] = local
+            torch.distributed.all_reduce(dv)
+            torch.cuda.synchronize()
+            rank_devices = [int(x) for x in dv.tolist()]
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 — the collective layer did not come up: say with which environment, and fail
+            if rank == 0:
+                print(json.dumps({"metric": "mapping iters/sec (fwd+bwd raster)", "value": None, "unit": "iter/s", "n_gpus": world,
+                                  "error": f"collective layer failed to initialise: {type(e).__name__}: {e}",
+                                  "config": {"backend_note": backend_note}}))
+            print(f"[bench r{rank}] collective init failed ({backend_note}): {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            sys.exit(4)
     else:
         rank_devices = [local]
     if args.growth_every is None:
@@ -1296,6 +1318,7 @@ def main():
                        "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
                        **({"allreduce": allreduce} if allreduce is not None else {}),
                        "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
+                       **({"backend_note": backend_note} if world > 1 else {}),
                        "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}),
                        **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
                                                                                    ("ok" if selfcheck_ok else "FAILED")), **stats},

@@ -42,7 +42,7 @@ class DqoObjectGate(ctypes.Structure):
 class DqoRastCtx(ctypes.Structure):
     _fields_ = [("geom", c_vp), ("geom_bytes", ctypes.c_size_t), ("binning", c_vp), ("binning_bytes", ctypes.c_size_t),
                 ("image", c_vp), ("image_bytes", ctypes.c_size_t), ("inst_capacity", ctypes.c_int64), ("tile_bucket_capacity", c_i32), ("keep_tile_order", c_i32), ("loss_tap", c_vp),
-                ("object_gate", c_vp), ("list_split", c_i32)]
+                ("object_gate", c_vp), ("list_split", c_i32), ("frame_prezeroed", c_i32)]
 
 
 class DqoRastGrads(ctypes.Structure):

@@ -337,6 +337,15 @@ static inline DqoView dqo_make_view(const DqoRastParams* p, const DqoRastInputs*
     return v;
 }
 
+// The per-frame scalars of the geometry buffer that must be zero when a frame starts: counters | statistics lines | (with a per-object
+// loss tap) the per-object loss counters — one contiguous range behind the header.  The forward's zero fill clears header + range;
+// dqo_rast_backward_adam's per-Gaussian kernel clears the range for the next frame (DqoRastCtx.frame_prezeroed).
+static inline size_t dqo_frame_scalar_words(const DqoRastCtx* ctx) {
+    const size_t obj_words = (ctx->loss_tap != nullptr && ctx->loss_tap->per_object)
+                                 ? sizeof(unsigned long long) * 4 * DQO_GATE_OBJECTS * DQO_OBJ_SPREAD / 4 : 0;
+    return (256 + 256 * DQO_SPREAD) / 4 + obj_words;
+}
+
 // Zero fill of caller memory on the launch stream.  The library never uses hipMemsetAsync for this: as a memset NODE of a captured
 // hipGraph the fill was observed (ROCm 7.2, gfx950) to write garbage on replay once other runtime activity had happened since the
 // capture; a kernel node carries its arguments by value.  Defined in rast_forward.hip.

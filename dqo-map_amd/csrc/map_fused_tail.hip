@@ -69,8 +69,16 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
                                                                         const float* scales, const float* rotations, const float* shs,
                                                                         const float4* __restrict__ partial,
                                                                         const uint32_t* __restrict__ valid, int64_t capacity, AdamArgs a,
-                                                                        uint8_t* __restrict__ moment_live) {
+                                                                        uint8_t* __restrict__ moment_live, const uint32_t frame_words) {
 #pragma clang fp contract(off)
+    // This kernel is the last consumer of the frame's counters (its blocks only read header.overflow): each block clears a slice of
+    // counters | statistics lines | loss-tap counters for the NEXT frame (DqoRastCtx.frame_prezeroed: a replayed iteration then has no
+    // zero-fill launch).  Before the overflow exit: an invalid frame must leave clean counters too.
+    {
+        const uint32_t per = (frame_words + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = blockIdx.x * per, z1 = min(frame_words, z0 + per);
+        for (uint32_t i = z0 + threadIdx.x; i < z1; i += TAIL_THREADS) g.counters[i] = 0u;
+    }
     // A frame flagged invalid by the forward must not train: nothing is read or written (adam_kernel's rule)
     if (a.frame_header != nullptr && a.frame_header->overflow != 0u) return;
     // one buffer: phase B's slot staging (4 KB), then phase C / D's gradient rows (7.75 KB)
@@ -297,9 +305,10 @@ int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, co
     if (rc) return rc;
     const float4* partial = reinterpret_cast<const float4*>(recs);
     const uint32_t* vw = reinterpret_cast<const uint32_t*>(valid);
+    const uint32_t frame_words = (uint32_t)dqo_frame_scalar_words(ctx);  // counters .. (per-object) loss counters, cleared for the next frame
 #define DQO_TAIL(SP, AT)                                                                                                              \
     DQO_LAUNCH("gaussian_tail_kernel", (gaussian_tail_kernel<SP, AT>), dim3(blocks), dim3(TAIL_THREADS), s, v, g, in->means3D, in->scales, \
-               in->rotations, in->shs, partial, vw, cap, a, st->moment_live)
+               in->rotations, in->shs, partial, vw, cap, a, st->moment_live, frame_words)
     if (st->moment_live != nullptr) {
         if (attach) DQO_TAIL(true, true);
         else DQO_TAIL(true, false);

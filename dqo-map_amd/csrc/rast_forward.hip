@@ -857,11 +857,11 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
     DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
     DqoImageLayout img = dqo_image_layout(ctx->image, p->W, p->H);
     const int T = v.gx * v.gy;
-    {  // header + counters + spread statistics counters
+    if (!(ctx->frame_prezeroed != 0 && p->P > 0)) {  // header + counters + spread statistics counters
         // (+ the per-object loss counters, which sit directly behind them, when the loss tap is per object)
-        const size_t obj_words = (ctx->loss_tap != nullptr && ctx->loss_tap->per_object)
-                                     ? sizeof(unsigned long long) * 4 * DQO_GATE_OBJECTS * DQO_OBJ_SPREAD / 4 : 0;
-        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(g.header), (512 + 256 * DQO_SPREAD) / 4 + obj_words, s);
+        // (frame_prezeroed: the previous frame's dqo_rast_backward_adam left counters .. loss counters at zero; the header is rewritten
+        // by every frame)
+        int rc = dqo_launch_zero_words(reinterpret_cast<uint32_t*>(g.header), 256 / 4 + dqo_frame_scalar_words(ctx), s);
         if (rc) return rc;
     }
     const size_t zero_words = (size_t)((img.tile_flag + T) - img.tile_count);  // histogram (padded) + flags

@@ -725,6 +725,9 @@ class FusedMapper:
             # the eager iteration left its tile launch order in g.img; the replays keep it (DqoRastCtx.keep_tile_order: the order is
             # a scheduling hint, and the lists of one camera change little between the iterations of a mapping call)
             g.cctx.keep_tile_order = 1 if (g.bucket > 0 and keep_tile_order) else 0
+            # ... and start from the counters the previous iteration's per-Gaussian kernel cleared (DqoRastCtx.frame_prezeroed: no
+            # zero-fill launch in a replay; only dqo_rast_backward_adam clears them, so only with the fused tail)
+            g.cctx.frame_prezeroed = 1 if g.fused_tail else 0
             g.graph = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (e.g. a collective library's watchdog) may keep issuing runtime calls
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):

@@ -170,6 +170,12 @@ typedef struct DqoRastCtx {
      * in the last bits (1e-7 relative; a pixel exactly on T_threshold may finish one entry earlier or later); shorter lists are treated
      * as with 0. */
     int32_t list_split;
+    /* ABI 4.  Non-zero: the caller guarantees that the per-frame scalars of ctx.geom (slot allocator, queue counters, statistics lines,
+     * loss-tap counters) are zero — as dqo_rast_backward_adam leaves them: its per-Gaussian kernel, the LAST consumer of a frame's
+     * counters, clears them for the next frame on the way — so the forward does not launch its zero-fill kernel.  For a captured iteration that is
+     * replayed back to back (forward, dqo_rast_backward_adam, forward, ...) on one context: one launch less per iteration.  Ignored when
+     * P == 0.  The device header (num_rendered ... overflow) is never cleared: every frame rewrites it. */
+    int32_t frame_prezeroed;
 } DqoRastCtx;
 
 /* Gradients (all caller-allocated, fully written by the backward; rasterize_points.cu:198-206).  dL_dcolors, dL_dcov3D and
