@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
                     help="N > 1: strong = ONE map sharded by object id over the ranks; weak = an independent map per rank")
     ap.add_argument("--no-graph", action="store_true", help="fused path: issue the kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph-unroll", type=int, default=4,
+                    help="fused path, one rank: iterations per captured hipGraph (one launch call runs that many iterations back to back; "
+                         "1 = one graph launch per iteration).  N > 1 always uses 1: the loss sums are all-reduced after every iteration")
     ap.add_argument("--growth-every", type=int, default=None,
                     help="map-growth step (knn on 40 800 new points + scale init + concat / delete + graph re-capture) every this many "
                          "iterations, inside the timed region; default: 100 for cfg 5 (its BASELINE workload), off otherwise")
@@ -288,7 +291,8 @@ class FusedRunner:
     """The fused path of one rank: a FusedMapper on the rank's shard, one hipGraph replay per iteration, the packed all-reduce of
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
 
-    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True, list_split=0):
+    def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True, list_split=0,
+                 unroll=1):
         from dqo_harness.fused_mapping import FusedMapper
         self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
         self.fm = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=attach_reducer(prob, world))
@@ -306,6 +310,10 @@ class FusedRunner:
         self.use_graph, self.loss_tap, self.fused_tail, self.list_split = use_graph, loss_tap, fused_tail, list_split
         self.growth_every, self.growth_seed, self.iters, self.growth_log = growth_every, growth_seed, 0, []
         self.first_loss = None
+        # iterations per graph launch (one rank only: at N > 1 every iteration's loss sums go into the packed all-reduce).  step() then
+        # issues one launch every `unroll` calls; flush() issues what is still due, iteration by iteration
+        self.unroll = max(1, int(unroll)) if (use_graph and world == 1) else 1
+        self._due = 0
         self.growth_pool = []  # the new points of every growth step: input data, resident in HBM before the timed region
         if use_graph:
             self._capture()
@@ -313,7 +321,7 @@ class FusedRunner:
     def _capture(self, reuse_probe=False):
         p = self.prob
         self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap, reuse_probe=reuse_probe,
-                        fused_tail=self.fused_tail, list_split=self.list_split)
+                        fused_tail=self.fused_tail, list_split=self.list_split, unroll=self.unroll)
         if self.first_loss is None:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
 
@@ -374,6 +382,7 @@ class FusedRunner:
         from dqo_harness import scenes
         from cuda_utils._C import accumulate_gaussian_error
         fm, p = self.fm, self.prob
+        self.flush()
         torch.cuda.synchronize()  # (drain the queued replays first, so that `ms` is the growth step alone)
         t0 = time.perf_counter()
         k = len(self.growth_log)
@@ -423,11 +432,24 @@ class FusedRunner:
                                               list_split=(int(g.ls_fwd), int(g.ls_bwd)) if g is not None else self.list_split)
         self.growth_log.append(st)
 
+    def flush(self):
+        """The iterations step() still owes (a graph launch holds `unroll` of them): issued one by one — the graph's own calls, eagerly."""
+        while self._due > 0:
+            self.fm.step_static()
+            self._due -= 1
+
     def step(self):
         if self.growth_every and self.iters and self.iters % self.growth_every == 0:
             self.grow()
         self.iters += 1
-        if self.use_graph:
+        if self.use_graph and self.unroll > 1:
+            # one launch call per `unroll` iterations: K calls of step() = K iterations once flush() has run (the timed region ends with it)
+            self._due += 1
+            if self._due == self.unroll:
+                self.fm.replay()
+                self._due = 0
+            out = self.fm._g.out
+        elif self.use_graph:
             out = self.fm.replay()
         else:
             out = self.fm.step(self.prob["gt_color"], self.prob["gt_depth"], self.mask_u8, tile_mask=self.prob["tile_mask"])
@@ -443,6 +465,7 @@ class FusedRunner:
 
     def finish(self):
         """Outside the timed region: overflow check + loss read-back."""
+        self.flush()
         if self.use_graph and self.fm.graph_overflowed():
             raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
         if self.world == 1:
@@ -835,7 +858,7 @@ def pmc_child(args, kernel_name, passes):
             inner += [flag]
     if args.as_shard:
         inner += ["--as-shard", args.as_shard]
-    inner += ["--list-split", args.list_split]
+    inner += ["--list-split", args.list_split, "--graph-unroll", str(args.graph_unroll)]
     res = {}
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("WORLD_SIZE", None)
@@ -995,7 +1018,7 @@ def main():
     if args.path == "fused":
         runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
                              loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail,
-                             list_split=parse_list_split(args.list_split))
+                             list_split=parse_list_split(args.list_split), unroll=args.graph_unroll)
         step = runner.step
     else:
         step_dropin = make_dropin_step(prob, device, loss_buf)
@@ -1010,6 +1033,8 @@ def main():
         runner.prepare_growth(args.warmup + args.steps)
     for _ in range(args.warmup):
         step()
+    if runner is not None:
+        runner.flush()  # (the timed region starts with no iteration owed)
     # the interpreter's cyclic collector off the timed region: a full collection over the set-up's objects (the synthetic maps, the
     # oracle's arrays) is a 40-80 ms pause, and the growth steps' temporaries trigger one now and then (nothing here builds cycles)
     import gc
@@ -1020,6 +1045,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if runner is not None:
+        runner.flush()  # --graph-unroll: the iterations of an incomplete last group (inside the timed region: K calls = K iterations)
     loss_buf.finish()  # outstanding asynchronous all-reduces of the sharded path (inside the timed region)
     sync_all()
     dt = time.perf_counter() - t0
@@ -1314,13 +1341,15 @@ def main():
                                       "depth L1 on the object's own mask)" if per_object else
                                       "one masked loss (0.8 L1 colour + 1.0 depth L1) over the rank's objects, objects of a rank occlude each other")
                                    + " + attach loss, raster fwd+bwd + Adam (6 groups); path=" + args.path
-                                   + ("" if args.path != "fused" or args.no_graph else " (one hipGraph replay per iteration)"),
+                                   + ("" if args.path != "fused" or args.no_graph else
+                                      (" (one hipGraph replay per iteration)" if runner.unroll == 1 else
+                                       f" (hipGraph replays of {runner.unroll} iterations each)")),
                        "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
                        **({"allreduce": allreduce} if allreduce is not None else {}),
                        "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
                        **({"backend_note": backend_note} if world > 1 else {}),
                        "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}),
-                       **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
+                       **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "graph_unroll": (runner.unroll if runner is not None else None), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
                                                                                    ("ok" if selfcheck_ok else "FAILED")), **stats},
             "loss": loss_now, "path": args.path,
         }

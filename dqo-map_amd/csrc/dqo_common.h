@@ -53,9 +53,12 @@ void dqo_profile_after(hipStream_t s);
 // geom buffer: header + per-Gaussian SoA tables, every table 256-B aligned.
 struct DqoGeomLayout {
     DqoRastHeader* header;   // 256 B reserved
-    uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator)
+    uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator of the packed-list mode), [1] long-list queue,
+                             //      [3..5] split-list queue / tickets, [6] the forward's list_split, [7] bucket mode: a slot region ran out
     uint32_t* spread;        // [DQO_SPREAD][64] statistics counters spread over DQO_SPREAD lines (same-address atomics serialise
-                             //       memory-side): word 0 = visible Gaussians, word 1 = (Gaussian, tile) pairs in the tile rects
+                             //       memory-side): word 0 = visible Gaussians, word 1 = (Gaussian, tile) pairs in the tile rects,
+                             //       words 2, 3 = longest list / non-empty tiles (keep_order frames), word 4 = bucket mode: the slot
+                             //       allocator of region `line` (bin_count_kernel), words 8..15 = loss tap
     unsigned long long* obj_tap;  // [DQO_OBJ_SPREAD][DQO_GATE_OBJECTS][4] per-object loss tap: colour error sum, mask pixels, depth error
                                   //   sum, valid depth pixels (2^-32 fixed point / counts), zeroed with the header when the tap is per object
     float4* conic_opacity;   // [P] (conic.x, conic.y, conic.z, opacity)           forward.cu:343

@@ -180,7 +180,30 @@ __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P
     uint32_t block_live;
     const uint32_t my_gb = block_exclusive_scan(my_cnt, s_wave, lane, wave, &block_live);
     s_gb[tid] = my_gb;
-    if (tid == 0) s_base = block_live ? atomicAdd(&g.counters[0], block_live) : 0u;
+    if (tid == 0) {
+        if (block_live == 0u) {
+            s_base = 0u;
+        } else if (bin.bucket <= 0) {
+            s_base = atomicAdd(&g.counters[0], block_live);
+        } else {
+            // Bucket mode (a caller that can re-run a frame): the slot space is cut into DQO_SPREAD regions with an allocator each — the
+            // ONE same-address returning atomic of this kernel is otherwise taken by all ~2 000 blocks at about the same time and served
+            // one per ~11 ns (same-address atomics serialise memory-side): up to 64 counters on 64 lines, 30 blocks each on cfg 3.  A region that
+            // runs out of its share invalidates the frame like running out of the capacity does (counters[7]; nothing is written out of
+            // bounds: the block's slots are placed past the capacity, where every slot-indexed write is skipped).
+            // (at least 16 blocks per region, so that a region's load stays near the mean — the capacity is ~3x the instances kept:
+            // a small map uses fewer regions, down to one)
+            const uint32_t regions = min((uint32_t)DQO_SPREAD, max(1u, gridDim.x / 16u));
+            const uint32_t r = blockIdx.x % regions, share = (uint32_t)(capacity / regions);
+            const uint32_t off = atomicAdd(&g.spread[(size_t)r * 64 + 4], block_live);
+            if (off + block_live > share) {
+                g.counters[7] = 1u;
+                s_base = (uint32_t)capacity;
+            } else {
+                s_base = r * share + off;
+            }
+        }
+    }
     __syncthreads();
     const uint32_t base = s_base;
     if (my_idx < P) {

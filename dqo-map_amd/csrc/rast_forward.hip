@@ -288,7 +288,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor((int)nv, off), nc += __shfl_xor((int)nc, off);
         if (tid == 0) s_stat[0] = nv, s_stat[1] = nc;
     }
-    bool overflow = (int64_t)g.counters[0] > capacity;  // instance total of bin_count_kernel
+    // instance total of bin_count_kernel's slot allocator (bucket mode: one allocator per region, an exhausted one raises counters[7])
+    bool overflow = bucket > 0 ? g.counters[7] != 0u : (int64_t)g.counters[0] > capacity;
     // the padded histogram is read from HBM once; the passes below work on an LDS copy (images up to ~2M pixels)
     const bool cached = T <= SCAN_CACHE;
     if (cached)
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(SORTW_THREADS, SORTW_WAVES) void tile_sort_wave_ker
         const uint32_t c = img.tile_count[(size_t)tile * DQO_TSTRIDE];
         // the slot tables are incomplete when the instance capacity ran out: every list is emptied, as tile_scan_kernel does; a
         // list that outgrew its bucket is cut at the bucket (bin_count_kernel dropped the rest); both invalidate the frame
-        const bool lost = (int64_t)g.counters[0] > capacity;
+        const bool lost = g.counters[7] != 0u;  // (bucket mode: a slot region ran out of its share, bin_count_kernel)
         const uint32_t n_keep = lost ? 0u : min(c, (uint32_t)bin.bucket);
         const uint32_t first = tile * (uint32_t)bin.bucket;
         rg = make_uint2(n_keep ? first : 0u, n_keep ? first + n_keep : 0u);
@@ -675,22 +676,24 @@ constexpr int SORTL_RUN = SORTP_RUN;  // 512
 
 // keep_order frames: the header tile_scan_kernel would have written, from the spread statistics lines (one wave)
 __device__ __forceinline__ void header_from_spread(const DqoGeomLayout& g, int64_t capacity, int bucket, int lane) {
-    uint32_t nv = 0, nc = 0, mx = 0, nt = 0;
+    uint32_t nv = 0, nc = 0, mx = 0, nt = 0, total = 0;
     for (int j = lane; j < DQO_SPREAD; j += 64) {
         const uint32_t* line = g.spread + (size_t)j * 64;
-        nv += line[0], nc += line[1], mx = max(mx, line[2]), nt += line[3];
+        nv += line[0], nc += line[1], mx = max(mx, line[2]), nt += line[3], total += line[4];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         nv += __shfl_xor((int)nv, off), nc += __shfl_xor((int)nc, off), nt += __shfl_xor((int)nt, off);
+        total += __shfl_xor((int)total, off);
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     }
     if (lane == 0) {
-        const uint32_t total = g.counters[0];  // instances counted by bin_count_kernel = the sum of the list lengths
+        // instances counted by bin_count_kernel's regional slot allocators (line word 4) = the sum of the list lengths
         DqoRastHeader h;
         h.num_rendered = total;
         h.num_tiles = nt;
-        h.overflow = ((int64_t)total > capacity || mx > (uint32_t)bucket) ? 1u : 0u;
+        (void)capacity;
+        h.overflow = (g.counters[7] != 0u || mx > (uint32_t)bucket) ? 1u : 0u;
         h.max_tile_count = mx;
         h.num_visible = nv;
         h.num_candidates = nc;

@@ -574,7 +574,7 @@ class FusedMapper:
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
-                loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0):
+                loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0, unroll=1):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
 
@@ -592,7 +592,9 @@ class FusedMapper:
         three (gradient rows and summed records through HBM).  All three leave every parameter and moment bit for bit as it is without
         them.  reuse_probe: size the capacities from
         the previous capture's counts (scaled by the map's growth) instead of a probing forward — for a re-capture right after a small
-        change of the map; falls back to probing if the eager iteration overflows."""
+        change of the map; falls back to probing if the eager iteration overflows.  unroll: iterations per graph — replay() then runs
+        `unroll` iterations with one launch call (back-to-back graph launches leave the GPU idle for ~9 us each on MI355X; the
+        iterations inside one graph follow each other without a gap); self._g.out / self.loss then show the last of them."""
         lib = N.lib()
         dev, P, M = self.device, self.P, self.M
         st = self.settings
@@ -719,7 +721,7 @@ class FusedMapper:
                 self._last_probe = None
                 return self.capture(gt_color, gt_depth, render_mask, tile_mask=tile_mask, capacity_margin=capacity_margin,
                                     tile_buckets=tile_buckets, keep_tile_order=keep_tile_order, loss_tap=loss_tap, reuse_probe=False,
-                                    fused_tail=fused_tail, list_split=list_split)
+                                    fused_tail=fused_tail, list_split=list_split, unroll=unroll)
             if not self.graph_overflowed():  # (an invalid frame is a no-op for the optimiser and its step count)
                 self.step_count += 1
             # the eager iteration left its tile launch order in g.img; the replays keep it (DqoRastCtx.keep_tile_order: the order is
@@ -730,8 +732,10 @@ class FusedMapper:
             g.cctx.frame_prezeroed = 1 if g.fused_tail else 0
             g.graph = torch.cuda.CUDAGraph()
             # thread_local: other threads of the process (e.g. a collective library's watchdog) may keep issuing runtime calls
+            g.unroll = max(1, int(unroll))
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
-                self._static_iteration()
+                for _ in range(g.unroll):
+                    self._static_iteration()
             g.expected_step = self.step_count + 1
         return self
 
@@ -789,7 +793,8 @@ class FusedMapper:
         N.check(lib.dqo_map_adam_step(ctypes.byref(g.adam), stream))
 
     def replay(self):
-        """One mapping iteration by replaying the captured graph; outputs are the persistent tensors in self._g.out."""
+        """One mapping iteration (capture(unroll=k): k of them) by replaying the captured graph; outputs are the persistent tensors in
+        self._g.out."""
         g = self._g
         if g.stale:
             raise RuntimeError("FusedMapper: begin_mapping_call() changed the attach set since capture(); capture again")
@@ -798,7 +803,7 @@ class FusedMapper:
         g.graph.replay()
         g.unsettled = True
         self._attach_n = ((self.P + 255) // 256) * (4 if g.fused_tail else 1)  # (a new mapping call in between had reset it)
-        self.step_count += 1  # (assumes a valid frame; capture() re-reads the device-side count after an overflow)
+        self.step_count += g.unroll  # (assumes valid frames; capture() re-reads the device-side count after an overflow)
         g.expected_step = self.step_count + 1
         return g.out
 
@@ -832,6 +837,8 @@ class FusedMapper:
         again on the current state with `capacity_margin` and the missing iterations are replayed.  Returns the number of
         re-captures.  The inputs of the last capture() (ground-truth images, masks) are reused."""
         g = self._g
+        if g.unroll != 1:
+            raise RuntimeError("FusedMapper.run counts single iterations: capture with unroll=1")
         target = self.step_count + n_iters
         recaptures = 0
         while self.step_count < target:
