@@ -275,7 +275,205 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
     adam_take_ticket(a);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The drop-in backward's per-Gaussian half as ONE kernel: record sum -> per-Gaussian chain -> gradient ROWS, written to the caller's
+// tensors in coalesced pieces.  Replaces record_sum_kernel + gaussian_backward_kernel (rast_backward.hip; kept behind
+// DQO_ROWS_KERNEL=0 for A/B): those two sent every Gaussian's 64-byte summed record through HBM, and gaussian_backward_kernel wrote a
+// Gaussian's 59 + 12 gradient floats from ONE thread — 71 store instructions per wave, each touching 64 different cache lines, for
+// visible and culled rows alike (the culled rows, 61 % of cfg 3, are plain zeros the reference's API contract still wants written).
+// Here phases A - C are gaussian_tail_kernel's (same block -> Gaussian mapping, same fixed-order sums, same chain: same bits), the
+// gradient row of every Gaussian of the block waits in LDS (41 floats, factored SH), and phase D streams the block's rows out tensor
+// by tensor: consecutive threads write consecutive floats, 16 consecutive Gaussians of a spread group at a time.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RROW_MEAN = 0, RROW_W = 3, RROW_RGB = 19, RROW_OP = 22, RROW_SC = 23, RROW_ROT = 26, RROW_COL = 30, RROW_G2 = 33, RROW_CV = 35,
+              RROW_STRIDE = 43;
+
+__global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_rows_kernel(const DqoView v, DqoGeomLayout g, const float* means3D,
+                                                                    const float* scales, const float* rotations, const float* shs,
+                                                                    const float4* __restrict__ partial,
+                                                                    const uint32_t* __restrict__ valid, int64_t capacity, DqoRastGrads gr) {
+#pragma clang fp contract(off)
+    __shared__ float4 s_buf[(TAIL_THREADS * RROW_STRIDE * 4 + 15) / 16];
+    float4* const s_rec = s_buf;
+    float* const s_g = reinterpret_cast<float*>(s_buf);
+    static_assert(sizeof(float4) * TAIL_THREADS * 4 <= sizeof(s_buf), "the slot staging must fit the buffer");
+    __shared__ uint32_t s_lohi[2];
+    __shared__ uint8_t s_vis[TAIL_THREADS];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_lohi[0] = 0xffffffffu, s_lohi[1] = 0u;
+    const int idx = dqo_spread_index(blockIdx.x * TAIL_THREADS + tid, v.P);
+    const bool in_range = idx < v.P;
+    uint2 rc = make_uint2(0u, 0u);
+    uint32_t base = 0, cnt = 0;
+    if (in_range) {
+        rc = g.rect16[idx];
+        cnt = g.tiles_touched[idx];
+        base = g.slot_base[idx];
+    }
+    float view[16], proj[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        view[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.view[i])));
+        proj[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.proj[i])));
+    }
+    const bool visible = in_range && ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
+    s_vis[tid] = visible ? (uint8_t)1 : (uint8_t)0;
+    __syncthreads();
+    if (cnt) {
+        atomicMin(&s_lohi[0], base);
+        atomicMax(&s_lohi[1], base + cnt);
+    }
+    __syncthreads();
+    const uint32_t lo = s_lohi[0];
+    const uint32_t hi = (uint32_t)min((int64_t)s_lohi[1], capacity);
+    const bool with_sh = shs != nullptr && gr.dL_dsh != nullptr;
+    DqoChainIn ci;
+#pragma unroll
+    for (int i = 0; i < 9; i++) ci.dd[i] = 0.f;
+    ci.cop = make_float4(0.f, 0.f, 0.f, 0.f);
+    ci.mx = ci.my = ci.mz = ci.sx = ci.sy = ci.sz = 0.f;
+    ci.qt = make_float4(1.f, 0.f, 0.f, 0.f);
+    ci.n_np = ci.pc = make_float4(0.f, 0.f, 0.f, 0.f);
+    ci.cl = 0;
+    if (visible) {
+        ci.cop = g.conic_opacity[idx];
+        ci.mx = means3D[3 * idx], ci.my = means3D[3 * idx + 1], ci.mz = means3D[3 * idx + 2];
+        ci.sx = scales[3 * idx], ci.sy = scales[3 * idx + 1], ci.sz = scales[3 * idx + 2];
+        ci.qt = reinterpret_cast<const float4*>(rotations)[idx];
+        ci.n_np = g.normal_c[idx], ci.pc = g.point_c[idx], ci.cl = g.clamped[idx];
+        if (with_sh) {
+            const float4* ddp = g.drgb_dir + 3 * (size_t)idx;
+            const float4 d0 = ddp[0], d1 = ddp[1], d2 = ddp[2];
+            ci.dd[0] = d0.x, ci.dd[1] = d0.y, ci.dd[2] = d0.z, ci.dd[3] = d1.x, ci.dd[4] = d1.y, ci.dd[5] = d1.z;
+            ci.dd[6] = d2.x, ci.dd[7] = d2.y, ci.dd[8] = d2.z;
+        }
+    }
+    // ---- B: fixed-order sum of the partial gradient records (gaussian_tail_kernel's statements) ----
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (lo < hi) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t c0 = lo; c0 < hi; c0 += TAIL_THREADS) {
+            const uint32_t slot = c0 + tid;
+            if (slot < hi) {
+                const uint32_t vw = valid[slot];
+                const float4* p = partial + (size_t)slot * 16;
+                float4 r[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4* src = ((vw >> (8 * q)) & 0xffu) ? p + 4 * q : partial;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) r[q][i] = src[i];
+                }
+                float4 m0 = z, m1 = z, m2 = z, m3 = z;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t bq = (vw >> (8 * q)) & 0xffu;
+                    if (bq) {
+                        const float4 r0 = r[q][0], r1 = r[q][1], r2 = r[q][2], r3 = r[q][3];
+                        m0.x += r0.x, m0.y += r0.y, m0.z += r0.z, m0.w += r0.w;
+                        m1.x += r1.x, m1.y += r1.y, m1.z += r1.z, m1.w += r1.w;
+                        m2.x += r2.x;
+                        if (bq & 2u) {
+                            m2.y += r2.y, m2.z += r2.z, m2.w += r2.w;
+                            m3.x += r3.x, m3.y += r3.y;
+                        }
+                    }
+                }
+                s_rec[tid * 4] = m0, s_rec[tid * 4 + 1] = m1, s_rec[tid * 4 + 2] = m2, s_rec[tid * 4 + 3] = m3;
+            }
+            __syncthreads();
+            const uint32_t k0 = max(base, c0), k1 = min(base + cnt, min(c0 + (uint32_t)TAIL_THREADS, hi));
+            for (uint32_t k = k0; k < k1; k++) {
+                const float4 r0 = s_rec[(k - c0) * 4], r1 = s_rec[(k - c0) * 4 + 1], r2 = s_rec[(k - c0) * 4 + 2], r3 = s_rec[(k - c0) * 4 + 3];
+                a0.x += r0.x, a0.y += r0.y, a0.z += r0.z, a0.w += r0.w;
+                a1.x += r1.x, a1.y += r1.y, a1.z += r1.z, a1.w += r1.w;
+                a2.x += r2.x, a2.y += r2.y, a2.z += r2.z, a2.w += r2.w;
+                a3.x += r3.x, a3.y += r3.y, a3.z += r3.z, a3.w += r3.w;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- C: the chain; the row goes to LDS at the thread's own position ----
+    if (visible) {
+        ci.a[0] = a0.x, ci.a[1] = a0.y, ci.a[2] = a0.z, ci.a[3] = a0.w;
+        ci.a[4] = a1.x, ci.a[5] = a1.y, ci.a[6] = a1.z, ci.a[7] = a1.w;
+        ci.a[8] = a2.x, ci.a[9] = a2.y, ci.a[10] = a2.z, ci.a[11] = a2.w;
+        ci.a[12] = a3.x, ci.a[13] = a3.y, ci.a[14] = a3.z, ci.a[15] = a3.w;
+        if (cnt == 0u) ci.cop = make_float4(0.f, 0.f, 0.f, 0.f);  // (a Gaussian without instances: gaussian_backward_kernel's rule)
+        DqoChainOut co;
+        dqo_gauss_chain(v, view, proj, ci, with_sh, co);
+        float* row = s_g + tid * RROW_STRIDE;
+        row[RROW_MEAN] = co.mean_g[0], row[RROW_MEAN + 1] = co.mean_g[1], row[RROW_MEAN + 2] = co.mean_g[2];
+#pragma unroll
+        for (int k = 0; k < 16; k++) row[RROW_W + k] = co.w[k];
+        row[RROW_RGB] = co.dRGB[0], row[RROW_RGB + 1] = co.dRGB[1], row[RROW_RGB + 2] = co.dRGB[2];
+        row[RROW_OP] = co.dop;
+        row[RROW_SC] = co.dsc[0], row[RROW_SC + 1] = co.dsc[1], row[RROW_SC + 2] = co.dsc[2];
+        row[RROW_ROT] = co.rot_g[0], row[RROW_ROT + 1] = co.rot_g[1], row[RROW_ROT + 2] = co.rot_g[2], row[RROW_ROT + 3] = co.rot_g[3];
+        row[RROW_COL] = co.dcolr[0], row[RROW_COL + 1] = co.dcolr[1], row[RROW_COL + 2] = co.dcolr[2];
+        row[RROW_G2] = co.g2x, row[RROW_G2 + 1] = co.g2y;
+#pragma unroll
+        for (int i = 0; i < 6; i++) row[RROW_CV + i] = co.dcv[i];
+    }
+    __syncthreads();
+    // ---- D: the block's rows, tensor by tensor: element e of a tensor with rows of `len` floats belongs to block row e / len; the
+    //      rows of a spread group of 16 Gaussians are consecutive in memory, so a wave writes runs of 16 x len floats ----
+    const bool skip = gr.skip_culled_rows != 0;
+    const int logical0 = blockIdx.x * TAIL_THREADS;
+    // A spread group's 16 rows of `len` floats are 4 x len whole float4s (16-byte aligned: the group starts at a multiple of 16
+    // Gaussians): thread q writes float4 q of the block's 8 groups, its four floats looked up in the LDS rows.  The last (partial)
+    // group of the map, and the sparse-row mode (culled rows stay unwritten), go float by float.
+    auto stream_rows = [&](float* out, const int len, auto value) {
+        if (out == nullptr) return;
+        const int per_group = 4 * len;  // float4s of one group
+        for (int q = tid; q < (TAIL_THREADS / 16) * per_group; q += TAIL_THREADS) {
+            const int grp = q / per_group, n = q - grp * per_group;
+            const int gi0 = dqo_spread_index(logical0 + 16 * grp, v.P);
+            if (gi0 >= v.P) continue;
+            const bool whole = !skip && gi0 + 15 < v.P;
+            float f[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = 4 * n + u, r = e / len, j = e - r * len;
+                const int t = 16 * grp + r;
+                const bool vis = s_vis[t] != 0;
+                f[u] = vis ? value(s_g + t * RROW_STRIDE, j) : 0.f;
+                if (!whole && gi0 + r < v.P && (vis || !skip)) out[(size_t)(gi0 + r) * len + j] = f[u];
+            }
+            if (whole) *reinterpret_cast<float4*>(out + (size_t)gi0 * len + 4 * n) = make_float4(f[0], f[1], f[2], f[3]);
+        }
+    };
+    stream_rows(gr.dL_dmeans3D, 3, [](const float* row, int j) { return row[RROW_MEAN + j]; });
+    if (gr.dL_dsh != nullptr && v.M > 0) {
+        const int used3 = 3 * (v.D + 1) * (v.D + 1);
+        const bool sh_on = with_sh;
+        stream_rows(gr.dL_dsh, 3 * v.M, [used3, sh_on](const float* row, int j) {
+#pragma clang fp contract(off)
+            // dL/dsh[k][c] = w[k] * dRGB[c] (backward.cu:152-268); coefficients above the active degree keep the reference's zeros
+            const int jc = j < used3 ? j : 0;
+            const int k = jc / 3, c = jc - 3 * k;
+            const float gsh = row[RROW_W + k] * row[RROW_RGB + c];
+            return (sh_on && j < used3) ? gsh : 0.f;
+        });
+    }
+    stream_rows(gr.dL_dcolors, 3, [](const float* row, int j) { return row[RROW_COL + j]; });
+    stream_rows(gr.dL_dopacity, 1, [](const float* row, int) { return row[RROW_OP]; });
+    stream_rows(gr.dL_dscales, 3, [](const float* row, int j) { return row[RROW_SC + j]; });
+    stream_rows(gr.dL_drotations, 4, [](const float* row, int j) { return row[RROW_ROT + j]; });
+    stream_rows(gr.dL_dcov3D, 6, [](const float* row, int j) { return row[RROW_CV + j]; });
+    stream_rows(gr.dL_dmeans2D, 3, [](const float* row, int j) { return j < 2 ? row[RROW_G2 + j] : 0.f; });
+}
+
 }  // namespace
+
+// the per-Gaussian half of dqo_rast_backward (dqo_launch_backward, rast_backward.hip)
+int dqo_launch_gaussian_rows(const DqoView& v, const DqoGeomLayout& g, const DqoRastInputs* in, const DqoGradRec* recs, const uint8_t* valid,
+                             int64_t cap, const DqoRastGrads& gr, hipStream_t s) {
+    const int blocks = dqo_spread_blocks(v.P) * (256 / TAIL_THREADS);
+    DQO_LAUNCH("gaussian_rows_kernel", gaussian_rows_kernel, dim3(blocks), dim3(TAIL_THREADS), s, v, g, in->means3D, in->scales, in->rotations,
+               in->shs, reinterpret_cast<const float4*>(recs), reinterpret_cast<const uint32_t*>(valid), cap, gr);
+    return DQO_OK;
+}
 
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* dL_dcolor, const float* dL_ddepth, DqoGradRec* recs, uint8_t* valid, int64_t capacity,

@@ -14,6 +14,8 @@
 //     slot (4 partial records per slot + a validity word);
 //   * record_sum_kernel sums each Gaussian's valid partial records in a fixed order (bitwise reproducible);
 //   * gaussian_backward_kernel finishes the chain rule (cov2D, projection, SH, cov3D, depth-hit Jacobians) per Gaussian.
+#include <cstdlib>
+
 #include "dqo_common.h"
 #include "dqo_cull.h"
 #include "dqo_gauss_chain.h"
@@ -230,6 +232,8 @@ __global__ __launch_bounds__(256) void gaussian_backward_kernel(const DqoView v,
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* dL_dcolor, const float* dL_ddepth, DqoGradRec* recs, uint8_t* valid, int64_t capacity,
                               const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s);
+int dqo_launch_gaussian_rows(const DqoView& v, const DqoGeomLayout& g, const DqoRastInputs* in, const DqoGradRec* recs, const uint8_t* valid,
+                             int64_t cap, const DqoRastGrads& gr, hipStream_t s);
 
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                         const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* gr, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -248,6 +252,13 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
     int rc = dqo_launch_blend_backward(v, g, img, bin, T, dL_dcolor, dL_ddepth, recs, valid, cap, dqo_tap_dev(ctx->loss_tap),
                                        dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s);
     if (rc) return rc;
+    // the per-Gaussian half: ONE kernel (record sum -> chain -> coalesced gradient rows, map_fused_tail.hip); DQO_ROWS_KERNEL=0
+    // (environment, read once) keeps the two kernels below for A/B
+    static const bool rows_kernel = [] {
+        const char* e = getenv("DQO_ROWS_KERNEL");
+        return e == nullptr || atoi(e) != 0;
+    }();
+    if (rows_kernel) return dqo_launch_gaussian_rows(v, g, in, recs, valid, cap, *gr, s);
     DqoGradRec* sums = reinterpret_cast<DqoGradRec*>(g.grad_sum);  // [P], lives in the forward's geometry buffer
     DQO_LAUNCH("record_sum_kernel", record_sum_kernel, dim3(dqo_spread_blocks(p->P)), dim3(256), s, p->P, g, reinterpret_cast<const float4*>(recs),
                reinterpret_cast<const uint32_t*>(valid), reinterpret_cast<float4*>(sums), cap);

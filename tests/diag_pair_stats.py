@@ -71,3 +71,21 @@ for slots in (1024 * 1, 1024 * 2, 1024 * 4):
     print(f"     perfectly balanced over {slots} wave slots: {tot / slots:.0f} live entries per slot (the longest wave alone has {per_wave.max():.0f})")
 lens = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
 print(f"  reference list length per tile: mean {lens.mean():.0f}, max {lens.max()}")
+
+# ---- aligned pairing (round 4): the two halves of a quadrant walk their own sub-lists, but an entry live in BOTH halves is taken by both in
+# the same step (so that its record stays one per (quadrant, entry)): between two such entries the top-only and the bottom-only
+# entries are paired up.  Steps per (tile, quadrant) = #both + sum over the segments between them of max(#top-only, #bottom-only).
+def aligned_steps(first, second):
+    """first / second: [N] bool liveness of the two halves of one quadrant position (tile-major list order)."""
+    both = first & second
+    seg = np.cumsum(both) - both  # segment id inside the whole array: entries between consecutive 'both' entries share it ...
+    seg = seg + tile_of * (N + 1)  # ... and never across tiles
+    uniq, inv = np.unique(seg, return_inverse=True)
+    t = np.bincount(inv, weights=(first & ~second), minlength=uniq.size)
+    b = np.bincount(inv, weights=(~first & second), minlength=uniq.size)
+    return both.sum() + np.maximum(t, b).sum()
+tot_tb = sum(aligned_steps(lh4[:, qr, 0, qc], lh4[:, qr, 1, qc]) for qr in range(2) for qc in range(2))
+print(f"  top / bottom halves, aligned on the entries live in both: {tot_tb / 1e6:.3f} M wave steps ({tot_tb / lq.sum():.1%} of the quadrant steps)")
+hv = bits.reshape(N, 2, 8, 4, 4).transpose(0, 1, 3, 2, 4).reshape(N, 2, 4, 32).any(3)  # [N, quad row, 4 column strips of 4 px]: left / right halves
+tot_lr = sum(aligned_steps(hv[:, qr, 2 * qc], hv[:, qr, 2 * qc + 1]) for qr in range(2) for qc in range(2))
+print(f"  left / right halves (4 wide x 8 high), aligned: {tot_lr / 1e6:.3f} M wave steps ({tot_lr / lq.sum():.1%})")
