@@ -135,6 +135,36 @@ __global__ void morton_kernel(int P, int P2, const float* __restrict__ xyz, cons
     keys[i] = ((uint64_t)code << 32) | (uint32_t)i;  // unique keys: order == stable sort by code
 }
 
+// The query search's reference set is not bound to the reference's 10 bits per axis (its ties are "resolved arbitrarily"): 13 bits per
+// axis (39-bit code above a 25-bit index: up to 33 M points) keep the 1024-point Morton boxes tight when the points spread over tens of
+// metres — the per-object growth search moves every object into a cell of its own (dqo_mapgrowth.object_offsets), and at 10 bits a
+// 30 m extent means 3 cm cells: boxes of neighbouring surfels overlap and the scan visits 2.3x the sub-boxes.
+constexpr int FINE_BITS = 13, FINE_IDX_BITS = 25;
+__device__ __forceinline__ uint64_t prep_morton64(uint64_t x) {  // bit i -> bit 3 i, up to 21 bits
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void morton_fine_kernel(int P, int P2, const float* __restrict__ xyz, const float* __restrict__ bbox, uint64_t* __restrict__ keys) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P2) return;
+    if (i >= P) {
+        keys[i] = ~0ull;
+        return;
+    }
+    const float mnx = bbox[0], mny = bbox[1], mnz = bbox[2], mxx = bbox[3], mxy = bbox[4], mxz = bbox[5];
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const float top = (float)((1 << FINE_BITS) - 1);
+    const uint64_t cx = prep_morton64(min(f2u(((x - mnx) / (mxx - mnx)) * top), (uint32_t)top));
+    const uint64_t cy = prep_morton64(min(f2u(((y - mny) / (mxy - mny)) * top), (uint32_t)top));
+    const uint64_t cz = prep_morton64(min(f2u(((z - mnz) / (mxz - mnz)) * top), (uint32_t)top));
+    keys[i] = ((cx | (cy << 1) | (cz << 2)) << FINE_IDX_BITS) | (uint64_t)i;
+}
+
 // classic bitonic network on a power-of-two array: LDS kernel handles every step with j < SORT_RUN of one k-level
 // (or all levels k <= SORT_RUN when `first`), the global kernel one step with j >= SORT_RUN.
 __global__ __launch_bounds__(SORT_T) void bitonic_lds_kernel(uint64_t* __restrict__ keys, int k_level, int first) {
@@ -273,10 +303,11 @@ __global__ __launch_bounds__(RDX_T) void radix_scatter_kernel(int n, const uint6
     }
 }
 
-__global__ void gather_sorted_kernel(int P, const float* __restrict__ xyz, const uint64_t* __restrict__ keys, float4* __restrict__ sorted) {
+__global__ void gather_sorted_kernel(int P, const float* __restrict__ xyz, const uint64_t* __restrict__ keys, float4* __restrict__ sorted,
+                                     uint64_t idx_mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const uint32_t src = (uint32_t)(keys[i] & 0xffffffffu);
+    const uint32_t src = (uint32_t)(keys[i] & idx_mask);
     sorted[i] = make_float4(xyz[3 * src], xyz[3 * src + 1], xyz[3 * src + 2], __uint_as_float(src));
 }
 
@@ -450,11 +481,13 @@ __device__ __forceinline__ float wave_min_f(float v) {
 __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float* __restrict__ q_xyz, int R,
                                                              const float4* __restrict__ sorted_r, const float* __restrict__ boxes,
                                                              const float* __restrict__ sub, const float* __restrict__ groups,
-                                                             float* __restrict__ dist2, int32_t* __restrict__ idx3) {
+                                                             float* __restrict__ dist2, int32_t* __restrict__ idx3, const float bound2) {
     const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (q >= Q) return;
     const float4 me = make_float4(q_xyz[3 * q], q_xyz[3 * q + 1], q_xyz[3 * q + 2], 0.f);
-    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;  // wave-uniform top 3 (ascending)
+    // wave-uniform top 3 (ascending).  bound2 (dqo_knn3_query_within): only references closer than sqrt(bound2) count — the search starts
+    // with that bound instead of an open one, so a query far from every reference prunes the whole map at once
+    float b0 = bound2, b1 = bound2, b2 = bound2;
     int i0 = -1, i1 = -1, i2 = -1;
     const int nb = (R + KNN_BOX - 1) / KNN_BOX, ns = (R + KNN_SUB - 1) / KNN_SUB;
 
@@ -532,8 +565,8 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
             }
         }
     }
-    if (lane == 0) {
-        dist2[3 * q + 0] = b0, dist2[3 * q + 1] = b1, dist2[3 * q + 2] = b2;
+    if (lane == 0) {  // (a slot no reference made it into: FLT_MAX / -1, whatever the starting bound was)
+        dist2[3 * q + 0] = i0 >= 0 ? b0 : FLT_MAX, dist2[3 * q + 1] = i1 >= 0 ? b1 : FLT_MAX, dist2[3 * q + 2] = i2 >= 0 ? b2 : FLT_MAX;
         idx3[3 * q + 0] = i0, idx3[3 * q + 1] = i1, idx3[3 * q + 2] = i2;
     }
 }
@@ -543,7 +576,9 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
 size_t dqo_knn3_ws_bytes(int P) { return knn_ws(nullptr, P).total; }
 
 // bounding box -> Morton keys -> sort -> gather into Morton order (-> boxes)
-static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, hipStream_t s) {
+// fine: morton_fine_kernel's 39-bit codes (the query search's reference set) instead of the reference's 30-bit ones
+static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, hipStream_t s, bool fine = false) {
+    fine = fine && P < (1 << FINE_IDX_BITS);
     const int P2 = next_pow2(P < SORT_RUN ? SORT_RUN : P);
     {   // (the partial boxes live at the start of the key array: P2 >= 4096 keys = 32 KB, and the keys are written after the fold)
         const int nb = std::min(BBOX_BLOCKS_MAX, (P + 1023) / 1024);
@@ -551,7 +586,8 @@ static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, h
         DQO_LAUNCH("bbox_kernel", bbox_kernel, dim3(nb), dim3(1024), s, P, xyz, partial);
         DQO_LAUNCH("bbox_fold_kernel", bbox_fold_kernel, dim3(1), dim3(512), s, nb, partial, w.bbox);
     }
-    DQO_LAUNCH("morton_kernel", morton_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
+    if (fine) DQO_LAUNCH("morton_kernel", morton_fine_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
+    else DQO_LAUNCH("morton_kernel", morton_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
 #ifdef KNN_BITONIC_SORT
     const int runs = P2 / SORT_RUN;
     DQO_LAUNCH("bitonic_lds_kernel", bitonic_lds_kernel, dim3(runs), dim3(SORT_T), s, w.keys, SORT_RUN, 1);
@@ -567,8 +603,11 @@ static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, h
         const int nblk = (P + RDX_BLK - 1) / RDX_BLK;
         uint64_t* a = w.keys;
         uint64_t* b = reinterpret_cast<uint64_t*>(w.sorted);
-        for (int pass = 0; pass < 4; pass++) {
-            const int shift = 32 + 8 * pass;
+        // (fine codes: 39 bits above the 25-bit index — five passes; an even pass count leaves the result in w.keys, so a sixth pass
+        // sorts by the top byte once more: a stable sort of sorted keys by a prefix of the key moves nothing but the buffer)
+        const int n_pass = fine ? 6 : 4, shift0 = fine ? FINE_IDX_BITS : 32;
+        for (int pass = 0; pass < n_pass; pass++) {
+            const int shift = pass < 5 ? shift0 + 8 * pass : 56;
             DQO_LAUNCH("radix_hist_kernel", radix_hist_kernel, dim3(nblk), dim3(RDX_T), s, P, a, shift, w.hist, nblk);
             DQO_LAUNCH("radix_scan_kernel", radix_scan_kernel, dim3(256), dim3(256), s, w.hist, nblk, w.hist + (size_t)256 * nblk);
             DQO_LAUNCH("radix_scatter_kernel", radix_scatter_kernel, dim3(nblk), dim3(RDX_T), s, P, a, b, shift, w.hist, nblk,
@@ -577,7 +616,8 @@ static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, h
         }
     }
 #endif
-    DQO_LAUNCH("gather_sorted_kernel", gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), s, P, xyz, w.keys, w.sorted);
+    DQO_LAUNCH("gather_sorted_kernel", gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), s, P, xyz, w.keys, w.sorted,
+               fine ? ((1ull << FINE_IDX_BITS) - 1ull) : 0xffffffffull);
     if (with_boxes) {
         const int nb = (P + KNN_BOX - 1) / KNN_BOX;
         DQO_LAUNCH("box_minmax_kernel", box_minmax_kernel, dim3(nb), dim3(256), s, P, w.sorted, w.boxes);
@@ -599,16 +639,16 @@ int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void
 size_t dqo_knn3_query_ws_bytes(int Q, int R) { return knn_ws(nullptr, Q).total + knn_ws(nullptr, R).total; }
 
 int dqo_launch_knn3_query(int Q, const float* q_xyz, int R, const float* r_xyz, float* dist2, int32_t* idx3, void* ws, size_t ws_bytes,
-                          hipStream_t s) {
+                          hipStream_t s, float bound2) {
     (void)ws_bytes;
     KnnWs wr = knn_ws(ws, R);
-    int rc = knn_build(R, r_xyz, wr, true, s);
+    int rc = knn_build(R, r_xyz, wr, true, s, true);
     if (rc) return rc;
     const int ns = (R + KNN_SUB - 1) / KNN_SUB;
     DQO_LAUNCH("sub_minmax_kernel", sub_minmax_kernel, dim3((ns * 64 + 255) / 256), dim3(256), s, R, wr.sorted, wr.sub);
     const int nb = (R + KNN_BOX - 1) / KNN_BOX, ng = (nb + 63) / 64;
     DQO_LAUNCH("group_minmax_kernel", group_minmax_kernel, dim3((ng * 64 + 255) / 256), dim3(256), s, nb, wr.boxes, wr.groups);
     DQO_LAUNCH("knn_query_wave_kernel", knn_query_wave_kernel, dim3(((size_t)Q * 64 + 255) / 256), dim3(256), s, Q, q_xyz, R, wr.sorted,
-               wr.boxes, wr.sub, wr.groups, dist2, idx3);
+               wr.boxes, wr.sub, wr.groups, dist2, idx3, bound2);
     return DQO_OK;
 }

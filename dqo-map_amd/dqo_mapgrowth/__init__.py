@@ -24,8 +24,9 @@ import _dqo_native as N
 from simple_knn._C import distCUDA2
 
 
-def knn_points_k3(p1, p2):
-    """(dists [Q, 3] squared L2 ascending, idx [Q, 3] int64 into p2).  Fewer than 3 references: FLT_MAX / -1 in the tail."""
+def knn_points_k3(p1, p2, max_dist=None):
+    """(dists [Q, 3] squared L2 ascending, idx [Q, 3] int64 into p2).  Fewer than 3 references: FLT_MAX / -1 in the tail.
+    max_dist (not a pytorch3d argument): only references closer than that count (dqo_knn3_query_within)."""
     N.require_gpu(p1, p2)
     if not (p1.is_cuda and p2.is_cuda):
         raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
@@ -41,7 +42,11 @@ def knn_points_k3(p1, p2):
     lib = N.lib()
     ws = torch.empty((lib.dqo_knn3_query_workspace_bytes(Q, R),), dtype=torch.uint8, device=q.device)
     with torch.cuda.device(q.device):
-        N.check(lib.dqo_knn3_query(Q, N.ptr(q), R, N.ptr(r), N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(), N.current_stream()))
+        if max_dist is None:
+            N.check(lib.dqo_knn3_query(Q, N.ptr(q), R, N.ptr(r), N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(), N.current_stream()))
+        else:
+            N.check(lib.dqo_knn3_query_within(Q, N.ptr(q), R, N.ptr(r), float(max_dist), N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(),
+                                              N.current_stream()))
     return d, i.long()
 
 
@@ -123,6 +128,10 @@ def update_geometry_scales(xyz, radius, extra_xyz, extra_radius, min_radius, max
 # filter only looks at distances below 0.6 x radius — so a gap of a metre is ample; the default of 16 m cells holds any room below 15 m
 # across, a caller that knows its scene (bench.py: 6 x 3 x 4 m rooms) passes tighter cells, which keeps the search's Morton grid fine.
 OBJECT_CELL = (16.0, 16.0, 16.0)
+# ... and a neighbour further away than this is as good as none for both decisions (radii up to 0.3 m), so the searches stop there
+# (dqo_knn3_query_within): a candidate whose object has nothing nearby — common at an object's rim — does not scan half the map for three
+# far neighbours that cannot change its scale.  Part of the per-object job's definition: the same on every shard layout.
+NEIGHBOUR_REACH = 1.0
 
 
 def object_offsets(obj, cell=None):
@@ -152,7 +161,7 @@ def temp_points_filter_mask_per_object(temp_xyz, temp_obj, exist_xyz, exist_radi
     exist_xyz, exist_radius, exist_obj = exist_xyz[inbbox], exist_radius[inbbox], exist_obj[inbbox]
     if torch.numel(exist_xyz) == 0:
         return None
-    _, nn_idx = knn_points_k3(temp_xyz + object_offsets(temp_obj, cell), exist_xyz + object_offsets(exist_obj, cell))
+    _, nn_idx = knn_points_k3(temp_xyz + object_offsets(temp_obj, cell), exist_xyz + object_offsets(exist_obj, cell), max_dist=NEIGHBOUR_REACH)
     j = nn_idx.clamp(min=0)
     valid = (nn_idx >= 0) & (exist_obj[j] == temp_obj[:, None])
     nn_dist = torch.sqrt((temp_xyz[:, None, :] - exist_xyz[j]).pow(2).sum(-1))  # (of the pairs found, unshifted)
@@ -175,11 +184,12 @@ def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius,
     if n > 1:
         _, i_new = distCUDA2(shifted)
         j = i_new.long().clamp(max=n - 1)
-        ok = (i_new < n) & (obj[j] == obj[:, None])
-        cand_d.append(torch.where(ok, (xyz[:, None, :] - xyz[j]).pow(2).sum(-1), inf))
+        d2_new = (xyz[:, None, :] - xyz[j]).pow(2).sum(-1)
+        ok = (i_new < n) & (obj[j] == obj[:, None]) & (d2_new < NEIGHBOUR_REACH * NEIGHBOUR_REACH)
+        cand_d.append(torch.where(ok, d2_new, inf))
         cand_r.append(radius[j])
     if torch.numel(extra_xyz) > 0:
-        _, i_old = knn_points_k3(shifted, extra_xyz + object_offsets(extra_obj, cell))
+        _, i_old = knn_points_k3(shifted, extra_xyz + object_offsets(extra_obj, cell), max_dist=NEIGHBOUR_REACH)
         j = i_old.clamp(min=0)
         ok = (i_old >= 0) & (extra_obj[j] == obj[:, None])
         cand_d.append(torch.where(ok, (xyz[:, None, :] - extra_xyz[j]).pow(2).sum(-1), inf))

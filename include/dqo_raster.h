@@ -276,6 +276,12 @@ int dqo_knn3(int32_t P, const float* xyz, float* mean_d2, int32_t* idx3, void* w
 size_t dqo_knn3_query_workspace_bytes(int32_t Q, int32_t R);
 int dqo_knn3_query(int32_t Q, const float* query_xyz, int32_t R, const float* ref_xyz, float* dist2, int32_t* idx3, void* workspace,
                    size_t workspace_bytes, void* hipStream);
+/* ABI 4: the same search restricted to references closer than max_dist (> 0): a slot no such reference fills comes back as FLT_MAX / -1.
+ * For callers whose decision saturates beyond a distance (the growth step's per-object decisions, dqo_mapgrowth: a neighbour further than
+ * 0.087 m + 3 x its radius clips the scale like a missing one): the search starts from that bound instead of an open one, so a query with
+ * no reference nearby prunes the whole map at once.  Same workspace as dqo_knn3_query. */
+int dqo_knn3_query_within(int32_t Q, const float* query_xyz, int32_t R, const float* ref_xyz, float max_dist, float* dist2, int32_t* idx3,
+                          void* workspace, size_t workspace_bytes, void* hipStream);
 
 /* Batched dual-quadric residual over B independent (object, view) pairs: loss = 1 - IoU(obs, bbox(ellipsoid, P34)),
  * with gradients.  valid[b] = 0 when loss == 1 (the reference skips that Adam step). */
