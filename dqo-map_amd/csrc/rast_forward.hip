@@ -714,6 +714,96 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImage
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
     uint4* gr = bin.recs + rg.x;
+#ifdef DQO_LONG_SORT_RADIX
+    // (build variant for the A/B recorded in DESIGN.md §2: lists of up to 2048 entries by north_star's "wavefront ballot / prefix-sum
+    // radix sort" — a stable LSD radix sort in LDS, 8-bit digits, a key's rank among the equal digits of its round from eight wave
+    // ballots + per-wave counts, the scheme of knn.hip's radix_scatter_kernel — instead of the bitonic network; longer lists keep it)
+    if (n <= 2048) {
+        __shared__ uint32_t s_run[256];
+        __shared__ uint32_t s_wc[SORT_THREADS / 64][256];
+        __shared__ uint32_t s_ws[4];
+        uint64_t* ka = s_keys;
+        uint64_t* kb = s_keys + 2048;
+        uint32_t* va = s_vals;
+        uint32_t* vb = s_vals + 2048;
+        for (int i = tid; i < n; i += SORT_THREADS) {
+            const uint4 e = gr[i];
+            ka[i] = ((uint64_t)e.y << 32) | e.x, va[i] = e.z;
+        }
+        const int shifts[7] = {0, 8, 16, 32, 40, 48, 56};  // Gaussian ids below 2^24, then the depth bits
+#pragma unroll 1
+        for (int pass = 0; pass < 7; pass++) {
+            const int shift = shifts[pass];
+            if (tid < 256) s_run[tid] = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_THREADS / 64; w++)
+                if (tid < 256) s_wc[w][tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += SORT_THREADS) atomicAdd(&s_run[(uint32_t)(ka[i] >> shift) & 255u], 1u);
+            __syncthreads();
+            if (tid < 256) {  // exclusive scan of the 256 digit counts (four waves)
+                const uint32_t c = s_run[tid];
+                uint32_t incl = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_up(incl, off);
+                    if (lane >= off) incl += o;
+                }
+                if (lane == 63) s_ws[wave] = incl;
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                s_run[tid] = incl - c;  // (wave-local; the wave bases are added below, after the barrier)
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t add = 0;
+                for (int w = 0; w < wave; w++) add += s_ws[w];
+                s_run[tid] += add;
+            }
+            __syncthreads();
+            for (int base = 0; base < n; base += SORT_THREADS) {
+                const int i = base + tid;
+                const bool ok = i < n;
+                const uint64_t key = ok ? ka[i] : 0ull;
+                const uint32_t val = ok ? va[i] : 0u;
+                const uint32_t d = (uint32_t)(key >> shift) & 255u;
+                unsigned long long peers = __builtin_amdgcn_ballot_w64(ok);
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool one = ((d >> bit) & 1u) != 0u;
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
+                    peers &= one ? bal : ~bal;
+                }
+                const uint32_t rank_w = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                if (ok && rank_w == 0u) s_wc[wave][d] = (uint32_t)__popcll(peers);
+                __syncthreads();
+                if (ok) {
+                    uint32_t pos = s_run[d] + rank_w;
+                    for (int w = 0; w < wave; w++) pos += s_wc[w][d];
+                    kb[pos] = key, vb[pos] = val;
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int w = 0; w < SORT_THREADS / 64; w++) c += s_wc[w][tid], s_wc[w][tid] = 0;
+                    s_run[tid] += c;
+                }
+                __syncthreads();
+            }
+            uint64_t* tk = ka;
+            ka = kb, kb = tk;
+            uint32_t* tv = va;
+            va = vb, vb = tv;
+        }
+        for (int i = tid; i < n; i += SORT_THREADS) {
+            bin.point_list[rg.x + i] = (uint32_t)(ka[i] & 0xffffffffu);
+            bin.slot_list[rg.x + i] = va[i];
+        }
+        __syncthreads();
+        continue;
+    }
+#endif
     int n2 = 2 * SORTL_RUN;
     while (n2 < n) n2 <<= 1;
     const int seg_len = min(n2, SORTL_SEG);
