@@ -1,0 +1,182 @@
+// Fused SSIM term of the mapping loss for gfx950 ("masked L1 + depth L1 + SSIM in one pass") — the unmasked branch of
+// Mapping.loss_update, /root/reference/SLAM/multiprocess/mapper.py:839-845:  loss += 0.2 * (1 - ssim(image, gt)),  ssim =
+// /root/reference/utils/loss_utils.py:41-100 (11 x 11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over
+// all channels and pixels), and its gradient w.r.t. the rendered image (torch autograd through five conv2d calls in the reference:
+// ~40 eager launches forward + backward).
+//
+// Two kernels, a 16 x 16 pixel tile of one channel per workgroup, the 26 x 26 halo tile staged in LDS, separable window:
+//   ssim_map_kernel   mu1, mu2, E[x1^2], E[x2^2], E[x1 x2] per pixel -> the SSIM value of the pixel (summed per workgroup, fixed order ->
+//                     partial[block]) and the three partial derivatives of it that the backward needs:
+//                         m = A1 A2 / (B1 B2),  A1 = 2 mu1 mu2 + C1,  A2 = 2 s12 + C2,  B1 = mu1^2 + mu2^2 + C1,  B2 = s1 + s2 + C2,
+//                         s1 = E[x1^2] - mu1^2,  s12 = E[x1 x2] - mu1 mu2
+//                         dm/dmu1 (at fixed E[.]),  dm/dE[x1^2] = -m / B2,  dm/dE[x1 x2] = 2 A1 / (B1 B2)
+//   ssim_grad_kernel  dL/dx1(q) = scale * ( conv(dm/dmu1)(q) + 2 x1(q) conv(dm/dE11)(q) + x2(q) conv(dm/dE12)(q) )   (the window is
+//                     symmetric: correlation = convolution), scale = -weight / (3 H W); written to, or added onto, dL_dimg.
+// The per-workgroup partial sums are added up by one wave in a fixed order (ssim_finish_kernel): reproducible.
+#include "dqo_common.h"
+
+namespace {
+
+constexpr int SS_T = 16, SS_R = 5, SS_W = SS_T + 2 * SS_R;  // tile, window radius, halo tile
+
+struct SsimWin {
+    float g[11];
+};
+
+// horizontal then vertical pass over one quantity held in LDS: s_in [SS_W][SS_W] -> value at the thread's pixel
+// (the horizontal partial sums of the 26 rows live in s_h [SS_W][SS_T])
+__device__ __forceinline__ float conv_sep(const float (*s_in)[SS_W + 1], float (*s_h)[SS_T + 1], const SsimWin& w, int tx, int ty, int tid) {
+    for (int i = tid; i < SS_W * SS_T; i += SS_T * SS_T) {
+        const int r = i / SS_T, c = i - r * SS_T;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) a += w.g[k] * s_in[r][c + k];
+        s_h[r][c] = a;
+    }
+    __syncthreads();
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) v += w.g[k] * s_h[ty + k][tx];
+    __syncthreads();
+    return v;
+}
+
+__global__ __launch_bounds__(SS_T* SS_T) void ssim_map_kernel(int W, int H, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                             SsimWin w, float* __restrict__ maps, float* __restrict__ partial) {
+    __shared__ float s_a[SS_W][SS_W + 1], s_b[SS_W][SS_W + 1], s_q[SS_W][SS_W + 1];
+    __shared__ float s_h[SS_W][SS_T + 1];
+    __shared__ float s_red[SS_T * SS_T / 64];
+    const int tid = threadIdx.x, tx = tid & (SS_T - 1), ty = tid / SS_T;
+    const int ch = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const size_t HW = (size_t)W * H;
+    const float* p1 = img1 + (size_t)ch * HW;
+    const float* p2 = img2 + (size_t)ch * HW;
+    for (int i = tid; i < SS_W * SS_W; i += SS_T * SS_T) {  // zero padding outside the image (conv2d padding = 5)
+        const int r = i / SS_W, c = i - r * SS_W;
+        const int x = x0 + c - SS_R, y = y0 + r - SS_R;
+        const bool in = x >= 0 && x < W && y >= 0 && y < H;
+        s_a[r][c] = in ? p1[(size_t)y * W + x] : 0.f;
+        s_b[r][c] = in ? p2[(size_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    const float mu1 = conv_sep(s_a, s_h, w, tx, ty, tid);
+    const float mu2 = conv_sep(s_b, s_h, w, tx, ty, tid);
+    for (int i = tid; i < SS_W * SS_W; i += SS_T * SS_T) {
+        const int r = i / SS_W, c = i - r * SS_W;
+        s_q[r][c] = s_a[r][c] * s_a[r][c];
+    }
+    __syncthreads();
+    const float e11 = conv_sep(s_q, s_h, w, tx, ty, tid);
+    for (int i = tid; i < SS_W * SS_W; i += SS_T * SS_T) {
+        const int r = i / SS_W, c = i - r * SS_W;
+        s_q[r][c] = s_b[r][c] * s_b[r][c];
+    }
+    __syncthreads();
+    const float e22 = conv_sep(s_q, s_h, w, tx, ty, tid);
+    for (int i = tid; i < SS_W * SS_W; i += SS_T * SS_T) {
+        const int r = i / SS_W, c = i - r * SS_W;
+        s_q[r][c] = s_a[r][c] * s_b[r][c];
+    }
+    __syncthreads();
+    const float e12 = conv_sep(s_q, s_h, w, tx, ty, tid);
+    const int x = x0 + tx, y = y0 + ty;
+    const bool in = x < W && y < H;
+    float m = 0.f;
+    if (in) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
+        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s1 + s2 + C2;
+        const float inv = 1.f / (B1 * B2);
+        m = A1 * A2 * inv;
+        // dm/dmu1 at fixed E[.]: mu1 enters A1 (2 mu2), A2 (-2 mu2 through s12), B1 (2 mu1) and B2 (-2 mu1 through s1)
+        const float dmu1 = (2.f * mu2 * A2 - 2.f * mu2 * A1) * inv - m * (2.f * mu1 / B1 - 2.f * mu1 / B2);
+        const float de11 = -m / B2;
+        const float de12 = 2.f * A1 * inv;
+        const size_t o = (size_t)ch * HW + (size_t)y * W + x;
+        maps[o] = dmu1, maps[3 * HW + o] = de11, maps[6 * HW + o] = de12;
+    }
+    // the workgroup's sum of the pixel values, in a fixed order
+    float v = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int i = 0; i < SS_T * SS_T / 64; i++) t += s_red[i];
+        partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+__global__ void ssim_finish_kernel(int n, const float* __restrict__ partial, double inv_count, float weight, float* __restrict__ out) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) t += (double)partial[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if (threadIdx.x == 0) {
+        const float ssim = (float)(t * inv_count);
+        out[0] = ssim;                   // ssim(image, gt)
+        out[1] = weight * (1.f - ssim);  // the loss term
+    }
+}
+
+__global__ __launch_bounds__(SS_T* SS_T) void ssim_grad_kernel(int W, int H, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                              SsimWin w, const float* __restrict__ maps, float scale, int accumulate,
+                                                              float* __restrict__ dL_dimg) {
+    __shared__ float s_q[SS_W][SS_W + 1];
+    __shared__ float s_h[SS_W][SS_T + 1];
+    const int tid = threadIdx.x, tx = tid & (SS_T - 1), ty = tid / SS_T;
+    const int ch = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const size_t HW = (size_t)W * H;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float* mp = maps + (size_t)(3 * k + ch) * HW;
+        for (int i = tid; i < SS_W * SS_W; i += SS_T * SS_T) {  // (the SSIM map only exists on image pixels: zero outside)
+            const int r = i / SS_W, cc = i - r * SS_W;
+            const int x = x0 + cc - SS_R, y = y0 + r - SS_R;
+            s_q[r][cc] = (x >= 0 && x < W && y >= 0 && y < H) ? mp[(size_t)y * W + x] : 0.f;
+        }
+        __syncthreads();
+        c[k] = conv_sep(s_q, s_h, w, tx, ty, tid);
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    if (x < W && y < H) {
+        const size_t o = (size_t)ch * HW + (size_t)y * W + x;
+        const float g = scale * (c[0] + 2.f * img1[o] * c[1] + img2[o] * c[2]);
+        dL_dimg[o] = accumulate ? dL_dimg[o] + g : g;
+    }
+}
+
+}  // namespace
+
+size_t dqo_map_ssim_ws_bytes(int W, int H) {
+    const size_t HW = (size_t)W * H;
+    const size_t blocks = (size_t)((W + SS_T - 1) / SS_T) * ((H + SS_T - 1) / SS_T) * 3;
+    return dqo_align_up(sizeof(float) * 9 * HW, 256) + dqo_align_up(sizeof(float) * blocks, 256);
+}
+
+int dqo_launch_map_ssim(int W, int H, const float* img, const float* gt, float weight, float* ssim_out, float* dL_dimg, int accumulate,
+                        void* ws, hipStream_t s) {
+    const size_t HW = (size_t)W * H;
+    float* maps = reinterpret_cast<float*>(ws);
+    float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + dqo_align_up(sizeof(float) * 9 * HW, 256));
+    // utils/loss_utils.py:41-58: exp(-(x - 5)^2 / (2 sigma^2)) as float32, normalised in float32
+    SsimWin w;
+    float sum = 0.f;
+    for (int i = 0; i < 11; i++) {
+        w.g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+        sum += w.g[i];
+    }
+    for (int i = 0; i < 11; i++) w.g[i] /= sum;
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, 3), block(SS_T * SS_T);
+    const int nblocks = (int)(grid.x * grid.y * grid.z);
+    DQO_LAUNCH("ssim_map_kernel", ssim_map_kernel, grid, block, s, W, H, img, gt, w, maps, partial);
+    DQO_LAUNCH("ssim_finish_kernel", ssim_finish_kernel, dim3(1), dim3(64), s, nblocks, partial, 1.0 / (3.0 * (double)HW), weight, ssim_out);
+    if (dL_dimg != nullptr) {
+        const float scale = (float)(-(double)weight / (3.0 * (double)HW));
+        DQO_LAUNCH("ssim_grad_kernel", ssim_grad_kernel, grid, block, s, W, H, img, gt, w, maps, scale, accumulate, dL_dimg);
+    }
+    return DQO_OK;
+}

@@ -301,6 +301,7 @@ int dqo_quadric_adam(int32_t n_obj, int32_t n_iters, const int32_t* view_offset,
  *   dqo_map_activate      <- SLAM/gaussian_pointcloud.py:732-733, 746-747 (sigmoid / exp / F.normalize)
  *   dqo_map_loss_fwd_bwd  <- SLAM/multiprocess/mapper.py:836-875 with a render mask (masked L1 colour + masked depth L1; SSIM
  *                            is skipped in that case, B14) and its autograd backward
+ *   dqo_map_ssim_fwd_bwd  <- SLAM/multiprocess/mapper.py:839-845 without a render mask: the SSIM term (utils/loss_utils.py:41-100)
  *   dqo_map_adam_step     <- autograd through the activations + torch.optim.Adam(eps=1e-15) over the six parameter groups
  *                            (SLAM/gaussian_pointcloud.py:331-378, mapper.py:548) */
 int dqo_map_activate(int32_t P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
@@ -315,6 +316,16 @@ int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const float* 
                          const float* gt_color, const float* gt_depth, const uint8_t* render_mask, float color_weight,
                          float depth_weight, float add_depth_thres, float* loss_out, float* dL_dcolor, float* dL_ddepth,
                          void* workspace, size_t workspace_bytes, void* hipStream);
+
+/* The SSIM term of Mapping.loss_update's unmasked branch (SLAM/multiprocess/mapper.py:839-845: loss += 0.2 * (1 - ssim(image, gt)),
+ * ssim = utils/loss_utils.py:41-100: 11 x 11 Gaussian window, sigma 1.5, zero padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over all
+ * channels and pixels) with its gradient, in three launches in place of the five conv2d calls, ~25 elementwise ops and their autograd
+ * backward.  image, gt_image [3,H,W]; ssim_out[2] = {ssim, weight * (1 - ssim)}; dL_dimage [3,H,W] (may be NULL: value only) receives
+ * d(weight * (1 - ssim)) / d image — written when accumulate == 0, added onto what it holds otherwise (e.g. onto the L1 gradient
+ * image dqo_map_loss_fwd_bwd wrote).  The sum over pixels is formed per 16 x 16 tile and then over tiles in a fixed order: reproducible. */
+size_t dqo_map_ssim_workspace_bytes(int32_t W, int32_t H);
+int dqo_map_ssim_fwd_bwd(int32_t W, int32_t H, const float* image, const float* gt_image, float weight, float* ssim_out,
+                         float* dL_dimage, int32_t accumulate, void* workspace, size_t workspace_bytes, void* hipStream);
 
 /* The attach loss of Mapping.loss_update (SLAM/multiprocess/mapper.py:812-829) with its gradient, for callers that keep their own
  * optimiser (ABI 3):  loss[0] = 1000 * (mse(scaling[a], scaling0[a]) + mse(xyz[a], xyz0[a]) + mse(rotation[a], rotation0[a])),  a =
