@@ -127,7 +127,7 @@ def lib():
         L.dqo_map_loss_workspace_bytes.argtypes = []
         L.dqo_map_ssim_workspace_bytes.restype = ctypes.c_size_t
         L.dqo_map_ssim_workspace_bytes.argtypes = [c_i32, c_i32]
-        L.dqo_map_ssim_fwd_bwd.argtypes = [c_i32, c_i32, c_vp, c_vp, c_f, c_vp, c_vp, c_i32, c_vp, ctypes.c_size_t, c_vp]
+        L.dqo_map_ssim_fwd_bwd.argtypes = [c_i32, c_i32, c_vp, c_vp, c_f, c_vp, c_vp, c_i32, c_vp, c_vp, ctypes.c_size_t, c_vp]
         L.dqo_map_loss_fwd_bwd.argtypes = [c_i32, c_i32] + [c_vp] * 6 + [c_f, c_f, c_f] + [c_vp] * 4 + [ctypes.c_size_t, c_vp]
         L.dqo_map_adam_step.argtypes = [P(DqoAdamStep), c_vp]
         L.dqo_map_attach_workspace_bytes.restype = ctypes.c_size_t

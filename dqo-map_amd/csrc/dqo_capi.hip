@@ -34,7 +34,7 @@ int dqo_launch_map_loss(int W, int H, const float* color, const float* depth, co
                         float* loss_out, float* dL_dcolor, float* dL_ddepth, void* ws, hipStream_t s);
 size_t dqo_map_ssim_ws_bytes(int W, int H);
 int dqo_launch_map_ssim(int W, int H, const float* img, const float* gt, float weight, float* ssim_out, float* dL_dimg, int accumulate,
-                        void* ws, hipStream_t s);
+                        float* loss8, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
 size_t dqo_map_attach_ws_bytes(int P);
 int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s);
@@ -403,14 +403,14 @@ DQO_API int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const
 DQO_API size_t dqo_map_ssim_workspace_bytes(int32_t W, int32_t H) { return (W > 0 && H > 0) ? dqo_map_ssim_ws_bytes(W, H) : 0; }
 
 DQO_API int dqo_map_ssim_fwd_bwd(int32_t W, int32_t H, const float* image, const float* gt_image, float weight, float* ssim_out,
-                                 float* dL_dimage, int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+                                 float* dL_dimage, int32_t accumulate, float* loss_out8, void* ws, size_t ws_bytes, void* stream) {
     DQO_CHECK_ARG(W > 0 && H > 0, "bad image size");
     DQO_CHECK_ARG(image && gt_image && ssim_out, "null pointer");
     if (ws == nullptr || ws_bytes < dqo_map_ssim_ws_bytes(W, H)) {
         dqo_set_error("ssim workspace too small (%zu < %zu)", ws_bytes, dqo_map_ssim_ws_bytes(W, H));
         return DQO_ERR_WORKSPACE;
     }
-    return dqo_launch_map_ssim(W, H, image, gt_image, weight, ssim_out, dL_dimage, accumulate != 0, ws, (hipStream_t)stream);
+    return dqo_launch_map_ssim(W, H, image, gt_image, weight, ssim_out, dL_dimage, accumulate != 0, loss_out8, ws, (hipStream_t)stream);
 }
 
 DQO_API size_t dqo_map_attach_workspace_bytes(int32_t P) { return dqo_map_attach_ws_bytes(P < 0 ? 0 : P); }

@@ -14,8 +14,9 @@ host synchronisation, the Adam step count, the attach set and its size kept on t
 eager path is otherwise longer than the GPU work.  `reserve()` + `grow()` + `begin_mapping_call()` keep the captured graph valid across
 map-growth steps and mapping calls (everything they change is rewritten in place).
 
-Only the masked-loss case is fused (SSIM needs an 11x11 convolution and is skipped by the reference when a render mask is
-given, B14); without a mask use the autograd path of dqo_harness/mapping.py.  GPU only.
+With a render mask (every live call site of the reference) the loss is the masked L1 pair and the reference skips SSIM (B14); without
+one the SSIM term of mapper.py:839-845 is added by dqo_map_ssim_fwd_bwd (three launches; the loss tap is off then — the SSIM gradient
+is an image).  GPU only.
 """
 import ctypes
 import os
@@ -129,6 +130,9 @@ class FusedMapper:
         self.loss = torch.zeros(8, **f)  # dqo_map_loss_fwd_bwd: total, colour, depth, 0, then the four unnormalised sums
         lib = N.lib()
         self.loss_ws = torch.empty((lib.dqo_map_loss_workspace_bytes(),), dtype=torch.uint8, device=device)
+        # the unmasked branch of Mapping.loss_update adds 0.2 * (1 - ssim) (mapper.py:839-845): dqo_map_ssim_fwd_bwd, buffers made on first use
+        self.ssim_weight = mapping.SSIM_WEIGHT
+        self.ssim_out = self.ssim_ws = None
         self._empty = torch.Tensor([])
         self.tile_mask = torch.ones(((H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=device)
 
@@ -679,6 +683,10 @@ class FusedMapper:
             # DqoLossTap: the masked loss is summed by the forward's blend kernel and its gradient images are formed inside the
             # backward's (bit for bit what dqo_map_loss_fwd_bwd computes): no loss kernels, no passes over the full image
             g.tap = None
+            if g.mask is None and self.ssim_weight != 0:
+                # the SSIM term's gradient is an image (an 11 x 11 window around every pixel): the tap, which forms sign(error) x weight
+                # inside the backward's blend kernel, cannot carry it -> loss kernels + gradient images (three more launches + the SSIM's three)
+                loss_tap = False
             if loss_tap:
                 g.grad_scale = torch.zeros((2,), **f)
                 g.tap = N.DqoLossTap(gt_color=N.ptr(gt_color), gt_depth=N.ptr(gt_depth), render_mask=N.ptr(g.mask), out_color=o[0].data_ptr(),
@@ -782,6 +790,8 @@ class FusedMapper:
             N.check(lib.dqo_map_loss_fwd_bwd(W, H, o[0].data_ptr(), o[1].data_ptr(), o[3].data_ptr(), N.ptr(g.gt_color), N.ptr(g.gt_depth),
                                              N.ptr(g.mask), self.color_weight, self.depth_weight, self.add_depth_thres, N.ptr(self.loss),
                                              N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws), self.loss_ws.numel(), stream))
+            if g.mask is None and self.ssim_weight != 0:
+                self._ssim_term(o[0].data_ptr(), g.gt_color, stream)
         dLc, dLd = (self.dL_dcolor.data_ptr(), self.dL_ddepth.data_ptr()) if g.tap is None else (None, None)
         self._attach_n = ((self.P + 255) // 256) * (4 if g.fused_tail else 1)
         if g.fused_tail:
@@ -791,6 +801,17 @@ class FusedMapper:
         N.check(lib.dqo_rast_backward(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.cctx), dLc, dLd, o[3].data_ptr(),
                                       ctypes.byref(g.cgrads), g.ws.data_ptr(), g.ws.numel(), stream))
         N.check(lib.dqo_map_adam_step(ctypes.byref(g.adam), stream))
+
+    def _ssim_term(self, color_ptr, gt_color, stream):
+        """Without a render mask the loss carries the SSIM term (mapper.py:839-845; with one the reference skips it, B14): its gradient
+        is added onto the colour-gradient image dqo_map_loss_fwd_bwd just wrote, its value onto self.loss[0] (slot 3 = 1 - ssim)."""
+        lib = N.lib()
+        H, W = int(self.settings.image_height), int(self.settings.image_width)
+        if self.ssim_ws is None:
+            self.ssim_ws = torch.empty((lib.dqo_map_ssim_workspace_bytes(W, H),), dtype=torch.uint8, device=self.device)
+            self.ssim_out = torch.zeros((2,), dtype=torch.float32, device=self.device)
+        N.check(lib.dqo_map_ssim_fwd_bwd(W, H, color_ptr, N.ptr(gt_color), self.ssim_weight, N.ptr(self.ssim_out), N.ptr(self.dL_dcolor), 1,
+                                         N.ptr(self.loss), N.ptr(self.ssim_ws), self.ssim_ws.numel(), stream))
 
     def replay(self):
         """One mapping iteration (capture(unroll=k): k of them) by replaying the captured graph; outputs are the persistent tensors in
@@ -919,6 +940,8 @@ class FusedMapper:
                                                  N.ptr(mask_u8), self.color_weight, self.depth_weight, self.add_depth_thres,
                                                  N.ptr(self.loss), N.ptr(self.dL_dcolor), N.ptr(self.dL_ddepth), N.ptr(self.loss_ws),
                                                  self.loss_ws.numel(), stream))
+                if mask_u8 is None and self.ssim_weight != 0:
+                    self._ssim_term(N.ptr(color), gt_color, stream)
             ctx.sparse_grad_rows = True  # gradient rows of culled Gaussians stay unwritten; the Adam kernel gets radii instead
             grads = dgr._RasterizeGaussians.backward(ctx, self.dL_dcolor, self.dL_ddepth, None, None, None, None, None, None, None)
             g_means3D, g_sh, _, g_opacity, g_scales, g_rot = grads[0], grads[1], grads[2], grads[3], grads[4], grads[5]

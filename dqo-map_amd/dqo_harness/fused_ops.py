@@ -54,12 +54,50 @@ class _MaskedMappingLoss(torch.autograd.Function):
         return g_total * dC, g_total * dD, None, None, None, None, None, None, None
 
 
+class _Ssim(torch.autograd.Function):
+    """utils/loss_utils.py:60-100 (ssim, window 11, size_average=True) in three launches: the value and d ssim / d img1 come out of the forward."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        lib = N.lib()
+        N.require_gpu(img1, img2)
+        if not img1.is_cuda:
+            raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
+        a, b = img1.detach().float().contiguous(), img2.detach().float().contiguous()
+        if a.dim() != 3 or a.shape[0] != 3 or a.shape != b.shape:
+            raise RuntimeError(f"fused_ssim: two [3,H,W] images expected, got {tuple(a.shape)} and {tuple(b.shape)}")
+        H, W, dev = a.shape[1], a.shape[2], a.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(a)
+        ws = torch.empty(lib.dqo_map_ssim_workspace_bytes(W, H), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            # weight -1: the term is -(1 - ssim) = ssim - 1, its gradient d ssim / d img1
+            N.check(lib.dqo_map_ssim_fwd_bwd(W, H, N.ptr(a), N.ptr(b), -1.0, N.ptr(out), N.ptr(grad), 0, None, N.ptr(ws), ws.numel(),
+                                             N.current_stream()))
+        ctx.save_for_backward(grad)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g * grad, None
+
+
+def fused_ssim(img1, img2):
+    """ssim(img1, img2) of utils/loss_utils.py:60-100 for [3,H,W] images, differentiable w.r.t. img1 (img2 = the ground truth)."""
+    return _Ssim.apply(img1, img2)
+
+
 def masked_mapping_loss(out, gt_color, gt_depth, render_mask, add_depth_thres=0.1, color_weight=mapping.COLOR_WEIGHT,
                         depth_weight=mapping.DEPTH_WEIGHT):
-    """mapping.mapping_loss for the masked case (mapper.py:836-875: 0.8 L1 colour + 1.0 depth L1; the SSIM term is skipped when a render
-    mask is given, B14) in two launches.  `out` = the dict of mapping.render / Renderer.render.  Returns (total, parts) like mapping_loss."""
+    """mapping.mapping_loss (mapper.py:836-875: 0.8 L1 colour + 1.0 depth L1 in two launches; the SSIM term is skipped when a render
+    mask is given, B14, and added by fused_ssim — three launches — when render_mask is None).  `out` = the dict of mapping.render / Renderer.render.  Returns (total, parts) like mapping_loss."""
     total, loss = _MaskedMappingLoss.apply(out["render"], out["depth"], out["depth_index_map"], gt_color, gt_depth, render_mask,
                                            color_weight, depth_weight, add_depth_thres)
+    if render_mask is None:  # mapper.py:839-845: the SSIM term exists only without a render mask
+        ssim_loss = 1 - fused_ssim(out["render"], gt_color)
+        total = total + mapping.SSIM_WEIGHT * ssim_loss
+        return total, dict(total_loss=total.detach(), color_loss=loss[1], depth_loss=loss[2], ssim_loss=ssim_loss.detach())
     return total, dict(total_loss=loss[0], color_loss=loss[1], depth_loss=loss[2], ssim_loss=loss[3])
 
 

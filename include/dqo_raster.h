@@ -322,10 +322,13 @@ int dqo_map_loss_fwd_bwd(int32_t W, int32_t H, const float* color, const float* 
  * channels and pixels) with its gradient, in three launches in place of the five conv2d calls, ~25 elementwise ops and their autograd
  * backward.  image, gt_image [3,H,W]; ssim_out[2] = {ssim, weight * (1 - ssim)}; dL_dimage [3,H,W] (may be NULL: value only) receives
  * d(weight * (1 - ssim)) / d image — written when accumulate == 0, added onto what it holds otherwise (e.g. onto the L1 gradient
- * image dqo_map_loss_fwd_bwd wrote).  The sum over pixels is formed per 16 x 16 tile and then over tiles in a fixed order: reproducible. */
+ * image dqo_map_loss_fwd_bwd wrote).  loss_out8 (may be NULL) = the loss_out of a dqo_map_loss_fwd_bwd call issued before on the same
+ * stream: its total [0] grows by the term and slot [3] receives 1 - ssim, so the eight floats read like Mapping.loss_update's report.
+ * The sum over pixels is formed per 16 x 16 tile and then over tiles in a fixed order: reproducible. */
 size_t dqo_map_ssim_workspace_bytes(int32_t W, int32_t H);
 int dqo_map_ssim_fwd_bwd(int32_t W, int32_t H, const float* image, const float* gt_image, float weight, float* ssim_out,
-                         float* dL_dimage, int32_t accumulate, void* workspace, size_t workspace_bytes, void* hipStream);
+                         float* dL_dimage, int32_t accumulate, float* loss_out8, void* workspace, size_t workspace_bytes,
+                         void* hipStream);
 
 /* The attach loss of Mapping.loss_update (SLAM/multiprocess/mapper.py:812-829) with its gradient, for callers that keep their own
  * optimiser (ABI 3):  loss[0] = 1000 * (mse(scaling[a], scaling0[a]) + mse(xyz[a], xyz0[a]) + mse(rotation[a], rotation0[a])),  a =

@@ -159,6 +159,46 @@ def test_fused_iteration_matches_autograd_path(env):
         assert bad.mean() < 2e-3, (k, bad.mean(), np.abs(a - b).max())
 
 
+def test_unmasked_fused_iteration_carries_the_ssim_term(env):
+    """No render mask: Mapping.loss_update adds 0.2 * (1 - ssim) (mapper.py:839-845).  Eager fused steps and the captured graph against
+    the autograd path."""
+    torch = env
+    from dqo_harness import mapping
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    params = mapping.GaussianParams(scene, dev)
+    opt = mapping.make_optimizer(params)
+    init_stat = params.init_stat()
+    fm = FusedMapper(scene, settings, dev)
+    fg = FusedMapper(scene, settings, dev)
+    fg.capture(gt_color, gt_depth, None)  # (its eager warm-up iteration is step 1)
+    assert fg._g.tap is None  # the SSIM gradient is an image: loss kernels, not the tap
+    ref_losses, fused_losses, graph_losses = [], [], []
+    for it in range(3):
+        out = mapping.render(settings, params.activated())
+        loss, parts = mapping.mapping_loss(out, gt_color, gt_depth, render_mask=None)
+        (loss + mapping.attach_loss(params, init_stat)).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        ref_losses.append([parts[k].item() for k in ("total_loss", "color_loss", "depth_loss", "ssim_loss")])
+        fm.step(gt_color, gt_depth, None)
+        fused_losses.append(fm.loss.cpu().numpy()[:4].tolist())
+        if it > 0:
+            fg.replay()
+        graph_losses.append(fg.loss.cpu().numpy()[:4].tolist())
+    assert ref_losses[0][3] > 0.01
+    np.testing.assert_allclose(fused_losses[:2], ref_losses[:2], rtol=2e-5)
+    np.testing.assert_allclose(fused_losses, ref_losses, rtol=3e-4)
+    np.testing.assert_allclose(graph_losses, fused_losses, rtol=1e-5)
+    ref = dict(xyz=params._xyz, scaling=params._scaling)
+    got = fm._params()
+    for k in ref:
+        a, b = got[k].detach().cpu().numpy().reshape(-1), ref[k].detach().cpu().numpy().reshape(-1)
+        lr = dict(xyz=0.001, scaling=0.004)[k]
+        bad = np.abs(a - b) > 0.02 * 3 * lr + 1e-7
+        assert bad.mean() < 2e-3, (k, bad.mean(), np.abs(a - b).max())
+
+
 def test_graph_replay_matches_eager_steps(env):
     """capture() runs one iteration eagerly over the persistent buffers and records the next ones into a hipGraph (Adam step
     count on the device): capture + 3 replays must leave the same parameters / moments as 4 eager step() calls."""
@@ -295,6 +335,7 @@ def test_loss_tap_equals_the_loss_kernels(env):
         m = mask if use_mask else None
         a = FusedMapper(scene, settings, dev)
         b = FusedMapper(scene, settings, dev)
+        a.ssim_weight = b.ssim_weight = 0.0  # (without a mask the SSIM term would switch the tap off: this is the L1 pair alone)
         a.capture(gt_color, gt_depth, m, tile_mask=tile_mask, loss_tap=True)
         b.capture(gt_color, gt_depth, m, tile_mask=tile_mask, loss_tap=False)
         assert a._g.tap is not None and b._g.tap is None

@@ -117,3 +117,71 @@ def test_dqo_adam_is_torch_adam(env):
             o.param_groups[0]["lr"] = 1e-2 / (it + 1)
         o1.step(), o2.step()
     assert torch.allclose(q, r, rtol=2e-6, atol=1e-7)
+
+
+def test_fused_ssim_against_the_reference_fixture(env):
+    """tests/golden/loss_golden.npz: values and gradients of the reference's own utils/loss_utils.py::ssim (make_loss_golden.py)."""
+    torch = env
+    import os
+    from dqo_harness import fused_ops
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_golden.npz"))
+    for k in range(3):
+        a = torch.tensor(d[f"ssim{k}_img1"], device="cuda", requires_grad=True)
+        b = torch.tensor(d[f"ssim{k}_img2"], device="cuda")
+        s = fused_ops.fused_ssim(a, b)
+        (g,) = torch.autograd.grad(1 - s, [a])  # the fixture holds the gradient of `1 - ssim`, the loss term
+        np.testing.assert_allclose(s.item(), float(d[f"ssim{k}_value"]), rtol=0, atol=2e-6)
+        ref = d[f"ssim{k}_grad"]
+        # fp32 windows summed in another order than conv2d's: compare against the gradient's own scale; pair 2 (identical images) has
+        # a true gradient of zero: the fixture holds 3e-8 of rounding noise there, the kernel 5e-8 (tools/diag_ssim.py: both against float64)
+        assert np.abs(g.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-7, (k, np.abs(g.cpu().numpy() - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("H,W", [(48, 64), (123, 211), (16, 16), (7, 5), (480, 640)])
+def test_fused_ssim_matches_eager_ssim_on_ragged_sizes(env, H, W):
+    """Sizes that are not multiples of the 16 x 16 tile and smaller than the window: value and gradient against the eager statement
+    (dqo_harness.mapping.ssim, itself pinned by the fixture) evaluated in float64."""
+    torch = env
+    from dqo_harness import mapping, fused_ops
+    g = torch.Generator(device="cuda").manual_seed(H * 1000 + W)
+    gt = torch.rand((3, H, W), device="cuda", generator=g)
+    img = (gt + 0.15 * torch.randn((3, H, W), device="cuda", generator=g)).clamp(0, 1).requires_grad_(True)
+    i64 = img.detach().double().requires_grad_(True)
+    w64 = mapping._gaussian_window(11, 1.5, 3, "cuda").double()
+    F = torch.nn.functional
+    c = lambda x: F.conv2d(x[None], w64, padding=5, groups=3)
+    mu1, mu2 = c(i64), c(gt.double())
+    s1, s2, s12 = c(i64 * i64) - mu1 * mu1, c(gt.double() ** 2) - mu2 * mu2, c(i64 * gt.double()) - mu1 * mu2
+    ref = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+    (gr,) = torch.autograd.grad(ref, [i64])
+    s = fused_ops.fused_ssim(img, gt)
+    (gg,) = torch.autograd.grad(3.0 * s, [img])
+    np.testing.assert_allclose(s.item(), ref.item(), rtol=0, atol=3e-6)
+    err = (gg.double() / 3.0 - gr).abs().max().item()
+    assert err <= 2e-4 * gr.abs().max().item() + 1e-7, (err, gr.abs().max().item())
+    # and the fp32 eager statement is no closer to float64 than the kernel by more than rounding
+    e32 = mapping.ssim(img, gt)
+    assert abs(s.item() - ref.item()) <= abs(e32.item() - ref.item()) + 2e-6
+
+
+def test_unmasked_mapping_loss_function_carries_the_ssim_term(env):
+    torch = env
+    from dqo_harness import mapping, fused_ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    H, W = 90, 130
+    gt_color = torch.rand((3, H, W), device="cuda", generator=g)
+    render = (gt_color + 0.1 * torch.randn((3, H, W), device="cuda", generator=g)).clamp(0, 1).requires_grad_(True)
+    depth = (torch.rand((1, H, W), device="cuda", generator=g) * 2.5 + 0.5).requires_grad_(True)
+    gt_depth = torch.rand((1, H, W), device="cuda", generator=g) * 2.6 + 0.4
+    idx = torch.randint(-1, 50, (1, H, W), device="cuda", generator=g, dtype=torch.int32)
+    out = dict(render=render, depth=depth, depth_index_map=idx)
+    ref, rparts = mapping.mapping_loss(out, gt_color, gt_depth, render_mask=None)
+    gr = torch.autograd.grad(ref, [render, depth])
+    got, gparts = fused_ops.masked_mapping_loss(out, gt_color, gt_depth, None)
+    gg = torch.autograd.grad(got, [render, depth])
+    assert rparts["ssim_loss"].item() > 0.01
+    for k in ("total_loss", "color_loss", "depth_loss", "ssim_loss"):
+        np.testing.assert_allclose(gparts[k].item(), rparts[k].item(), rtol=1e-5)
+    np.testing.assert_allclose(gg[1].cpu().numpy(), gr[1].cpu().numpy(), rtol=2e-6, atol=1e-12)
+    a, b = gg[0].cpu().numpy(), gr[0].cpu().numpy()
+    assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
