@@ -107,6 +107,16 @@ def test_cfg3_full_size_gated_vs_oracle(torch_cuda, oracle):
 
 
 def test_cfg3_fused_iteration_vs_cpu_oracle_iteration(torch_cuda, oracle):
+    _fused_iteration_case(torch_cuda, oracle, 3)
+
+
+def test_cfg5_fused_iteration_vs_cpu_oracle_iteration(torch_cuda, oracle):
+    """The same at 2 M Gaussians, where the timed path also splits its long tile lists (list_split "auto": composed transmittance maps
+    in the forward, the queue of long-list sorts) — bench.py --cfg 5's instantiation."""
+    _fused_iteration_case(torch_cuda, oracle, 5)
+
+
+def _fused_iteration_case(torch_cuda, oracle, cfg):
     """ONE iteration of the path bench.py times (FusedMapper on cfg 3 at 500 k: tile_objects binning, gated blend kernels, the
     per-object loss tap, gaussian_tail_kernel with the sparse Adam — the capture's own eager iteration issues exactly the calls the
     graph holds) against the full CPU iteration bench.py's cpu_baseline runs: oracle raster forward (gated) -> per-object masked loss
@@ -119,8 +129,8 @@ def test_cfg3_fused_iteration_vs_cpu_oracle_iteration(torch_cuda, oracle):
     from dqo_harness import mapping, sharding
     from dqo_harness.fused_mapping import FusedMapper
     from oracle import map_oracle as mo
-    cam, sc = scenes.make_config(3)
-    go, po, tgt = _bench_gate(3, cam, sc)
+    cam, sc = scenes.make_config(cfg)
+    go, po, tgt = _bench_gate(cfg, cam, sc)
     dev = torch.device("cuda")
     settings = mapping.make_settings(cam, dev)
     own = po >= 0
@@ -170,7 +180,8 @@ def test_cfg3_fused_iteration_vs_cpu_oracle_iteration(torch_cuda, oracle):
     assert moved[has_g].mean() > 0.99 and not moved[~has_g & (hr.res["radii"] == 0)].any()
     fs = dict(loss_hip=loss_hip.tolist(), loss_oracle=[float(tot), float(col), float(dep)], flipped_px=int(bad[own].sum()), P=int(len(go)),
               N_reference=int(orc["f32"][1].num_rendered), N_kept=int(fm.header()["num_rendered"]))
-    _report("cfg3_fused_iteration", fs, gs)
+    fs["list_split"] = [int(fm._g.ls_fwd), int(fm._g.ls_bwd)]
+    _report(f"cfg{cfg}_fused_iteration", fs, gs)
 
 
 def test_cfg2_full_size_vs_oracle(torch_cuda, oracle):
