@@ -75,7 +75,7 @@ class DqoAdamTensor(ctypes.Structure):
 
 
 EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_enable", "dqo_profile_collect", "dqo_map_activate",
-           "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_ssim_workspace_bytes", "dqo_map_ssim_fwd_bwd", "dqo_map_adam_step", "dqo_map_attach_workspace_bytes",
+           "dqo_map_loss_workspace_bytes", "dqo_map_loss_fwd_bwd", "dqo_map_ssim_workspace_bytes", "dqo_map_ssim_fwd_bwd", "dqo_map_adam_step", "dqo_adam_multi_dev", "dqo_map_attach_workspace_bytes",
            "dqo_map_attach_loss_fwd_bwd", "dqo_adam_multi", "dqo_accumulate_gaussian_error", "dqo_accumulate_gaussian_confidence", "dqo_rast_geom_bytes", "dqo_rast_image_bytes",
            "dqo_rast_binning_bytes", "dqo_rast_binning_bytes_bucketed",
            "dqo_rast_backward_workspace_bytes", "dqo_rast_forward_prepare", "dqo_rast_read_header", "dqo_rast_forward_render",
@@ -133,6 +133,7 @@ def lib():
         L.dqo_map_attach_workspace_bytes.restype = ctypes.c_size_t
         L.dqo_map_attach_workspace_bytes.argtypes = [c_i32]
         L.dqo_adam_multi.argtypes = [c_vp, c_i32, c_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp]
+        L.dqo_adam_multi_dev.argtypes = [c_vp, c_i32, c_vp, c_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_vp]
         L.dqo_map_attach_loss_fwd_bwd.argtypes = [c_i32] + [c_vp] * 7 + [c_i32] + [c_vp] * 5 + [ctypes.c_size_t, c_vp]
         L.dqo_accumulate_gaussian_error.argtypes = [c_i32] * 3 + [c_vp] * 5 + [c_f] * 3 + [c_i32] + [c_vp] * 6
         L.dqo_accumulate_gaussian_confidence.argtypes = [c_i32] * 3 + [c_vp] * 7

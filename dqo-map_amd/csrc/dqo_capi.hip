@@ -37,7 +37,8 @@ int dqo_launch_map_ssim(int W, int H, const float* img, const float* gt, float w
                         float* loss8, void* ws, hipStream_t s);
 int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
 size_t dqo_map_attach_ws_bytes(int P);
-int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s);
+int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s,
+                          int32_t* step_dev = nullptr, int bump = 0);
 int dqo_launch_map_attach(int P, const float* scaling, const float* xyz, const float* rotation, const float* scaling0, const float* xyz0,
                           const float* rotation0, const uint8_t* mask, int attach_count, float* loss, float* g_scaling, float* g_xyz,
                           float* g_rotation, void* ws, hipStream_t s);
@@ -432,10 +433,9 @@ DQO_API int dqo_map_attach_loss_fwd_bwd(int32_t P, const float* scaling_raw, con
                                  loss, g_scaling_raw, g_xyz, g_rotation_raw, ws, (hipStream_t)stream);
 }
 
-DQO_API int dqo_adam_multi(const DqoAdamTensor* ts, int32_t n_tensors, int32_t step, double beta1, double beta2, double eps, void* stream) {
+static int check_adam_multi(const DqoAdamTensor* ts, int32_t n_tensors, double beta1, double beta2, double eps) {
     DQO_CHECK_ARG(n_tensors >= 0 && n_tensors <= DQO_ADAM_MULTI_MAX, "n_tensors out of range");
     DQO_CHECK_ARG(n_tensors == 0 || ts != nullptr, "null tensor list");
-    DQO_CHECK_ARG(step >= 1, "step is the 1-based count of this update");
     DQO_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "bad betas / eps");
     int64_t total = 0;
     for (int t = 0; t < n_tensors; t++) {
@@ -444,7 +444,22 @@ DQO_API int dqo_adam_multi(const DqoAdamTensor* ts, int32_t n_tensors, int32_t s
         total += ts[t].n;
     }
     DQO_CHECK_ARG(total < ((int64_t)1 << 40), "too many elements");
+    return DQO_OK;
+}
+
+DQO_API int dqo_adam_multi(const DqoAdamTensor* ts, int32_t n_tensors, int32_t step, double beta1, double beta2, double eps, void* stream) {
+    DQO_CHECK_ARG(step >= 1, "step is the 1-based count of this update");
+    const int rc = check_adam_multi(ts, n_tensors, beta1, beta2, eps);
+    if (rc) return rc;
     return dqo_launch_adam_multi(ts, n_tensors, step, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+DQO_API int dqo_adam_multi_dev(const DqoAdamTensor* ts, int32_t n_tensors, int32_t* step_dev, int32_t advance, double beta1, double beta2,
+                               double eps, void* stream) {
+    DQO_CHECK_ARG(step_dev != nullptr, "null step counter");
+    const int rc = check_adam_multi(ts, n_tensors, beta1, beta2, eps);
+    if (rc) return rc;
+    return dqo_launch_adam_multi(ts, n_tensors, 1, beta1, beta2, eps, (hipStream_t)stream, step_dev, advance != 0);
 }
 
 DQO_API int dqo_accumulate_gaussian_error(int32_t H, int32_t W, int32_t P, const float* ce, const float* de, const float* ne,

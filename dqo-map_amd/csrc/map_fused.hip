@@ -414,13 +414,28 @@ struct AdamMultiArgs {
     uint32_t first_block[DQO_ADAM_MULTI_MAX + 1];  // tensor t owns blocks [first_block[t], first_block[t + 1])
     int n_tensors;
     float beta1, beta2, omb1, omb2, eps, bc2_sqrt;
+    // dqo_adam_multi_dev: the step count lives on the device (a captured graph replays with the count of ITS step, not the capture's)
+    const int32_t* step_dev;  // steps taken so far, or NULL: step_size[] / bc2_sqrt above are the host's
+    double beta1_d, beta2_d;
+    double lr[DQO_ADAM_MULTI_MAX];
 };
+__global__ void adam_step_bump_kernel(int32_t* step_dev) { step_dev[0] += 1; }
 __global__ __launch_bounds__(ADAMM_THREADS) void adam_multi_kernel(const AdamMultiArgs q) {
     int t = 0;  // (block-uniform: at most 16 trips)
     while (t + 1 < q.n_tensors && blockIdx.x >= q.first_block[t + 1]) t++;
     AdamArgs a;  // (adam1 reads these fields only)
     a.beta2 = q.beta2, a.omb1 = q.omb1, a.omb2 = q.omb2, a.eps = q.eps, a.bc2_sqrt = q.bc2_sqrt;
-    const float ss = q.step_size[t];
+    float ss = q.step_size[t];
+    if (q.step_dev != nullptr) {  // (kernel-uniform) the host path's expressions, in double, by one thread of the block
+        __shared__ float s_bc[2];
+        if (threadIdx.x == 0) {
+            const double st = (double)(q.step_dev[0] + 1);
+            const double bc1 = 1.0 - pow(q.beta1_d, st), bc2 = 1.0 - pow(q.beta2_d, st);
+            s_bc[0] = (float)sqrt(bc2), s_bc[1] = (float)(q.lr[t] / bc1);
+        }
+        __syncthreads();
+        a.bc2_sqrt = s_bc[0], ss = s_bc[1];
+    }
     float* const p = q.p[t];
     const float* const g = q.g[t];
     float* const m = q.m[t];
@@ -444,9 +459,12 @@ __global__ __launch_bounds__(ADAMM_THREADS) void adam_multi_kernel(const AdamMul
 }
 }  // namespace
 
-int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s) {
+int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s,
+                          int32_t* step_dev, int bump) {
     AdamMultiArgs q;
+    if (step_dev != nullptr) step = 1;  // (placeholders below; the kernel forms the corrections from the device count)
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    q.step_dev = step_dev, q.beta1_d = beta1, q.beta2_d = beta2;
     q.n_tensors = n_tensors, q.beta1 = (float)beta1, q.beta2 = (float)beta2, q.eps = (float)eps, q.bc2_sqrt = (float)sqrt(bc2);
     q.omb1 = (float)(1.0 - beta1), q.omb2 = (float)(1.0 - beta2);
     uint32_t blocks = 0;
@@ -455,13 +473,14 @@ int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, doub
         q.p[t] = in ? ts[t].p : nullptr, q.g[t] = in ? ts[t].g : nullptr, q.m[t] = in ? ts[t].m : nullptr, q.v[t] = in ? ts[t].v : nullptr;
         q.n[t] = in ? ts[t].n : 0;
         q.step_size[t] = in ? (float)(ts[t].lr / bc1) : 0.f;
+        q.lr[t] = in ? ts[t].lr : 0.0;
         q.first_block[t] = blocks;
         if (in) blocks += (uint32_t)((ts[t].n + ADAMM_THREADS * ADAMM_PER_THREAD - 1) / (ADAMM_THREADS * ADAMM_PER_THREAD));
     }
     q.first_block[DQO_ADAM_MULTI_MAX] = blocks;
     for (int t = n_tensors; t <= DQO_ADAM_MULTI_MAX; t++) q.first_block[t] = blocks;
-    if (blocks == 0) return DQO_OK;
-    DQO_LAUNCH("adam_multi_kernel", adam_multi_kernel, dim3(blocks), dim3(ADAMM_THREADS), s, q);
+    if (blocks != 0) DQO_LAUNCH("adam_multi_kernel", adam_multi_kernel, dim3(blocks), dim3(ADAMM_THREADS), s, q);
+    if (step_dev != nullptr && bump) DQO_LAUNCH("adam_step_bump_kernel", adam_step_bump_kernel, dim3(1), dim3(1), s, step_dev);
     return DQO_OK;
 }
 

@@ -34,7 +34,7 @@ import threading
 
 _lock = threading.RLock()
 _list_split = 0         # DqoRastCtx.list_split of the forwards issued through this module (set_list_split)
-_sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy" / "deferred": reuse / grow the previous capacity, no sync
+_sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy" / "deferred" / "graph": reuse the previous capacity, no sync
 _cap_hint = {}
 _pending = []          # lazy mode: (event, pinned header tensor, key, capacity) of forwards not yet verified
 _last = {"num_rendered": None, "num_visible": None, "header": None}   # header: (event, pinned host copy) or a weak reference to the geometry buffer
@@ -98,13 +98,27 @@ def set_sync_mode(mode):
     frame that outgrew the capacity raises before any gradient of it exists.  'deferred': like 'lazy' without that wait — the host
     never blocks; an overflowed frame (empty lists: its outputs are background, its gradients exact zeros, nothing is written out of
     bounds) raises at a later forward / backward / verify_pending() call, typically one iteration later, and the optimiser steps taken
-    in between saw zero gradients.  For loops that can tolerate that (or call verify_pending() where it matters)."""
+    in between saw zero gradients.  For loops that can tolerate that (or call verify_pending() where it matters).
+    'graph': for callers that capture their iteration with torch.cuda.graph (the op, the caller's loss, autograd and a capturable
+    optimiser in ONE graph replay — on config 3 the host time of the ~130 eager launches of DQO-MAP's loop is what bounds it): nothing
+    the op does touches the host — no header copy, no event, no check; the capacity is the one earlier calls measured (run at least one
+    iteration in 'lazy' mode first — the usual warm-up before a capture — or call set_capacity(P, W, H, instances)), and the frame's
+    header stays on the device: last_header() (after the replay) reads it; `overflow` there means the frame was invalid (background
+    outputs, zero gradients) and the graph must be captured again with a larger capacity."""
     global _sync_mode
-    if mode not in ("exact", "lazy", "deferred"):
+    if mode not in ("exact", "lazy", "deferred", "graph"):
         raise ValueError(mode)
     if _pending:
         _verify_pending(block=True)  # forwards issued in lazy mode are still checked (raises if one of them overflowed)
     _sync_mode = mode
+
+
+def set_capacity(P, W, H, instances, device_index=None):
+    """Instance capacity (Gaussian-tile pairs) of later forwards of this shape in 'lazy' / 'deferred' / 'graph' mode; it only grows."""
+    dev_index = torch.cuda.current_device() if device_index is None else int(device_index)
+    key = (dev_index, int(P), int(W), int(H))
+    with _lock:
+        _cap_hint[key] = max(_cap_hint.get(key, 0), int(instances))
 
 
 def verify_pending():
@@ -262,11 +276,27 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cctx.object_gate = ctypes.addressof(gate)
             key = (dev.index, P, W, H)
             cap = None
-            if _sync_mode != "exact":
+            if _sync_mode == "graph":
+                with _lock:
+                    cap = _cap_hint.get(key)
+                if cap is None:
+                    raise RuntimeError("diff_gaussian_rasterization_depth ('graph' mode): no instance capacity known for "
+                                       f"P={P}, {W}x{H}: run one forward in 'lazy' mode first (the warm-up before the capture) or call "
+                                       "set_capacity(P, W, H, instances)")
+                # nothing below touches the host: the launches of both stages, no header copy, no event
+                num_rendered = -1
+                binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
+                cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
+                N.check(lib.dqo_rast_forward_async(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
+                                                   ctypes.byref(cctx), None, None, stream))
+                _last["header"] = geomBuffer  # (a captured forward: the graph's own buffer, valid after every replay)
+            elif _sync_mode != "exact":
                 _verify_pending(block=False)
                 with _lock:
                     cap = _cap_hint.get(key)
-            if cap is None:
+            if _sync_mode == "graph":
+                pass
+            elif cap is None:
                 # 'exact', or the first call for this shape in 'lazy' / 'deferred' (measure once): stage 1, the one D2H read, stage 2
                 N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
                                                      ctypes.byref(cctx), stream))
@@ -332,7 +362,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          opacities, tile_mask) = ctx.saved_tensors
         if tile_mask.numel() == 0:
             tile_mask = None
-        if _sync_mode != "exact":
+        if _sync_mode in ("lazy", "deferred"):
             _verify_pending(block=(_sync_mode == "lazy"))  # (lazy: no gradient of an invalid frame; deferred: never wait, see set_sync_mode)
         P, M = means3D.size(0), ctx.M
         H, W = int(rs.image_height), int(rs.image_width)

@@ -148,12 +148,17 @@ class DqoAdam(torch.optim.Optimizer):
     with the whole step as ONE kernel launch over every parameter tensor of every group (dqo_adam_multi; up to 16 tensors per launch),
     instead of torch's per-group launches and their host time (six groups: 0.28 ms per iteration on the drop-in path).  Same param
     groups (per-group `lr`, scheduler-compatible), same state keys (`step`, `exp_avg`, `exp_avg_sq`), same element arithmetic;
-    parameters whose `.grad` is None are skipped like torch skips them.  betas / eps must be common to the groups."""
+    parameters whose `.grad` is None are skipped like torch skips them.  betas / eps must be common to the groups.
+    capturable=True: the step count lives on the device (ONE int32 shared by all parameters: `state[p]["step"]` is that tensor), so
+    step() can be captured into a torch.cuda.graph and replayed — the kernel forms the bias corrections of the replayed step itself
+    (dqo_adam_multi_dev); every parameter must then have a gradient at every step (one count for all of them)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         if not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError("DqoAdam: bad betas / eps")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = bool(capturable)
+        self._step_dev = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -172,6 +177,9 @@ class DqoAdam(torch.optim.Optimizer):
                 raise RuntimeError("DqoAdam: betas and eps must be the same in every group")
             for p in group["params"]:
                 if p.grad is None:
+                    if self.capturable:
+                        raise RuntimeError("DqoAdam(capturable=True): every parameter needs a gradient at every step (one device-side "
+                                           "step count serves all of them)")
                     continue
                 if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise RuntimeError("DqoAdam: dense contiguous float32 GPU parameters only; there is no CPU path")
@@ -181,13 +189,22 @@ class DqoAdam(torch.optim.Optimizer):
                     raise RuntimeError("DqoAdam: all parameters must live on one GPU (one launch on that device's current stream)")
                 st = self.state[p]
                 if len(st) == 0:
-                    st["step"] = 0
+                    if self.capturable:
+                        if self._step_dev is None:
+                            self._step_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+                        st["step"] = self._step_dev
+                    else:
+                        st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 keep.append(g)
-                by_step.setdefault(int(st["step"]), []).append(
+                if self.capturable:
+                    key = -1
+                else:
+                    st["step"] += 1
+                    key = int(st["step"])
+                by_step.setdefault(key, []).append(
                     N.DqoAdamTensor(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(), v=st["exp_avg_sq"].data_ptr(), n=p.numel(),
                                     lr=float(group["lr"])))
         for step, ts in by_step.items():
@@ -195,5 +212,10 @@ class DqoAdam(torch.optim.Optimizer):
                 for i in range(0, len(ts), 16):
                     chunk = ts[i:i + 16]
                     arr = (N.DqoAdamTensor * len(chunk))(*chunk)
-                    N.check(lib.dqo_adam_multi(ctypes.cast(arr, ctypes.c_void_p), len(chunk), step, betas[0], betas[1], eps, N.current_stream()))
+                    if self.capturable:
+                        N.check(lib.dqo_adam_multi_dev(ctypes.cast(arr, ctypes.c_void_p), len(chunk), N.ptr(self._step_dev),
+                                                       1 if i + 16 >= len(ts) else 0, betas[0], betas[1], eps, N.current_stream()))
+                    else:
+                        N.check(lib.dqo_adam_multi(ctypes.cast(arr, ctypes.c_void_p), len(chunk), step, betas[0], betas[1], eps,
+                                                   N.current_stream()))
         return loss

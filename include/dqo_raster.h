@@ -358,6 +358,12 @@ typedef struct DqoAdamTensor {
     double lr;  /* the group's learning rate as the python float it is: lr / (1 - beta1^t) is formed in double and rounded once, as torch does */
 } DqoAdamTensor;
 int dqo_adam_multi(const DqoAdamTensor* tensors, int32_t n_tensors, int32_t step, double beta1, double beta2, double eps, void* hipStream);
+/* The same with the step count on the device, for a step that is captured into a hipGraph (a replay must take the count of ITS step,
+ * not the capture's): step_dev[0] = steps taken so far; the launch applies step step_dev[0] + 1 — its bias corrections are formed by the
+ * kernel with the host path's double-precision expressions (torch's capturable Adam forms them in float) — and, with advance != 0, a
+ * one-thread launch behind it stores the new count (advance = 0 on all but the last call when one step takes several calls). */
+int dqo_adam_multi_dev(const DqoAdamTensor* tensors, int32_t n_tensors, int32_t* step_dev, int32_t advance, double beta1, double beta2,
+                       double eps, void* hipStream);
 
 /* dqo_accumulate_gaussian_error <- cuda_utils._C.accumulate_gaussian_error (submodules/cuda_utils/ext.cpp, cuda_utils.cu:17-62,
  * map_process.cu:33-245; caller SLAM/multiprocess/mapper.py:1034-1047).  Maps are [H*W]; outputs [P] are fully written
