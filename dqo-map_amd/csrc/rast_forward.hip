@@ -445,7 +445,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int SORT_THREADS = 512;   // tile_sort_kernel: eight waves = the eight 512-key runs of a 4096-key segment in one round
 constexpr int SORT_GRID = 768;      // its persistent grid: 256 CUs x 3 blocks of 48 KB LDS
-constexpr int SORTW_CAP = 1024;
+#ifndef DQO_SORTW_CAP
+#define DQO_SORTW_CAP 1024
+#endif
+constexpr int SORTW_CAP = DQO_SORTW_CAP;
 
 // The value of lane ^ D, D a power of two, without the LDS crossbar (ds_bpermute costs 20-60 cycles per dependent use and shares
 // the LDS pipe of the CU; DPP moves 3-5, the gfx950 row / half swaps 4-9: tools/ubench_valu.hip):
