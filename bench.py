@@ -274,7 +274,6 @@ def make_dropin_graph_step(prob, device):
     DqoAdam(capturable=True: the step count lives on the device) — the reference's operator surface with the host time of its ~60 eager
     launches gone.  (The reference's own eager loss / attach loss cannot be captured as they stand: boolean-mask indexing and
     `.item()` synchronise.)  Returns (step, graph)."""
-    import diff_gaussian_rasterization_depth as dgr
     from dqo_harness import mapping, fused_ops
     scene = {k: v for k, v in prob["scene"].items() if k != "normals"}  # (render()'s normal gather indexes with a boolean mask: a sync)
     params = mapping.GaussianParams(scene, device)
@@ -291,29 +290,15 @@ def make_dropin_graph_step(prob, device):
         opt.step()
         keep["out"], keep["loss"] = out, parts["total_loss"]
 
-    mode = dgr._sync_mode
-    dgr.set_sync_mode("lazy")
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):  # warm-up (also measures the op's instance capacity)
-        for _ in range(3):
-            opt.zero_grad(set_to_none=True)
-            iteration()
-    torch.cuda.current_stream().wait_stream(side)
-    dgr.verify_pending()
-    dgr.set_sync_mode("graph")
-    graph = torch.cuda.CUDAGraph()
-    opt.zero_grad(set_to_none=True)
-    with torch.cuda.graph(graph):
-        iteration()
-    dgr.set_sync_mode(mode)
+    cap = fused_ops.CapturedIteration(iteration, opt, warmup=3)
 
     def step():
-        graph.replay()
+        cap.replay()
         return keep["out"]
 
-    step.header = lambda: params  # (keeps the parameters alive with the step)
-    return step, graph
+    step.captured = cap
+    step.params = params  # (keeps the parameters alive with the step)
+    return step, cap
 
 
 def attach_reducer(prob, world):
@@ -1210,7 +1195,7 @@ def main():
             try:
                 sg, graph_ = make_dropin_graph_step(prob, device)
                 d6 = sorted(time_path(sg) for _ in range(3))[1]
-                hdr_ = dgr.last_header()
+                hdr_ = graph_.check()
                 alt_optin["captured_in_a_torch_cuda_graph"] = {
                     "value": round(1.0 / d6, 3), "unit": "iter/s", "ms_per_step": round(d6 * 1e3, 4), "overflow": int(hdr_["overflow"]),
                     "what": "the same opt-in loop (op, loss Functions, autograd, DqoAdam(capturable=True)) captured once with "

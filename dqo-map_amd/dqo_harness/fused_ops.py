@@ -219,3 +219,64 @@ class DqoAdam(torch.optim.Optimizer):
                         N.check(lib.dqo_adam_multi(ctypes.cast(arr, ctypes.c_void_p), len(chunk), step, betas[0], betas[1], eps,
                                                    N.current_stream()))
         return loss
+
+
+class CapturedIteration:
+    """One mapping iteration of a caller on the reference's API — `iteration()` = render through the drop-in op, loss, `.backward()`,
+    `optimizer.step()` — captured into ONE torch.cuda.graph and replayed (the op's 'graph' mode):
+
+        it = CapturedIteration(iteration, optimizer)      # warm-up iterations (they train too), then the capture
+        for _ in range(n): it.replay()
+        it.check()                                         # one small D2H read: raises if a replayed frame outgrew the capacity
+
+    `iteration` must not synchronise with the host (no `.item()`, no boolean-mask indexing: fused_ops.masked_mapping_loss /
+    fused_attach_loss instead of the eager loss), the optimiser must be capturable (DqoAdam(capturable=True) or torch.optim.Adam(
+    capturable=True)), and every tensor the iteration reads from outside (ground truth, masks, camera) is read in place at every
+    replay.  The op's synchronisation mode is restored after the capture."""
+
+    def __init__(self, iteration, optimizer, warmup=3):
+        import diff_gaussian_rasterization_depth as dgr
+        self._dgr, self.iteration, self.optimizer = dgr, iteration, optimizer
+        self.warmup = max(1, int(warmup))
+        self.graph = None
+        self.replays = 0
+        self._capture()
+
+    def _capture(self):
+        dgr = self._dgr
+        mode = dgr._sync_mode
+        try:
+            dgr.set_sync_mode("lazy")
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # the warm-up also measures the op's instance capacity (kept with 25 % headroom)
+                for _ in range(self.warmup):
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self.iteration()
+            torch.cuda.current_stream().wait_stream(side)
+            dgr.verify_pending()
+            dgr.set_sync_mode("graph")
+            self.graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self.iteration()
+            self._header = dgr._last["header"]  # the captured forward's own geometry buffer: its header is valid after every replay
+        finally:
+            dgr.set_sync_mode(mode)
+
+    def replay(self):
+        self.graph.replay()
+        self.replays += 1
+
+    def header(self):
+        h = self._header[:32].view(torch.int32).cpu().tolist()
+        return dict(num_rendered=h[0], num_tiles=h[1], overflow=h[2], max_tile_count=h[3], num_visible=h[4], num_candidates=h[5])
+
+    def check(self):
+        """Raises if the last replayed frame outgrew the captured capacity (its outputs were background, its gradients zeros)."""
+        h = self.header()
+        if h["overflow"]:
+            raise RuntimeError(f"CapturedIteration: the frame produced more Gaussian-tile instances than the captured capacity "
+                               f"({h['num_candidates']} candidates); capture again (a new CapturedIteration measures the capacity anew)")
+        return h
+

@@ -67,23 +67,32 @@ def _loop(torch, dgr, scene, settings, gt_color, gt_depth, mask, dev, optin, n_i
             losses[it] = cell
         dgr.verify_pending()
     else:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # the warm-up iteration (also measures the op's capacity): iteration 0
-            opt.zero_grad(set_to_none=True)
-            iteration()
+        if optin:  # the helper: warm-up iteration(s) on a side stream in 'lazy' mode, capture in 'graph' mode, mode restored
+            cap = fused_ops.CapturedIteration(iteration, opt, warmup=1)
+            assert dgr._sync_mode == "lazy"
             losses[0] = cell
-        torch.cuda.current_stream().wait_stream(side)
-        dgr.verify_pending()
-        dgr.set_sync_mode("graph")
-        g = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):  # capturing runs nothing: iteration 1 is the first replay
-            iteration()
-        for it in range(1, n_iters):
-            g.replay()
-            losses[it] = cell
-        hdr = dgr.last_header()
+            for it in range(1, n_iters):
+                cap.replay()
+                losses[it] = cell
+            hdr = cap.check()
+        else:  # ... and by hand
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # the warm-up iteration (also measures the op's capacity): iteration 0
+                opt.zero_grad(set_to_none=True)
+                iteration()
+                losses[0] = cell
+            torch.cuda.current_stream().wait_stream(side)
+            dgr.verify_pending()
+            dgr.set_sync_mode("graph")
+            g = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):  # capturing runs nothing: iteration 1 is the first replay
+                iteration()
+            for it in range(1, n_iters):
+                g.replay()
+                losses[it] = cell
+            hdr = dgr.last_header()
         assert hdr["overflow"] == 0 and hdr["num_rendered"] > 0
     torch.cuda.synchronize()
     return losses.cpu().numpy(), [p.detach().cpu().numpy() for p in (params._xyz, params._features_dc, params._features_rest,
@@ -118,7 +127,7 @@ def test_graph_mode_needs_a_known_capacity(env):
         mapping.render(settings, params.activated())
     dgr.set_capacity(777, settings.image_width, settings.image_height, 200000)
     out = mapping.render(settings, params.activated())
-    assert dgr.last_header()["overflow"] == 0 and float(out["render"].sum()) > 0
+    assert dgr.last_header()["overflow"] == 0 and float(out["render"].detach().sum()) > 0
 
 
 def test_dqo_adam_capturable_is_dqo_adam(env):
