@@ -375,11 +375,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_out_color, grad_out_depth = _f32(grad_out_color, "grad_out_color"), _f32(grad_out_depth, "grad_out_depth")
         with torch.cuda.device(dev):
             stream = N.current_stream()
+            # dL/dmeans2D is computed by the reference's C++ and dropped by its Python (__init__.py:247-283 returns no slot for it);
+            # dL/dcolors_precomp and dL/dcov3D_precomp only have a receiver when those inputs were given: rows nobody reads are not
+            # written (NULL = the per-Gaussian kernel skips the tensor: 24 of its 142 MB of stores on config 3)
+            want_colors, want_cov = colors_precomp.numel() != 0, cov3Ds_precomp.numel() != 0
             g_means3D = torch.empty((P, 3), **f32)
-            g_means2D = torch.empty((P, 3), **f32)
-            g_colors = torch.empty((P, 3), **f32)
+            g_colors = torch.empty((P, 3), **f32) if want_colors else None
             g_opacity = torch.empty((P, 1), **f32)
-            g_cov3D = torch.empty((P, 6), **f32)
+            g_cov3D = torch.empty((P, 6), **f32) if want_cov else None
             g_sh = torch.empty((P, M, 3), **f32)
             g_scales = torch.empty((P, 3), **f32)
             g_rot = torch.empty((P, 4), **f32)
@@ -394,16 +397,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if getattr(ctx, "object_gate", None) is not None:
                     gate = N.DqoObjectGate(gaussian_object=N.ptr(ctx.object_gate[0]), pixel_object=N.ptr(ctx.object_gate[1]))
                     cctx.object_gate = ctypes.addressof(gate)
-                grads = N.DqoRastGrads(dL_dmeans3D=g_means3D.data_ptr(), dL_dsh=N.ptr(g_sh), dL_dcolors=g_colors.data_ptr(),
+                grads = N.DqoRastGrads(dL_dmeans3D=g_means3D.data_ptr(), dL_dsh=N.ptr(g_sh), dL_dcolors=N.ptr(g_colors),
                                        dL_dopacity=g_opacity.data_ptr(), dL_dscales=g_scales.data_ptr(),
-                                       dL_drotations=g_rot.data_ptr(), dL_dcov3D=g_cov3D.data_ptr(), dL_dmeans2D=g_means2D.data_ptr(),
+                                       dL_drotations=g_rot.data_ptr(), dL_dcov3D=N.ptr(g_cov3D), dL_dmeans2D=None,
                                        skip_culled_rows=1 if getattr(ctx, "sparse_grad_rows", False) else 0)
                 N.check(lib.dqo_rast_backward(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(cctx),
                                               grad_out_color.data_ptr(), grad_out_depth.data_ptr(), hit_depth.data_ptr(),
                                               ctypes.byref(grads), ws.data_ptr(), ws.numel(), stream))
         # gradient slots of the reference (__init__.py:273-283); inputs handed over as empty tensors get None
         def slot(g, inp):
-            return g if inp.numel() != 0 else None
+            return g if (g is not None and inp.numel() != 0) else None
         return (g_means3D, slot(g_sh, sh), slot(g_colors, colors_precomp), g_opacity.view_as(opacities) if opacities.numel() else None,
                 slot(g_scales, scales), slot(g_rot, rotations), slot(g_cov3D, cov3Ds_precomp), None, None, None, None)
 
