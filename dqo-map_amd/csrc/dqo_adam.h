@@ -57,6 +57,27 @@ template <typename T>
 __device__ __forceinline__ void stnt(T v, T* p) {
     __builtin_nontemporal_store(v, p);
 }
+// The moments of the SMALL groups ([P,3] xyz / scaling, [P] opacity): plain accesses.  A non-temporal access to part of a line is
+// served memory-side without the neighbours' help; through L2 the rows of adjacent Gaussians share their lines (measured, round 4:
+// fused tail 129 -> 121 us on cfg 3, 508 -> 467 us on cfg 5; without any of this traffic: 111 / 368 — `-DDQO_SMALL_MV_NT` restores the
+// non-temporal form).  The SH moments (whole 192-byte rows, 0.7 GB touched once per iteration) stay non-temporal: plain accesses there
+// measured +0 / +20 us.
+template <typename T>
+__device__ __forceinline__ T ldsm(const T* p) {
+#ifdef DQO_SMALL_MV_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stsm(T v, T* p) {
+#ifdef DQO_SMALL_MV_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 __device__ __forceinline__ float adam_wave_red(float v) {
 #pragma unroll
@@ -135,9 +156,9 @@ __device__ __forceinline__ void adam_xyz_update(const AdamArgs& a, const uint32_
         att_sum += 0.5f * a.attach_g3 * (dx * dx + ds * ds);
     }
     adam1(p, gx, m, v, a, a.step_xyz);
-    a.xyz[i] = p, stnt(m, &a.m_xyz[i]), stnt(v, &a.v_xyz[i]);
+    a.xyz[i] = p, stsm(m, &a.m_xyz[i]), stsm(v, &a.v_xyz[i]);
     adam1(ps, gs, ms, vs, a, a.step_scaling);
-    a.scaling_raw[i] = ps, stnt(ms, &a.m_scaling[i]), stnt(vs, &a.v_scaling[i]);
+    a.scaling_raw[i] = ps, stsm(ms, &a.m_scaling[i]), stsm(vs, &a.v_scaling[i]);
     if (a.act_scales) a.act_scales[i] = expf(ps);  // = activate_kernel on the updated value
 }
 
@@ -153,7 +174,7 @@ __device__ __forceinline__ void adam_row_update(const AdamArgs& a, const uint32_
     float4 q = x.q, mq = x.mq, vq = x.vq;
     const float sg = 1.0f / (1.0f + expf(-p));
     adam1(p, (has_g ? x.go_ld : 0.f) * (sg * (1.f - sg)), m, v, a, a.step_opacity);
-    a.opacity_raw[i] = p, stnt(m, &a.m_opacity[i]), stnt(v, &a.v_opacity[i]);
+    a.opacity_raw[i] = p, stsm(m, &a.m_opacity[i]), stsm(v, &a.v_opacity[i]);
     if (a.act_opacity) a.act_opacity[i] = 1.0f / (1.0f + expf(-p));
 
     const float4 g = has_g ? x.gr_ld : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -198,8 +219,8 @@ __device__ __forceinline__ float adam_passes(const AdamArgs& a, const uint32_t* 
         const size_t i = (size_t)(r & 0x3fffffffu) * 3 + j;
         // all loads of the element in one round (a row outside the attach set reads element 0 and discards it)
         AdamXyzVals x;
-        x.p = a.xyz[i], x.m = ldnt(&a.m_xyz[i]), x.v = ldnt(&a.v_xyz[i]);
-        x.ps = a.scaling_raw[i], x.ms = ldnt(&a.m_scaling[i]), x.vs = ldnt(&a.v_scaling[i]);
+        x.p = a.xyz[i], x.m = ldsm(&a.m_xyz[i]), x.v = ldsm(&a.v_xyz[i]);
+        x.ps = a.scaling_raw[i], x.ms = ldsm(&a.m_scaling[i]), x.vs = ldsm(&a.v_scaling[i]);
         x.gx_ld = gsrc.xyz((int)k, j, i, has_g), x.gs_ld = gsrc.scales((int)k, j, i, has_g);
         x.p0 = x.ps0 = 0.f;
         if (ATTACH) {
@@ -262,7 +283,7 @@ __device__ __forceinline__ float adam_passes(const AdamArgs& a, const uint32_t* 
         const bool has_g = (r >> 31) != 0u;
         // all loads of the row in one round
         AdamRowVals x;
-        x.p = a.opacity_raw[i], x.m = ldnt(&a.m_opacity[i]), x.v = ldnt(&a.v_opacity[i]);
+        x.p = a.opacity_raw[i], x.m = ldsm(&a.m_opacity[i]), x.v = ldsm(&a.v_opacity[i]);
         x.q = reinterpret_cast<float4*>(a.rotation_raw)[i];
         x.mq = reinterpret_cast<float4*>(a.m_rotation)[i], x.vq = reinterpret_cast<float4*>(a.v_rotation)[i];
         x.go_ld = gsrc.opacity(tid, i, has_g);
@@ -300,8 +321,8 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
         const bool has_g = (r >> 31) != 0u;
         const size_t i = (size_t)(r & 0x3fffffffu) * 3 + j;
         AdamXyzVals x;
-        x.p = a.xyz[i], x.m = ldnt(&a.m_xyz[i]), x.v = ldnt(&a.v_xyz[i]);
-        x.ps = a.scaling_raw[i], x.ms = ldnt(&a.m_scaling[i]), x.vs = ldnt(&a.v_scaling[i]);
+        x.p = a.xyz[i], x.m = ldsm(&a.m_xyz[i]), x.v = ldsm(&a.v_xyz[i]);
+        x.ps = a.scaling_raw[i], x.ms = ldsm(&a.m_scaling[i]), x.vs = ldsm(&a.v_scaling[i]);
         x.gx_ld = gsrc.xyz((int)k, j, i, has_g), x.gs_ld = gsrc.scales((int)k, j, i, has_g);
         x.p0 = x.ps0 = 0.f;
         if (ATTACH) {
@@ -357,7 +378,7 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
         const uint32_t r = s_rows[tid], i = r & 0x3fffffffu;
         const bool has_g = (r >> 31) != 0u;
         AdamRowVals x;
-        x.p = a.opacity_raw[i], x.m = ldnt(&a.m_opacity[i]), x.v = ldnt(&a.v_opacity[i]);
+        x.p = a.opacity_raw[i], x.m = ldsm(&a.m_opacity[i]), x.v = ldsm(&a.v_opacity[i]);
         x.q = reinterpret_cast<float4*>(a.rotation_raw)[i];
         x.mq = reinterpret_cast<float4*>(a.m_rotation)[i], x.vq = reinterpret_cast<float4*>(a.v_rotation)[i];
         x.go_ld = gsrc.opacity(tid, i, has_g);
