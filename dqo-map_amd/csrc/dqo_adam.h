@@ -102,11 +102,12 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 // k = list row of the block, i = element index in the parameter tensor, has_g = the Gaussian has a gradient row.
 struct AdamGradGlobal {
     const AdamArgs& a;
-    __device__ __forceinline__ float xyz(int, uint32_t, size_t i, bool has_g) const { return ldnt(&a.g_xyz[has_g ? i : 0]); }
-    __device__ __forceinline__ float scales(int, uint32_t, size_t i, bool has_g) const { return ldnt(&a.g_scales[has_g ? i : 0]); }
+    // (the small rows through plain loads, like their moments: ldsm)
+    __device__ __forceinline__ float xyz(int, uint32_t, size_t i, bool has_g) const { return ldsm(&a.g_xyz[has_g ? i : 0]); }
+    __device__ __forceinline__ float scales(int, uint32_t, size_t i, bool has_g) const { return ldsm(&a.g_scales[has_g ? i : 0]); }
     // SH element j of the row; ei = its element index, e0 = a valid element index of the same trip
     __device__ __forceinline__ float sh(int, uint32_t, uint32_t ei, uint32_t e0, bool has_g) const { return ldnt(&a.g_shs[has_g ? ei : e0]); }
-    __device__ __forceinline__ float opacity(int, uint32_t i, bool has_g) const { return ldnt(&a.g_opacity[has_g ? i : 0u]); }
+    __device__ __forceinline__ float opacity(int, uint32_t i, bool has_g) const { return ldsm(&a.g_opacity[has_g ? i : 0u]); }
     __device__ __forceinline__ float4 rot(int, uint32_t i, bool has_g) const { return reinterpret_cast<const float4*>(a.g_rot)[has_g ? i : 0u]; }
 };
 
