@@ -68,6 +68,23 @@ def test_python_surface_matches_reference(native):
     assert callable(distCUDA2)
 
 
+def test_sync_modes_of_the_operator(native):
+    """Host logic only: the four modes are accepted, anything else is refused, and the capacity hint of a shape only grows."""
+    import diff_gaussian_rasterization_depth as m
+    try:
+        for mode in ("lazy", "deferred", "graph", "exact"):
+            m.set_sync_mode(mode)
+            assert m._sync_mode == mode
+        with pytest.raises(ValueError):
+            m.set_sync_mode("eager")
+        m.set_capacity(1234, 64, 48, 1000, device_index=0)
+        m.set_capacity(1234, 64, 48, 500, device_index=0)
+        assert m._cap_hint[(0, 1234, 64, 48)] == 1000
+    finally:
+        m.set_sync_mode("exact")
+        m._cap_hint.pop((0, 1234, 64, 48), None)
+
+
 def test_no_cpu_fallback(native):
     import torch
     from simple_knn._C import distCUDA2
