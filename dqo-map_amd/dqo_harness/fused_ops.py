@@ -249,10 +249,19 @@ class CapturedIteration:
             dgr.set_sync_mode("lazy")
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # the warm-up also measures the op's instance capacity (kept with 25 % headroom)
-                for _ in range(self.warmup):
-                    self.optimizer.zero_grad(set_to_none=True)
-                    self.iteration()
+            # (the parameters' AccumulateGrad nodes were created on the caller's stream and the warm-up runs on a side stream, as
+            # torch's capture recipe asks: the mismatch is intended, its warning is switched off for the warm-up)
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
+            try:
+                with torch.cuda.stream(side):  # the warm-up also measures the op's instance capacity (kept with 25 % headroom)
+                    for _ in range(self.warmup):
+                        self.optimizer.zero_grad(set_to_none=True)
+                        self.iteration()
+            finally:
+                if quiet is not None:
+                    quiet(True)
             torch.cuda.current_stream().wait_stream(side)
             dgr.verify_pending()
             dgr.set_sync_mode("graph")
