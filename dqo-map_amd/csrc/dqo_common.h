@@ -312,6 +312,13 @@ struct DqoView {
     int P, D, M;
 };
 
+// The inputs of the late part of the per-Gaussian forward (dqo_k1_late.h) for the extra blocks of the tile_sort_wave_kernel launch
+struct DqoK1Late {
+    DqoView v;
+    const float *means3D, *scales, *rotations, *shs, *colors_precomp;
+    int first_block;  // blocks [first_block, gridDim.x) of the launch do the late part, the launch's block size of Gaussians each
+};
+
 static inline DqoView dqo_make_view(const DqoRastParams* p, const DqoRastInputs* in) {
     DqoView v;
     v.view = in->viewmatrix;

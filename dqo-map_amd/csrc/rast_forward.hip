@@ -17,6 +17,7 @@
 #include "dqo_common.h"
 #include "dqo_cull.h"
 #include "dqo_gauss_chain.h"
+#include "dqo_k1_late.h"
 
 #ifndef K1_WAVES
 #define K1_WAVES 4     // preprocess_kernel: waves per SIMD the register allocation leaves room for
@@ -37,128 +38,6 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int K1_THREADS = 256;
 constexpr int K1_ITEMS = 1;
-
-__device__ __forceinline__ void quat_to_R(const float4 q, float Rm[3][3]) {
-#pragma clang fp contract(off)
-    const float r = q.x, x = q.y, y = q.z, z = q.w;
-    Rm[0][0] = 1.f - 2.f * (y * y + z * z);
-    Rm[0][1] = 2.f * (x * y - r * z);
-    Rm[0][2] = 2.f * (x * z + r * y);
-    Rm[1][0] = 2.f * (x * y + r * z);
-    Rm[1][1] = 1.f - 2.f * (x * x + z * z);
-    Rm[1][2] = 2.f * (y * z - r * x);
-    Rm[2][0] = 2.f * (x * z - r * y);
-    Rm[2][1] = 2.f * (y * z + r * x);
-    Rm[2][2] = 1.f - 2.f * (x * x + y * y);
-}
-
-__device__ __forceinline__ int arg_min3(float a, float b, float c) { return (a <= b && a <= c) ? 0 : ((b <= a && b <= c) ? 1 : 2); }
-__device__ __forceinline__ int arg_max3(float a, float b, float c) { return (a >= b && a >= c) ? 0 : ((b >= a && b >= c) ? 1 : 2); }
-
-__constant__ float kSH_C0 = 0.28209479177387814f;
-__constant__ float kSH_C1 = 0.4886025119029199f;
-__constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
-                                0.5462742152960396f};
-__constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
-                                -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
-
-// Where the late part of the per-Gaussian forward runs (k1_late_part below).  Inside preprocess_kernel it costs 15-20 us on a 500 k map;
-// in the extra blocks of the tile_sort_wave_kernel launch it runs in the shadow of the per-tile sorts, whose few busy waves leave the
-// GPU idle for their whole serial chain: -7 us per iteration on cfg 3 (-15 us with every Gaussian in view), -3 us on cfg 2, +-0 on cfg 4
-// (1 M), +12 us on cfg 5 (2 M: more late work than the sorts can hide, and it loses its overlap with the early part's arithmetic) —
-// hence a rule on the map size (same-box A/B; DQO_K1_SPLIT_MAX_P overrides it: 0 = never).
-static int dqo_k1_split(int P) {
-    static const long max_p = [] {
-        const char* e = getenv("DQO_K1_SPLIT_MAX_P");
-        return (e != nullptr && e[0] != '\0') ? atol(e) : 786432L;
-    }();
-    return (long)P <= max_p;
-}
-
-// The part of the per-Gaussian forward that only the blend kernels and the backward need (colour from SH + its direction derivative,
-// surfel normal, camera-space point): the statements of forward.cu:104-155 and :54-74, 779-785.  Called by preprocess_kernel itself, or
-// — on maps of up to DQO_K1_SPLIT_MAX_P Gaussians (dqo_k1_split) — by the extra blocks of the tile_sort_wave_kernel launch (k1_late_block), where it runs beside the per-tile sorts:
-// those keep a few waves busy for their whole serial chain and leave the rest of the GPU idle, this part is memory traffic (the 192-byte
-// SH row) and plain arithmetic that nothing before the blend kernel waits for.
-__device__ __forceinline__ void k1_late_part(const DqoView& v, const float (&view)[16], const float cam0, const float cam1, const float cam2,
-                                             const int idx, const float px, const float py, const float pz, const float tvx, const float tvy,
-                                             const float tvz, const float sx, const float sy, const float sz, const float (&Rm)[3][3],
-                                             const float* __restrict__ shs, const float* __restrict__ colors_precomp, const DqoGeomLayout& g) {
-#pragma clang fp contract(off)
-    // colour: computeColorFromSH, forward.cu:104-155
-    float rgb[3];
-    float dd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t clampbits = 0;
-    if (colors_precomp == nullptr) {
-        const float dxx = px - cam0, dyy = py - cam1, dzz = pz - cam2;
-        const float len = sqrtf(dxx * dxx + dyy * dyy + dzz * dzz);
-        const float x = dxx / len, y = dyy / len, z = dzz / len;
-        // all coefficients of the active degree in ONE batch of loads: fetched inside the per-degree blocks below they
-        // would come in twelve small groups (three channels x four degrees), each waited for before the next is issued
-        const float* shp = shs + (size_t)idx * v.M * 3;
-        float sh[48];
-        if (v.D >= 3) {
-#pragma unroll
-            for (int i = 0; i < 48; i++) sh[i] = shp[i];
-        } else if (v.D == 2) {
-#pragma unroll
-            for (int i = 0; i < 27; i++) sh[i] = shp[i];
-        } else if (v.D == 1) {
-#pragma unroll
-            for (int i = 0; i < 12; i++) sh[i] = shp[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; i++) sh[i] = shp[i];
-        }
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            float result = kSH_C0 * sh[ch];
-            if (v.D > 0) {
-                result = result - kSH_C1 * y * sh[3 + ch] + kSH_C1 * z * sh[6 + ch] - kSH_C1 * x * sh[9 + ch];
-                if (v.D > 1) {
-                    result = result + kSH_C2[0] * xy * sh[12 + ch] + kSH_C2[1] * yz * sh[15 + ch] +
-                             kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + kSH_C2[3] * xz * sh[21 + ch] +
-                             kSH_C2[4] * (xx - yy) * sh[24 + ch];
-                    if (v.D > 2) {
-                        result = result + kSH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] + kSH_C3[1] * xy * z * sh[30 + ch] +
-                                 kSH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
-                                 kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
-                                 kSH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] + kSH_C3[5] * z * (xx - yy) * sh[42 + ch] +
-                                 kSH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
-                    }
-                }
-            }
-            result += 0.5f;
-            if (result < 0.f) clampbits |= 1u << ch;
-            rgb[ch] = fmaxf(result, 0.0f);
-        }
-        // d(colour)/d(direction) for the backward's view-direction gradient (backward.cu:168-258): a function of the coefficients
-        // and the direction alone, both in registers here — 9 floats instead of the backward gathering the 48-float row again
-        dqo_sh_dir_grad(v.D, sh, x, y, z, dd);
-    } else {
-        rgb[0] = colors_precomp[3 * idx], rgb[1] = colors_precomp[3 * idx + 1], rgb[2] = colors_precomp[3 * idx + 2];
-    }
-    // surfel normal / camera-space point, hoisted from the blend loop (forward.cu:54-74, 779-785)
-    const int naxis = arg_min3(sx, sy, sz), maxis = arg_max3(sx, sy, sz);
-    const float nwx = Rm[0][naxis], nwy = Rm[1][naxis], nwz = Rm[2][naxis];
-    const float smax = (maxis == 0 ? sx : (maxis == 1 ? sy : sz)) * v.scale_mod;
-    const float ncx = view[0] * nwx + view[4] * nwy + view[8] * nwz;
-    const float ncy = view[1] * nwx + view[5] * nwy + view[9] * nwz;
-    const float ncz = view[2] * nwx + view[6] * nwy + view[10] * nwz;
-    const float npc = tvx * ncx + tvy * ncy + tvz * ncz;
-
-    g.rgb_smax[idx] = make_float4(rgb[0], rgb[1], rgb[2], smax);
-    g.normal_c[idx] = make_float4(ncx, ncy, ncz, npc);
-    // .w = max of the RAW scales: the backward's depth test uses it without scale_modifier (backward.cu:1009, quirk B6)
-    g.point_c[idx] = make_float4(tvx, tvy, tvz, maxis == 0 ? sx : (maxis == 1 ? sy : sz));
-    g.clamped[idx] = (uint8_t)clampbits;
-    if (colors_precomp == nullptr) {
-        float4* const ddp = g.drgb_dir + 3 * (size_t)idx;
-        ddp[0] = make_float4(dd[0], dd[1], dd[2], 0.f), ddp[1] = make_float4(dd[3], dd[4], dd[5], 0.f);
-        ddp[2] = make_float4(dd[6], dd[7], dd[8], 0.f);
-    }
-}
 
 // LATE: the late part runs here (one kernel); !LATE: it runs in the shadow of the per-tile sorts (tile_sort_wave_kernel<true>)
 template <bool LATE>
@@ -642,42 +521,12 @@ __device__ __forceinline__ void pair_sort_tile(const DqoBinLayout& bin, uint32_t
 // one block (two waves) per tile slot; the second wave only works on lists longer than 512 entries
 constexpr int SORTW_THREADS = 128;
 
-// The inputs of the late part of the per-Gaussian forward, for the extra blocks of the tile_sort_wave_kernel launch.
-struct K1Late {
-    DqoView v;
-    const float *means3D, *scales, *rotations, *shs, *colors_precomp;
-    int first_block;  // blocks [first_block, gridDim.x) of the launch: SORTW_THREADS Gaussians each
-};
-__device__ __forceinline__ void k1_late_block(const K1Late& a, const DqoGeomLayout& g, const int block) {
-#pragma clang fp contract(off)
-    const int idx = block * SORTW_THREADS + (int)threadIdx.x;
-    if (idx >= a.v.P) return;
-    // the Gaussians preprocess_kernel kept: a non-empty tile rect (every cull of forward.cu:238-354 leaves an empty one)
-    const uint2 rc = g.rect16[idx];
-    if (!(((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu)))) return;
-    float view[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) view[i] = a.v.view[i];
-    const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
-    const float tvx = view[0] * px + view[4] * py + view[8] * pz + view[12];
-    const float tvy = view[1] * px + view[5] * py + view[9] * pz + view[13];
-    const float tvz = view[2] * px + view[6] * py + view[10] * pz + view[14];
-    const float sx = a.scales[3 * idx], sy = a.scales[3 * idx + 1], sz = a.scales[3 * idx + 2];
-    const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
-    float Rm[3][3];
-    quat_to_R(q, Rm);
-    k1_late_part(a.v, view, a.v.campos[0], a.v.campos[1], a.v.campos[2], idx, px, py, pz, tvx, tvy, tvz, sx, sy, sz, Rm, a.shs, a.colors_precomp, g);
-}
-// keep_order (DqoRastCtx.keep_tile_order, bucket mode): no tile_scan_kernel ran for this frame.  tile_order is the one an earlier
-// frame left in the image buffer (any permutation of the tiles gives the same results), a list's range follows from its own
-// counter, and the frame statistics the header needs go to the spread lines (words 2..3), which tile_sort_kernel's first block
-// sums up (header_from_spread).
 template <bool LATE>
 __global__ __launch_bounds__(SORTW_THREADS, LATE ? SORTW_LATE_WAVES : SORTW_WAVES) void tile_sort_wave_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g,
-                                                                       int64_t capacity, int keep_order, int list_split, const K1Late late) {
+                                                                       int64_t capacity, int keep_order, int list_split, const DqoK1Late late) {
     if constexpr (LATE) {
         if ((int)blockIdx.x >= late.first_block) {  // (block-uniform; the sort blocks come first: the longest lists start at once)
-            k1_late_block(late, g, (int)blockIdx.x - late.first_block);
+            k1_late_block<SORTW_THREADS>(late, g, (int)blockIdx.x - late.first_block);
             return;
         }
     }
@@ -1034,7 +883,7 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;
         const int32_t* gobj = ctx->object_gate ? ctx->object_gate->gaussian_object : nullptr;
-        if (dqo_k1_split(p->P)) {
+        if (dqo_k1_where(p->P) != 0) {
             DQO_LAUNCH("preprocess_kernel", preprocess_kernel<false>, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
                        in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words, gobj);
         } else {
@@ -1074,10 +923,10 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
             if (rc) return rc;
         }
         const int slots = 8 * ((T + 7) / 8);  // tile_order is [8][T8]
-        K1Late late;
+        DqoK1Late late;
         late.v = v, late.means3D = in->means3D, late.scales = in->scales, late.rotations = in->rotations, late.shs = in->shs;
         late.colors_precomp = in->colors_precomp, late.first_block = slots;
-        if (dqo_k1_split(p->P)) {
+        if (dqo_k1_where(p->P) == 1) {
             DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel<true>, dim3(slots + (p->P + SORTW_THREADS - 1) / SORTW_THREADS),
                        dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order, dqo_list_split(ctx), late);
         } else {
