@@ -1064,16 +1064,19 @@ def main():
 
     if runner is not None:
         runner.prepare_growth(args.warmup + args.steps)
-    for _ in range(args.warmup):
-        step()
-    if runner is not None:
-        runner.flush()  # (the timed region starts with no iteration owed)
     # the interpreter's cyclic collector off the timed region: a full collection over the set-up's objects (the synthetic maps, the
-    # oracle's arrays) is a 40-80 ms pause, and the growth steps' temporaries trigger one now and then (nothing here builds cycles)
+    # oracle's arrays) is a 40-80 ms pause, and the growth steps' temporaries trigger one now and then (nothing here builds cycles).
+    # BEFORE the warm-up, not between it and the timed region: a GPU left idle for 50 ms clocks down and needs ~10 ms of load to come
+    # back (tools/replay_times.py: the first five graph launches after such a pause run 3-6 % slower) — a 20-step timed region behind a
+    # collector pause measured the ramp, not the iteration.
     import gc
     gc.collect()
     gc.freeze()
     gc.disable()
+    for _ in range(args.warmup):
+        step()
+    if runner is not None:
+        runner.flush()  # (the timed region starts with no iteration owed)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -1147,10 +1150,10 @@ def main():
             # (host-bound loops: the allocator's block cache, the op's capacity hint and header ring, torch's kernel modules all settle
             # over the first iterations — at least ten of them, whatever --warmup says; a driver-style `--warmup 5` run used to time
             # these loops cold)
+            gc.collect()
+            gc.disable()  # (as in the main timed region: no collector pause inside the measurement, none between warm-up and measurement)
             for _ in range(max(10, args.warmup // 2)):
                 step_other()
-            gc.collect()
-            gc.disable()  # (as in the main timed region: no collector pause inside the measurement)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             k = min(args.steps, 50)
