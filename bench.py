@@ -520,7 +520,34 @@ def reduced_losses(buf, world, per_object=False):
 # ------------------------------------------------------------------------------------------------------------------
 # self checks of the sharded path
 # ------------------------------------------------------------------------------------------------------------------
-def selfcheck(args, prob, runner, device, n_iters):
+def run_twin(prob, runner, device, n_iters):
+    """The reference of self-check (2): a second mapper on the same initial state stepped alone for n_iters iterations (after its capture,
+    which holds one itself, like the timed runner's) — its final loss sums.  Independent of the timed run, so main() runs it BEFORE the
+    warm-up: the timed region then starts on a GPU that has just been working (a GPU idle through the set-up needs ~10 ms of load to
+    clock up again, tools/replay_times.py)."""
+    from dqo_harness.fused_mapping import FusedMapper
+    gate = prob.get("gate")
+    twin = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=(None if not prob.get("sharded") else
+                                                                                      (lambda n: prob["n_attach_full"])))
+    if gate is not None:
+        twin.set_object_gate(gate[0], gate[1])
+    mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
+    if runner.use_graph:
+        # (the same order of arithmetic as the timed run: list_split regroups the transmittance products, and 1e-7 between two
+        # trajectories grows to 1e-3 of the loss within dozens of Adam steps)
+        twin.capture(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"], list_split=runner.list_split)
+        for _ in range(n_iters):
+            twin.replay()
+    else:
+        for _ in range(n_iters):
+            twin.step(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"])
+    torch.cuda.synchronize()
+    out = twin.loss.clone()
+    del twin
+    return out
+
+
+def selfcheck(args, prob, runner, device, n_iters, twin_loss=None):
     """(1) the fused path's loss of the INITIAL state against the eager autograd path on the same shard (different code: drop-in op
     + torch ops): catches a blank / invalid frame inside the captured graph; (2) the END state of the timed run against the same
     shard stepped alone — a second mapper on the same initial state, same number of iterations, no collective in flight — to 1e-5.
@@ -550,22 +577,8 @@ def selfcheck(args, prob, runner, device, n_iters):
         fails += grown_shard_vs_unsharded(prob, runner, device)
     if not runner.growth_log:  # (a grown shard is compared with the unsharded job instead: grown_shard_vs_unsharded)
         end = runner.fm.loss.clone()
-        twin = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=(None if not prob.get("sharded") else
-                                                                                          (lambda n: prob["n_attach_full"])))
-        if gate is not None:
-            twin.set_object_gate(gate[0], gate[1])
-        mask_u8 = prob["render_mask"].to(torch.uint8).contiguous()
-        if runner.use_graph:
-            # (the same order of arithmetic as the timed run: list_split regroups the transmittance products, and 1e-7 between two
-            # trajectories grows to 1e-3 of the loss within dozens of Adam steps)
-            twin.capture(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"], list_split=runner.list_split)
-            for _ in range(n_iters):
-                twin.replay()
-        else:
-            for _ in range(n_iters):
-                twin.step(prob["gt_color"], prob["gt_depth"], mask_u8, tile_mask=prob["tile_mask"])
-        torch.cuda.synchronize()
-        a, b = end[:3].tolist(), twin.loss[:3].tolist()
+        twin_loss = twin_loss if twin_loss is not None else run_twin(prob, runner, device, n_iters)
+        a, b = end[:3].tolist(), twin_loss[:3].tolist()
         if not np.allclose(a, b, rtol=1e-5, atol=1e-8):
             fails.append(f"loss after {n_iters} iterations {a} != the same shard run alone {b}")
         # training happened (a silently skipped optimiser would leave the loss where it was).  Whether the loss FALLS over the first
@@ -576,7 +589,6 @@ def selfcheck(args, prob, runner, device, n_iters):
             fails.append(f"non-finite loss after {n_iters} iterations: {a}")
         if in_view and a[0] == got0[0]:
             fails.append(f"the loss did not move in {n_iters} iterations ({a[0]}): no optimiser step took effect")
-        del twin
     torch.cuda.empty_cache()
     return fails
 
@@ -1073,6 +1085,9 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
+    twin_loss = None
+    if runner is not None and not args.no_selfcheck and not runner.growth_every:
+        twin_loss = run_twin(prob, runner, device, args.warmup + args.steps)  # (self-check (2)'s reference, see run_twin)
     for _ in range(args.warmup):
         step()
     if runner is not None:
@@ -1106,7 +1121,7 @@ def main():
     fails = []
     if runner is not None and not args.no_selfcheck:
         n_iters = args.warmup + args.steps  # replays after the capture (which holds one eager iteration itself)
-        fails = selfcheck(args, prob, runner, device, n_iters)
+        fails = selfcheck(args, prob, runner, device, n_iters, twin_loss=twin_loss)
         for f in fails:
             print(f"[bench] SELF-CHECK FAILED on rank {rank}: {f}", file=sys.stderr, flush=True)
     # the collective's own cost ("the all-reduce time share"): the packed all-reduce of the iteration — the same payload,
