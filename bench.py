@@ -603,6 +603,38 @@ def object_rows(fm, k):
     return r[np.lexsort((r[:, 2], r[:, 1], r[:, 0]))]
 
 
+def replicas_reference(args, prob, runner, device, world):
+    """Beside the strong-scaling number of an N-rank run: every rank steps the WHOLE unsharded map (the N = 1 job) for the same K
+    iterations, barrier to barrier — N independent replicas, the aggregate the prompt's "replicas only" reading of this path would
+    report.  What limits the sharded job (object granularity, the per-shard launch floor: DESIGN.md §6) is the distance between the two."""
+    from dqo_harness import sharding
+    from dqo_harness.sharding import PackedAllReduce
+    full_prob = dict(prob, scene=prob["full"], sharded=False, P_shard=prob["P"], render_mask=prob["pix_obj"] >= 0,
+                     gate=(None if prob.get("gate") is None else
+                           (torch.tensor(np.asarray(prob["full"]["obj_id"], np.int32), device=device), prob["pix_obj"])))
+    full_prob["tile_mask"] = torch.tensor(sharding.tile_mask_from_pixel_mask(full_prob["render_mask"].cpu().numpy()), device=device)
+    rep = FusedRunner(full_prob, device, PackedAllReduce(LOSS_SPEC, device), 1, use_graph=runner.use_graph, loss_tap=runner.loss_tap,
+                      fused_tail=runner.fused_tail, list_split=parse_list_split(args.list_split), unroll=args.graph_unroll)
+    for _ in range(max(args.warmup, 8)):
+        rep.step()
+    rep.flush()
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rep.step()
+    rep.flush()
+    torch.cuda.synchronize()
+    tt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt.item())
+    del rep
+    torch.cuda.empty_cache()
+    return {"value": round(world * args.steps / dt, 3), "unit": "iter/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "what": f"{world} replicas: every rank steps the whole unsharded map (the N = 1 job) for the same {args.steps} iterations, "
+                    "barrier to barrier, max over the ranks — the aggregate of independent replicas, beside the strong-scaling value above"}
+
+
 def grown_shard_vs_unsharded(prob, runner, device):
     """Growth under sharding computes the N = 1 function: the UNSHARDED job — the full map, the same candidate batches, the same growth
     schedule, the same list-split thresholds as this rank (so that every list is blended in the same grouping) — is run beside on this
@@ -1158,6 +1190,10 @@ def main():
         torch.distributed.all_reduce(n_fail)
     selfcheck_ok = int(n_fail.item()) == 0
 
+    replicas = None
+    if world > 1 and runner is not None and args.scaling == "strong" and not args.no_aux and not args.growth_every:
+        replicas = replicas_reference(args, prob, runner, device, world)
+
     # ---- the other path, timed the same way (single GPU only), so both numbers come from one run ----
     alt = alt_optin = None
     if world == 1:
@@ -1425,6 +1461,8 @@ def main():
             line["other_workload"] = other
         if aux is not None:
             line["config"]["aux"] = aux
+        if replicas is not None:
+            line["config"]["replicas_reference"] = replicas
         if roofline is not None:
             line["roofline"] = roofline
         if cpu is not None:
