@@ -206,3 +206,35 @@ def test_backward_deterministic(torch_cuda):
     _, g2 = U.run_hip(cam, sc, dL=dL)
     for k in g1:
         np.testing.assert_array_equal(g1[k], g2[k])
+
+
+def test_late_part_placement_gives_identical_bits(torch_cuda):
+    """The late part of the per-Gaussian forward (SH colour, its direction derivative, surfel normal) runs inside preprocess_kernel or in
+    extra blocks of the sort launch (csrc/dqo_k1_late.h, DQO_K1_WHERE): the same statements — outputs and gradients must agree bit for
+    bit.  The switch is read once per process, so each placement renders in a child process and reports a digest."""
+    import os, subprocess, sys
+    code = r'''
+import hashlib, sys, os
+import numpy as np
+sys.path[:0] = [os.environ["DQO_TEST_ROOT"], os.environ["DQO_TEST_ROOT"] + "/dqo-map_amd", os.environ["DQO_TEST_ROOT"] + "/tests"]
+from dqo_harness import scenes
+import util_rast as U
+cam, sc = scenes.make_config(1, P=7000)
+rng = np.random.default_rng(5)
+dL = (rng.normal(size=(3, cam.H, cam.W)).astype(np.float32), rng.normal(size=(1, cam.H, cam.W)).astype(np.float32))
+res, grads = U.run_hip(cam, sc, dL=dL)
+h = hashlib.sha256()
+for k in sorted(res):
+    h.update(np.ascontiguousarray(res[k]).tobytes())
+for k in sorted(grads):
+    h.update(np.ascontiguousarray(grads[k]).tobytes())
+print("DIGEST", h.hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for where in ("0", "1"):
+        env = dict(os.environ, DQO_K1_WHERE=where, DQO_TEST_ROOT=root)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
