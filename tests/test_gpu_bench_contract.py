@@ -54,3 +54,5 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert "sharded by object id over 2 ranks" in d["config"]["workload"]
     assert 0 < d["config"]["P_shard"] < d["config"]["P"] and d["loss"][0] > 0
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    rep = d["config"]["replicas_reference"]  # every rank stepping the whole unsharded map: the aggregate of two replicas
+    assert rep["unit"] == "iter/s" and rep["value"] > 0 and rep["ms_per_step"] > 0
