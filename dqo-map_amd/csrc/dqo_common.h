@@ -312,7 +312,7 @@ struct DqoView {
     int P, D, M;
 };
 
-// The inputs of the late part of the per-Gaussian forward (dqo_k1_late.h) for the extra blocks of the tile_sort_wave_kernel launch
+// The inputs of the late part of the per-Gaussian forward (dqo_k1_late.h) for the extra blocks of a sort launch
 struct DqoK1Late {
     DqoView v;
     const float *means3D, *scales, *rotations, *shs, *colors_precomp;

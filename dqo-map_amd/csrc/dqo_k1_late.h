@@ -1,5 +1,5 @@
 // The late part of the per-Gaussian forward (forward.cu:104-155 colour from SH, :54-74 / 779-785 surfel normal and camera-space point) and
-// where it runs (preprocess_kernel<true> or tile_sort_wave_kernel<true>, rast_forward.hip).  Everything here has internal linkage.
+// where it runs (preprocess_kernel<true>, tile_sort_wave_kernel<true> or tile_sort_kernel<true>, rast_forward.hip).  Everything here has internal linkage.
 #pragma once
 #include <cstdlib>
 
@@ -32,26 +32,30 @@ __constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315
 __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                 -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
 
-// Where the late part of the per-Gaussian forward runs (k1_late_part below).  Inside preprocess_kernel it costs 15-20 us on a 500 k map;
-// in the extra blocks of the tile_sort_wave_kernel launch it runs in the shadow of the per-tile sorts, whose few busy waves leave the
-// GPU idle for their whole serial chain: -7 us per iteration on cfg 3 (-15 us with every Gaussian in view), -3 us on cfg 2, +-0 on cfg 4
-// (1 M), +12 us on cfg 5 (2 M: more late work than the sorts can hide, and it loses its overlap with the early part's arithmetic) —
-// hence a rule on the map size (same-box A/B).
-// 0: inside preprocess_kernel<true>;  1: extra blocks of the tile_sort_wave_kernel<true> launch (DQO_K1_WHERE forces one of them).
-// (Extra blocks of the bin_count_kernel launch were measured too: that kernel's atomics keep the memory system busy — the late part
-// does not hide there at all: bin_count 55 -> 72 us on cfg 3, 137 -> 276 us on cfg 5.)
+// Where the late part of the per-Gaussian forward runs (k1_late_part below).  Inside preprocess_kernel it costs 15-20 us on a 500 k map
+// and 100 us on a 2 M one; nothing before the blend kernel needs its results, and the sort kernels between are serial chains (per-tile
+// sorts: a few busy waves) or LDS / barrier-bound (the long-list sorts) that leave the memory pipes idle.  So it rides one of their
+// launches as EXTRA BLOCKS behind the sort blocks (one heterogeneous launch: no second stream, the sorts start first):
+//   0: inside preprocess_kernel<true> (DQO_K1_WHERE=0 forces it: the A/B baseline);
+//   1: tile_sort_wave_kernel<true>  — maps of up to 768 Ki Gaussians: -5..7 us per iteration on cfg 3 (-15 us with every Gaussian in
+//      view), -3 us on cfg 2; on bigger maps there is more late work than the per-tile sorts can hide (+-0 on cfg 4, +12 us on cfg 5);
+//   2: tile_sort_kernel<true>       — bigger maps, whose long lists keep that kernel running for 30-95 us: -56 us per iteration on
+//      cfg 5 (preprocess 154 -> 48 us, long-list sort 94 -> 131 us), +-0 on cfg 4.
+// Measured and not used: extra blocks of the bin_count_kernel launch (its atomics keep the memory system busy: nothing hides, bin_count
+// 55 -> 72 us on cfg 3, 137 -> 276 us on cfg 5) and a kernel of its own on a side stream (no gain on any configuration).
+// Same-box A/B with tools/ab_where.sh.
 static int dqo_k1_where(int P) {
     static const int forced = [] {
         const char* e = getenv("DQO_K1_WHERE");
         return (e != nullptr && e[0] != '\0') ? atoi(e) : -1;
     }();
-    if (forced == 0 || forced == 1) return forced;
-    return P <= 786432 ? 1 : 0;
+    if (forced >= 0 && forced <= 2) return forced;
+    return P <= 786432 ? 1 : 2;
 }
 
 // The part of the per-Gaussian forward that only the blend kernels and the backward need (colour from SH + its direction derivative,
 // surfel normal, camera-space point): the statements of forward.cu:104-155 and :54-74, 779-785.  Called by preprocess_kernel itself, or
-// — where dqo_k1_where says so — by the extra blocks of the tile_sort_wave_kernel launch (k1_late_block), where it runs beside the per-tile sorts:
+// — where dqo_k1_where says so — by the extra blocks of a sort launch (k1_late_block), where it runs beside the sorts:
 // those keep a few waves busy for their whole serial chain and leave the rest of the GPU idle, this part is memory traffic (the 192-byte
 // SH row) and plain arithmetic that nothing before the blend kernel waits for.
 __device__ __forceinline__ void k1_late_part(const DqoView& v, const float (&view)[16], const float cam0, const float cam1, const float cam2,

@@ -619,14 +619,22 @@ __device__ __forceinline__ void header_from_spread(const DqoGeomLayout& g, int64
     }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g, int64_t capacity,
-                                                                 int keep_order) {
+template <bool LATE>
+__global__ __launch_bounds__(SORT_THREADS, LATE ? 4 : 6) void tile_sort_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g, int64_t capacity,
+                                                                 int keep_order, const DqoK1Late late) {
+    if constexpr (LATE) {  // (the late part of the per-Gaussian forward behind the long-list sort blocks: dqo_k1_where == 2)
+        if ((int)blockIdx.x >= late.first_block) {
+            k1_late_block<SORT_THREADS>(late, g, (int)blockIdx.x - late.first_block);
+            return;
+        }
+    }
+    const uint32_t sort_blocks = LATE ? (uint32_t)late.first_block : gridDim.x;
     __shared__ uint64_t s_keys[SORTL_SEG];
     __shared__ uint32_t s_vals[SORTL_SEG];
     if (keep_order && blockIdx.x == 0 && threadIdx.x < 64) header_from_spread(g, capacity, bin.bucket, (int)threadIdx.x);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t n_long = min(g.counters[1], (uint32_t)T);  // tiles queued by tile_sort_wave_kernel
-    for (uint32_t q = blockIdx.x; q < n_long; q += gridDim.x) {  // (block-uniform trip count; every helper ends with a barrier)
+    for (uint32_t q = blockIdx.x; q < n_long; q += sort_blocks) {  // (block-uniform trip count; every helper ends with a barrier)
     const uint32_t tile = img.long_tiles[q];
     const uint2 rg = img.ranges[tile];
     const int n = (int)(rg.y - rg.x);
@@ -933,7 +941,13 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
             DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel<false>, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order,
                        dqo_list_split(ctx), late);
         }
-        DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order);
+        if (dqo_k1_where(p->P) == 2) {
+            late.first_block = SORT_GRID;
+            DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel<true>, dim3(SORT_GRID + (p->P + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), s, T,
+                       img, bin, g, cap, keep_order, late);
+        } else {
+            DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel<false>, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order, late);
+        }
     }
     if (header_host != nullptr) DQO_CHECK_HIP(hipMemcpyAsync(header_host, g.header, sizeof(DqoRastHeader), hipMemcpyDeviceToHost, s));
     if (header_event != nullptr) DQO_CHECK_HIP(hipEventRecord(header_event, s));
