@@ -90,6 +90,10 @@ def parse():
                          "makes every N compute the N = 1 function")
     ap.add_argument("--shard-by", default="work", choices=("work", "count"),
                     help="strong scaling: balance the objects over the ranks by their on-screen work in the bench view (default) or by Gaussian count")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one rank: bring the collective layer up anyway (a ONE-rank process group on the nccl = RCCL backend) and run the "
+                         "job as a rank of an N-rank job does: one graph launch per iteration, the packed all-reduce of the loss sums started "
+                         "asynchronously beside it; the first execution of RCCL's init / all-reduce / stream semantics on a one-GPU box")
     ap.add_argument("--as-shard", default=None, metavar="R/N",
                     help="analysis on one GPU: run shard R of an N-rank strong-scaling job alone (no collective partner; not a scaling measurement)")
     return ap.parse_args()
@@ -325,9 +329,11 @@ class FusedRunner:
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
 
     def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True, list_split=0,
-                 unroll=1):
+                 unroll=1, collective=None):
         from dqo_harness.fused_mapping import FusedMapper
         self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
+        # every iteration's loss sums go into the packed all-reduce (N > 1, or the one-rank group of --force-collective)
+        self.collective = (world > 1) if collective is None else bool(collective)
         self.fm = FusedMapper(prob["scene"], prob["settings"], device, attach_count_reducer=attach_reducer(prob, world))
         if prob.get("gate") is not None:
             self.fm.set_object_gate(prob["gate"][0], prob["gate"][1])
@@ -345,7 +351,7 @@ class FusedRunner:
         self.first_loss = None
         # iterations per graph launch (one rank only: at N > 1 every iteration's loss sums go into the packed all-reduce).  step() then
         # issues one launch every `unroll` calls; flush() issues what is still due, iteration by iteration
-        self.unroll = max(1, int(unroll)) if (use_graph and world == 1) else 1
+        self.unroll = max(1, int(unroll)) if (use_graph and not self.collective) else 1
         self._due = 0
         self.growth_pool = []  # the new points of every growth step: input data, resident in HBM before the timed region
         if use_graph:
@@ -486,13 +492,13 @@ class FusedRunner:
             out = self.fm.replay()
         else:
             out = self.fm.step(self.prob["gt_color"], self.prob["gt_depth"], self.mask_u8, tile_mask=self.prob["tile_mask"])
-        if self.world > 1:  # the per-iteration collective stays outside the graph and off its critical path
+        if self.collective:  # the per-iteration collective stays outside the graph and off its critical path
             self.loss_buf.reduce_async(src=self.fm.loss)
         return out
 
     def step_static(self):  # the graph's own calls issued eagerly: what the per-kernel profile pass times
         out = self.fm.step_static()
-        if self.world > 1:
+        if self.collective:
             self.loss_buf.reduce_async(src=self.fm.loss)
         return out
 
@@ -501,7 +507,7 @@ class FusedRunner:
         self.flush()
         if self.use_graph and self.fm.graph_overflowed():
             raise RuntimeError("captured graph: instance capacity exceeded, outputs invalid")
-        if self.world == 1:
+        if not self.collective:
             self.loss_buf.buf.copy_(self.fm.loss)
 
 
@@ -1040,11 +1046,18 @@ def main():
     backend_note = (f"backend {backend}; HSA_ENABLE_IPC_MODE_LEGACY=" + ("unset" if ipc is None else ipc)
                     + (" (filled in by bench.py's launcher because the caller left it unset)" if os.environ.get("DQO_BENCH_IPC_MODE_SET_BY_LAUNCHER") else
                        " (the caller's environment)") + f"; MASTER_ADDR={os.environ.get('MASTER_ADDR')}")
-    if world > 1:
+    coll = world > 1 or args.force_collective  # the collective layer is up and every iteration uses it
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
             # one process per GPU; device_id binds the communicator to this rank's GPU up front (no guessing at the first barrier)
-            torch.distributed.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+            kw = {"device_id": device} if backend == "nccl" else {}
+            if "WORLD_SIZE" not in os.environ:  # --force-collective without a launcher: a one-rank group with its own rendezvous
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    kw.update(init_method=f"tcp://127.0.0.1:{sk.getsockname()[1]}", rank=0, world_size=1)
+            torch.distributed.init_process_group(backend, **kw)
             if torch.distributed.get_world_size() != args.gpus:
                 raise SystemExit(f"bench.py: the process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
             # the first collective (it is what brings RCCL's transports up): every rank's device index, for config.devices
@@ -1090,10 +1103,10 @@ def main():
         with torch.no_grad():
             g0 = None if prob.get("gate") is None else (torch.tensor(np.asarray(prob["full"]["obj_id"], np.int32), device=device), prob["pix_obj"])
             render0 = mapping.render(prob["settings"], mapping.GaussianParams(prob["full"], device).activated(), object_gate=g0)["render"].cpu().numpy()
-    loss_buf = PackedAllReduce(LOSS_SPEC, device)
+    loss_buf = PackedAllReduce(LOSS_SPEC, device, force=coll)
     runner = step_dropin = None
     if args.path == "fused":
-        runner = FusedRunner(prob, device, loss_buf, world, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
+        runner = FusedRunner(prob, device, loss_buf, world, collective=coll, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
                              loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail,
                              list_split=parse_list_split(args.list_split), unroll=args.graph_unroll)
         step = runner.step
@@ -1102,7 +1115,7 @@ def main():
         step = step_dropin
 
     def sync_all():
-        if world > 1:
+        if coll:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -1137,7 +1150,7 @@ def main():
         runner.finish()  # overflow check + loss read-back, outside the timed region
     if args.sync_mode == "lazy":
         dgr._verify_pending(block=True)  # raises if any timed iteration overflowed its instance capacity
-    if world > 1:
+    if coll:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -1160,7 +1173,7 @@ def main():
     # the same staging path — issued back to back with nothing else in flight, max over the ranks.  In the timed loop it runs
     # asynchronously beside the next iteration's graph, so this is what it would add if it were on the critical path, not what it adds.
     allreduce = None
-    if world > 1:
+    if coll:
         n_ops = 50
         torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -1186,7 +1199,7 @@ def main():
             fails.append(f"all-reduced initial loss of the {world} shards {fl.tolist()} != the unsharded job's {want}")
             print(f"[bench] SELF-CHECK FAILED on rank {rank}: {fails[-1]}", file=sys.stderr, flush=True)
     n_fail = torch.tensor([len(fails)], device=device, dtype=torch.int32)
-    if world > 1:
+    if coll:
         torch.distributed.all_reduce(n_fail)
     selfcheck_ok = int(n_fail.item()) == 0
 
@@ -1444,10 +1457,10 @@ def main():
                                    + ("" if args.path != "fused" or args.no_graph else
                                       (" (one hipGraph replay per iteration)" if runner.unroll == 1 else
                                        f" (hipGraph replays of {runner.unroll} iterations each)")),
-                       "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
+                       "shards": world, "rccl_ranks": (torch.distributed.get_world_size() if coll else 1),
                        **({"allreduce": allreduce} if allreduce is not None else {}),
-                       "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
-                       **({"backend_note": backend_note} if world > 1 else {}),
+                       "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if coll else "none (one rank)",
+                       **({"backend_note": backend_note} if coll else {}),
                        "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}),
                        **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "graph_unroll": (runner.unroll if runner is not None else None), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
                                                                                    ("ok" if selfcheck_ok else "FAILED")), **stats},
@@ -1468,7 +1481,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if coll:
         torch.distributed.destroy_process_group()
     if not selfcheck_ok:
         sys.exit(3)

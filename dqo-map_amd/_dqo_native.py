@@ -53,7 +53,7 @@ class DqoRastGrads(ctypes.Structure):
 class DqoRastHeader(ctypes.Structure):
     _fields_ = [("num_rendered", ctypes.c_uint32), ("num_tiles", ctypes.c_uint32), ("overflow", ctypes.c_uint32),
                 ("max_tile_count", ctypes.c_uint32), ("num_visible", ctypes.c_uint32), ("num_candidates", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32 * 2)]
+                ("stage", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class DqoProfileEntry(ctypes.Structure):

@@ -210,11 +210,16 @@ DQO_API int dqo_rast_read_header(const DqoRastCtx* ctx, DqoRastHeader* host_out,
     DQO_CHECK_HIP(hipMemcpyAsync(buf, ctx->geom, sizeof(buf), hipMemcpyDeviceToHost, (hipStream_t)stream));
     DQO_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     memcpy(host_out, buf, sizeof(DqoRastHeader));
-    const uint32_t* counters = buf + 64;  // second 256-byte slot of the geom buffer
-    // after `prepare` only the counters are valid; `render` fills the header proper
-    host_out->num_rendered = counters[0];
+    // Stage 2 has written the frame's header (tile_scan_kernel / the sort kernel's header_from_spread): report it as it is.  The
+    // counters and statistics lines it was formed from are NOT a second source: bucket mode allocates slots per region (counters[0]
+    // stays 0) and dqo_rast_backward_adam's tail clears them for the next frame.
+    if (host_out->stage == 2u) return host_out->overflow ? DQO_ERR_OVERFLOW : DQO_OK;
+    // after `prepare` only the statistics lines are valid: visible Gaussians and the candidate count (>= N) a caller sizes its
+    // binning buffer from; everything else is not known yet
     uint32_t nv = 0, nc = 0;
     for (int j = 0; j < DQO_SPREAD; j++) nv += buf[128 + 64 * j], nc += buf[128 + 64 * j + 1];
+    memset(host_out, 0, sizeof(*host_out));
+    host_out->stage = 1u;
     host_out->num_visible = nv;
     host_out->num_candidates = nc;
     return host_out->overflow ? DQO_ERR_OVERFLOW : DQO_OK;

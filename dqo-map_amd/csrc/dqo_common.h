@@ -54,7 +54,8 @@ void dqo_profile_after(hipStream_t s);
 struct DqoGeomLayout {
     DqoRastHeader* header;   // 256 B reserved
     uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator of the packed-list mode), [1] long-list queue,
-                             //      [3..5] split-list queue / tickets, [6] the forward's list_split, [7] bucket mode: a slot region ran out
+                             //      [3..5] split-list queue / tickets, [6] the forward's list_split, [7] bucket mode: a slot region ran out,
+                             //      [8] frame_prezeroed was promised but the per-frame scalars were not zero (preprocess_kernel)
     uint32_t* spread;        // [DQO_SPREAD][64] statistics counters spread over DQO_SPREAD lines (same-address atomics serialise
                              //       memory-side): word 0 = visible Gaussians, word 1 = (Gaussian, tile) pairs in the tile rects,
                              //       words 2, 3 = longest list / non-empty tiles (keep_order frames), word 4 = bucket mode: the slot

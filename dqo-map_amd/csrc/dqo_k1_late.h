@@ -159,9 +159,4 @@ __device__ __forceinline__ void k1_late_block(const DqoK1Late& a, const DqoGeomL
     quat_to_R(q, Rm);
     k1_late_part(a.v, view, a.v.campos[0], a.v.campos[1], a.v.campos[2], idx, px, py, pz, tvx, tvy, tvz, sx, sy, sz, Rm, a.shs, a.colors_precomp, g);
 }
-// keep_order (DqoRastCtx.keep_tile_order, bucket mode): no tile_scan_kernel ran for this frame.  tile_order is the one an earlier
-// frame left in the image buffer (any permutation of the tiles gives the same results), a list's range follows from its own
-// counter, and the frame statistics the header needs go to the spread lines (words 2..3), which tile_sort_kernel's first block
-// sums up (header_from_spread).
-
 }  // namespace

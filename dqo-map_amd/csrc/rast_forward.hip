@@ -50,7 +50,8 @@ __global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const 
                                                                 const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
                                                                 int32_t* __restrict__ radii_out,
                                                                 int32_t* __restrict__ n_touched_out, uint32_t* __restrict__ zero_base,
-                                                                size_t zero_words, const int32_t* __restrict__ gobj) {
+                                                                size_t zero_words, const int32_t* __restrict__ gobj,
+                                                                const int check_prezeroed) {
 #pragma clang fp contract(off)
     __shared__ uint32_t s_visible;
     const int tid = threadIdx.x;
@@ -61,6 +62,21 @@ __global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const 
     const float cam0 = v.campos[0], cam1 = v.campos[1], cam2 = v.campos[2];
     __shared__ uint32_t s_cand;
     if (tid == 0) s_visible = 0, s_cand = 0;
+    // (a frame_prezeroed frame still holds the previous frame's header: mark it "stage 1" until the sort kernels rewrite it)
+    if (blockIdx.x == 0 && tid == 0) g.header->stage = 1u;
+    // DqoRastCtx.frame_prezeroed is a promise of the caller (the previous frame on this ctx ended in dqo_rast_backward_adam, whose tail
+    // clears the per-frame scalars).  A broken promise — a forward-only render, dqo_rast_backward, an error return in between — would
+    // give wrong slot bases and doubled statistics without a sign: the first block looks at the words no kernel of THIS frame has
+    // touched yet (slot allocators, queue counters, loss-tap sums; not words 0, 1 of the lines, which this launch is adding to) and
+    // raises counters[8], which both header writers fold into header.overflow.
+    if (check_prezeroed && blockIdx.x == 0 && tid < DQO_SPREAD) {
+        const uint32_t* line = g.spread + (size_t)tid * 64;
+        uint32_t bad = line[2] | line[3] | line[4];
+#pragma unroll
+        for (int i = 8; i < 16; i++) bad |= line[i];
+        if (tid < 8) bad |= g.counters[tid];
+        if (bad != 0u) atomicOr(&g.counters[8], 1u);
+    }
     // this launch also zeroes the tile histogram + tile flags for bin_count_kernel (one contiguous range, a slice per block)
     {
         const size_t per = (zero_words + gridDim.x - 1) / gridDim.x;
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         if (tid == 0) s_stat[0] = nv, s_stat[1] = nc;
     }
     // instance total of bin_count_kernel's slot allocator (bucket mode: one allocator per region, an exhausted one raises counters[7])
-    bool overflow = bucket > 0 ? g.counters[7] != 0u : (int64_t)g.counters[0] > capacity;
+    bool overflow = (bucket > 0 ? g.counters[7] != 0u : (int64_t)g.counters[0] > capacity) || g.counters[8] != 0u;
     // the padded histogram is read from HBM once; the passes below work on an LDS copy (images up to ~2M pixels)
     const bool cached = T <= SCAN_CACHE;
     if (cached)
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
         h.max_tile_count = s_max;
         h.num_visible = s_stat[0];
         h.num_candidates = s_stat[1];
-        h.reserved[0] = h.reserved[1] = 0;
+        h.stage = 2u, h.reserved = 0u;
         *g.header = h;
     }
 }
@@ -591,6 +607,10 @@ __global__ __launch_bounds__(SORTW_THREADS, LATE ? SORTW_LATE_WAVES : SORTW_WAVE
 constexpr int SORTL_SEG = 4096;
 constexpr int SORTL_RUN = SORTP_RUN;  // 512
 
+// keep_order (DqoRastCtx.keep_tile_order, bucket mode): no tile_scan_kernel ran for this frame.  tile_order is the one an earlier
+// frame left in the image buffer (any permutation of the tiles gives the same results), a list's range follows from its own
+// counter, and the frame statistics the header needs go to the spread lines (words 2..3), which tile_sort_kernel's first block
+// sums up (header_from_spread).
 // keep_order frames: the header tile_scan_kernel would have written, from the spread statistics lines (one wave)
 __device__ __forceinline__ void header_from_spread(const DqoGeomLayout& g, int64_t capacity, int bucket, int lane) {
     uint32_t nv = 0, nc = 0, mx = 0, nt = 0, total = 0;
@@ -610,11 +630,11 @@ __device__ __forceinline__ void header_from_spread(const DqoGeomLayout& g, int64
         h.num_rendered = total;
         h.num_tiles = nt;
         (void)capacity;
-        h.overflow = (g.counters[7] != 0u || mx > (uint32_t)bucket) ? 1u : 0u;
+        h.overflow = (g.counters[7] != 0u || g.counters[8] != 0u || mx > (uint32_t)bucket) ? 1u : 0u;
         h.max_tile_count = mx;
         h.num_visible = nv;
         h.num_candidates = nc;
-        h.reserved[0] = h.reserved[1] = 0;
+        h.stage = 2u, h.reserved = 0u;
         *g.header = h;
     }
 }
@@ -891,12 +911,13 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;
         const int32_t* gobj = ctx->object_gate ? ctx->object_gate->gaussian_object : nullptr;
+        const int prez = ctx->frame_prezeroed != 0 ? 1 : 0;
         if (dqo_k1_where(p->P) != 0) {
             DQO_LAUNCH("preprocess_kernel", preprocess_kernel<false>, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
-                       in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words, gobj);
+                       in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words, gobj, prez);
         } else {
             DQO_LAUNCH("preprocess_kernel", preprocess_kernel<true>, dim3(grid), dim3(K1_THREADS), s, v, in->means3D, in->scales, in->rotations,
-                       in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words, gobj);
+                       in->opacities, in->shs, in->colors_precomp, in->tile_mask, g, out->radii, out->n_touched, img.tile_count, zero_words, gobj, prez);
         }
     }
     return DQO_OK;

@@ -31,6 +31,7 @@ import _dqo_native as N
 # (SLAM/render.py:163), so state hung off the module instance would not survive from one call to the next — and the lazy mode's capacity
 # hint has to.  One lock guards it (tracker and mapper threads of one process may render concurrently).
 import threading
+import weakref
 
 _lock = threading.RLock()
 _list_split = 0         # DqoRastCtx.list_split of the forwards issued through this module (set_list_split)
@@ -104,7 +105,8 @@ def set_sync_mode(mode):
     the op does touches the host — no header copy, no event, no check; the capacity is the one earlier calls measured (run at least one
     iteration in 'lazy' mode first — the usual warm-up before a capture — or call set_capacity(P, W, H, instances)), and the frame's
     header stays on the device: last_header() (after the replay) reads it; `overflow` there means the frame was invalid (background
-    outputs, zero gradients) and the graph must be captured again with a larger capacity."""
+    outputs, zero gradients) and the graph must be captured again with a larger capacity.  The gated op's object ids are not range-checked
+    in this mode (the check reads scalars back): run one gated call in another mode first, as the warm-up does."""
     global _sync_mode
     if mode not in ("exact", "lazy", "deferred", "graph"):
         raise ValueError(mode)
@@ -152,25 +154,29 @@ def _verify_pending(block):
                            "been raised — re-run that iteration (or use set_sync_mode('exact')).")
 
 
-_gate_checked = {}  # (data_ptr, numel, version) of object-id tensors whose value range has been checked (one reduction per new tensor)
+_gate_checked = {}  # id(tensor) -> (weak reference, version) of object-id tensors whose value range has been checked
 
 
 def _check_gate_ids(gaussian_object, pixel_object):
     """The object gate's ids must lie in [0, 64) (pixel ids: < 64, negative = no owner): the kernels keep a quadrant's owners as a
     64-bit set and skip the exact id comparison where a quadrant has one owner, so an id of 69 would act on the pixels of object 5
-    (DqoObjectGate, include/dqo_raster.h).  Checked once per tensor (and again when it is modified in place)."""
+    (DqoObjectGate, include/dqo_raster.h).  Checked once per tensor OBJECT (and again when it is modified in place): the cache is
+    keyed on a weak reference, so a new tensor that the caching allocator places at a freed tensor's address is checked again.  The
+    check reads two scalars back (a host synchronisation): the 'graph' mode, whose contract is no host touch, skips it — its caller
+    validates the ids once before capturing (set_sync_mode's docstring)."""
+    if _sync_mode == "graph":
+        return
     for t, lo_ok in ((gaussian_object, False), (pixel_object, True)):
-        key = (t.data_ptr(), t.numel(), t._version)
-        if _gate_checked.get(key):
+        hit = _gate_checked.get(id(t))
+        if hit is not None and hit[0]() is t and hit[1] == t._version:
             continue
         if t.numel():
             mn, mx = int(t.min().item()), int(t.max().item())
             if mx > 63 or (mn < 0 and not lo_ok):
                 raise RuntimeError("object gate: object ids must lie in [0, 64) (negative pixel ids = no owner); got "
                                    f"[{mn}, {mx}] in {'pixel_object' if lo_ok else 'gaussian_object'}")
-        if len(_gate_checked) > 64:
-            _gate_checked.clear()
-        _gate_checked[key] = True
+        key = id(t)
+        _gate_checked[key] = (weakref.ref(t, lambda _r, k=key: _gate_checked.pop(k, None)), t._version)
 
 
 def _f32(t, name):

@@ -66,8 +66,11 @@ def tile_mask_from_pixel_mask(pixel_mask):
 class PackedAllReduce:
     """One all-reduce per iteration over a packed fp32 buffer of named shared quantities."""
 
-    def __init__(self, spec, device, group=None):
+    def __init__(self, spec, device, group=None, force=False):
+        """force: issue the collective on a ONE-rank group too (a sum over one rank: the values come back unchanged): the N-rank code
+        path, with its staging ring and stream semantics, on the backend the group was created with."""
         import torch
+        self.force = bool(force)
         self.spec = [(name, int(n)) for name, n in spec]
         self.offsets, off = {}, 0
         for name, n in self.spec:
@@ -82,7 +85,7 @@ class PackedAllReduce:
 
     def reduce(self):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force):
             dist.all_reduce(self.buf, group=self.group)
         return self
 
@@ -97,7 +100,7 @@ class PackedAllReduce:
         first src.numel() entries, the others zero) without waiting for it."""
         import torch
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+        if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)):
             return self
         if not hasattr(self, "_ring"):
             self._ring = [torch.zeros_like(self.buf) for _ in range(self.RING)]

@@ -147,7 +147,10 @@ typedef struct DqoRastCtx {
      * dqo_rast_binning_bytes_bucketed): the binning kernel writes an instance straight to tile * bucket + rank, no scan and no
      * placement pass sit between it and the sort.  A tile that outgrows its bucket raises the same overflow flag as running out
      * of inst_capacity (outputs invalid, nothing written out of bounds) — for callers that can re-run, like the captured mapping
-     * iteration.  Same lists, same order, same results as the packed mode. */
+     * iteration.  Same lists, same order, same results as the packed mode.  Capacity in bucket mode: the instance slots are handed
+     * out by up to 64 regional allocators, each owning inst_capacity / regions slots, so a frame is also flagged invalid when ONE
+     * region of the map outgrows its share although the total fits — size inst_capacity with headroom (the captured iteration
+     * uses 3 x the measured N), or use the packed mode when the capacity is tight. */
     int32_t tile_bucket_capacity;
     /* Bucket mode only.  Non-zero: keep the tile launch order (longest list first, XCD bands) that an earlier forward left in
      * `image` instead of recomputing it — the caller guarantees that a forward with this flag at 0 has run on this `image` buffer
@@ -205,7 +208,9 @@ typedef struct DqoRastHeader {
     uint32_t num_visible;    /* Gaussians with radius > 0 */
     uint32_t num_candidates; /* (Gaussian, tile) pairs inside the tile rects = the reference's num_rendered
                                 (rasterizer_impl.cu:303-309); an upper bound of N, valid after stage 1 */
-    uint32_t reserved[2];
+    uint32_t stage;          /* 1 after stage 1 (only num_visible / num_candidates are meaningful), 2 once stage 2 has written the
+                                frame's header; dqo_rast_read_header reports the device header as it is at stage 2 */
+    uint32_t reserved;
 } DqoRastHeader;
 
 int dqo_abi_version(void);
@@ -235,10 +240,17 @@ size_t dqo_rast_backward_workspace_bytes(int64_t inst_capacity);
 /* Stage 1 (per-Gaussian preprocess).  Needs ctx.geom and ctx.image; leaves num_candidates (>= N) in the device
  * header: the capacity a caller that wants a guaranteed fit allocates.  rasterizer_impl.cu:272-307 (K1, K2). */
 int dqo_rast_forward_prepare(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
-/* D2H read of the header (the ONLY synchronising call; replaces the reference's cudaMemcpy at rasterizer_impl.cu:307). */
+/* D2H read of the header (the ONLY synchronising call; replaces the reference's cudaMemcpy at rasterizer_impl.cu:307).  After
+ * stage 1 (header.stage == 1): num_visible and num_candidates, everything else 0.  After stage 2 (stage == 2): the device header as
+ * the frame's sort kernels wrote it — still valid after dqo_rast_backward / dqo_rast_backward_adam, which clear the counters the
+ * header was formed from but not the header. */
 int dqo_rast_read_header(const DqoRastCtx*, DqoRastHeader* host_out, void* hipStream);
 /* Stage 2 (footprint test + tile binning, per-tile sort, blend).  Needs ctx.binning with inst_capacity >= N, otherwise
  * the device header's overflow flag is raised, nothing is written out of bounds and the outputs are invalid.
+ * Stage 2 reads the inputs again (means3D, scales, rotations, shs / colors_precomp: the colour / surfel-normal part of the
+ * per-Gaussian forward rides in the sort launches): a two-stage caller passes the SAME, unmodified, still-alive input arrays to
+ * both stages.  With ctx.frame_prezeroed the caller promises that the previous frame on this ctx ended in dqo_rast_backward_adam
+ * (the only call that restores the zeroed per-frame scalars); any other sequence must leave the flag at 0.
  * rasterizer_impl.cu:309-440 (K3-K6). */
 int dqo_rast_forward_render(const DqoRastParams*, const DqoRastInputs*, DqoRastOutputs*, DqoRastCtx*, void* hipStream);
 /* Both stages back to back, no host synchronisation (caller guarantees / later checks capacity). */

@@ -89,3 +89,31 @@ print(f"  top / bottom halves, aligned on the entries live in both: {tot_tb / 1e
 hv = bits.reshape(N, 2, 8, 4, 4).transpose(0, 1, 3, 2, 4).reshape(N, 2, 4, 32).any(3)  # [N, quad row, 4 column strips of 4 px]: left / right halves
 tot_lr = sum(aligned_steps(hv[:, qr, 2 * qc], hv[:, qr, 2 * qc + 1]) for qr in range(2) for qc in range(2))
 print(f"  left / right halves (4 wide x 8 high), aligned: {tot_lr / 1e6:.3f} M wave steps ({tot_lr / lq.sum():.1%})")
+
+# ---- per-DPP-row sub-lists (round 5): a quadrant wave whose four 16-lane rows each walk their OWN compacted sub-list ----
+def row_sublists(name, blocks4):
+    """blocks4: [N, 4 quadrants, 4 rows] bool — is the entry live for that 16-pixel group of that quadrant."""
+    tot_async = 0.0
+    tot_sync = {64: 0.0, 128: 0.0}
+    # list position inside the tile among the entries with any arithmetic (approximates the culled HIP list)
+    pos_live = np.cumsum(live_tile) - live_tile
+    first = np.zeros(T, np.int64); first[tile_of[::-1]] = np.arange(N)[::-1]  # first instance index of each tile
+    pos_live = pos_live - pos_live[first[tile_of]]
+    for q_ in range(4):
+        rows = blocks4[:, q_, :]  # [N, 4]
+        per_row = np.stack([np.bincount(tile_of, weights=rows[:, r_], minlength=T) for r_ in range(4)], 1)
+        tot_async += per_row.max(1).sum()
+        for CH in tot_sync:
+            key = tile_of * 4096 + pos_live // CH
+            uniq, inv = np.unique(key[live_tile], return_inverse=True)
+            pr = np.stack([np.bincount(inv, weights=rows[live_tile, r_], minlength=uniq.size) for r_ in range(4)], 1)
+            tot_sync[CH] += pr.max(1).sum()
+    s = f"  {name:34s} rows free-running: {tot_async / 1e6:.3f} M steps ({tot_async / lq.sum():.1%} of today's)"
+    for CH, v_ in tot_sync.items():
+        s += f"; in step per {CH}-entry chunk: {v_ / 1e6:.3f} M ({v_ / lq.sum():.1%})"
+    print(s)
+l44q = l44.reshape(N, 2, 2, 2, 2).transpose(0, 1, 3, 2, 4).reshape(N, 4, 4)   # [N, by, bx] -> [N, quadrant (qy, qx), row (ry, rx)]
+row_sublists("4x4 blocks as DPP rows", l44q)
+s82 = bits.reshape(N, 8, 2, 2, 8).transpose(0, 1, 3, 2, 4).reshape(N, 8, 2, 16).any(3)   # [N, strip y (8), qx (2)]
+s82q = s82.reshape(N, 2, 4, 2).transpose(0, 1, 3, 2).reshape(N, 4, 4)                      # [N, quadrant (qy, qx), strip]
+row_sublists("8x2 strips as DPP rows (today's map)", s82q)

@@ -37,17 +37,6 @@ def _report(name, fs, gs):
     print(name, "fwd", fs, "grads", gs)
 
 
-def _bench_gate(cfg, cam, sc):
-    """The object gate of the per-object job exactly as bench.py builds it (build_problem -> mapping.perturbed_target): a pixel belongs
-    to the object of the Gaussian that fixes its depth in the render of the perturbed map.  Returns (gaussian_object [P], pixel_object
-    [H, W]) int32 arrays and the target's dict of GPU tensors."""
-    import torch
-    from dqo_harness import mapping
-    dev = torch.device("cuda")
-    tgt = mapping.perturbed_target(sc, mapping.make_settings(cam, dev), dev, scenes.CONFIGS[cfg]["seed"] + 7)
-    return np.asarray(sc["obj_id"], np.int32), tgt["pix_obj"].cpu().numpy().astype(np.int32), tgt
-
-
 def _full_size_case(oracle, cfg, name, fp64=True, P=None, gated=False):
     """One BASELINE configuration at its full size against the OpenMP build of the oracle (same statements as the serial one, bitwise
     equal results: tests/test_oracle_rast.py::test_openmp_build_equals_serial): forward within 1e-4, flipped pixels within the 0.1 %
@@ -61,7 +50,7 @@ def _full_size_case(oracle, cfg, name, fp64=True, P=None, gated=False):
     dL = (rng.normal(size=(3, cam.H, cam.W)).astype(np.float32), rng.normal(size=(1, cam.H, cam.W)).astype(np.float32))
     gate, gate_kw = None, {}
     if gated:
-        go, po, _ = _bench_gate(cfg, cam, sc)
+        go, po, _ = U.bench_gate(cfg, cam, sc)
         gate, gate_kw = (go, po), dict(gaussian_object=go, pixel_object=po)
     hr = U.HipRun(cam, sc, object_gate=gate)
     o = oracle.OracleRasterizer(np.float32, omp=True)
@@ -107,81 +96,15 @@ def test_cfg3_full_size_gated_vs_oracle(torch_cuda, oracle):
 
 
 def test_cfg3_fused_iteration_vs_cpu_oracle_iteration(torch_cuda, oracle):
-    _fused_iteration_case(torch_cuda, oracle, 3)
+    fs, gs = U.fused_iteration_case(torch_cuda, oracle, 3)
+    _report("cfg3_fused_iteration", fs, gs)
 
 
 def test_cfg5_fused_iteration_vs_cpu_oracle_iteration(torch_cuda, oracle):
     """The same at 2 M Gaussians, where the timed path also splits its long tile lists (list_split "auto": composed transmittance maps
     in the forward, the queue of long-list sorts) — bench.py --cfg 5's instantiation."""
-    _fused_iteration_case(torch_cuda, oracle, 5)
-
-
-def _fused_iteration_case(torch_cuda, oracle, cfg):
-    """ONE iteration of the path bench.py times (FusedMapper on cfg 3 at 500 k: tile_objects binning, gated blend kernels, the
-    per-object loss tap, gaussian_tail_kernel with the sparse Adam — the capture's own eager iteration issues exactly the calls the
-    graph holds) against the full CPU iteration bench.py's cpu_baseline runs: oracle raster forward (gated) -> per-object masked loss
-    (oracle/map_oracle.py <- SLAM/multiprocess/mapper.py:836-875) -> oracle raster backward (backward.cu:808-1066, 152-548) ->
-    activation Jacobians.  The gradient row of the fused tail never reaches HBM; its first Adam moment does:
-    exp_avg / (1 - beta1) IS the gradient the tail consumed (zero moments before, attach loss zero at the initial state), compared
-    through util_rast.compare_grads at 1e-3 with the fp64 oracle beside.  Flipped pixels (util_rast.flipped_pixels, found with the
-    eager gated op on the same activated inputs) are taken out of the render mask on both sides."""
-    torch = torch_cuda
-    from dqo_harness import mapping, sharding
-    from dqo_harness.fused_mapping import FusedMapper
-    from oracle import map_oracle as mo
-    cam, sc = scenes.make_config(cfg)
-    go, po, tgt = _bench_gate(cfg, cam, sc)
-    dev = torch.device("cuda")
-    settings = mapping.make_settings(cam, dev)
-    own = po >= 0
-    tile_mask = sharding.tile_mask_from_pixel_mask(own)
-    fm = FusedMapper(sc, settings, dev).set_object_gate(go, po)
-    # the rasteriser's inputs of the first iteration = the mapper's activations of its raw parameters (sigmoid(logit(o)) is o up to
-    # an ulp): both the flipped-pixel probe and the oracle get exactly these
-    act = [a.detach().cpu().numpy().copy() for a in fm.activate()]
-    sca = dict(sc, opacity=act[0], scales=act[1], rotations=act[2])
-    raw = [fm.opacity_raw.cpu().numpy().copy(), fm.scaling_raw.cpu().numpy().copy(), fm.rotation_raw.cpu().numpy().copy()]
-    hr = U.HipRun(cam, sca, grad=False, object_gate=(go, po), tile_mask=tile_mask)
-    st = U.oracle_settings(oracle, cam)
-    orc = {}
-    for name, dt in (("f32", np.float32), ("f64", np.float64)):
-        o = oracle.OracleRasterizer(dt, omp=True)
-        r = o.forward(st, sca["xyz"], sca["opacity"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center, shs=sca["shs"],
-                      scales=sca["scales"], rotations=sca["rotations"], tile_mask=tile_mask, gaussian_object=go, pixel_object=po)
-        orc[name] = (o, r, {k: getattr(r, k) for k in U.HipRun.names})
-    bad = U.flipped_pixels(hr.res, orc["f32"][2], orc["f64"][2])
-    assert bad[own].mean() <= 1e-3, f"flipped pixels {int(bad[own].sum())} over the 0.1 % budget"
-    mask = own & ~bad
-    gtc, gtd = tgt["gt_color"].cpu().numpy(), tgt["gt_depth"].cpu().numpy()
-    # ---- the GPU iteration: capture() = one eager iteration of the graph's own calls (+ the capture, unused here) ----
-    fm.capture(tgt["gt_color"], tgt["gt_depth"], torch.tensor(mask, device=dev), tile_mask=torch.tensor(tile_mask, device=dev),
-               loss_tap=True, fused_tail=True, list_split="auto")
-    torch.cuda.synchronize()
-    assert not fm.graph_overflowed() and fm.step_count == 1
-    loss_hip = fm.loss[:3].double().cpu().numpy()
-    b1 = fm.betas[0]
-    hg = {k: (fm.state[s][0].double() / (1.0 - b1)).cpu().numpy() for k, s in
-          (("means3D", "xyz"), ("sh", "shs"), ("opacity", "opacity"), ("scales", "scaling"), ("rotations", "rotation"))}
-    # ---- the CPU iteration ----
-    og = {}
-    for name in ("f32", "f64"):
-        o, r, _ = orc[name]
-        tot, col, dep, dC, dD = mo.per_object_masked_loss(r.color, r.depth, r.hit_depth, gtc, gtd, po, mask)
-        if name == "f32":
-            np.testing.assert_allclose(loss_hip, [tot, col, dep], rtol=1e-5, err_msg="loss of the fused iteration vs the CPU iteration")
-            dL = (dC.astype(np.float32), dD.astype(np.float32))
-        g = o.backward(*dL)  # (the same incoming gradient for the fp64 twin: it explains rows, it is not a second target)
-        g_op, g_sc, g_rot = mo.raw_grads(raw[0], raw[1], raw[2], g.opacity, g.scales, g.rotations)
-        og[name] = dict(means3D=np.asarray(g.means3D), sh=np.asarray(g.sh), opacity=g_op, scales=g_sc, rotations=g_rot)
-    gs = U.compare_grads(hg, og["f32"], og["f64"])
-    # the step was taken: every Gaussian with a gradient moved by about one learning rate (Adam's first step is lr x g / (|g| + eps))
-    moved = (fm.xyz.cpu().numpy() != sc["xyz"]).any(1)
-    has_g = (np.abs(og["f32"]["means3D"]) > 0).any(1)
-    assert moved[has_g].mean() > 0.99 and not moved[~has_g & (hr.res["radii"] == 0)].any()
-    fs = dict(loss_hip=loss_hip.tolist(), loss_oracle=[float(tot), float(col), float(dep)], flipped_px=int(bad[own].sum()), P=int(len(go)),
-              N_reference=int(orc["f32"][1].num_rendered), N_kept=int(fm.header()["num_rendered"]))
-    fs["list_split"] = [int(fm._g.ls_fwd), int(fm._g.ls_bwd)]
-    _report(f"cfg{cfg}_fused_iteration", fs, gs)
+    fs, gs = U.fused_iteration_case(torch_cuda, oracle, 5)
+    _report("cfg5_fused_iteration", fs, gs)
 
 
 def test_cfg2_full_size_vs_oracle(torch_cuda, oracle):

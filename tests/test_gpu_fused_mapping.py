@@ -612,6 +612,44 @@ def test_run_recaptures_after_an_overflow_and_delivers_valid_iterations(env):
     assert torch.equal(a.loss, b.loss)
 
 
+def test_read_header_after_the_fused_tail_and_the_prezeroed_guard(env):
+    """(1) dqo_rast_read_header reports the device header stage 2 wrote — also in bucket mode, whose slot allocators are regional
+    (counters[0] stays 0), and after dqo_rast_backward_adam, whose tail clears the counters the header was formed from.
+    (2) DqoRastCtx.frame_prezeroed is a promise (the previous frame on the ctx ended in the fused tail): a forward-only render in
+    between breaks it, and the next frame must SAY so (header.overflow, a no-op for the optimiser) instead of binning with dirty slot
+    allocators; that frame's tail clears the scalars again, so the frame after it is valid."""
+    torch = env
+    import ctypes
+    import _dqo_native as N
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    fm = FusedMapper(scene, settings, dev)
+    fm.capture(gt_color, gt_depth, mask, fused_tail=True)
+    g = fm._g
+    assert g.cctx.frame_prezeroed == 1 and g.cctx.tile_bucket_capacity > 0
+    fm.replay()
+    torch.cuda.synchronize()
+    lib = N.lib()
+    hdr = N.DqoRastHeader()
+    N.check(lib.dqo_rast_read_header(ctypes.byref(g.cctx), ctypes.byref(hdr), N.current_stream()))
+    dev_hdr = g.geom[:32].view(torch.int32).cpu().numpy()
+    assert hdr.stage == 2 and hdr.overflow == 0 and hdr.num_rendered > 0 and hdr.num_visible > 0 and hdr.num_tiles > 0
+    assert [hdr.num_rendered, hdr.num_tiles, hdr.overflow, hdr.max_tile_count, hdr.num_visible, hdr.num_candidates] == list(dev_hdr[:6])
+    assert hdr.num_candidates >= hdr.num_rendered
+    steps = int(g.step_dev.item())
+    # a forward-only render on the graph's ctx: its own frame is fine (it started from clean scalars) ...
+    N.check(lib.dqo_rast_forward(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.outputs), ctypes.byref(g.cctx), N.current_stream()))
+    torch.cuda.synchronize()
+    assert not fm.graph_overflowed()
+    # ... but it leaves them dirty: the next prezeroed frame is flagged and trains nothing
+    fm.replay()
+    torch.cuda.synchronize()
+    assert fm.graph_overflowed() and int(g.step_dev.item()) == steps
+    fm.replay()
+    torch.cuda.synchronize()
+    assert not fm.graph_overflowed() and int(g.step_dev.item()) == steps + 1
+
+
 def test_capture_takes_the_reference_cameras_noncontiguous_matrices(env):
     """scene/cameras.py:137-139 builds world_view_transform as torch.tensor(...).transpose(0, 1).cuda(): a non-contiguous view.  The
     op's forward makes it contiguous per call; the captured path must do the same once (its raw pointers would otherwise read the
