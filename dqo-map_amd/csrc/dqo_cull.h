@@ -67,3 +67,18 @@ __device__ __forceinline__ float dqo_power(float A, float B, float C, float dx, 
 __device__ __forceinline__ float dqo_gauss(float power) { return __expf(power); }
 // 1/x by v_rcp_f32 (1 ulp) for the T / (1 - alpha) recurrences of the backward (backward.cu:948, 980)
 __device__ __forceinline__ float dqo_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Lane -> pixel of the blend kernels' quadrant wave (one wave64 per 8x8 quadrant, one pixel per lane): every 16-lane DPP row owns one
+// 4x4 block of the quadrant — row r = lane >> 4 at ((r & 1) * 4, (r >> 1) * 4), lane s = lane & 15 of the row at (s & 3, s >> 2) inside
+// it.  The forward records per list entry WHICH rows saw it (a 4-bit row code in the entry's live byte), and the backward lets every
+// row walk its own sub-list (rast_backward_blend.hip): an entry costs a row a step only if one of ITS 16 pixels has work for it.
+__device__ __forceinline__ uint32_t dqo_lane_x(int lane) { return (uint32_t)(((lane >> 4) & 1) * 4 + (lane & 3)); }
+__device__ __forceinline__ uint32_t dqo_lane_y(int lane) { return (uint32_t)((lane >> 5) * 4 + ((lane >> 2) & 3)); }
+// 64-bit lane mask -> 4-bit row code: bit r = some lane of DPP row r is set (two s_quadmask: 64 lanes -> 16 quads -> 4 rows)
+__device__ __forceinline__ uint32_t dqo_row_code(unsigned long long m) {
+    unsigned long long q;
+    uint32_t c;
+    asm("s_quadmask_b64 %0, %1" : "=s"(q) : "s"(m) : "scc");
+    asm("s_quadmask_b32 %0, %1" : "=s"(c) : "s"((uint32_t)q) : "scc");
+    return c;
+}

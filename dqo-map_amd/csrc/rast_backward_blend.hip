@@ -155,6 +155,70 @@ __device__ __forceinline__ float wave_reduce32(const float (&v)[32], int lane) {
     return __uint_as_float(r32.x) + __uint_as_float(r32.y);
 }
 
+// ---- per-row (16-lane) reduce-scatter for the row walk ------------------------------------------------------------------
+// SIXTY-FOUR values per lane, reduced over the 16 lanes of each DPP row separately: afterwards lane s of a row holds the row's totals of
+// v[4 s .. 4 s + 3].  Four halving stages (lane ^ 8, ^ 4: two bank-masked v_add_f32_dpp per output; lane ^ 2, ^ 1: quad_perm with
+// selects), no permlane swap: 64 + 32 + 24 + 12 = 132 VALU for 4 x 63 sums — per row and entry what the 64-lane butterfly costs per
+// wave and entry, but the four rows work on four DIFFERENT entries.
+__device__ __forceinline__ void row_stage8(const float (&lo)[8], const float (&hi)[8], float (&c)[8]) {
+    // lanes with bit 3 clear (DPP banks 0, 1) take lo[i] + the lo[i] of lane ^ 8, the others hi[i] + the partner's hi[i]
+#define DQO_R8(i) "v_add_f32_dpp %[c" #i "], %[l" #i "], %[l" #i "] row_ror:8 row_mask:0xf bank_mask:0x3\n" \
+                  "v_add_f32_dpp %[c" #i "], %[h" #i "], %[h" #i "] row_ror:8 row_mask:0xf bank_mask:0xc\n"
+    asm volatile("s_nop 1\n" DQO_R8(0) DQO_R8(1) DQO_R8(2) DQO_R8(3) DQO_R8(4) DQO_R8(5) DQO_R8(6) DQO_R8(7)
+                 : [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3]), [c4] "=&v"(c[4]), [c5] "=&v"(c[5]),
+                   [c6] "=&v"(c[6]), [c7] "=&v"(c[7])
+                 : [l0] "v"(lo[0]), [l1] "v"(lo[1]), [l2] "v"(lo[2]), [l3] "v"(lo[3]), [l4] "v"(lo[4]), [l5] "v"(lo[5]), [l6] "v"(lo[6]),
+                   [l7] "v"(lo[7]), [h0] "v"(hi[0]), [h1] "v"(hi[1]), [h2] "v"(hi[2]), [h3] "v"(hi[3]), [h4] "v"(hi[4]), [h5] "v"(hi[5]),
+                   [h6] "v"(hi[6]), [h7] "v"(hi[7]));
+#undef DQO_R8
+}
+__device__ __forceinline__ void row_stage4(const float (&lo)[8], const float (&hi)[8], float (&d)[8]) {
+    // lanes with bit 2 clear (even DPP banks) take lo[i] + the lo[i] of lane + 4, the others hi[i] + the hi[i] of lane - 4
+#define DQO_R4(i) "v_add_f32_dpp %[d" #i "], %[l" #i "], %[l" #i "] row_shl:4 row_mask:0xf bank_mask:0x5\n" \
+                  "v_add_f32_dpp %[d" #i "], %[h" #i "], %[h" #i "] row_shr:4 row_mask:0xf bank_mask:0xa\n"
+    asm volatile("s_nop 1\n" DQO_R4(0) DQO_R4(1) DQO_R4(2) DQO_R4(3) DQO_R4(4) DQO_R4(5) DQO_R4(6) DQO_R4(7) "s_nop 1\n"
+                 : [d0] "=&v"(d[0]), [d1] "=&v"(d[1]), [d2] "=&v"(d[2]), [d3] "=&v"(d[3]), [d4] "=&v"(d[4]), [d5] "=&v"(d[5]),
+                   [d6] "=&v"(d[6]), [d7] "=&v"(d[7])
+                 : [l0] "v"(lo[0]), [l1] "v"(lo[1]), [l2] "v"(lo[2]), [l3] "v"(lo[3]), [l4] "v"(lo[4]), [l5] "v"(lo[5]), [l6] "v"(lo[6]),
+                   [l7] "v"(lo[7]), [h0] "v"(hi[0]), [h1] "v"(hi[1]), [h2] "v"(hi[2]), [h3] "v"(hi[3]), [h4] "v"(hi[4]), [h5] "v"(hi[5]),
+                   [h6] "v"(hi[6]), [h7] "v"(hi[7]));
+#undef DQO_R4
+}
+__device__ __forceinline__ void row_reduce64(const float (&v)[64], float (&out)[4], int lane) {
+    float c[32];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // c[i] = v[i] (+) v[i + 32], i = 8 q .. 8 q + 7
+        float lo[8], hi[8], r[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) lo[i] = v[8 * q + i], hi[i] = v[32 + 8 * q + i];
+        row_stage8(lo, hi, r);
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[8 * q + i] = r[i];
+    }
+    float d[16];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {  // d[i] = c[i] (+) c[i + 16]
+        float lo[8], hi[8], r[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) lo[i] = c[8 * q + i], hi[i] = c[16 + 8 * q + i];
+        row_stage4(lo, hi, r);
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[8 * q + i] = r[i];
+    }
+    const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float keep = b1 ? d[i + 8] : d[i], send = b1 ? d[i] : d[i + 8];
+        e[i] = keep + dpp_mov<0x4E>(send);  // partner lane ^ 2
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float keep = b0 ? e[i + 4] : e[i], send = b0 ? e[i] : e[i + 4];
+        out[i] = keep + dpp_mov<0xB1>(send);  // partner lane ^ 1
+    }
+}
+
 __device__ __forceinline__ float3 pixel_ray_b(uint32_t px, uint32_t py, float fx, float fy, float cx, float cy) {
 #pragma clang fp contract(off)
     float rx = ((float)px - cx) / fx, ry = ((float)py - cy) / fy, rz = 1.0f;
@@ -190,6 +254,36 @@ constexpr int BWD_THREADS = 64;
 // LDS of one wave: the gathered records of its chunk's live entries (three float4 tables, three word tables) and the depth-hit sums
 constexpr int BWD_BLK = 3 * BWD_THREADS * 4 + 3 * BWD_THREADS + 5 * BWD_THREADS;  // words: 1280 = 5120 B
 constexpr int BWD_XCH = 5 * BWD_THREADS;                                            // words of one wave's pass-1 result (SEGS > 1)
+// ---- the row walk (ROWS): every 16-lane DPP row (4x4 pixel block, dqo_lane_x / _y) of the quadrant wave walks ITS OWN sub-list ----
+// The forward's live byte of a (quadrant, list position) is a 4-bit row code: which rows have a pixel with work for the entry.  The
+// wave collects RG live entries at a time (walk order, whatever list positions they sit at), gathers their records into LDS once, and
+// builds four sub-lists from the codes; step k of the group hands row r the k-th entry of ITS list — four different entries per wave
+// step, each evaluated by the 16 pixels that may have work for it (a wave stepping through the union evaluates every entry on all 64:
+// 37 % useful lanes on cfg 3; the rows' own lists: 1.008 M -> 0.78 M wave steps at RG = 56, tests/diag_row_model.py).  Seven steps at
+// a time, each row's 63 sums go through a ROW-LOCAL reduce-scatter (row_reduce64) and land in part[row][entry][9]; a (row, entry)
+// pair is produced exactly once, so these are plain stores; at the end of the group lane j adds entry j's four row partials in the
+// fixed order 0..3 and writes the 64-byte (quadrant, entry) record.  No atomics; the sum order depends on nothing but the pixels and
+// the entry, so the records are bitwise reproducible AND bitwise equal between a shard and the unsharded job (a shard's lists hold
+// fewer entries, which moves group and batch boundaries, but neither a row's partial nor the order 0..3 sees that).
+#ifndef DQO_BWD_RG
+#define DQO_BWD_RG 42  // live entries per group: a multiple of 7, at most 56 (a row's list has 8 batches of 7 steps); 42: 9 KB of LDS per
+                       // wave = four waves per SIMD (56: 11.7 KB, 3.5 waves, and 159 instead of 145 us on cfg 3 although it saves 3.6 % more steps)
+#endif
+constexpr int RG = DQO_BWD_RG;
+static_assert(RG % 7 == 0 && RG >= 7 && RG <= 56, "RG: whole batches of 7, 64 list slots per row");
+constexpr int R_ENT_W = 12;                          // words of an entry record: conic + opacity | x, y, object id, position | r, g, b, slot
+constexpr int R_ENT = 0;                             // [RG + 1] records (the last one: the dummy a finished row keeps stepping on)
+constexpr int R_LIST = R_ENT + (RG + 1) * R_ENT_W;   // [4 rows][64] u16: byte offset of the entry record, 8 slots per batch (7 used)
+constexpr int R_NB = RG / 7;                         // batches of a group at most
+constexpr int R_PART = R_LIST + 4 * 64 / 2;          // [4 rows][R_NB batches][64] floats: a row's reduced sums of a batch exactly as the
+constexpr int R_PART_W = 4 * R_NB * 64 + 12;         //   reduce-scatter leaves them (value 9 b + f at [9 b + f]), + 12 zeros (the prologue's
+                                                     //   depth-hit sums use this space first)
+constexpr int R_MPOS = R_PART + R_PART_W;            // [64] ints + [64] bytes: list positions and row codes of the NEXT group (collected while
+constexpr int R_MCODE = R_MPOS + 64;                 //        the current one is walked: its ids are in flight during the walk)
+constexpr int ROWS_BLK = ((R_MCODE + 16 + 3) / 4) * 4;   // words per wave
+static_assert(R_LIST % 4 == 0 && R_PART % 4 == 0, "16-byte aligned tables");
+static_assert(5 * 64 <= R_PART_W, "the depth-hit staging fits the partial table");
+
 struct BwdTap {  // DqoLossTap, backward half: the two gradient scales of the frame
     float gc, gdw;
 };
@@ -221,24 +315,52 @@ __device__ __forceinline__ BwdTap tap_frame_scales(const DqoGeomLayout& g, const
 //   pass 2  the walk itself on the chunk from that state: the gradient sums and records exactly as the single wave forms them.
 // The backward has no early exit, so unlike the forward nothing is evaluated that the single wave would have skipped; pass 1 costs
 // a quarter of pass 2.  T and S are grouped by chunk instead of strictly back to front: last-bit differences, like the forward's.
-template <int BWD_NB, bool GATE, int SEGS>
+template <int BWD_NB, bool GATE, int SEGS, bool ROWS = false>
 __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                                                    const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths,
                                                    float* __restrict__ recs, uint8_t* __restrict__ valid, const int64_t capacity,
                                                    const DqoTapDev& tap, const DqoGateDev& gate, const int tile, const int quad, const int wave, const int lane, uint32_t* const lds, const int skip_over) {
-    uint32_t* const blk = lds + wave * BWD_BLK;
+    static_assert(!ROWS || (SEGS == 1 && BWD_NB == 7), "the row walk is the single-wave walk");
+    uint32_t* const blk = lds + wave * (ROWS ? ROWS_BLK : BWD_BLK);
     float4* const s_co = reinterpret_cast<float4*>(blk);
     float4* const s_xy = s_co + BWD_THREADS;
     float4* const s_rgb = s_xy + BWD_THREADS;
     int* const s_id = reinterpret_cast<int*>(s_rgb + BWD_THREADS);
     uint32_t* const s_slot = reinterpret_cast<uint32_t*>(s_id + BWD_THREADS);
     int* const s_pos = reinterpret_cast<int*>(s_slot + BWD_THREADS);
-    float* const s_hit = reinterpret_cast<float*>(s_pos + BWD_THREADS);
+    float* const s_hit = ROWS ? reinterpret_cast<float*>(blk + R_PART) : reinterpret_cast<float*>(s_pos + BWD_THREADS);
     const uint2 range = img.ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n == 0 || n > skip_over) return;  // (n > skip_over: SEGS == 1 beside the split blocks, which own the long lists)
     const int L = min((int)img.walk4[tile * 4 + quad], n);  // list positions [0, L) matter to this quadrant
     if (L == 0) return;
+    const int tile_x = tile % v.gx, tile_y = tile / v.gx;
+    const size_t HW = (size_t)v.W * v.H;
+    const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + dqo_lane_x(lane);
+    const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + dqo_lane_y(lane);
+    const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
+    const size_t pid = (size_t)v.W * py + px;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const uint8_t* const live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;  // this quadrant's live bytes of this tile's segment
+    // ---- ONE round of loads for everything that depends on the pixel alone (a wave of this kernel lives for ~30 us of which it issues
+    // arithmetic for ~8: its time is a chain of dependent memory rounds, so independent loads are issued together — unconditionally, the
+    // lanes outside the image read pixel 0 and discard it — instead of one round per `if`) ----
+    const size_t ps = inside ? pid : (size_t)0;
+    const float T_final_ld = img.final_T[ps];
+    const uint32_t n_contrib_ld = img.n_contrib[ps], hit_word_ld = img.hit_pos[ps];
+    int owner_ld = 0;
+    if (GATE) owner_ld = gate.pobj[ps];
+    float in0, in1, in2, in3, in4 = 0.f, in5 = 0.f, in6 = 0.f, in7 = 0.f;
+    uint8_t mask_ld = 1;
+    if (tap.scale == nullptr) {
+        in0 = dL_dpixels[ps], in1 = dL_dpixels[HW + ps], in2 = dL_dpixels[2 * HW + ps], in3 = dL_ddepths[ps];
+    } else {
+        if (tap.mask) mask_ld = tap.mask[ps];
+        in0 = tap.out_color[ps], in1 = tap.out_color[HW + ps], in2 = tap.out_color[2 * HW + ps], in3 = tap.out_depth[ps];
+        in4 = tap.gt_color[ps], in5 = tap.gt_color[HW + ps], in6 = tap.gt_color[2 * HW + ps], in7 = tap.gt_depth[ps];
+    }
+    uint8_t lv_first = 0;  // the row walk's first chunk of live bytes
+    if (ROWS) lv_first = (L - 1 - lane >= 0) ? live[L - 1 - lane] : (uint8_t)0;
     // DqoLossTap, backward half: every wave that has work derives the two gradient scales from the frame totals the forward left in
     // the spread lines (one load per lane + a wave sum)
     float tap_gc = 0.f, tap_gdw = 0.f;
@@ -246,23 +368,64 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
         const BwdTap t = tap_frame_scales(g, tap, lane, false);
         tap_gc = t.gc, tap_gdw = t.gdw;
     }
-    const int tile_x = tile % v.gx, tile_y = tile / v.gx;
-    const size_t HW = (size_t)v.W * v.H;
-
-    const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + (lane & 7);
-    const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + (lane >> 3);
-    const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
-    const size_t pid = (size_t)v.W * py + px;
-    const float pixfx = (float)px, pixfy = (float)py;
-    const float T_final = inside ? img.final_T[pid] : 0.f;
+    const float T_final = inside ? T_final_ld : 0.f;
     float T = T_final;
-    const int last_contrib = inside ? (int)img.n_contrib[pid] : 0;
-    const uint32_t hit_word = inside ? img.hit_pos[pid] : 0u;
+    const int last_contrib = inside ? (int)n_contrib_ld : 0;
+    const uint32_t hit_word = inside ? hit_word_ld : 0u;
     const int hit_pos = (int)(hit_word & 0x7fffffffu);
     const bool hit_plane = (hit_word >> 31) != 0u;  // the forward decided backward.cu:1016's branch for this pixel
+    const int hit_c0 = hit_pos - 1;                 // list position of the entry that fixed this pixel's depth (-1: none)
+    const bool has_hit = hit_pos > 0;               // implies inside
+    // ---- second round, issued before anything waits: the depth-hit entry's id and slot (a safe position for the pixels without one),
+    // and — row walk — the first group's ids and slots ----
+    const int gid_h = (int)bin.point_list[range.x + max(hit_c0, 0)];
+    const uint32_t slot_h_ld = bin.slot_list[range.x + max(hit_c0, 0)];
+    // the row walk's state (declared here: its first group is collected and its loads are started in the shadow of the work below)
+    char* const ent_base = reinterpret_cast<char*>(blk + R_ENT);
+    int* const s_mpos = reinterpret_cast<int*>(blk + R_MPOS);
+    uint8_t* const s_mcode = reinterpret_cast<uint8_t*>(blk + R_MCODE);
+    const int chunks = (L + BWD_THREADS - 1) / BWD_THREADS;
+    int chunk_i = 0;                  // next chunk of 64 list positions (walk order: from L - 1 down)
+    unsigned long long pend = 0ull;   // lanes of the chunk in flight whose live entry has not been taken into a group yet
+    uint32_t my_code = 0u;
+    uint8_t lv_nx = lv_first;
+    // set bits of a wave-uniform mask below this lane (v_mbcnt: no lane-mask constant in registers)
+    auto below = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    int cnt = 0;                      // entries of the group in flight
+    // collect: the next RG live entries in walk order (their list positions and row codes into LDS, lane order == walk order)
+    auto collect = [&]() -> int {
+        int cnt = 0;
+        while (cnt < RG) {
+            if (pend == 0ull) {
+                if (chunk_i >= chunks) break;
+                my_code = (uint32_t)lv_nx & 0xfu;
+                chunk_i++;
+                const int pn = L - 1 - (chunk_i * BWD_THREADS + lane);
+                lv_nx = pn >= 0 ? live[pn] : (uint8_t)0;  // the next chunk's live bytes, in flight while this group is walked
+                pend = __builtin_amdgcn_ballot_w64(my_code != 0u);
+                continue;
+            }
+            const int rank = below(pend);
+            const bool take = ((pend >> lane) & 1ull) != 0ull && rank < RG - cnt;
+            // (the chunk in flight is chunk_i - 1: its lane l sits at list position L - 1 - ((chunk_i - 1) * 64 + l))
+            if (take) s_mpos[cnt + rank] = L - 1 - ((chunk_i - 1) * BWD_THREADS + lane), s_mcode[cnt + rank] = (uint8_t)my_code;
+            const unsigned long long tm = __builtin_amdgcn_ballot_w64(take);
+            cnt += (int)__popcll(tm);
+            pend &= ~tm;
+        }
+        return cnt;
+    };
+    // gather, first hop: lane j starts the load of entry j's Gaussian id (every lane takes part, with a safe position: no value of the
+    // previous group stays alive in the lanes beyond the count)
+    int g_id = 0;
+    auto gather_ids = [&](const int c) { g_id = (int)bin.point_list[range.x + (lane < c ? s_mpos[lane] : 0)]; };
+    if constexpr (ROWS) {
+        cnt = collect();
+        gather_ids(cnt);
+    }
     int owner = (int)0x80000000;  // object gate: this pixel's owner ("none" equals no Gaussian's non-negative object id)
     if (GATE) {
-        if (inside) owner = gate.pobj[pid];
+        if (inside) owner = owner_ld;
         if (owner < 0) owner = (int)0x80000000;
         if (tap.scale != nullptr && tap.per_object) {
             // per-object gradient scales: one trip per distinct owner among the quadrant's pixels (usually one or two, wave-uniform);
@@ -289,15 +452,14 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     }
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, ddep = 0.f;
     if (tap.scale == nullptr) {
-        if (inside) dp0 = dL_dpixels[pid], dp1 = dL_dpixels[HW + pid], dp2 = dL_dpixels[2 * HW + pid], ddep = dL_ddepths[pid];
+        if (inside) dp0 = in0, dp1 = in1, dp2 = in2, ddep = in3;
     } else if (inside) {
         // DqoLossTap, backward half: the gradient images of the masked L1 loss, formed in place (what loss_grad_kernel writes:
         // sign(error) x weight / count, 0 outside the mask; a tile with a list always has hit id -1 <=> hit_pos 0)
         const float gc = tap_gc, gdw = tap_gdw;
-        const bool m = (tap.mask ? tap.mask[pid] != 0 : true) && (!(GATE && tap.per_object) || owner >= 0);
-        const float d0 = tap.out_color[pid] - tap.gt_color[pid], d1 = tap.out_color[HW + pid] - tap.gt_color[HW + pid];
-        const float d2 = tap.out_color[2 * HW + pid] - tap.gt_color[2 * HW + pid];
-        const float gd = tap.gt_depth[pid], err = tap.out_depth[pid] - gd;
+        const bool m = mask_ld != 0 && (!(GATE && tap.per_object) || owner >= 0);
+        const float d0 = in0 - in4, d1 = in1 - in5, d2 = in2 - in6;
+        const float gd = in7, err = in3 - gd;
         dp0 = m ? (d0 > 0.f ? gc : (d0 < 0.f ? -gc : 0.f)) : 0.f;
         dp1 = m ? (d1 > 0.f ? gc : (d1 < 0.f ? -gc : 0.f)) : 0.f;
         dp2 = m ? (d2 > 0.f ? gc : (d2 < 0.f ? -gc : 0.f)) : 0.f;
@@ -312,10 +474,9 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     // arguments only, like the reference's.
     if (__builtin_amdgcn_ballot_w64(dp0 != 0.f || dp1 != 0.f || dp2 != 0.f || ddep != 0.f) == 0ull) {
         if (SEGS > 1 && wave != 0) return;  // (every wave of the quadrant sees the same pixels: a block-uniform branch)
-        const uint8_t* live0 = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;
         for (int p0 = 0; p0 < L; p0 += BWD_THREADS) {
             const int pos = p0 + lane;
-            if (pos < L && live0[pos] != 0) {
+            if (pos < L && live[pos] != 0) {
                 const uint32_t slot = bin.slot_list[range.x + pos];
                 if ((int64_t)slot < capacity) valid[(size_t)slot * 4 + quad] = (uint8_t)0;
             }
@@ -324,8 +485,22 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     }
     const float bgdot = v.bg[0] * dp0 + v.bg[1] * dp1 + v.bg[2] * dp2;
     const float bg_term = -T_final * bgdot;  // d(background term)/d(alpha) = bg_term / (1 - alpha): end_T, not the running T (quirk B2)
-    const int hit_c0 = hit_pos - 1;          // list position of the entry that fixed this pixel's depth (-1: none)
     const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
+    // ---- third round: the depth-hit entry's surfel normal and — row walk — the first group's records ----
+    const float4 n_np_h = g.normal_c[gid_h];
+    // gather, second hop: entry j's records by its id, its instance slot, and its position / row code back from the collect's tables
+    float4 g_co, g_xy, g_cs;
+    int g_pos = 0;
+    uint32_t g_code = 0u, g_slot = 0xffffffffu;
+    auto gather_records = [&](const int c) {
+        const bool on = lane < c;
+        g_pos = on ? s_mpos[lane] : 0;
+        g_code = on ? (uint32_t)s_mcode[lane] : 0u;
+        g_slot = on ? bin.slot_list[range.x + g_pos] : 0xffffffffu;
+        g_co = g.conic_opacity[g_id], g_xy = g.xy_depth[g_id], g_cs = g.rgb_smax[g_id];
+    };
+    if constexpr (ROWS) gather_records(cnt);
+    else g_co = g_xy = g_cs = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- depth-hit sums (backward.cu:997-1065): ONCE per pixel, outside the entry loop ----
     // Every pixel has at most one entry that fixed its depth (hit_pos) and the gradient it sends to that Gaussian depends on
     // nothing the walk below computes.  Only the pixel-dependent factors are summed here (DqoGradRec::hit).  Pixels of the
@@ -334,16 +509,13 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     // private to the wave, so the sums are reproducible — and the leader writes floats 9..13 of the (quadrant, instance) record.
     // The walk marks those records with validity 3 when it writes their colour part.
     {
-        const bool has_hit = hit_pos > 0;  // implies inside
         const unsigned long long hm = __builtin_amdgcn_ballot_w64(has_hit);
         if (hm != 0ull && (SEGS == 1 || wave == 0)) {
             float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            uint32_t slot_h = 0xffffffffu;
+            const uint32_t slot_h = has_hit ? slot_h_ld : 0xffffffffu;
             if (has_hit) {
 #pragma clang fp contract(off)
-                const int gid = (int)bin.point_list[range.x + hit_pos - 1];
-                slot_h = bin.slot_list[range.x + hit_pos - 1];
-                const float4 n_np = g.normal_c[gid];
+                const float4 n_np = n_np_h;
                 const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
                 const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
                 const float inv_nr = dqo_rcp(nr);               // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
@@ -384,14 +556,151 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
             }
         }
     }
+    if constexpr (ROWS) {
+        // (the depth-hit staging shares LDS with the partial table: its last reads happened-before in program order)
+        float S0 = 0.f, S1 = 0.f, S2 = 0.f;  // colour blended behind the current entry (see below)
+        uint16_t* const s_list = reinterpret_cast<uint16_t*>(blk + R_LIST);
+        float* const s_part = reinterpret_cast<float*>(blk + R_PART);
+        const int row = lane >> 4, sl = lane & 15;
+        const char* const list_row = reinterpret_cast<const char*>(s_list) + row * 128;  // this row's sub-list (64 u16)
+        // after row_reduce64 lane sl of a row holds the totals of values 4 sl .. 4 sl + 3 (value 9 b + f = float f of the batch's b-th
+        // entry): one 16-byte store per lane and batch puts them at part[row][batch][4 sl ..]
+        float* const part_lane = s_part + row * (R_NB * 64) + sl * 4;
+        float* const s_zero = s_part + 4 * R_NB * 64;  // nine zeros: what a row that has nothing for an entry contributes
+        constexpr uint32_t DUMMY = (uint32_t)(RG * R_ENT_W * 4);  // byte offset of the dummy record
+        {   // the dummy record: opacity 0 -> alpha 0 -> every term an exact zero and the pixel state untouched; position -2 matches no hit
+            if (lane < R_ENT_W) reinterpret_cast<uint32_t*>(ent_base + DUMMY)[lane] = lane == 7 ? 0xfffffffeu : 0u;
+            if (lane < 12) s_zero[lane] = 0.f;
+        }
+        for (;;) {
+            if (cnt == 0) break;
+            // ---- commit: entry j's records into LDS (the loads were started a round ago) ----
+            const uint32_t code = g_code;
+            if (lane < cnt) {
+                const uint32_t slot_j = g_slot;
+                float4* e = reinterpret_cast<float4*>(ent_base + lane * (R_ENT_W * 4));
+                e[0] = g_co;
+                e[1] = make_float4(g_xy.x, g_xy.y, g_xy.w, __int_as_float(g_pos));
+                e[2] = make_float4(g_cs.x, g_cs.y, g_cs.z, __uint_as_float(slot_j));
+            }
+            // does entry j also carry depth-hit sums?  The group's positions descend from lane 0 to lane cnt - 1: a pixel whose hit
+            // position lies in that range names one of the group's entries (a hit entry is live for its pixel's row); one trip per
+            // distinct such position, and every pixel's turn comes exactly once in the whole walk
+            bool hit_j = false;
+            {
+                const int p_hi = __builtin_amdgcn_readlane(g_pos, 0), p_lo = __builtin_amdgcn_readlane(g_pos, cnt - 1);
+                const bool in_grp = has_hit && hit_c0 <= p_hi && hit_c0 >= p_lo;
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(in_grp);
+                while (todo != 0ull) {
+                    const int key = __builtin_amdgcn_readlane(hit_c0, (int)__builtin_ctzll(todo));
+                    hit_j = hit_j || (lane < cnt && g_pos == key);
+                    todo &= ~__builtin_amdgcn_ballot_w64(in_grp && hit_c0 == key);
+                }
+            }
+            // ---- the four sub-lists: rank r_k of entry j in row r's list -> slot (r_k / 7) * 8 + r_k % 7 (8 u16 = one 16-byte read per batch) ----
+            reinterpret_cast<uint2*>(s_list)[lane] = make_uint2(DUMMY | (DUMMY << 16), DUMMY | (DUMMY << 16));  // 4 x 64 u16 = 512 B
+            int nsteps = 0;
+            uint32_t where = 0x3f3f3f3fu;  // byte r: entry j's slot in row r's list (batch * 8 + step), 63 = not in that list
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool in = ((code >> r) & 1u) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                const int rk = below(m);
+                const int sidx = rk + ((rk * 37) >> 8);  // (rk * 37) >> 8 == rk / 7 for rk < 64
+                if (in) s_list[r * 64 + sidx] = (uint16_t)(lane * (R_ENT_W * 4));
+                where = in ? ((where & ~(0xffu << (8 * r))) | ((uint32_t)sidx << (8 * r))) : where;
+                nsteps = max(nsteps, (int)__popcll(m));
+            }
+            // ---- the NEXT group's entries are collected now and their ids fetched while this group is walked (one memory round of the
+            // two a group's gather takes leaves the critical path) ----
+            const int cnt_next = collect();
+            gather_ids(cnt_next);
+            // ---- walk: seven steps per batch ----
+            auto batch = [&](const int t, auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                const uint4 li = *reinterpret_cast<const uint4*>(list_row + t * 16);
+                const uint32_t lw[4] = {li.x, li.y, li.z, li.w};
+                float v64[64];
+                v64[63] = 0.f;
+#pragma unroll
+                for (int b = 0; b < 7; b++) {
+                    float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
+                    if (FULL || t * 7 + b < nsteps) {  // wave-uniform
+                        const uint32_t off = (b & 1) ? (lw[b >> 1] >> 16) : (lw[b >> 1] & 0xffffu);
+                        const float4* e = reinterpret_cast<const float4*>(ent_base + off);
+                        const float4 co = e[0], xy = e[1], cs = e[2];
+                        const int c0 = __float_as_int(xy.w);  // 0-based list position == the reference's `contributor` after its --
+                        // ---- predicated per-pixel gradient terms (backward.cu:932-994): the statements of the union walk below ----
+                        const float dx = xy.x - pixfx, dy = xy.y - pixfy;
+                        const float power = dqo_power(co.x, co.y, co.z, dx, dy);
+                        const float Gx = dqo_gauss(power);
+                        const float alpha_x = fminf(0.99f, co.w * Gx);
+                        const bool did_color = (c0 < last_contrib) & (power <= 0.0f) & (alpha_x >= 1.0f / 255.0f) & (!GATE || __float_as_int(xy.z) == owner);
+                        const float alpha = did_color ? alpha_x : 0.f;
+                        const float G = did_color ? Gx : 0.f;
+                        const float inv_1ma = dqo_rcp(1.f - alpha);
+                        T = T * inv_1ma;
+                        const float e0 = cs.x - S0, e1 = cs.y - S1, e2 = cs.z - S2;
+                        float dL_dalpha = (e0 * dp0 + e1 * dp1 + e2 * dp2) * T;
+                        dL_dalpha += bg_term * inv_1ma;
+                        const float dchannel_dcolor = alpha * T;
+                        S0 += alpha * e0;
+                        S1 += alpha * e1;
+                        S2 += alpha * e2;
+                        const float q = G * dL_dalpha;
+                        const float qx = q * dx, qy = q * dy;
+                        r_c0 = dchannel_dcolor * dp0;
+                        r_c1 = dchannel_dcolor * dp1;
+                        r_c2 = dchannel_dcolor * dp2;
+                        r_mx = qx, r_my = qy;
+                        r_ka = qx * dx;
+                        r_kb = qx * dy;
+                        r_kc = qy * dy;
+                        r_op = q;
+                    }
+                    v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
+                    v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;
+                }
+                float out[4];
+                row_reduce64(v64, out, lane);
+                // the row's sums of the batch's entries, as they are: part[row][batch][9 b + f] (every (row, entry) pair exists once)
+                *reinterpret_cast<float4*>(part_lane + t * 64) = make_float4(out[0], out[1], out[2], out[3]);
+            };
+            {
+                int t = 0;
+                for (; (t + 1) * 7 <= nsteps; t++) batch(t, std::true_type{});
+                if (t * 7 < nsteps) batch(t, std::false_type{});
+            }
+            // ---- write-out: lane j adds entry j's row partials in the fixed order 0..3 and stores the record's nine floats ----
+            const uint32_t slot_j = lane < cnt ? reinterpret_cast<const uint32_t*>(ent_base)[lane * R_ENT_W + 11] : 0xffffffffu;
+            if (lane < cnt && (int64_t)slot_j < capacity) {
+                const float* pr[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t sidx = (where >> (8 * r)) & 0xffu;
+                    pr[r] = sidx == 63u ? s_zero : s_part + (r * R_NB + (int)(sidx >> 3)) * 64 + (int)(sidx & 7u) * 9;
+                }
+                float acc[9];
+#pragma unroll
+                for (int f = 0; f < 9; f++) acc[f] = ((pr[0][f] + pr[1][f]) + pr[2][f]) + pr[3][f];
+                float* rec = recs + ((size_t)slot_j * 4 + quad) * 16;
+                reinterpret_cast<float4*>(rec)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                reinterpret_cast<float4*>(rec)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                rec[8] = acc[8];
+                valid[(size_t)slot_j * 4 + quad] = hit_j ? (uint8_t)3 : (uint8_t)1;  // 3: the depth-hit floats 9..13 are there as well
+            }
+            // ---- the next group ----
+            cnt = cnt_next;
+            if (cnt == 0) break;
+            gather_records(cnt);
+        }
+        return;
+    }
     // colour blended behind the current entry (the reference's accum_rec after folding in last_alpha / last_color,
     // backward.cu:957-962, evaluated one step earlier: same operands, same rounding)
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
     const int lane_b = lane / 9, lane_f = lane - 9 * lane_b;  // this lane's (entry of the batch, record float) after the butterfly
-    const uint8_t* live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;
-
-    const int chunks = (L + BWD_THREADS - 1) / BWD_THREADS;
-    int cnt = 0;  // live entries of the chunk in flight (compacted in LDS)
+    cnt = 0;  // live entries of the chunk in flight (compacted in LDS)
     // The live entries of the chunk are processed BWD_NB at a time: their 9 colour-path sums each go through ONE reduce-scatter
     // butterfly, after which lane l = 9 b + f holds float f of entry b's record.  A batch whose BWD_NB entries all exist runs as
     // one straight-line block (FULL): no wave-uniform branch sits between two entries, so the scheduler interleaves the parts of
@@ -499,7 +808,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     };
     if (SEGS == 1) {
         // chunk c covers list positions L-1-c*64 ... descending; lane l looks at position L-1-(c*64+l): lane order == walk order
-        uint8_t lv_nx = (L - 1 - lane >= 0) ? live[L - 1 - lane] : (uint8_t)0;
+        lv_nx = (L - 1 - lane >= 0) ? live[L - 1 - lane] : (uint8_t)0;
         for (int c = 0; c < chunks; c++) {
             const int pos = L - 1 - (c * BWD_THREADS + lane);
             const bool is_live = lv_nx != 0;
@@ -516,7 +825,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
         float* const s_x = reinterpret_cast<float*>(lds + SEGS * BWD_BLK);  // [round parity][wave][Q, B, A0, A1, A2][lane]
         float T_round = T_final, R0 = 0.f, R1 = 0.f, R2 = 0.f;              // the state at the start of the round (same bits in every wave)
         int p_nx = L - 1 - (wave * BWD_THREADS + lane);
-        uint8_t lv_nx = p_nx >= 0 ? live[p_nx] : (uint8_t)0;
+        lv_nx = p_nx >= 0 ? live[p_nx] : (uint8_t)0;
         for (int r = 0; r * SEGS < chunks; r++) {
             const int pos = L - 1 - ((r * SEGS + wave) * BWD_THREADS + lane);
             const bool is_live = lv_nx != 0;
@@ -565,13 +874,16 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
 #ifndef BWD_WPB
 #define BWD_WPB 1  // waves (= quadrants of ONE tile) per workgroup; independent of each other either way
 #endif
-template <int BWD_NB, bool GATE>
-__global__ __launch_bounds__(BWD_THREADS * BWD_WPB, BWD_NB == 7 ? 5 : 8) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+#ifndef DQO_BWD_ROWS_WAVES
+#define DQO_BWD_ROWS_WAVES 4  // the row walk's LDS (ROWS_BLK words per wave) leaves room for 4 waves per SIMD at RG = 42
+#endif
+template <int BWD_NB, bool GATE, bool ROWS = false>
+__global__ __launch_bounds__(BWD_THREADS * BWD_WPB, ROWS ? DQO_BWD_ROWS_WAVES : (BWD_NB == 7 ? 5 : 8)) void blend_backward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                      DqoBinLayout bin, const float* __restrict__ dL_dpixels,
                                                                      const float* __restrict__ dL_ddepths,
                                                                      float* __restrict__ recs, uint8_t* __restrict__ valid,
                                                                      int64_t capacity, const DqoTapDev tap, const DqoGateDev gate) {
-    __shared__ uint32_t lds[BWD_BLK * BWD_WPB];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[(ROWS ? ROWS_BLK : BWD_BLK) * BWD_WPB];
     const int wave = BWD_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int lane = (int)(threadIdx.x & 63);
     // DqoLossTap: the first block also reports the loss (before the early exits below: block 0 may have no list)
@@ -583,8 +895,8 @@ __global__ __launch_bounds__(BWD_THREADS * BWD_WPB, BWD_NB == 7 ? 5 : 8) void bl
     const int T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
     if (tile_u == 0xffffffffu) return;  // unused slot
-    blend_quadrant_bwd<BWD_NB, GATE, 1>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, jg & 3, wave, lane,
-                                         lds, 0x7fffffff);
+    blend_quadrant_bwd<BWD_NB, GATE, 1, ROWS>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, jg & 3, wave,
+                                               lane, lds, 0x7fffffff);
 }
 
 // DqoRastCtx.list_split, the backward's half (the layout of blend_forward_split_kernel): blocks of eight waves; the first BSPLIT_GRID and
@@ -683,6 +995,20 @@ int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const Dq
         return DQO_OK;
     }
     const dim3 grid(8 * ((T + 7) / 8) * 4 / BWD_WPB);
+    // DQO_BWD_ROWS=0 (measurement / A-B only): the union walk (every entry on all 64 pixels of the quadrant) instead of the row walk
+    static const bool rows = [] {
+        const char* e = getenv("DQO_BWD_ROWS");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (rows && nb == 7) {
+        if (gate.gobj != nullptr)
+            DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true, true>), grid, dim3(BWD_THREADS * BWD_WPB), s, v, g, img, bin, dL_dcolor,
+                       dL_ddepth, r, valid, capacity, tap, gate);
+        else
+            DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, false, true>), grid, dim3(BWD_THREADS * BWD_WPB), s, v, g, img, bin, dL_dcolor,
+                       dL_ddepth, r, valid, capacity, tap, gate);
+        return DQO_OK;
+    }
     if (gate.gobj != nullptr)
         DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true>), grid, dim3(BWD_THREADS * BWD_WPB), s, v, g, img, bin, dL_dcolor, dL_ddepth, r,
                    valid, capacity, tap, gate);

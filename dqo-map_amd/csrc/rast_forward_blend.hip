@@ -12,8 +12,8 @@
 // A wave stops as soon as its own 64 pixels are finished (the reference keeps a whole 256-thread block alive until its
 // last pixel is done, and so did the previous 4-wave version of this kernel, paying a block barrier per batch).
 //
-// Per (quadrant, list position) the wave records a live byte: 1 iff some unfinished pixel of the quadrant saw the entry with
-// alpha >= 1/255 — a superset of "blended it or took it as its depth hit", i.e. of the (pixel, entry) pairs the backward has
+// Per (quadrant, list position) the wave records a live byte: non-zero iff some unfinished pixel of the quadrant saw the entry with
+// alpha >= 1/255 (bit r: some pixel of DPP row r = 4x4 block r did) — a superset of "blended it or took it as its depth hit", i.e. of the (pixel, entry) pairs the backward has
 // work for; the backward walks live entries only.  The per-Gaussian surfel normal / camera-space point are read from the preprocess tables (forward.cu:779-791 rebuilds
 // them from the quaternion for every (pixel, Gaussian) pair).
 #include "dqo_common.h"
@@ -140,8 +140,8 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     float* const s_part = reinterpret_cast<float*>(lds);  // run j, word k, lane l: s_part[j * PART_STRIDE + k * 64 + l]
 
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
-    const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + (lane & 7);
-    const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + (lane >> 3);
+    const uint32_t px = tile_x * DQO_TILE + (quad & 1) * 8 + dqo_lane_x(lane);
+    const uint32_t py = tile_y * DQO_TILE + (quad >> 1) * 8 + dqo_lane_y(lane);
     const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
     const size_t HW = (size_t)v.W * v.H;
     const size_t pix_id = (size_t)v.W * py + px;
@@ -239,7 +239,8 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             const bool other = GATE && mixed && __float_as_int(xy_cur.w) != owner;
             const float a_g = (power <= 0.0f && !other) ? alpha * pix_gate : 0.f;
             const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
-            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+            const unsigned long long valid_m = __builtin_amdgcn_ballot_w64(valid);
+            if (valid_m != 0ull) {
                 const uint32_t contributor = (uint32_t)(PF ? pos_now : s_pos[k]);
                 const float4 cs = PF ? cs_now : s_rgb[k];
                 const int gid = PF ? id_now : s_id[k];
@@ -286,7 +287,9 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
                 const float t_half = blend ? test_T : 0.f;
                 unsigned long long half_m;
                 asm volatile("v_cmp_lt_f32 %0, 0.5, %1" : "=s"(half_m) : "v"(t_half));
-                s_half[k] = (int)__popcll(half_m);
+                // ... and with it WHICH 16-lane rows (4x4 pixel blocks, dqo_lane_x / _y) saw the entry: the backward's rows walk their
+                // own sub-lists
+                s_half[k] = (int)__popcll(half_m) | (int)(dqo_row_code(valid_m) << 8);
                 live_m |= 1ull << k;
                 all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;
             }
@@ -313,9 +316,10 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     // what the chunk leaves behind: one scattered integer atomic per touched Gaussian, and the live byte of every list position
     // (coalesced 64-byte store)
     auto chunk_results = [&](int pos, bool reach, int myk) {
-        const int half_k = ((live_m >> lane) & 1ull) ? s_half[lane] : 0;
+        const int half_k = ((live_m >> lane) & 1ull) ? (s_half[lane] & 0xff) : 0;
         if (half_k > 0) atomicAdd(&out.n_touched[s_id[lane]], half_k);
-        if (pos < n) live[pos] = (reach && ((live_m >> myk) & 1ull)) ? (uint8_t)1 : (uint8_t)0;
+        // live byte = the entry's row code (0: no pixel of the quadrant has work for it)
+        if (pos < n) live[pos] = (reach && ((live_m >> myk) & 1ull)) ? (uint8_t)((s_half[myk] >> 8) & 0xf) : (uint8_t)0;
     };
 
     // prologue: loads of the wave's first chunk (chunk `wave`; SEGS == 1: chunk 0)

@@ -57,9 +57,7 @@ def test_split_forward_is_the_serial_forward_within_rounding(env, cfg, P, runs):
     dLm = (dL[0] * same, dL[1] * same)
     ga = a.backward(dLm, retain=False)
     gb = b.backward(dLm, retain=False)
-    for k in ga:
-        den = np.abs(ga[k]).max() + 1e-30
-        assert np.abs(ga[k] - gb[k]).max() / den < 1e-3, (k, np.abs(ga[k] - gb[k]).max() / den)
+    U.assert_grads_match(ga, gb, "split vs serial forward")
 
 
 @pytest.mark.parametrize("runs", [64, 256])
@@ -178,9 +176,7 @@ def test_split_backward_with_quadrants_that_get_no_gradient(env):
             assert np.array_equal(g_half[k], g_half2[k]), (runs, k)  # bitwise: a function of its arguments
         res[runs] = (g_half, g_full)
     for ga, gb in zip(res[0], res[128]):
-        for k in ga:
-            den = np.abs(ga[k]).max() + 1e-30
-            assert np.abs(ga[k] - gb[k]).max() / den < 1e-3, (k, np.abs(ga[k] - gb[k]).max() / den)
+        U.assert_grads_match(ga, gb, "split vs single-wave backward")
 
 
 def test_fused_mapper_with_split_lists_and_a_partial_render_mask(env):

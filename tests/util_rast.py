@@ -234,6 +234,17 @@ def compare_grads(hg, og, og64=None, rtol=1e-3):
     return stats
 
 
+def assert_grads_match(ga, gb, what="", rtol=1e-3, worst=1e-2):
+    """Two HIP evaluations of the same gradients that differ by ROUNDING only (another summation order, a forward whose per-pixel state
+    differs in the last bits): every Gaussian row within `rtol` of the tensor's largest magnitude, except — the per-Gaussian chain of
+    backward.cu:331-355 is ill-conditioned for thin surfels and amplifies last-bit differences of its inputs ~1e4 times on a handful of
+    rows (compare_grads, which has the fp64 oracle to say which) — at most max(2, 2e-5 x rows) rows, none beyond `worst`."""
+    for k in ga:
+        e = _row_err(gb[k], ga[k])
+        n_out = int((e > rtol).sum())
+        assert n_out <= max(2, int(2e-5 * e.size)) and (e.max() if e.size else 0.0) < worst, (what, k, n_out, float(e.max()))
+
+
 def parity_case(ol, cam, sc, dL, fp64=False, device="cuda", **kw):
     """The full protocol on one scene: forward of HIP and oracle, flipped pixels, incoming gradient zeroed on them for BOTH, then
     backward of both.  Returns (forward stats, gradient stats)."""

@@ -20,7 +20,8 @@ def main():
                 k = row.get("Kernel_Name", "")
                 if flt and flt not in k:
                     continue
-                k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0][-48:]
+                k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                k = k[-64:] if os.environ.get("PMC_KEEP_TEMPLATE") else k.split("<")[0][-48:]  # (template arguments kept on request)
                 c = row.get("Counter_Name")
                 a = acc[k][c]
                 a[0] += float(row.get("Counter_Value", 0))
