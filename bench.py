@@ -1018,8 +1018,11 @@ def pmc_valu(args, kernel_name, avg_launch_us):
     return dict(insts=int(insts), issue_frac_of_measured_roof=round(insts / roof, 4),
                 exec_lane_utilisation=round(res["SQ_THREAD_CYCLES_VALU"] / max(res["SQ_ACTIVE_INST_VALU"] * 64.0, 1.0), 4),
                 lane_utilisation=None,
-                lane_utilisation_note="useful lanes per wave step (pixels with alpha >= 1/255 among the 64): 37 % on cfg 3, from the oracle's "
-                                      "per-entry pixel masks (tests/diag_pair_stats.py, round 2); the exec mask is full: predication is arithmetic",
+                lane_utilisation_note="useful lanes per wave step (pixels with alpha >= 1/255 among the 64) on cfg 3, from the oracle's per-entry "
+                                      "pixel masks (tests/diag_pair_stats.py, tests/diag_row_model.py): 37 % for a wave that steps through the union "
+                                      "of its quadrant's entries (the forward; the backward until round 4), 46 % for the backward's row walk (each "
+                                      "16-lane row on its own sub-list: 0.81 M instead of 1.008 M wave steps); the exec mask is full: predication "
+                                      "is arithmetic",
                 wave_cycles_waiting_frac=round(res["SQ_WAIT_ANY"] / wc, 4), wave_cycles_issue_stall_frac=round(res["SQ_WAIT_INST_ANY"] / wc, 4),
                 waves=int(res["SQ_WAVES"]), roof="0.90 G wave64 instr / s / SIMD x 1024 SIMDs (profiles/r02_ubench_fma_peak.txt)",
                 source="rocprofv3 --pmc SQ_* child pass over `" + note + "`"), note
@@ -1335,6 +1338,10 @@ def main():
         N.profile_enable(False)
         kernels = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in prof.items()}  # average microseconds per launch
         stats["kernel_us"] = kernels
+        stats["kernel_us_source"] = ("HIP events around every launch of an EAGER pass over the iteration's own calls (events cannot be recorded inside a "
+                                     "graph replay); every bracket carries ~4-5 us of event overhead that a replay does not pay, so the sum "
+                                     f"({round(sum(kernels.values()), 1)} us over {len(kernels)} kernels) exceeds ms_per_step by about that much per kernel; "
+                                     "rocprofv3 --kernel-trace --stats of the same command: profiles/r05_kernel_stats.csv")
         dom = max(prof.items(), key=lambda kv: kv[1][0])
         dom_name, dom_ms = dom[0], dom[1][0] / max(dom[1][1], 1)
         # workload counts of the current state from the device header of the last forward
@@ -1370,8 +1377,17 @@ def main():
         # the contract's own per-unit figure for the dominant kernel's share of an iteration: 40 B per instance (bwd
         # gather) + 16 B per active pixel (dL_dcolor, dL_ddepth) for the backward blend; 28 B + 36 B for the forward blend
         contract = {"blend_backward_kernel": 40 * n_inst + 16 * HWa, "blend_forward_kernel": 28 * n_inst + 36 * HWa}
-        bytes_dom = alg.get(dom_name, 0)
+        # `achieved` / `frac`: the CONTRACT's figure — SURVEY.md §8d's per-unit bytes x the units of one launch over the launch's measured
+        # duration; the builder's own traffic model of the kernel (what it must move given its design: records instead of atomics, the
+        # loss tap's images, the gate's ids) is reported beside it as model_*
+        per_unit = {"blend_backward_kernel": "40 B x N instances (bwd gather: id, xy, conic + opacity, rgb) + 16 B x active pixels (dL_dcolor, dL_ddepth)",
+                    "blend_forward_kernel": "28 B x N instances (fwd tile gather: id, xy, conic + opacity) + 36 B x active pixels (colour, depth, 2 ids, 2 weights, T)"}
+        model_unit = {"blend_backward_kernel": f"{120 + gate_i} B x N instances (id, slot, 3 records in, one 64-byte gradient record out) + {32 + tap_px + gate_px} B x active pixels",
+                      "blend_forward_kernel": f"{40 + gate_i} B x N instances (id + 3 records, live bytes) + {36 + tap_px + gate_px} B x active pixels"}
+        bytes_model = alg.get(dom_name, 0)
+        bytes_dom = contract.get(dom_name, bytes_model)
         achieved = bytes_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        model_achieved = bytes_model / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic, traffic_note, valu = None, "not collected", None
         if rank == 0 and world == 1 and not args.no_pmc:
             tr, traffic_note = pmc_traffic(args, dom_name)
@@ -1388,15 +1404,20 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_note,
                         bound_measured=("valu" if "blend" in dom_name else "latency"), valu=valu,
                         avg_launch_us=round(dom_ms * 1e3, 2), algorithmic_bytes=int(bytes_dom),
-                        contract_bytes=int(contract.get(dom_name, bytes_dom)),
-                        contract_frac=round(contract.get(dom_name, bytes_dom) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom_ms > 0 else None,
+                        algorithmic_bytes_per_unit=per_unit.get(dom_name, "DESIGN.md section 4 (the contract has no per-kernel share for this kernel: the builder's model)"),
+                        contract_bytes=int(bytes_dom), contract_frac=round(achieved / HBM_PEAK_GBS, 5),
+                        model_bytes=int(bytes_model), model_achieved=round(model_achieved, 2), model_frac=round(model_achieved / HBM_PEAK_GBS, 5),
+                        model_bytes_per_unit=model_unit.get(dom_name, "DESIGN.md section 4"),
+                        n_instances=int(n_inst), active_pixels=int(HWa),
                         iteration=dict(contract_bytes=int(b_iter), gbs=round(b_iter / (ms_step * 1e-3) / 1e9, 1),
                                        frac=round(b_iter / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
-                        note="`bound` / achieved / peak / frac price the dominant kernel against HBM as the bench contract asks (algorithmic_bytes = "
-                             "DESIGN.md's per-launch model: 120 B / instance + 32 B / active pixel for the backward blend; contract_bytes = "
-                             "SURVEY.md §8d's own share); what actually bounds it is `bound_measured`: the blend kernels are VALU-execution "
-                             "bound (`valu`: SQ counters of this run against the measured issue roof), the fused per-Gaussian tail by the "
-                             "latency of its dependent memory rounds; per-kernel GB/s of every kernel: kernel_gbs",
+                        note="`bound` / achieved / peak / frac price the dominant kernel against HBM as the bench contract asks: algorithmic_bytes = "
+                             "SURVEY.md §8d's per-unit figure (algorithmic_bytes_per_unit) x the units of one launch (n_instances, active_pixels), "
+                             "over avg_launch_us (HIP events in this run).  model_* = the same with the builder's traffic model of the kernel as "
+                             "designed (model_bytes_per_unit), `traffic` = what the memory-side counters saw.  What actually bounds the kernel is "
+                             "`bound_measured`: the blend kernels are VALU bound (`valu`: SQ counters of this run against the measured issue "
+                             "roof), the fused per-Gaussian tail by the latency of its dependent memory rounds; kernel_gbs = every kernel "
+                             "against the builder's model",
                         kernel_gbs={k: round(alg[k] / (us * 1e-6) / 1e9, 1) for k, us in kernels.items() if k in alg and us > 0})
 
     cpu = None

@@ -184,6 +184,39 @@ __device__ __forceinline__ void row_stage4(const float (&lo)[8], const float (&h
                    [h6] "v"(hi[6]), [h7] "v"(hi[7]));
 #undef DQO_R4
 }
+// ... and for THIRTY-TWO values (three entries per batch): lane s of a row ends up with the row's totals of v[2 s], v[2 s + 1]; 66 VALU
+// for 27 sums — more per sum than the 64-value form, but half the registers (what decides how many waves share a SIMD)
+__device__ __forceinline__ void row_reduce32(const float (&v)[32], float (&out)[2], int lane) {
+    float c[16];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {  // c[i] = v[i] (+) v[i + 16]
+        float lo[8], hi[8], r[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) lo[i] = v[8 * q + i], hi[i] = v[16 + 8 * q + i];
+        row_stage8(lo, hi, r);
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[8 * q + i] = r[i];
+    }
+    float d[8];
+    {
+        float lo[8], hi[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) lo[i] = c[i], hi[i] = c[8 + i];
+        row_stage4(lo, hi, d);
+    }
+    const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    float e[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float keep = b1 ? d[i + 4] : d[i], send = b1 ? d[i] : d[i + 4];
+        e[i] = keep + dpp_mov<0x4E>(send);  // partner lane ^ 2
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float keep = b0 ? e[i + 2] : e[i], send = b0 ? e[i] : e[i + 2];
+        out[i] = keep + dpp_mov<0xB1>(send);  // partner lane ^ 1
+    }
+}
 __device__ __forceinline__ void row_reduce64(const float (&v)[64], float (&out)[4], int lane) {
     float c[32];
 #pragma unroll
@@ -254,6 +287,11 @@ constexpr int BWD_THREADS = 64;
 // LDS of one wave: the gathered records of its chunk's live entries (three float4 tables, three word tables) and the depth-hit sums
 constexpr int BWD_BLK = 3 * BWD_THREADS * 4 + 3 * BWD_THREADS + 5 * BWD_THREADS;  // words: 1280 = 5120 B
 constexpr int BWD_XCH = 5 * BWD_THREADS;                                            // words of one wave's pass-1 result (SEGS > 1)
+__device__ __forceinline__ void row_reduce(const float (&v)[64], float (&out)[4], int lane) { row_reduce64(v, out, lane); }
+__device__ __forceinline__ void row_reduce(const float (&v)[32], float (&out)[2], int lane) { row_reduce32(v, out, lane); }
+__device__ __forceinline__ void row_store(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+__device__ __forceinline__ void row_store(float* p, const float (&o)[2]) { *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]); }
+
 // ---- the row walk (ROWS): every 16-lane DPP row (4x4 pixel block, dqo_lane_x / _y) of the quadrant wave walks ITS OWN sub-list ----
 // The forward's live byte of a (quadrant, list position) is a 4-bit row code: which rows have a pixel with work for the entry.  The
 // wave collects RG live entries at a time (walk order, whatever list positions they sit at), gathers their records into LDS once, and
@@ -270,13 +308,20 @@ constexpr int BWD_XCH = 5 * BWD_THREADS;                                        
                        // wave = four waves per SIMD (56: 11.7 KB, 3.5 waves, and 159 instead of 145 us on cfg 3 although it saves 3.6 % more steps)
 #endif
 constexpr int RG = DQO_BWD_RG;
-static_assert(RG % 7 == 0 && RG >= 7 && RG <= 56, "RG: whole batches of 7, 64 list slots per row");
+#ifndef DQO_BWD_ROW_NB
+#define DQO_BWD_ROW_NB 7  // steps per batch: 7 (63 of 64 values through row_reduce64) or 3 (27 of 32 through row_reduce32: fewer registers)
+#endif
+constexpr int RNB = DQO_BWD_ROW_NB;
+constexpr int RNV = RNB == 7 ? 64 : 32;     // values per lane and batch
+constexpr int RLS = RNB == 7 ? 8 : 4;       // list slots per batch (the last one is padding)
+static_assert(RNB == 7 || RNB == 3, "batches of 7 or 3 steps");
+static_assert(RG % RNB == 0 && RG >= RNB && (RG / RNB) * RLS <= 64 && (RG / RNB) * RLS - 2 < 63, "RG: whole batches, 64 list slots per row, slot 63 free");
 constexpr int R_ENT_W = 12;                          // words of an entry record: conic + opacity | x, y, object id, position | r, g, b, slot
 constexpr int R_ENT = 0;                             // [RG + 1] records (the last one: the dummy a finished row keeps stepping on)
 constexpr int R_LIST = R_ENT + (RG + 1) * R_ENT_W;   // [4 rows][64] u16: byte offset of the entry record, 8 slots per batch (7 used)
-constexpr int R_NB = RG / 7;                         // batches of a group at most
-constexpr int R_PART = R_LIST + 4 * 64 / 2;          // [4 rows][R_NB batches][64] floats: a row's reduced sums of a batch exactly as the
-constexpr int R_PART_W = 4 * R_NB * 64 + 12;         //   reduce-scatter leaves them (value 9 b + f at [9 b + f]), + 12 zeros (the prologue's
+constexpr int R_NB = RG / RNB;                       // batches of a group at most
+constexpr int R_PART = R_LIST + 4 * 64 / 2;          // [4 rows][R_NB batches][RNV] floats: a row's reduced sums of a batch exactly as the
+constexpr int R_PART_W = 4 * R_NB * RNV + 12;        //   reduce-scatter leaves them (value 9 b + f at [9 b + f]), + 12 zeros (the prologue's
                                                      //   depth-hit sums use this space first)
 constexpr int R_MPOS = R_PART + R_PART_W;            // [64] ints + [64] bytes: list positions and row codes of the NEXT group (collected while
 constexpr int R_MCODE = R_MPOS + 64;                 //        the current one is walked: its ids are in flight during the walk)
@@ -565,8 +610,8 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
         const char* const list_row = reinterpret_cast<const char*>(s_list) + row * 128;  // this row's sub-list (64 u16)
         // after row_reduce64 lane sl of a row holds the totals of values 4 sl .. 4 sl + 3 (value 9 b + f = float f of the batch's b-th
         // entry): one 16-byte store per lane and batch puts them at part[row][batch][4 sl ..]
-        float* const part_lane = s_part + row * (R_NB * 64) + sl * 4;
-        float* const s_zero = s_part + 4 * R_NB * 64;  // nine zeros: what a row that has nothing for an entry contributes
+        float* const part_lane = s_part + row * (R_NB * RNV) + sl * (RNV / 16);
+        float* const s_zero = s_part + 4 * R_NB * RNV;  // nine zeros: what a row that has nothing for an entry contributes
         constexpr uint32_t DUMMY = (uint32_t)(RG * R_ENT_W * 4);  // byte offset of the dummy record
         {   // the dummy record: opacity 0 -> alpha 0 -> every term an exact zero and the pixel state untouched; position -2 matches no hit
             if (lane < R_ENT_W) reinterpret_cast<uint32_t*>(ent_base + DUMMY)[lane] = lane == 7 ? 0xfffffffeu : 0u;
@@ -606,7 +651,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
                 const bool in = ((code >> r) & 1u) != 0u;
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
                 const int rk = below(m);
-                const int sidx = rk + ((rk * 37) >> 8);  // (rk * 37) >> 8 == rk / 7 for rk < 64
+                const int sidx = RNB == 7 ? rk + ((rk * 37) >> 8) : rk + ((rk * 43) >> 7);  // rk + rk / RNB for rk < 64: batch * RLS + step
                 if (in) s_list[r * 64 + sidx] = (uint16_t)(lane * (R_ENT_W * 4));
                 where = in ? ((where & ~(0xffu << (8 * r))) | ((uint32_t)sidx << (8 * r))) : where;
                 nsteps = max(nsteps, (int)__popcll(m));
@@ -618,14 +663,21 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
             // ---- walk: seven steps per batch ----
             auto batch = [&](const int t, auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
-                const uint4 li = *reinterpret_cast<const uint4*>(list_row + t * 16);
-                const uint32_t lw[4] = {li.x, li.y, li.z, li.w};
-                float v64[64];
-                v64[63] = 0.f;
+                uint32_t lw[4];
+                if constexpr (RNB == 7) {
+                    const uint4 li = *reinterpret_cast<const uint4*>(list_row + t * 16);
+                    lw[0] = li.x, lw[1] = li.y, lw[2] = li.z, lw[3] = li.w;
+                } else {
+                    const uint2 li = *reinterpret_cast<const uint2*>(list_row + t * 8);
+                    lw[0] = li.x, lw[1] = li.y, lw[2] = lw[3] = 0u;
+                }
+                float v64[RNV];
 #pragma unroll
-                for (int b = 0; b < 7; b++) {
+                for (int i = 9 * RNB; i < RNV; i++) v64[i] = 0.f;
+#pragma unroll
+                for (int b = 0; b < RNB; b++) {
                     float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
-                    if (FULL || t * 7 + b < nsteps) {  // wave-uniform
+                    if (FULL || t * RNB + b < nsteps) {  // wave-uniform
                         const uint32_t off = (b & 1) ? (lw[b >> 1] >> 16) : (lw[b >> 1] & 0xffffu);
                         const float4* e = reinterpret_cast<const float4*>(ent_base + off);
                         const float4 co = e[0], xy = e[1], cs = e[2];
@@ -661,15 +713,15 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
                     v64[9 * b + 0] = r_c0, v64[9 * b + 1] = r_c1, v64[9 * b + 2] = r_c2, v64[9 * b + 3] = r_mx, v64[9 * b + 4] = r_my;
                     v64[9 * b + 5] = r_ka, v64[9 * b + 6] = r_kb, v64[9 * b + 7] = r_kc, v64[9 * b + 8] = r_op;
                 }
-                float out[4];
-                row_reduce64(v64, out, lane);
                 // the row's sums of the batch's entries, as they are: part[row][batch][9 b + f] (every (row, entry) pair exists once)
-                *reinterpret_cast<float4*>(part_lane + t * 64) = make_float4(out[0], out[1], out[2], out[3]);
+                float out[RNV / 16];
+                row_reduce(v64, out, lane);
+                row_store(part_lane + t * RNV, out);
             };
             {
                 int t = 0;
-                for (; (t + 1) * 7 <= nsteps; t++) batch(t, std::true_type{});
-                if (t * 7 < nsteps) batch(t, std::false_type{});
+                for (; (t + 1) * RNB <= nsteps; t++) batch(t, std::true_type{});
+                if (t * RNB < nsteps) batch(t, std::false_type{});
             }
             // ---- write-out: lane j adds entry j's row partials in the fixed order 0..3 and stores the record's nine floats ----
             const uint32_t slot_j = lane < cnt ? reinterpret_cast<const uint32_t*>(ent_base)[lane * R_ENT_W + 11] : 0xffffffffu;
@@ -678,7 +730,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint32_t sidx = (where >> (8 * r)) & 0xffu;
-                    pr[r] = sidx == 63u ? s_zero : s_part + (r * R_NB + (int)(sidx >> 3)) * 64 + (int)(sidx & 7u) * 9;
+                    pr[r] = sidx == 63u ? s_zero : s_part + (r * R_NB + (int)(sidx / RLS)) * RNV + (int)(sidx % RLS) * 9;
                 }
                 float acc[9];
 #pragma unroll
