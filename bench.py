@@ -388,14 +388,9 @@ class FusedRunner:
             import dqo_mapgrowth as mg
             fm, b = self.fm, self.growth_pool[0]
             sc = b["scales"]
-            if fm.gaussian_object is not None:  # (the per-object forms of the two decisions: what grow() runs with an object gate)
-                keep = mg.temp_points_filter_mask_per_object(b["xyz"], b["obj_id"], fm.xyz, fm.radius(), fm.gaussian_object, cell=fm.object_cell)
-                mg.update_geometry_scales_per_object(b["xyz"], b["obj_id"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(),
-                                                     fm.gaussian_object, 0.001, 0.05, cell=fm.object_cell)
-            else:
-                keep = mg.temp_points_filter_mask(b["xyz"], fm.xyz, fm.radius())
-                mg.update_geometry_scales(b["xyz"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(), 0.001, 0.05)
-            if self.stable_mask is not None:  # (on a thread and a stream of its own, as grow() runs it)
+            th = None
+            if self.stable_mask is not None:  # (on a thread and a stream of its own and BESIDE the searches, as grow() runs it: the
+                # allocator's high-water mark of the step is the sum of both sides' temporaries)
                 import threading
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream())
@@ -406,6 +401,15 @@ class FusedRunner:
                                                temp_obj=b["obj_id"] if fm.gaussian_object is not None else None)
                 th = threading.Thread(target=warm)
                 th.start()
+            if fm.gaussian_object is not None:  # (the per-object forms of the two decisions: what grow() runs with an object gate)
+                few = torch.arange(0, fm.P, 512, device=self.device)  # (a small reference set, like the unstable cloud the filter sees)
+                keep = mg.temp_points_filter_mask_per_object(b["xyz"], b["obj_id"], fm.xyz[few], fm.radius()[few], fm.gaussian_object[few], cell=fm.object_cell)
+                mg.update_geometry_scales_per_object(b["xyz"], b["obj_id"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(),
+                                                     fm.gaussian_object, 0.001, 0.05, cell=fm.object_cell)
+            else:
+                keep = mg.temp_points_filter_mask(b["xyz"], fm.xyz, fm.radius())
+                mg.update_geometry_scales(b["xyz"], (sc.sum(1) - sc.min(1).values) / 2, fm.xyz, fm.radius(), 0.001, 0.05)
+            if th is not None:
                 th.join()
                 torch.cuda.current_stream().wait_stream(side)
             del keep

@@ -20,7 +20,8 @@ int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void
 size_t dqo_knn3_ws_bytes(int P);
 size_t dqo_knn3_query_ws_bytes(int Q, int R);
 int dqo_launch_knn3_query(int Q, const float* q_xyz, int R, const float* r_xyz, float* dist2, int32_t* idx3, void* ws, size_t ws_bytes,
-                          hipStream_t s, float bound2);
+                          hipStream_t s, float bound2, const int32_t* q_group = nullptr, const int32_t* r_group = nullptr,
+                          const float* group_box = nullptr);
 int dqo_launch_quadric_iou(int B, const float* axes, const float* R, const float* center, const float* P34, const float* obs,
                            float* bbox, float* loss, int32_t* valid, float* g_axes, float* g_R, float* g_center, hipStream_t s);
 int dqo_launch_quadric_adam(int n_obj, int n_iters, const int32_t* view_offset, const float* P34_views, const float* obs_views,
@@ -337,7 +338,8 @@ DQO_API int dqo_mark_visible(int32_t P, const float* means3D, const float* view,
 DQO_API size_t dqo_knn3_query_workspace_bytes(int32_t Q, int32_t R) { return dqo_knn3_query_ws_bytes(Q < 1 ? 1 : Q, R < 1 ? 1 : R); }
 
 static int knn3_query(int32_t Q, const float* q_xyz, int32_t R, const float* r_xyz, float max_dist, float* dist2, int32_t* idx3, void* ws,
-                      size_t ws_bytes, void* stream) {
+                      size_t ws_bytes, void* stream, const int32_t* q_group = nullptr, const int32_t* r_group = nullptr,
+                      const float* group_box = nullptr) {
     DQO_CHECK_ARG(Q >= 0 && R >= 0, "negative size");
     DQO_CHECK_ARG(max_dist > 0.f, "max_dist must be positive");
     if (Q == 0) return DQO_OK;
@@ -348,7 +350,7 @@ static int knn3_query(int32_t Q, const float* q_xyz, int32_t R, const float* r_x
         return DQO_ERR_WORKSPACE;
     }
     const float bound2 = max_dist < 1.8e19f ? max_dist * max_dist : 3.402823466e+38f;
-    return dqo_launch_knn3_query(Q, q_xyz, R, r_xyz, dist2, idx3, ws, ws_bytes, (hipStream_t)stream, bound2);
+    return dqo_launch_knn3_query(Q, q_xyz, R, r_xyz, dist2, idx3, ws, ws_bytes, (hipStream_t)stream, bound2, q_group, r_group, group_box);
 }
 
 DQO_API int dqo_knn3_query(int32_t Q, const float* q_xyz, int32_t R, const float* r_xyz, float* dist2, int32_t* idx3, void* ws, size_t ws_bytes,
@@ -359,6 +361,13 @@ DQO_API int dqo_knn3_query(int32_t Q, const float* q_xyz, int32_t R, const float
 DQO_API int dqo_knn3_query_within(int32_t Q, const float* q_xyz, int32_t R, const float* r_xyz, float max_dist, float* dist2, int32_t* idx3,
                                   void* ws, size_t ws_bytes, void* stream) {
     return knn3_query(Q, q_xyz, R, r_xyz, max_dist, dist2, idx3, ws, ws_bytes, stream);
+}
+
+DQO_API int dqo_knn3_query_grouped(int32_t Q, const float* q_xyz, const int32_t* q_group, int32_t R, const float* r_xyz, const int32_t* r_group,
+                                   const float* group_box, float max_dist, float* dist2, int32_t* idx3, void* ws, size_t ws_bytes, void* stream) {
+    DQO_CHECK_ARG(Q == 0 || (q_group && r_group), "null group ids");
+    DQO_CHECK_ARG(R < (1 << 25), "the grouped search carries the group id in the index word: at most 2^25 - 1 reference points");
+    return knn3_query(Q, q_xyz, R, r_xyz, max_dist, dist2, idx3, ws, ws_bytes, stream, q_group, r_group, group_box);
 }
 
 DQO_API size_t dqo_knn3_workspace_bytes(int32_t P) { return dqo_knn3_ws_bytes(P < 0 ? 0 : P); }

@@ -86,14 +86,25 @@ __device__ __forceinline__ void bbox_block_reduce(float mn[3], float mx[3], floa
         out[threadIdx.x] = r;
     }
 }
-__global__ __launch_bounds__(1024) void bbox_kernel(int P, const float* __restrict__ xyz, float* __restrict__ partial) {
+// group (dqo_knn3_query_grouped): points without a group (id outside [0, 64): spare rows parked far away, deleted Gaussians) take no part
+// in the search — they do not stretch the bounding box the Morton grid is laid over, sort behind every real point and are gathered as
+// a far sentinel, so the boxes they fill are pruned by distance
+__device__ __forceinline__ bool knn_in_group(const int32_t* __restrict__ group, int i) {
+    if (group == nullptr) return true;
+    const int gid = group[i];
+    return gid >= 0 && gid < 64;
+}
+__global__ __launch_bounds__(1024) void bbox_kernel(int P, const float* __restrict__ xyz, float* __restrict__ partial,
+                                                    const int32_t* __restrict__ group) {
     float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
+        if (!knn_in_group(group, i)) continue;
         for (int a = 0; a < 3; a++) {
             const float v = xyz[3 * i + a];
             mn[a] = fminf(mn[a], v);
             mx[a] = fmaxf(mx[a], v);
         }
+    }
     bbox_block_reduce(mn, mx, partial + 8 * blockIdx.x);
 }
 __global__ __launch_bounds__(512) void bbox_fold_kernel(int n, const float* __restrict__ partial, float* __restrict__ bbox) {
@@ -148,12 +159,17 @@ __device__ __forceinline__ uint64_t prep_morton64(uint64_t x) {  // bit i -> bit
     x = (x | (x << 2)) & 0x1249249249249249ull;
     return x;
 }
-__global__ void morton_fine_kernel(int P, int P2, const float* __restrict__ xyz, const float* __restrict__ bbox, uint64_t* __restrict__ keys) {
+__global__ void morton_fine_kernel(int P, int P2, const float* __restrict__ xyz, const float* __restrict__ bbox, uint64_t* __restrict__ keys,
+                                   const int32_t* __restrict__ group) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P2) return;
     if (i >= P) {
         keys[i] = ~0ull;
+        return;
+    }
+    if (!knn_in_group(group, i)) {  // behind every real point (the padding keys ~0 are larger still)
+        keys[i] = (((1ull << (3 * FINE_BITS)) - 1ull) << FINE_IDX_BITS) | (uint64_t)i;
         return;
     }
     const float mnx = bbox[0], mny = bbox[1], mnz = bbox[2], mxx = bbox[3], mxy = bbox[4], mxz = bbox[5];
@@ -303,37 +319,72 @@ __global__ __launch_bounds__(RDX_T) void radix_scatter_kernel(int n, const uint6
     }
 }
 
+// group (dqo_knn3_query_grouped): the point's group id + 1 rides in bits 25..31 of the index word (0 = the point belongs to no group)
+constexpr int KNN_GROUP_SHIFT = 25;
 __global__ void gather_sorted_kernel(int P, const float* __restrict__ xyz, const uint64_t* __restrict__ keys, float4* __restrict__ sorted,
-                                     uint64_t idx_mask) {
+                                     uint64_t idx_mask, const int32_t* __restrict__ group) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const uint32_t src = (uint32_t)(keys[i] & idx_mask);
-    sorted[i] = make_float4(xyz[3 * src], xyz[3 * src + 1], xyz[3 * src + 2], __uint_as_float(src));
+    uint32_t w = src;
+    if (group != nullptr) {
+        const int gid = group[src];
+        if (!(gid >= 0 && gid < 64)) {
+            sorted[i] = make_float4(1e18f, 1e18f, 1e18f, __uint_as_float(w));  // no group: a far sentinel (group word 0 matches no query)
+            return;
+        }
+        w |= (uint32_t)(gid + 1) << KNN_GROUP_SHIFT;
+    }
+    sorted[i] = make_float4(xyz[3 * src], xyz[3 * src + 1], xyz[3 * src + 2], __uint_as_float(w));
 }
 
+// Every pruning record (level-1 box, run of 64 points, group of 64 boxes: 8 floats, 6 of them min / max) carries in its two spare words
+// the SET OF GROUPS present among its points (dqo_knn3_query_grouped; all zero without groups): a record without the query's group is
+// skipped whatever its distance — objects are spatially coherent, so most Morton boxes hold one or two of them.
+__device__ __forceinline__ unsigned long long knn_group_bit(float w) {
+    const uint32_t g1 = __float_as_uint(w) >> KNN_GROUP_SHIFT;  // group id + 1, 0 = none (always 0 in an ungrouped build of the set)
+    return g1 ? 1ull << (g1 - 1u) : 0ull;
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (unsigned long long)__shfl_xor((long long)v, off);
+    return v;
+}
+__device__ __forceinline__ unsigned long long knn_record_groups(const float* rec) {
+    return ((unsigned long long)__float_as_uint(rec[7]) << 32) | (unsigned long long)__float_as_uint(rec[6]);
+}
 // boxMinMax, simple_knn.cu:78-117
-__global__ __launch_bounds__(256) void box_minmax_kernel(int P, const float4* __restrict__ sorted, float* __restrict__ boxes) {
+__global__ __launch_bounds__(256) void box_minmax_kernel(int P, const float4* __restrict__ sorted, float* __restrict__ boxes, int grouped) {
     __shared__ float s[6][4];
+    __shared__ unsigned long long s_g[4];
     const int b = blockIdx.x;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    unsigned long long gm = 0ull;
     for (int i = b * KNN_BOX + threadIdx.x; i < min(P, (b + 1) * KNN_BOX); i += blockDim.x) {
         const float4 p = sorted[i];
         mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
         mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+        if (grouped) gm |= knn_group_bit(p.w);
     }
+    gm = wave_or64(gm);
     for (int a = 0; a < 3; a++)
         for (int off = 32; off > 0; off >>= 1) {
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
         }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0)
+    if (lane == 0) {
         for (int a = 0; a < 3; a++) s[a][wave] = mn[a], s[3 + a][wave] = mx[a];
+        s_g[wave] = gm;
+    }
     __syncthreads();
     if (threadIdx.x < 6) {
         float r = s[threadIdx.x][0];
         for (int w = 1; w < 4; w++) r = threadIdx.x < 3 ? fminf(r, s[threadIdx.x][w]) : fmaxf(r, s[threadIdx.x][w]);
         boxes[8 * b + threadIdx.x] = r;
+    } else if (threadIdx.x < 8) {
+        const unsigned long long g = s_g[0] | s_g[1] | s_g[2] | s_g[3];
+        boxes[8 * b + threadIdx.x] = __uint_as_float(threadIdx.x == 6 ? (uint32_t)g : (uint32_t)(g >> 32));
     }
 }
 
@@ -434,8 +485,10 @@ __global__ __launch_bounds__(256) void sub_minmax_kernel(int P, const float4* __
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
         }
+    const unsigned long long g = wave_or64(i < P ? knn_group_bit(p.w) : 0ull);
     if (lane < 3) sub[8 * w + lane] = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
     else if (lane < 6) sub[8 * w + lane] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
+    else if (lane < 8) sub[8 * w + lane] = __uint_as_float(lane == 6 ? (uint32_t)g : (uint32_t)(g >> 32));
 }
 
 // third pruning level of the query search: min / max over runs of 64 level-1 boxes (one wave per group)
@@ -450,8 +503,10 @@ __global__ __launch_bounds__(256) void group_minmax_kernel(int nb, const float* 
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
         }
+    const unsigned long long g = wave_or64(gidx * 64 + lane < nb ? knn_record_groups(bx) : 0ull);
     if (lane < 3) groups[8 * gidx + lane] = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
     else if (lane < 6) groups[8 * gidx + lane] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
+    else if (lane < 8) groups[8 * gidx + lane] = __uint_as_float(lane == 6 ? (uint32_t)g : (uint32_t)(g >> 32));
 }
 
 // wave64 minimum, result wave-uniform.  DPP lanes that are not written keep `v` itself (old = v), so the minimum is unaffected.
@@ -478,13 +533,37 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // the second pass starts with finite bounds.  (The first version gave each query a lane and scanned a box with the whole wave as
 // soon as ANY of its 64 queries needed it: with few queries against a large map — the growth step's 40 800 new points against
 // 2 M Gaussians — a wave's queries lie far apart and it scanned ~45 boxes of 1024 points each: 39 ms, now 1 ms.)
+// GROUPED (dqo_knn3_query_grouped): a reference only counts for a query of the same group (ids in [0, 64); a point with another id
+// belongs to no group) and, with `group_box`, if it lies strictly inside its group's box [lo xyz, hi xyz] — the per-object growth
+// decisions of the mapper in one search over the map as it is stored: no shifted copies, no gathered subsets.
+template <bool GROUPED>
 __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float* __restrict__ q_xyz, int R,
                                                              const float4* __restrict__ sorted_r, const float* __restrict__ boxes,
                                                              const float* __restrict__ sub, const float* __restrict__ groups,
-                                                             float* __restrict__ dist2, int32_t* __restrict__ idx3, const float bound2) {
+                                                             float* __restrict__ dist2, int32_t* __restrict__ idx3, const float bound2,
+                                                             const int32_t* __restrict__ q_group, const float* __restrict__ group_box) {
     const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (q >= Q) return;
     const float4 me = make_float4(q_xyz[3 * q], q_xyz[3 * q + 1], q_xyz[3 * q + 2], 0.f);
+    uint32_t my_group = 0u;  // group id + 1
+    unsigned long long my_bit = ~0ull;
+    float gl0 = -FLT_MAX, gl1 = -FLT_MAX, gl2 = -FLT_MAX, gh0 = FLT_MAX, gh1 = FLT_MAX, gh2 = FLT_MAX;
+    if (GROUPED) {
+        const int gid = q_group[q];
+        if (!(gid >= 0 && gid < 64)) {  // a query without a group has no neighbours
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) dist2[3 * q + k] = FLT_MAX, idx3[3 * q + k] = -1;
+            }
+            return;
+        }
+        my_group = (uint32_t)(gid + 1);
+        my_bit = 1ull << gid;
+        if (group_box != nullptr) {
+            const float* b = group_box + 6 * gid;
+            gl0 = b[0], gl1 = b[1], gl2 = b[2], gh0 = b[3], gh1 = b[4], gh2 = b[5];
+        }
+    }
     // wave-uniform top 3 (ascending).  bound2 (dqo_knn3_query_within): only references closer than sqrt(bound2) count — the search starts
     // with that bound instead of an open one, so a query far from every reference prunes the whole map at once
     float b0 = bound2, b1 = bound2, b2 = bound2;
@@ -500,7 +579,12 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
             const float dx = c.x - me.x, dy = c.y - me.y, dz = c.z - me.z;
             dist = i < R ? dx * dx + dy * dy + dz * dz : FLT_MAX;
         }
-        const int cid = (int)__float_as_uint(c.w);
+        if (GROUPED) {
+            const bool ok = (__float_as_uint(c.w) >> KNN_GROUP_SHIFT) == my_group && c.x > gl0 && c.y > gl1 && c.z > gl2 && c.x < gh0 &&
+                            c.y < gh1 && c.z < gh2;
+            dist = ok ? dist : FLT_MAX;
+        }
+        const int cid = (int)(__float_as_uint(c.w) & (GROUPED ? (1u << KNN_GROUP_SHIFT) - 1u : 0xffffffffu));
         for (int rep = 0; rep < 3; rep++) {
             const float m = wave_min_f(dist);
             if (!(m < b2)) break;
@@ -516,7 +600,8 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
         const int s = b * (KNN_BOX / KNN_SUB) + lane;
         const bool in = lane < KNN_BOX / KNN_SUB && s < ns;
         const float ds = in ? dist_box_point(sub + 8 * (size_t)s, me) : FLT_MAX;
-        unsigned long long m2 = __builtin_amdgcn_ballot_w64(in && !(ds > b2));
+        const bool has = !GROUPED || (in && (knn_record_groups(sub + 8 * (size_t)s) & my_bit) != 0ull);
+        unsigned long long m2 = __builtin_amdgcn_ballot_w64(in && has && !(ds > b2));
         while (m2 != 0ull) {
             const int l = (int)__builtin_ctzll(m2);
             m2 &= m2 - 1ull;
@@ -532,7 +617,8 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
         int bl = 0;
         for (int bb = 0; bb < nb; bb += 64) {
             const int b = bb + lane;
-            const float d = b < nb ? dist_box_point(boxes + 8 * (size_t)b, me) : FLT_MAX;
+            float d = b < nb ? dist_box_point(boxes + 8 * (size_t)b, me) : FLT_MAX;
+            if (GROUPED && b < nb && (knn_record_groups(boxes + 8 * (size_t)b) & my_bit) == 0ull) d = FLT_MAX;  // (nothing of the query's group)
             if (d < dmin) dmin = d, bl = b;
         }
         const float m = wave_min_f(dmin);
@@ -546,7 +632,8 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
     for (int gg = 0; gg < ng; gg += 64) {
         const int gr = gg + lane;
         const float dg = gr < ng ? dist_box_point(groups + 8 * (size_t)gr, me) : FLT_MAX;
-        unsigned long long mg = __builtin_amdgcn_ballot_w64(gr < ng && !(dg > b2));
+        const bool hasg = !GROUPED || (gr < ng && (knn_record_groups(groups + 8 * (size_t)gr) & my_bit) != 0ull);
+        unsigned long long mg = __builtin_amdgcn_ballot_w64(gr < ng && hasg && !(dg > b2));
         while (mg != 0ull) {
             const int lg = (int)__builtin_ctzll(mg);
             mg &= mg - 1ull;
@@ -555,7 +642,8 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(int Q, const float*
             const int b = (gg + lg) * 64 + lane;
             const bool in = b < nb && b != bmin;
             const float d = in ? dist_box_point(boxes + 8 * (size_t)b, me) : FLT_MAX;
-            unsigned long long m1 = __builtin_amdgcn_ballot_w64(in && !(d > b2));
+            const bool hasb = !GROUPED || (in && (knn_record_groups(boxes + 8 * (size_t)b) & my_bit) != 0ull);
+            unsigned long long m1 = __builtin_amdgcn_ballot_w64(in && hasb && !(d > b2));
             while (m1 != 0ull) {
                 const int l = (int)__builtin_ctzll(m1);
                 m1 &= m1 - 1ull;
@@ -577,16 +665,16 @@ size_t dqo_knn3_ws_bytes(int P) { return knn_ws(nullptr, P).total; }
 
 // bounding box -> Morton keys -> sort -> gather into Morton order (-> boxes)
 // fine: morton_fine_kernel's 39-bit codes (the query search's reference set) instead of the reference's 30-bit ones
-static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, hipStream_t s, bool fine = false) {
+static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, hipStream_t s, bool fine = false, const int32_t* group = nullptr) {
     fine = fine && P < (1 << FINE_IDX_BITS);
     const int P2 = next_pow2(P < SORT_RUN ? SORT_RUN : P);
     {   // (the partial boxes live at the start of the key array: P2 >= 4096 keys = 32 KB, and the keys are written after the fold)
         const int nb = std::min(BBOX_BLOCKS_MAX, (P + 1023) / 1024);
         float* partial = reinterpret_cast<float*>(w.keys);
-        DQO_LAUNCH("bbox_kernel", bbox_kernel, dim3(nb), dim3(1024), s, P, xyz, partial);
+        DQO_LAUNCH("bbox_kernel", bbox_kernel, dim3(nb), dim3(1024), s, P, xyz, partial, group);
         DQO_LAUNCH("bbox_fold_kernel", bbox_fold_kernel, dim3(1), dim3(512), s, nb, partial, w.bbox);
     }
-    if (fine) DQO_LAUNCH("morton_kernel", morton_fine_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
+    if (fine) DQO_LAUNCH("morton_kernel", morton_fine_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys, group);
     else DQO_LAUNCH("morton_kernel", morton_kernel, dim3((P2 + 255) / 256), dim3(256), s, P, P2, xyz, w.bbox, w.keys);
 #ifdef KNN_BITONIC_SORT
     const int runs = P2 / SORT_RUN;
@@ -617,10 +705,10 @@ static int knn_build(int P, const float* xyz, const KnnWs& w, bool with_boxes, h
     }
 #endif
     DQO_LAUNCH("gather_sorted_kernel", gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), s, P, xyz, w.keys, w.sorted,
-               fine ? ((1ull << FINE_IDX_BITS) - 1ull) : 0xffffffffull);
+               fine ? ((1ull << FINE_IDX_BITS) - 1ull) : 0xffffffffull, group);
     if (with_boxes) {
         const int nb = (P + KNN_BOX - 1) / KNN_BOX;
-        DQO_LAUNCH("box_minmax_kernel", box_minmax_kernel, dim3(nb), dim3(256), s, P, w.sorted, w.boxes);
+        DQO_LAUNCH("box_minmax_kernel", box_minmax_kernel, dim3(nb), dim3(256), s, P, w.sorted, w.boxes, group != nullptr ? 1 : 0);
     }
     return DQO_OK;
 }
@@ -639,16 +727,20 @@ int dqo_launch_knn3(int P, const float* xyz, float* mean_d2, int32_t* idx3, void
 size_t dqo_knn3_query_ws_bytes(int Q, int R) { return knn_ws(nullptr, Q).total + knn_ws(nullptr, R).total; }
 
 int dqo_launch_knn3_query(int Q, const float* q_xyz, int R, const float* r_xyz, float* dist2, int32_t* idx3, void* ws, size_t ws_bytes,
-                          hipStream_t s, float bound2) {
+                          hipStream_t s, float bound2, const int32_t* q_group, const int32_t* r_group, const float* group_box) {
     (void)ws_bytes;
     KnnWs wr = knn_ws(ws, R);
-    int rc = knn_build(R, r_xyz, wr, true, s, true);
+    int rc = knn_build(R, r_xyz, wr, true, s, true, r_group);
     if (rc) return rc;
     const int ns = (R + KNN_SUB - 1) / KNN_SUB;
     DQO_LAUNCH("sub_minmax_kernel", sub_minmax_kernel, dim3((ns * 64 + 255) / 256), dim3(256), s, R, wr.sorted, wr.sub);
     const int nb = (R + KNN_BOX - 1) / KNN_BOX, ng = (nb + 63) / 64;
     DQO_LAUNCH("group_minmax_kernel", group_minmax_kernel, dim3((ng * 64 + 255) / 256), dim3(256), s, nb, wr.boxes, wr.groups);
-    DQO_LAUNCH("knn_query_wave_kernel", knn_query_wave_kernel, dim3(((size_t)Q * 64 + 255) / 256), dim3(256), s, Q, q_xyz, R, wr.sorted,
-               wr.boxes, wr.sub, wr.groups, dist2, idx3, bound2);
+    if (q_group != nullptr)
+        DQO_LAUNCH("knn_query_wave_kernel", knn_query_wave_kernel<true>, dim3(((size_t)Q * 64 + 255) / 256), dim3(256), s, Q, q_xyz, R, wr.sorted,
+                   wr.boxes, wr.sub, wr.groups, dist2, idx3, bound2, q_group, group_box);
+    else
+        DQO_LAUNCH("knn_query_wave_kernel", knn_query_wave_kernel<false>, dim3(((size_t)Q * 64 + 255) / 256), dim3(256), s, Q, q_xyz, R, wr.sorted,
+                   wr.boxes, wr.sub, wr.groups, dist2, idx3, bound2, q_group, group_box);
     return DQO_OK;
 }

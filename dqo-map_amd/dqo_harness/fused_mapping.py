@@ -330,29 +330,12 @@ class FusedMapper:
         # takes for its objects: the N-rank map grows like the N = 1 map.  Without a gate: the reference's decisions.
         per_obj = nobj is not None
         live_rows = None if self.alive is None else self.alive.bool()
-        if Q > 0:
-            if stable_mask is None and not per_obj:
-                inside = mg.temp_points_filter_mask(nx, exist_xyz, exist_radius)
-            else:  # the reference filters against its unstable cloud
-                un = torch.ones((self.P,), dtype=torch.bool, device=dev) if stable_mask is None else ~stable_mask.to(dev).bool().reshape(-1)
-                if live_rows is not None:
-                    un = un & live_rows  # (spare rows are no Gaussians of the map)
-                un = un.nonzero().reshape(-1)
-                if per_obj:
-                    inside = mg.temp_points_filter_mask_per_object(nx, nobj, exist_xyz[un], exist_radius[un], self.gaussian_object[un],
-                                                                   cell=self.object_cell)
-                else:
-                    inside = mg.temp_points_filter_mask(nx, exist_xyz[un], exist_radius[un])
-            if inside is not None:
-                keep &= ~inside
-                stats["inside_existing"] = int(inside.sum().item())
-        idx = keep.nonzero().reshape(-1)
-        nx, nsc, nrot, nop, nsh = nx[idx], nsc[idx], nrot[idx], nop[idx], nsh[idx]
-        nobj = None if nobj is None else nobj[idx]
         attach_job = None
-        if stable_mask is not None and nx.shape[0] > 0:
-            # temp_points_attach only changes opacities, update_geometry only reads positions and radii: the two run side by side (the
-            # attach on a stream and a host thread of its own — both wait on the host for small results in between their kernels)
+        if stable_mask is not None and Q > 0:
+            # temp_points_attach only changes opacities and judges every candidate by itself; the filter and update_geometry only read
+            # positions and radii: the attach runs beside BOTH, on ALL candidates (the ones the filter drops are dropped from its
+            # answer afterwards) — on a stream and a host thread of its own (both sides wait on the host for small results in between
+            # their kernels).  Round 4 started it behind the filter: the step's critical path was filter + attach.
             import threading
             if not self._act_valid:
                 N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
@@ -377,13 +360,32 @@ class FusedMapper:
                 attach_work()
                 attach_job = threading.Thread(target=lambda: None)
                 attach_job.start()
+        if Q > 0:
+            if stable_mask is None and not per_obj:
+                inside = mg.temp_points_filter_mask(nx, exist_xyz, exist_radius)
+            else:  # the reference filters against its unstable cloud
+                un = torch.ones((self.P,), dtype=torch.bool, device=dev) if stable_mask is None else ~stable_mask.to(dev).bool().reshape(-1)
+                if live_rows is not None:
+                    un = un & live_rows  # (spare rows are no Gaussians of the map)
+                un = un.nonzero().reshape(-1)  # (the unstable cloud is small: a few thousand rows of a 2 M map)
+                if per_obj:
+                    inside = mg.temp_points_filter_mask_per_object(nx, nobj, exist_xyz[un], exist_radius[un], self.gaussian_object[un],
+                                                                   cell=self.object_cell)
+                else:
+                    inside = mg.temp_points_filter_mask(nx, exist_xyz[un], exist_radius[un])
+            if inside is not None:
+                keep &= ~inside
+                stats["inside_existing"] = int(inside.sum().item())
+        idx = keep.nonzero().reshape(-1)
+        nx, nsc, nrot, nop, nsh = nx[idx], nsc[idx], nrot[idx], nop[idx], nsh[idx]
+        nobj = None if nobj is None else nobj[idx]
         log_scales = None
         if nx.shape[0] > 0:
             nrad = (nsc.sum(dim=1) - nsc.min(dim=1).values) / 2
             if per_obj:
-                rows_all = torch.arange(self.P, device=dev) if live_rows is None else live_rows.nonzero().reshape(-1)
-                scales, invalid = mg.update_geometry_scales_per_object(nx, nobj, nrad, exist_xyz[rows_all], exist_radius[rows_all],
-                                                                       self.gaussian_object[rows_all], min_radius, max_radius, cell=self.object_cell)
+                gobj_live = self.gaussian_object if live_rows is None else torch.where(live_rows, self.gaussian_object, -1)
+                scales, invalid = mg.update_geometry_scales_per_object(nx, nobj, nrad, exist_xyz, exist_radius, gobj_live, min_radius, max_radius,
+                                                                       cell=self.object_cell)
             else:
                 scales, invalid = mg.update_geometry_scales(nx, nrad, exist_xyz, exist_radius, min_radius, max_radius)
         if attach_job is not None:
@@ -391,7 +393,10 @@ class FusedMapper:
             torch.cuda.current_stream().wait_stream(side)
             if "err" in box:
                 raise box["err"]
-            att = box["att"]
+            # (the attach judged all Q candidates: keep its answer for the ones the filter kept, as positions among them)
+            att_all = torch.zeros((Q,), dtype=torch.bool, device=dev)
+            att_all[box["att"]] = True
+            att = att_all[idx].nonzero().reshape(-1)
             stats["attached"] = int(att.numel())
             nop = nop.clone()
             nop[att] = unstable_opacity_low

@@ -24,9 +24,12 @@ import _dqo_native as N
 from simple_knn._C import distCUDA2
 
 
-def knn_points_k3(p1, p2, max_dist=None):
+def knn_points_k3(p1, p2, max_dist=None, groups=None, group_box=None):
     """(dists [Q, 3] squared L2 ascending, idx [Q, 3] int64 into p2).  Fewer than 3 references: FLT_MAX / -1 in the tail.
-    max_dist (not a pytorch3d argument): only references closer than that count (dqo_knn3_query_within)."""
+    max_dist (not a pytorch3d argument): only references closer than that count (dqo_knn3_query_within).
+    groups = (g1 [Q], g2 [R]) int32 ids in [0, 64) (any other value: the point belongs to no group): a reference only counts for a
+    query of the same group; group_box [64, 6] (lo xyz, hi xyz): ... and only if it lies strictly inside its group's box
+    (dqo_knn3_query_grouped)."""
     N.require_gpu(p1, p2)
     if not (p1.is_cuda and p2.is_cuda):
         raise RuntimeError("libdqoraster operators need GPU (ROCm) tensors; there is no CPU path.")
@@ -42,7 +45,16 @@ def knn_points_k3(p1, p2, max_dist=None):
     lib = N.lib()
     ws = torch.empty((lib.dqo_knn3_query_workspace_bytes(Q, R),), dtype=torch.uint8, device=q.device)
     with torch.cuda.device(q.device):
-        if max_dist is None:
+        if groups is not None:
+            g1 = groups[0].to(torch.int32).contiguous()
+            g2 = groups[1].to(torch.int32).contiguous()
+            assert g1.shape[0] == Q and g2.shape[0] == R
+            gb = None if group_box is None else group_box.float().contiguous()
+            assert gb is None or tuple(gb.shape) == (64, 6)
+            N.check(lib.dqo_knn3_query_grouped(Q, N.ptr(q), N.ptr(g1), R, N.ptr(r), N.ptr(g2), None if gb is None else N.ptr(gb),
+                                               float(max_dist) if max_dist is not None else 3.0e38, N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(),
+                                               N.current_stream()))
+        elif max_dist is None:
             N.check(lib.dqo_knn3_query(Q, N.ptr(q), R, N.ptr(r), N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(), N.current_stream()))
         else:
             N.check(lib.dqo_knn3_query_within(Q, N.ptr(q), R, N.ptr(r), float(max_dist), N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(),
@@ -119,14 +131,14 @@ def update_geometry_scales(xyz, radius, extra_xyz, extra_radius, min_radius, max
 
 # ---- the per-object job: every growth decision of a candidate looks at the Gaussians of the candidate's own object only ----
 # A shard of the map holds whole objects, so a decision that only looks at the candidate's object is the same on every shard layout:
-# the N-rank map grows exactly like the N = 1 map.  One search per step, as in the reference's form: every object is moved to a cell
-# of its own on a grid (ids in [0, 64): 4 x 4 x 4 cells of `cell` metres per axis, powers of two so that the shift is exact for most
-# coordinates), so a point's nearest neighbours are its own object's whenever that object has three nearby — checked explicitly, never
-# assumed — and the distances the decisions use are recomputed from the unshifted coordinates of the pairs found (the shift only selects
-# neighbours, it never enters a value).  The cells must keep two objects apart by more than the distance at which a neighbour still
-# matters: a neighbour beyond 0.087 m + 3 x its radius saturates the scale at max_radius (0.05) exactly like a missing one, and the
-# filter only looks at distances below 0.6 x radius — so a gap of a metre is ample; the default of 16 m cells holds any room below 15 m
-# across, a caller that knows its scene (bench.py: 6 x 3 x 4 m rooms) passes tighter cells, which keeps the search's Morton grid fine.
+# the N-rank map grows exactly like the N = 1 map.  The search against the EXISTING map is the group-restricted one
+# (dqo_knn3_query_grouped, round 5): object ids compared inside the search, the per-object bounding boxes tested inside it too — one
+# search over the map as it is stored (round 4 moved every object to a cell of its own and searched shifted copies of gathered subsets:
+# 3.5 ms against 1.5 ms for the search alone on cfg 5, plus a 0.9 ms mask and the gathers per call).  The new points among themselves
+# (40 800 of them: distCUDA2, 0.3 ms) still use the cells: every object is moved to a cell of its own on a grid (ids in [0, 64): 4 x 4 x 4
+# cells of `cell` metres per axis, powers of two so that the shift is exact for most coordinates), so a point's nearest neighbours are
+# its own object's whenever that object has three nearby — checked explicitly, never assumed — and the distances the decisions use are
+# recomputed from the unshifted coordinates of the pairs found (the shift only selects neighbours, it never enters a value).
 OBJECT_CELL = (16.0, 16.0, 16.0)
 # ... and a neighbour further away than this is as good as none for both decisions (radii up to 0.3 m), so the searches stop there
 # (dqo_knn3_query_within): a candidate whose object has nothing nearby — common at an object's rim — does not scan half the map for three
@@ -141,15 +153,23 @@ def object_offsets(obj, cell=None):
     return torch.stack([o % 4, (o // 4) % 4, o // 16], dim=1).to(torch.float32) * c
 
 
-def _per_object_bbox_mask(query_xyz, query_obj, ref_xyz, ref_obj, padding=0.05, n_objects=64):
-    """bbox_filter per object: a reference point passes iff it lies strictly inside the padded bounding box of the QUERY points of its
-    own object (no query of that object: it does not pass)."""
+def _per_object_boxes(query_xyz, query_obj, padding=0.05, n_objects=64):
+    """[n_objects, 6] (lo xyz, hi xyz): the padded bounding box of every object's QUERY points (an object without queries: an empty box)."""
     inf = float("inf")
     idx = query_obj.long()[:, None].expand(-1, 3)
     lo = torch.full((n_objects, 3), inf, device=query_xyz.device).scatter_reduce(0, idx, query_xyz, "amin", include_self=True)
     hi = torch.full((n_objects, 3), -inf, device=query_xyz.device).scatter_reduce(0, idx, query_xyz, "amax", include_self=True)
-    ro = ref_obj.long()
-    return (ref_xyz > lo[ro] - padding).all(dim=-1) & (ref_xyz < hi[ro] + padding).all(dim=-1)
+    return torch.cat([lo - padding, hi + padding], dim=1)
+
+
+def _per_object_bbox_mask(query_xyz, query_obj, ref_xyz, ref_obj, padding=0.05, n_objects=64):
+    """bbox_filter per object: a reference point passes iff it lies strictly inside the padded bounding box of the QUERY points of its
+    own object (no query of that object: it does not pass).  (What dqo_knn3_query_grouped tests inside the search; kept as the
+    statement the tests compare it with.)"""
+    box = _per_object_boxes(query_xyz, query_obj, padding, n_objects)
+    ro = ref_obj.long().clamp(0, n_objects - 1)
+    ok = (ref_obj >= 0) & (ref_obj < n_objects)
+    return ok & (ref_xyz > box[ro, :3]).all(dim=-1) & (ref_xyz < box[ro, 3:]).all(dim=-1)
 
 
 def temp_points_filter_mask_per_object(temp_xyz, temp_obj, exist_xyz, exist_radius, exist_obj, cell=None):
@@ -157,15 +177,11 @@ def temp_points_filter_mask_per_object(temp_xyz, temp_obj, exist_xyz, exist_radi
     that lie within 0.6 x radius of one of the (up to) 3 nearest existing centres of their object.  None: nothing to test against."""
     if torch.numel(exist_xyz) == 0 or torch.numel(temp_xyz) == 0:
         return None
-    inbbox = _per_object_bbox_mask(temp_xyz, temp_obj, exist_xyz, exist_obj)
-    exist_xyz, exist_radius, exist_obj = exist_xyz[inbbox], exist_radius[inbbox], exist_obj[inbbox]
-    if torch.numel(exist_xyz) == 0:
-        return None
-    _, nn_idx = knn_points_k3(temp_xyz + object_offsets(temp_obj, cell), exist_xyz + object_offsets(exist_obj, cell), max_dist=NEIGHBOUR_REACH)
+    nn_d2, nn_idx = knn_points_k3(temp_xyz, exist_xyz, max_dist=NEIGHBOUR_REACH, groups=(temp_obj, exist_obj),
+                                  group_box=_per_object_boxes(temp_xyz, temp_obj))
     j = nn_idx.clamp(min=0)
-    valid = (nn_idx >= 0) & (exist_obj[j] == temp_obj[:, None])
-    nn_dist = torch.sqrt((temp_xyz[:, None, :] - exist_xyz[j]).pow(2).sum(-1))  # (of the pairs found, unshifted)
-    return ((nn_dist < exist_radius.reshape(-1)[j] * 0.6) & valid).any(dim=-1)
+    valid = nn_idx >= 0
+    return ((torch.sqrt(nn_d2) < exist_radius.reshape(-1)[j] * 0.6) & valid).any(dim=-1)
 
 
 def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius, extra_obj, min_radius, max_radius, cell=None):
@@ -175,9 +191,6 @@ def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius,
     n = xyz.shape[0]
     xyz = xyz.float().contiguous()
     radius, extra_radius = radius.reshape(-1), extra_radius.reshape(-1)
-    if torch.numel(extra_xyz) > 0:
-        inbbox = _per_object_bbox_mask(xyz, obj, extra_xyz, extra_obj)
-        extra_xyz, extra_radius, extra_obj = extra_xyz[inbbox], extra_radius[inbbox], extra_obj[inbbox]
     inf = torch.full((n, 3), float("inf"), device=xyz.device)
     shifted = (xyz + object_offsets(obj, cell)).contiguous()
     cand_d, cand_r = [inf], [torch.zeros_like(inf)]
@@ -189,10 +202,9 @@ def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius,
         cand_d.append(torch.where(ok, d2_new, inf))
         cand_r.append(radius[j])
     if torch.numel(extra_xyz) > 0:
-        _, i_old = knn_points_k3(shifted, extra_xyz + object_offsets(extra_obj, cell), max_dist=NEIGHBOUR_REACH)
+        d2_old, i_old = knn_points_k3(xyz, extra_xyz, max_dist=NEIGHBOUR_REACH, groups=(obj, extra_obj), group_box=_per_object_boxes(xyz, obj))
         j = i_old.clamp(min=0)
-        ok = (i_old >= 0) & (extra_obj[j] == obj[:, None])
-        cand_d.append(torch.where(ok, (xyz[:, None, :] - extra_xyz[j]).pow(2).sum(-1), inf))
+        cand_d.append(torch.where(i_old >= 0, d2_old, inf))
         cand_r.append(extra_radius[j])
     cd, cr = torch.cat(cand_d, 1), torch.cat(cand_r, 1)
     top = torch.topk(cd, 3, dim=1, largest=False)

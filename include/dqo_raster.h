@@ -294,6 +294,14 @@ int dqo_knn3_query(int32_t Q, const float* query_xyz, int32_t R, const float* re
  * no reference nearby prunes the whole map at once.  Same workspace as dqo_knn3_query. */
 int dqo_knn3_query_within(int32_t Q, const float* query_xyz, int32_t R, const float* ref_xyz, float max_dist, float* dist2, int32_t* idx3,
                           void* workspace, size_t workspace_bytes, void* hipStream);
+/* Row f3, the per-object job (not a reference feature): the same search where a reference point only counts for a
+ * query of the SAME GROUP (int32 ids in [0, 64) — the Gaussians' object ids; any other value: the point belongs to no group and is
+ * neither found nor finds anything) and, when `group_box` is given ([64][6] floats: lo xyz, hi xyz per group), only if it lies strictly
+ * inside its group's box (SLAM/utils.py:801-808 bbox_filter, per object).  One search over the map as it is stored: no shifted copies,
+ * no gathered subsets.  At most 2^25 - 1 reference points.  Same workspace as dqo_knn3_query. */
+int dqo_knn3_query_grouped(int32_t Q, const float* query_xyz, const int32_t* query_group, int32_t R, const float* ref_xyz,
+                           const int32_t* ref_group, const float* group_box, float max_dist, float* dist2, int32_t* idx3, void* workspace,
+                           size_t workspace_bytes, void* hipStream);
 
 /* Batched dual-quadric residual over B independent (object, view) pairs: loss = 1 - IoU(obs, bbox(ellipsoid, P34)),
  * with gradients.  valid[b] = 0 when loss == 1 (the reference skips that Adam step). */

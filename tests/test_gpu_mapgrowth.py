@@ -50,6 +50,49 @@ def test_knn3_query_vs_oracle(mg, Q, R, seed):
         np.testing.assert_allclose(np.sqrt(d), dk, rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("Q,R,n_groups,reach,seed", [(4000, 60000, 8, 0.25, 0), (3000, 20000, 64, None, 1), (500, 300, 3, 0.5, 2), (2000, 50000, 1, 0.1, 3)])
+def test_grouped_query_vs_brute_force(mg, Q, R, n_groups, reach, seed):
+    """dqo_knn3_query_grouped (the per-object growth decisions' search): a reference counts for a query only if it carries the same
+    group id, lies strictly inside the group's box and (reach) is closer than the bound — against a brute-force float32 statement of
+    exactly that, distances bit-exact.  Points with an id outside [0, 64) belong to no group: never found, never finding."""
+    torch, M = mg
+    rng = np.random.default_rng(seed)
+    r = rng.uniform(-2, 2, (R, 3)).astype(np.float32)
+    q = rng.uniform(-2, 2, (Q, 3)).astype(np.float32)
+    gr = rng.integers(0, n_groups, R).astype(np.int32)
+    gq = rng.integers(0, n_groups, Q).astype(np.int32)
+    gr[rng.choice(R, R // 50, replace=False)] = -1   # dead rows
+    gq[rng.choice(Q, max(Q // 100, 1), replace=False)] = 77  # queries without a group
+    box = np.full((64, 6), 0, np.float32)
+    box[:, :3], box[:, 3:] = -np.inf, np.inf
+    for g in range(0, n_groups, 2):  # every other group: a real box
+        c = rng.uniform(-1, 1, 3)
+        box[g, :3], box[g, 3:] = c - 1.2, c + 1.2
+    t = lambda a: torch.tensor(a, device="cuda")
+    d, i = M.knn_points_k3(t(q), t(r), max_dist=reach, groups=(t(gq), t(gr)), group_box=t(box))
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    FLT_MAX = np.float32(3.4028234663852886e38)
+    bound2 = FLT_MAX if reach is None else np.float32(reach) * np.float32(reach)
+    for k in rng.choice(Q, min(Q, 400), replace=False):
+        g = gq[k]
+        if not (0 <= g < 64):
+            assert (i[k] == -1).all() and (d[k] == FLT_MAX).all()
+            continue
+        ok = (gr == g) & (r > box[g, :3]).all(1) & (r < box[g, 3:]).all(1)
+        dd = (r - q[k]).astype(np.float32)
+        dd = dd * dd
+        d2 = ((dd[:, 0] + dd[:, 1]) + dd[:, 2]).astype(np.float32)
+        d2 = np.where(ok & (d2 < bound2), d2, FLT_MAX)
+        best = np.sort(d2)[:3]
+        best = np.concatenate([best, np.full(3 - len(best), FLT_MAX, np.float32)])
+        np.testing.assert_array_equal(d[k], best, err_msg=f"query {k}")
+        for j in range(3):
+            if best[j] < FLT_MAX:
+                assert i[k, j] >= 0 and gr[i[k, j]] == g and d2[i[k, j]] == best[j]
+            else:
+                assert i[k, j] == -1
+
+
 def test_clustered_points(mg):
     """Surfel-like data: points on a few planes, queries near them — the pruning path that real maps exercise."""
     torch, M = mg

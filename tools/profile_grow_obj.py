@@ -60,3 +60,36 @@ for i in range(4):
     st = fm.grow(new, new_mapping_call=True, stable_mask=stable)
     torch.cuda.synchronize()
     print(f"grow #{i}: {1e3 * (time.perf_counter() - t0):.2f} ms", {k: v for k, v in st.items() if k not in ("rows", "kept_rows")})
+
+# where a growth step's host time goes (the step is a chain of small kernels with host-side decisions in between)
+import cProfile, pstats, io
+pr = cProfile.Profile()
+torch.cuda.synchronize()
+pr.enable()
+fm.grow(new, new_mapping_call=True, stable_mask=stable)
+torch.cuda.synchronize()
+pr.disable()
+sio = io.StringIO()
+pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(28)
+print(sio.getvalue()[:6000])
+
+# ... and the step's pieces one after the other (every piece synchronised: their GPU cost without the overlap of attach and scale init)
+import functools
+acc = {}
+def wrap(obj, name, label):
+    f = getattr(obj, name)
+    @functools.wraps(f)
+    def g(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = f(*a, **k)
+        torch.cuda.synchronize(); acc[label] = acc.get(label, 0.0) + (time.perf_counter() - t0) * 1e3
+        return r
+    setattr(obj, name, g)
+wrap(fm, "_temp_points_attach", "attach (gated render of the stable cloud + gathers)")
+wrap(mg, "update_geometry_scales_per_object", "scale init (grouped 3-NN against the map + 3-NN among the new points)")
+wrap(mg, "temp_points_filter_mask_per_object", "filter (grouped 3-NN against the unstable cloud)")
+wrap(fm, "begin_mapping_call", "new mapping call (Adam reset, init_stat, attach set)")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+fm.grow(new, new_mapping_call=True, stable_mask=stable, attach_async=False)
+torch.cuda.synchronize(); tot = (time.perf_counter() - t0) * 1e3
+print(f"serialised growth step {tot:.2f} ms:", {k: round(v, 2) for k, v in acc.items()}, "rest", round(tot - sum(acc.values()), 2))
