@@ -199,8 +199,10 @@ class FusedMapper:
             self.attach_count = int(self.attach_count_reducer(self.attach_count))
         n = self.attach_count
         # the two factors exactly as the library derives them from attach_count: double arithmetic, rounded to float once
-        self.attach_gains.copy_(torch.tensor([2000.0 / (3.0 * n), 2000.0 / (4.0 * n)] if n > 0 else [0.0, 0.0], dtype=torch.float64)
-                                .to(torch.float32))
+        # (fill_ carries the python double as a kernel argument and rounds it to float once; a host tensor copied to the device would be
+        # a synchronous pageable copy: ~1 ms per mapping call)
+        self.attach_gains[0:1].fill_(2000.0 / (3.0 * n) if n > 0 else 0.0)
+        self.attach_gains[1:2].fill_(2000.0 / (4.0 * n) if n > 0 else 0.0)
 
     def activate(self):
         """(opacity [P,1], scales [P,3], rotations [P,4]): the activations of the current raw parameters (SLAM/gaussian_pointcloud.py:
@@ -258,7 +260,8 @@ class FusedMapper:
             return torch.cat([a, tail]).contiguous()
 
         park = self._park_position()
-        unit_q = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev)
+        import dqo_mapgrowth as mg
+        unit_q = mg.const_tensor([1.0, 0.0, 0.0, 0.0], dev)
         self.alive = pad(self.alive if self.alive is not None else torch.ones((P0,), dtype=torch.uint8, device=dev), 0)
         self.init_xyz, self.init_scaling, self.init_rotation = pad(self.init_xyz, park), pad(self.init_scaling, -10.0), pad(self.init_rotation, unit_q)
         self.xyz, self.shs = pad(self.xyz, park), pad(self.shs, 0.0)
@@ -404,7 +407,7 @@ class FusedMapper:
             stats["invalid_scale"] = int(invalid.sum().item())
             ok = (~invalid).nonzero().reshape(-1)
             if ok.numel() > 0:  # gaussian_pointcloud.py:558-568
-                fac = scale_factor * scales[:, None].repeat(1, 3) * torch.tensor(xyz_factor, dtype=torch.float32, device=dev)
+                fac = scale_factor * scales[:, None].repeat(1, 3) * mg.const_tensor(xyz_factor, dev)
                 log_scales = torch.log(fac)[ok]
             nx, nrot, nop, nsh = nx[ok], nrot[ok], nop[ok], nsh[ok]
             nobj = None if nobj is None else nobj[ok]
@@ -531,7 +534,7 @@ class FusedMapper:
         zero_fill = (cim == 0) & (out["color_hit_weight"] == 0)
         cim = torch.where(zero_fill, torch.full_like(cim, -1) if gated else first.to(cim.dtype).reshape(1, 1, 1), cim)
         H, W = int(st.image_height), int(st.image_width)
-        K = torch.tensor([[W / (2.0 * st.tanfovx), 0.0, st.cx], [0.0, H / (2.0 * st.tanfovy), st.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+        K = mg.const_tensor([[W / (2.0 * st.tanfovx), 0.0, st.cx], [0.0, H / (2.0 * st.tanfovy), st.cy], [0.0, 0.0, 1.0]], dev)
         return mg.temp_points_attach_indices(temp_xyz, temp_opacity, st.viewmatrix.T.contiguous(), K, W, H, cim, self.xyz,
                                              lambda rows: self.normals(rows), self.add_depth_thres, unstable_opacity_low,
                                              temp_obj=temp_obj if gated else None, stable_obj=self.gaussian_object if gated else None)

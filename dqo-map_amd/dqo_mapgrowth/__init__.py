@@ -146,10 +146,24 @@ OBJECT_CELL = (16.0, 16.0, 16.0)
 NEIGHBOUR_REACH = 1.0
 
 
+_const_cache = {}
+
+
+def const_tensor(values, device, dtype=torch.float32):
+    """A small constant on the device, made once per (values, device): torch.tensor(list, device=cuda) is a synchronous host-to-device
+    copy of pageable memory — about a millisecond each on MI355X boxes, and the growth step made four of them per call."""
+    import numpy as np
+    key = (tuple(np.asarray(values, np.float64).reshape(-1).tolist()), tuple(np.asarray(values).shape), str(device), dtype)
+    t = _const_cache.get(key)
+    if t is None:
+        t = _const_cache[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t
+
+
 def object_offsets(obj, cell=None):
     """[n, 3] float32 translation of every point's object cell (ids in [0, 64))."""
     o = obj.long()
-    c = torch.tensor(OBJECT_CELL if cell is None else cell, dtype=torch.float32, device=obj.device)
+    c = const_tensor(OBJECT_CELL if cell is None else cell, obj.device)
     return torch.stack([o % 4, (o // 4) % 4, o // 16], dim=1).to(torch.float32) * c
 
 

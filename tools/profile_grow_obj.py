@@ -93,3 +93,17 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 fm.grow(new, new_mapping_call=True, stable_mask=stable, attach_async=False)
 torch.cuda.synchronize(); tot = (time.perf_counter() - t0) * 1e3
 print(f"serialised growth step {tot:.2f} ms:", {k: round(v, 2) for k, v in acc.items()}, "rest", round(tot - sum(acc.values()), 2))
+
+# ... and with a NEW batch per step, as bench.py --cfg 5 feeds them (every step adds ~1 300 Gaussians, so the row writes, the new
+# mapping call over a changed attach set and a growing unstable cloud are in it): the serialised pieces of four such steps
+for i in range(4):
+    sc = scenes.surfel_room(9100 + 17 * i, 40_800, n_objects=32, rest_sigma=0.05)
+    nb = {n: torch.tensor(np.ascontiguousarray(sc[n], np.float32), device=dev) for n in ("xyz", "scales", "rotations", "opacity", "shs")}
+    nb["obj_id"] = torch.tensor(np.asarray(sc["obj_id"], np.int32), device=dev)
+    acc.clear()
+    asy = i % 2 == 1
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    st = fm.grow(nb, new_mapping_call=True, stable_mask=stable, attach_async=asy)
+    torch.cuda.synchronize(); tot = (time.perf_counter() - t0) * 1e3
+    print(f"new batch {i} ({'overlapped' if asy else 'serialised'}): {tot:.2f} ms, added {st['added']}:", {k.split(' (')[0]: round(v, 2) for k, v in acc.items()},
+          "rest", round(tot - sum(acc.values()), 2) if not asy else "-")
