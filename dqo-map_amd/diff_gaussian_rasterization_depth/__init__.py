@@ -179,6 +179,14 @@ def _check_gate_ids(gaussian_object, pixel_object):
         _gate_checked[key] = (weakref.ref(t, lambda _r, k=key: _gate_checked.pop(k, None)), t._version)
 
 
+def gate_ids_checked(t):
+    """The caller vouches for an object-id tensor it has just (re)written from values that were checked before (e.g. a subset of a
+    checked pixel_object with -1 elsewhere): _check_gate_ids will not read it back — no host synchronisation — until it is modified
+    again.  A wrong promise has the consequence _check_gate_ids describes."""
+    key = id(t)
+    _gate_checked[key] = (weakref.ref(t, lambda _r, k=key: _gate_checked.pop(k, None)), t._version)
+
+
 def _f32(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError(f"expected scalar type Float but found {t.dtype} ({name})")
@@ -191,13 +199,16 @@ def rasterize_gaussians(means3D, sh, colors_precomp, opacities, scales, rotation
 
 
 def rasterize_gaussians_gated(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, raster_settings,
-                              gaussian_object, pixel_object):
+                              gaussian_object, pixel_object, tile_objects=None):
     """NOT part of the reference's surface: the same op with libdqoraster's object gate (include/dqo_raster.h, DqoObjectGate) — a list
     entry acts on a pixel only if gaussian_object[id] == pixel_object[pixel] (int32 [P] / [H, W]; a negative pixel id: nothing
     acts), in the forward and in the backward.  The per-object render of the sharded mapping job: every pixel sees its
-    own object alone, so a shard that holds some of the objects computes exactly its pixels of the unsharded render."""
+    own object alone, so a shard that holds some of the objects computes exactly its pixels of the unsharded render.
+    tile_objects (optional, DqoObjectGate.tile_objects): int64 [tiles], per 16x16 tile the 64-bit set of the objects that own one of
+    its pixels — the binning then drops a (Gaussian, tile) pair whose object owns no pixel of the tile (it could act on none); must
+    be the sets of THIS pixel_object (dqo_harness.fused_mapping.tile_object_sets)."""
     return _RasterizeGaussians.apply(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask,
-                                     raster_settings, gaussian_object, pixel_object)
+                                     raster_settings, gaussian_object, pixel_object, tile_objects)
 
 
 def _params(rs, P, M):
@@ -219,7 +230,7 @@ def _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, raster_settings,
-                gaussian_object=None, pixel_object=None):
+                gaussian_object=None, pixel_object=None, tile_objects=None):
         rs = raster_settings
         lib = N.lib()
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
@@ -254,6 +265,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             gaussian_object, pixel_object = gaussian_object.contiguous(), pixel_object.contiguous()
             _check_gate_ids(gaussian_object, pixel_object)
             gate = N.DqoObjectGate(gaussian_object=N.ptr(gaussian_object), pixel_object=N.ptr(pixel_object))
+            if tile_objects is not None:
+                N.require_gpu(tile_objects)
+                if tile_objects.dtype != torch.int64 or tile_objects.numel() != ((H + 15) // 16) * ((W + 15) // 16):
+                    raise RuntimeError("object gate: tile_objects must be int64 with ceil(H/16) x ceil(W/16) elements")
+                tile_objects = tile_objects.contiguous()
+                gate.tile_objects = N.ptr(tile_objects)
+        elif tile_objects is not None:
+            raise RuntimeError("object gate: tile_objects without gaussian_object / pixel_object")
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -414,7 +433,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         def slot(g, inp):
             return g if (g is not None and inp.numel() != 0) else None
         return (g_means3D, slot(g_sh, sh), slot(g_colors, colors_precomp), g_opacity.view_as(opacities) if opacities.numel() else None,
-                slot(g_scales, scales), slot(g_rot, rotations), slot(g_cov3D, cov3Ds_precomp), None, None, None, None)
+                slot(g_scales, scales), slot(g_rot, rotations), slot(g_cov3D, cov3Ds_precomp), None, None, None, None, None)
 
 
 class GaussianRasterizationSettings(NamedTuple):

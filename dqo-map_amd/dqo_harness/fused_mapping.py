@@ -523,21 +523,50 @@ class FusedMapper:
         # lists are the stable cloud's), indices in map rows.  One quirk to carry over: a tile that renders nothing keeps the op's
         # zero fill, which the reference's `>= 0` test reads as a hit on Gaussian 0 OF THE STABLE CLOUD (F3 / rasterize_points.cu:79-89)
         # — here that is the first stable row, and such a pixel is told from a real hit on row 0 by its zero weight.
-        if not bool(sm.any()):
-            return torch.empty((0,), dtype=torch.long, device=dev)
-        first = torch.argmax(sm.to(torch.uint8)).reshape(1)  # (the first stable row)
+        gated = temp_obj is not None and self.gaussian_object is not None
+        if not gated:
+            if not bool(sm.any()):
+                return torch.empty((0,), dtype=torch.long, device=dev)
+            first = torch.argmax(sm.to(torch.uint8)).reshape(1)  # (the first stable row)
         data = dict(xyz=torch.where(sm[:, None], self.xyz, self._park_position()[None, :]), opacity=self.opacity, scales=self.scales,
                     rotations=self.rotations, shs=self.shs)
-        gated = temp_obj is not None and self.gaussian_object is not None
-        out = mapping.render(st, data, object_gate=(self.gaussian_object, self.pixel_object.reshape(-1)) if gated else None)
-        cim = out["color_index_map"]
-        zero_fill = (cim == 0) & (out["color_hit_weight"] == 0)
-        cim = torch.where(zero_fill, torch.full_like(cim, -1) if gated else first.to(cim.dtype).reshape(1, 1, 1), cim)
         H, W = int(st.image_height), int(st.image_width)
         K = mg.const_tensor([[W / (2.0 * st.tanfovx), 0.0, st.cx], [0.0, H / (2.0 * st.tanfovy), st.cy], [0.0, 0.0, 1.0]], dev)
+        if gated:
+            # Only the candidates' own pixels are ever looked at (one pixel in twenty of a frame): the render goes through the object
+            # gate with every OTHER pixel ownerless — such a pixel starts finished, an entry that reaches no owned pixel of a quadrant is
+            # dropped by the quadrant's owner set, a quadrant without a candidate ends at once; the owned pixels blend exactly what the
+            # full-frame gated render blends for them (pixels are independent).  Everything stays on the device: no boolean indexing.
+            import diff_gaussian_rasterization_depth as dgr
+            uv, inside = mg.temp_points_pixels(temp_xyz, st.viewmatrix.T.contiguous(), K, W, H)
+            lin = uv[:, 1].clamp(0, H - 1) * W + uv[:, 0].clamp(0, W - 1)
+            po = self.pixel_object.reshape(-1)
+            if getattr(self, "_attach_pixels", None) is None or self._attach_pixels.numel() != po.numel():
+                self._attach_pixels = torch.empty_like(po)
+            sparse = self._attach_pixels
+            sparse.fill_(-1)
+            # (several candidates may share a pixel, and a candidate outside the image is clamped onto a border pixel: amax with -1)
+            sparse.scatter_reduce_(0, lin, torch.where(inside, po[lin], torch.full_like(po[lin], -1)), "amax")
+            dgr.gate_ids_checked(sparse)  # (values of pixel_object, which has been checked, or -1)
+            # ... and the owners per tile (DqoObjectGate.tile_objects of `sparse`): the binning drops every (Gaussian, tile) pair whose
+            # object owns no candidate pixel of the tile.  Column 64 takes the candidates without an owner.
+            gx, gy = (W + 15) // 16, (H + 15) // 16
+            tile = (uv[:, 1].clamp(0, H - 1) // 16) * gx + uv[:, 0].clamp(0, W - 1) // 16
+            own = torch.where(inside, po[lin], torch.full_like(po[lin], -1)).long()
+            sets = torch.zeros((gx * gy, 65), dtype=torch.bool, device=dev)
+            sets[tile, torch.where(own >= 0, own, torch.full_like(own, 64))] = True
+            tile_sets = (sets[:, :64].long() << mg.const_tensor(list(range(64)), dev, torch.int64)).sum(dim=1)
+            out = mapping.render(st, data, object_gate=(self.gaussian_object, sparse, tile_sets))
+            ok = mg.temp_points_attach_mask_per_object(temp_xyz, temp_opacity, temp_obj, uv, inside, W, H, out["color_index_map"],
+                                                       out["color_hit_weight"], self.xyz, lambda rows: self.normals(rows),
+                                                       self.gaussian_object, self.add_depth_thres, unstable_opacity_low)
+            return ok.nonzero().reshape(-1)
+        out = mapping.render(st, data, object_gate=None)
+        cim = out["color_index_map"]
+        zero_fill = (cim == 0) & (out["color_hit_weight"] == 0)
+        cim = torch.where(zero_fill, first.to(cim.dtype).reshape(1, 1, 1), cim)
         return mg.temp_points_attach_indices(temp_xyz, temp_opacity, st.viewmatrix.T.contiguous(), K, W, H, cim, self.xyz,
-                                             lambda rows: self.normals(rows), self.add_depth_thres, unstable_opacity_low,
-                                             temp_obj=temp_obj if gated else None, stable_obj=self.gaussian_object if gated else None)
+                                             lambda rows: self.normals(rows), self.add_depth_thres, unstable_opacity_low)
 
     def attach_loss(self):
         """The reference's reported "scale_loss" of the most recent iteration (attach loss at its pre-update parameters)."""

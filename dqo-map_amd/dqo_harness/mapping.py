@@ -91,7 +91,8 @@ def render(settings, gaussian_data, tile_mask=None, object_gate=None):
     else:
         e = torch.Tensor([])
         r = rasterize_gaussians_gated(gaussian_data["xyz"], gaussian_data["shs"], e, gaussian_data["opacity"], gaussian_data["scales"],
-                                      gaussian_data["rotations"], e, tile_mask, settings, object_gate[0], object_gate[1])
+                                      gaussian_data["rotations"], e, tile_mask, settings, object_gate[0], object_gate[1],
+                                      object_gate[2] if len(object_gate) > 2 else None)
     out = {"render": r[0], "depth": r[1], "color_index_map": r[2], "depth_index_map": r[3], "color_hit_weight": r[4],
            "depth_hit_weight": r[5], "T_map": r[6], "n_touched": r[7], "radii": r[8]}
     if normal is not None:

@@ -230,6 +230,36 @@ def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius,
     return torch.clip(scales, min=min_radius, max=max_radius), invalid
 
 
+def temp_points_pixels(temp_xyz, w2c, intrinsic, image_width, image_height):
+    """scene/cameras.py:207-214 get_uv as mapper.py:1398-1404 uses it: pixel = trunc(K (R x + t) / z) of every point (long [N, 2]: u, v)
+    and whether it lies inside the image.  Row-wise arithmetic: a point's pixel does not depend on the other points of the batch."""
+    xyz_c = temp_xyz @ w2c[:3, :3].T + w2c[:3, 3]
+    uv = xyz_c @ intrinsic.T
+    uv = (uv[:, :2] / uv[:, 2:]).long()
+    inside = (uv[:, 0] >= 0) & (uv[:, 0] < image_width) & (uv[:, 1] >= 0) & (uv[:, 1] < image_height)
+    return uv, inside
+
+
+def temp_points_attach_mask_per_object(temp_xyz, temp_opacity, temp_obj, uv, inside, image_width, image_height, hit_index, hit_weight,
+                                       stable_xyz, stable_normal, stable_obj, add_depth_thres, unstable_opacity_low=0.1):
+    """The per-object job's decision of temp_points_attach_indices (temp_obj / stable_obj given) as ONE boolean mask over the candidates,
+    without a host synchronisation: every candidate is judged by itself (its own point, its own pixel, a stable Gaussian of its own
+    object), so the boolean-index chain of mapper.py:1393-1430 — five device-to-host round trips — becomes masked arithmetic over all N
+    rows.  uv / inside: temp_points_pixels(); hit_index / hit_weight: the op's hit_color / hit_color_weight maps of the gated render
+    of the stable cloud ([1, H, W] or flat), only read at the candidates' pixels; a pixel of a never-rendered tile (index 0 with weight
+    0, the op's zero fill) counts as no hit.  Returns bool [N]; mask.nonzero() equals temp_points_attach_indices(...) of the same
+    inputs (tests/test_gpu_mapgrowth.py)."""
+    keep = (temp_opacity > unstable_opacity_low).reshape(-1)
+    lin = uv[:, 1].clamp(0, image_height - 1) * image_width + uv[:, 0].clamp(0, image_width - 1)
+    s = hit_index.reshape(-1)[lin]
+    s = torch.where((s == 0) & (hit_weight.reshape(-1)[lin] == 0), torch.full_like(s, -1), s)
+    hit = keep & inside & (s >= 0)
+    sidx = s.clamp(min=0).long()
+    nrm = stable_normal(sidx) if callable(stable_normal) else stable_normal[sidx]
+    d = ((stable_xyz[sidx] - temp_xyz) * nrm).sum(dim=-1)
+    return hit & (d.abs() < 0.5 * add_depth_thres) & (stable_obj[sidx] == temp_obj)
+
+
 def temp_points_attach_indices(temp_xyz, temp_opacity, w2c, intrinsic, image_width, image_height, stable_color_index_map, stable_xyz,
                                stable_normal, add_depth_thres, unstable_opacity_low=0.1, temp_obj=None, stable_obj=None):
     """mapper.py:1384-1430: indices (into the temp cloud) of the points whose opacity the reference sets to `unstable_opacity_low`.

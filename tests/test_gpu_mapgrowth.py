@@ -445,3 +445,47 @@ def test_a_sharded_map_grows_exactly_like_the_unsharded_map(mg):
         want = canon(rows_w[obj_w == k])
         got = canon(rows_a[obj_a == k]) if k in objs_a else canon(rows_b[obj_b == k])
         assert want.shape == got.shape and np.array_equal(want, got), (int(k), want.shape, got.shape)
+
+
+def test_gated_attach_on_the_candidates_pixels_equals_the_full_frame_chain(mg):
+    """FusedMapper._temp_points_attach(temp_obj=...) renders the stable cloud for the candidates' own pixels only (every other pixel
+    ownerless in the object gate) and decides with masked arithmetic; the answer is the one of the reference's boolean-index chain
+    (dqo_mapgrowth.temp_points_attach_indices with temp_obj / stable_obj) over a FULL-frame gated render of the stable cloud."""
+    torch, M = mg
+    from dqo_harness import mapping, scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    dev, cam, scene, settings, gt_color, gt_depth, mask = _growth_problem()
+    go = np.asarray(scene["obj_id"], np.int32)
+    with torch.no_grad():
+        hit = mapping.render(settings, mapping.GaussianParams(scene, dev).activated())["depth_index_map"][0].cpu().numpy()
+    po = np.where(hit >= 0, go[np.clip(hit, 0, None)], -1).astype(np.int32)
+    fm = FusedMapper(scene, settings, dev).set_object_gate(go, po).reserve(500)
+    stable = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+    stable[: 12000 : 2] = True
+    new = scenes.surfel_room(85, 5000, n_objects=8)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
+    nx, nop = t(new["xyz"]), t(new["opacity"]).reshape(-1, 1)
+    nop[7::11] = 0.05  # some candidates below unstable_opacity_low: never attached
+    nobj = torch.tensor(np.asarray(new["obj_id"], np.int32), device=dev)
+    got = fm._temp_points_attach(nx, nop, stable, 0.1, temp_obj=nobj)
+    # the chain, over the full-frame gated render of the same stable cloud
+    sm = stable & fm.alive.bool()
+    op, sc, rot = fm.activate()
+    data = dict(xyz=torch.where(sm[:, None], fm.xyz, fm._park_position()[None, :]), opacity=op, scales=sc, rotations=rot, shs=fm.shs)
+    with torch.no_grad():
+        out = mapping.render(settings, data, object_gate=(fm.gaussian_object, fm.pixel_object.reshape(-1)))
+    cim = out["color_index_map"]
+    cim = torch.where((cim == 0) & (out["color_hit_weight"] == 0), torch.full_like(cim, -1), cim)
+    H, W = cam.H, cam.W
+    K = torch.tensor([[W / (2.0 * cam.tanfovx), 0.0, cam.cx], [0.0, H / (2.0 * cam.tanfovy), cam.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    want = M.temp_points_attach_indices(nx, nop, settings.viewmatrix.T.contiguous(), K, W, H, cim, fm.xyz, lambda r: fm.normals(r),
+                                        fm.add_depth_thres, 0.1, temp_obj=nobj, stable_obj=fm.gaussian_object)
+    assert torch.equal(torch.sort(got).values, torch.sort(want).values) and 0 < got.numel() < nx.shape[0]
+    # ... and the maps at the candidates' pixels are the full frame's
+    uv, inside = M.temp_points_pixels(nx, settings.viewmatrix.T.contiguous(), K, W, H)
+    lin = (uv[:, 1].clamp(0, H - 1) * W + uv[:, 0].clamp(0, W - 1))[inside]
+    with torch.no_grad():
+        sparse = mapping.render(settings, data, object_gate=(fm.gaussian_object, fm._attach_pixels))
+    for k in ("color_index_map", "color_hit_weight", "depth_index_map", "depth", "render"):
+        a, b = out[k].reshape(out[k].shape[0], -1)[:, lin], sparse[k].reshape(sparse[k].shape[0], -1)[:, lin]
+        assert torch.equal(a, b), k
