@@ -413,6 +413,7 @@ class FusedRunner:
                 th.join()
                 torch.cuda.current_stream().wait_stream(side)
             del keep
+            self._delete_mask()  # (first use of the error-accumulation kernels: 1.4 ms against 0.4 in the first timed step)
             torch.cuda.synchronize()
 
     def grow(self):
@@ -422,29 +423,13 @@ class FusedRunner:
         (accumulate_gaussian_error, mapper.py:1034-1075), the deleted become spare rows; new mapping call (fresh Adam + init_stat + attach
         set, mapper.py:533-548), all in place: the captured graph goes on.  (Out of spare rows: re-allocation + re-capture.)  Everything
         on the GPU, no process restart."""
-        from dqo_harness import scenes
-        from cuda_utils._C import accumulate_gaussian_error
         fm, p = self.fm, self.prob
         self.flush()
         torch.cuda.synchronize()  # (drain the queued replays first, so that `ms` is the growth step alone)
         t0 = time.perf_counter()
         k = len(self.growth_log)
         new = self.growth_pool[k] if k < len(self.growth_pool) else self.make_growth_batch(k)
-        out = fm._g.out if getattr(fm, "_g", None) is not None else None
-        delete = None
-        if out is not None:
-            H, W = p["cam"].H, p["cam"].W
-            depth_err = (p["gt_depth"] - out[1]).clamp(min=0)  # mapper.py:1016-1017
-            # (... and only on the pixels of this rank's objects: a tile the rank does not render keeps the op's initial fills — depth 0
-            # and hit id 0, quirk B7 — which would charge the whole ground-truth depth of those pixels to the rank's Gaussian 0)
-            invalid = (p["gt_depth"] == 0) | (out[3] == -1) | ~p["render_mask"][None]
-            depth_err[invalid] = 0
-            color_err = (p["gt_color"] - out[0]).abs().sum(0, keepdim=True)
-            color_err[(p["gt_depth"] == 0) | ~p["render_mask"][None]] = 0
-            zero = torch.zeros_like(depth_err)
-            _, g_depth, _, _ = accumulate_gaussian_error(H, W, fm.P, color_err.reshape(-1), depth_err.reshape(-1), zero.reshape(-1),
-                                                         out[2].reshape(-1), out[3].reshape(-1), 0.1, 0.1, 0.1, True)
-            delete = (g_depth.reshape(-1) > 2 * 0.1)
+        delete = self._delete_mask()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if self.use_graph and fm.graph_overflowed():
@@ -468,6 +453,32 @@ class FusedRunner:
                               recapture=round((t3 - t2) * 1e3, 2))
         st["P_after"] = fm.n_alive
         st["attach_set"] = fm.attach_count
+        self._grow_tail(st)
+
+    def _delete_mask(self):
+        """delete = the per-Gaussian depth error of the last frame above 2 x add_depth_thres (accumulate_gaussian_error,
+        mapper.py:1034-1075); None before the first captured iteration."""
+        from cuda_utils._C import accumulate_gaussian_error
+        fm, p = self.fm, self.prob
+        out = fm._g.out if getattr(fm, "_g", None) is not None else None
+        delete = None
+        if out is not None:
+            H, W = p["cam"].H, p["cam"].W
+            depth_err = (p["gt_depth"] - out[1]).clamp(min=0)  # mapper.py:1016-1017
+            # (... and only on the pixels of this rank's objects: a tile the rank does not render keeps the op's initial fills — depth 0
+            # and hit id 0, quirk B7 — which would charge the whole ground-truth depth of those pixels to the rank's Gaussian 0)
+            invalid = (p["gt_depth"] == 0) | (out[3] == -1) | ~p["render_mask"][None]
+            depth_err.masked_fill_(invalid, 0)  # (x[mask] = 0 is a nonzero + a staged host scalar: two host round trips)
+            color_err = (p["gt_color"] - out[0]).abs().sum(0, keepdim=True)
+            color_err.masked_fill_((p["gt_depth"] == 0) | ~p["render_mask"][None], 0)
+            zero = torch.zeros_like(depth_err)
+            _, g_depth, _, _ = accumulate_gaussian_error(H, W, fm.P, color_err.reshape(-1), depth_err.reshape(-1), zero.reshape(-1),
+                                                         out[2].reshape(-1), out[3].reshape(-1), 0.1, 0.1, 0.1, True)
+            delete = (g_depth.reshape(-1) > 2 * 0.1)
+        return delete
+
+    def _grow_tail(self, st):
+        fm, p = self.fm, self.prob
         if not self.growth_log and fm.gaussian_object is not None and (p.get("sharded") or p.get("job_wide_growth")) and torch.distributed.is_initialized():
             # the map right after the FIRST growth step, per owned object (selfcheck: grown_shard_vs_unsharded) — outside `ms`
             g = getattr(fm, "_g", None)

@@ -52,6 +52,11 @@ int dqo_launch_icp(int H, int W, const float* vertex0, const float* vertex1, con
 int dqo_launch_tile_count(int W, int H, int mode, const uint8_t* mask_in, const float* T_map, uint8_t* mask_out, int32_t* tile_count,
                           int32_t* total, hipStream_t s);
 int dqo_launch_tile_color_error(int W, int H, const float* render, const float* gt, float* err_px, float* tile_sum, hipStream_t s);
+int dqo_launch_attach_pixels(int n, const float* xyz, const float* V, float fx, float fy, float cx, float cy, int W, int H,
+                             const int32_t* pixel_object, int32_t* lin, int32_t* sparse, unsigned long long* tile_objects, hipStream_t s);
+int dqo_launch_attach_decide(int n, const float* xyz, const float* opacity, const int32_t* obj, const int32_t* lin, const int32_t* hit_index,
+                             const float* hit_weight, const float* sxyz, const float* scaling_raw, const float* rotation_raw,
+                             const int32_t* gobj, float plane_thr, float opacity_low, uint8_t* out, hipStream_t s);
 int dqo_launch_tap_report(const DqoGeomLayout& g, const DqoTapDev& tap, hipStream_t s);
 int dqo_launch_accumulate_confidence(int H, int W, int P, const int32_t* index, const float* confidence, float* gmax, float* gmin,
                                      float* gmean, int32_t* counter, hipStream_t s);
@@ -513,6 +518,27 @@ DQO_API int dqo_tile_color_error(int32_t W, int32_t H, const float* render, cons
                                  void* stream) {
     DQO_CHECK_ARG(W > 0 && H > 0 && render && gt && tile_sum, "bad size / null pointer");
     return dqo_launch_tile_color_error(W, H, render, gt, color_error, tile_sum, (hipStream_t)stream);
+}
+
+DQO_API int dqo_attach_pixels(int32_t n, const float* temp_xyz, const float* viewmatrix, float fx, float fy, float cx, float cy, int32_t W,
+                              int32_t H, const int32_t* pixel_object, int32_t* lin, int32_t* sparse_pixel_object, uint64_t* tile_objects,
+                              void* stream) {
+    DQO_CHECK_ARG(n >= 0 && W > 0 && H > 0 && (int64_t)W * H < (1ll << 31), "bad size");
+    DQO_CHECK_ARG(viewmatrix && pixel_object && sparse_pixel_object && tile_objects && (n == 0 || (temp_xyz && lin)), "null pointer");
+    return dqo_launch_attach_pixels(n, temp_xyz, viewmatrix, fx, fy, cx, cy, W, H, pixel_object, lin, sparse_pixel_object,
+                                    reinterpret_cast<unsigned long long*>(tile_objects), (hipStream_t)stream);
+}
+
+DQO_API int dqo_attach_decide(int32_t n, const float* temp_xyz, const float* temp_opacity, const int32_t* temp_object, const int32_t* lin,
+                              const int32_t* hit_index, const float* hit_weight, const float* xyz, const float* scaling_raw,
+                              const float* rotation_raw, const int32_t* gaussian_object, float plane_thr, float opacity_low, uint8_t* out,
+                              void* stream) {
+    DQO_CHECK_ARG(n >= 0, "bad size");
+    if (n == 0) return DQO_OK;
+    DQO_CHECK_ARG(temp_xyz && temp_opacity && temp_object && lin && hit_index && hit_weight && xyz && scaling_raw && rotation_raw &&
+                      gaussian_object && out, "null pointer");
+    return dqo_launch_attach_decide(n, temp_xyz, temp_opacity, temp_object, lin, hit_index, hit_weight, xyz, scaling_raw, rotation_raw,
+                                    gaussian_object, plane_thr, opacity_low, out, (hipStream_t)stream);
 }
 
 DQO_API size_t dqo_icp_workspace_bytes(void) { return dqo_icp_ws_bytes(); }

@@ -115,6 +115,7 @@ class FusedMapper:
         self.object_cell = None  # per-object growth decisions: cell size of dqo_mapgrowth.object_offsets (None = its 16 m default)
         self.per_object_loss = False
         self.alive = None  # reserve(): uint8 [P], 0 = a spare row (parked behind the camera, no Gaussian of the map)
+        self._n_spare = 0
         # DqoAdamStep.attach_gains: the attach term's two factors in device memory, rewritten in place by begin_mapping_call — a captured
         # graph survives a new mapping call
         self.attach_gains = torch.zeros((2,), dtype=torch.float32, device=device)
@@ -273,6 +274,7 @@ class FusedMapper:
             self.gaussian_object = pad(self.gaussian_object, 0)
         self.attach_mask = pad(self.attach_mask, 0)
         self._spare_rows = n
+        self._n_spare = int(self.alive.numel() - int(self.alive.sum().item()))  # (host copy of the spare-row count: grow() keeps it up to date)
         self.P = P = P0 + n
         f = dict(dtype=torch.float32, device=dev)
         self.opacity, self.scales, self.rotations = torch.empty((P, 1), **f), torch.empty((P, 3), **f), torch.empty((P, 4), **f)
@@ -398,11 +400,11 @@ class FusedMapper:
                 raise box["err"]
             # (the attach judged all Q candidates: keep its answer for the ones the filter kept, as positions among them)
             att_all = torch.zeros((Q,), dtype=torch.bool, device=dev)
-            att_all[box["att"]] = True
+            att_all.index_fill_(0, box["att"], True)  # (x[rows] = scalar stages the scalar through a host tensor: a blocking copy)
             att = att_all[idx].nonzero().reshape(-1)
             stats["attached"] = int(att.numel())
             nop = nop.clone()
-            nop[att] = unstable_opacity_low
+            nop.index_fill_(0, att, unstable_opacity_low)
         if nx.shape[0] > 0:
             stats["invalid_scale"] = int(invalid.sum().item())
             ok = (~invalid).nonzero().reshape(-1)
@@ -417,30 +419,34 @@ class FusedMapper:
             log_scales = torch.empty((0, 3), dtype=torch.float32, device=dev)
         stats["added"] = n_add = int(nx.shape[0])
         opc = nop.clamp(1e-4, 1 - 1e-4)
-        spare = 0 if self.alive is None else self.P - int(self.alive.sum().item())
+        spare = 0 if self.alive is None else self._n_spare
         if self.alive is not None:
-            dm = torch.zeros((self.P,), dtype=torch.bool, device=dev) if delete_mask is None else delete_mask.to(dev).bool().reshape(-1)
-            dm = dm & self.alive.bool()
-            stats["deleted"] = n_del = int(dm.sum().item())
+            # (the deleted rows as indices, found once: four boolean-mask writes were four passes over the map + four host round trips)
+            if delete_mask is None:
+                del_rows = torch.empty((0,), dtype=torch.long, device=dev)
+            else:
+                del_rows = (delete_mask.to(dev).bool().reshape(-1) & live_rows).nonzero().reshape(-1)
+            stats["deleted"] = n_del = int(del_rows.numel())
             if new_mapping_call and n_add <= spare + n_del:
                 # ---- in place: deleted Gaussians become spare rows, the new ones take spare rows ----
                 if n_del:
-                    self.alive[dm] = 0
-                    self.xyz[dm] = self._park_position()
-                    self.opacity_raw[dm], self.scaling_raw[dm] = -10.0, -10.0
+                    self.alive.index_fill_(0, del_rows, 0)
+                    self.xyz[del_rows] = self._park_position()
+                    self.opacity_raw.index_fill_(0, del_rows, -10.0), self.scaling_raw.index_fill_(0, del_rows, -10.0)
+                self._n_spare += n_del - n_add
                 if n_add:
                     rows = (self.alive == 0).nonzero().reshape(-1)[:n_add]
                     self.xyz[rows], self.shs[rows], self.rotation_raw[rows] = nx, nsh, nrot
                     self.opacity_raw[rows], self.scaling_raw[rows] = torch.log(opc / (1 - opc)), log_scales
                     if self.gaussian_object is not None:
                         self.gaussian_object[rows] = nobj
-                    self.alive[rows] = 1
+                    self.alive.index_fill_(0, rows, 1)
                     stats["rows"] = rows
                     if stable_mask is not None:
                         # what growth adds belongs to the UNSTABLE cloud (mapper.py:1438-1466) — also when it lands in a row a deleted
                         # stable Gaussian just freed (spare rows are handed out lowest index first): the caller's mask is updated in
                         # place, so the next step's filter / stable-only render see the row as unstable
-                        stable_mask[rows] = False
+                        stable_mask.index_fill_(0, rows, False)
                 # (a captured iteration starts from the activations its previous Adam launch left: bring them up to date for the new rows)
                 N.check(N.lib().dqo_map_activate(self.P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
                                                  N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
@@ -449,8 +455,10 @@ class FusedMapper:
                 stats["in_place"] = True
                 return stats
             # spare rows exhausted (or the mapping call goes on): compact — spare rows go with the deleted ones — and reserve again
-            delete_mask = dm | ~self.alive.bool()
+            delete_mask = ~live_rows
+            delete_mask.index_fill_(0, del_rows, True)
             self.alive = None
+            self._n_spare = 0
             stats["in_place"] = False
         keep_old = None
         if delete_mask is not None:
@@ -535,31 +543,17 @@ class FusedMapper:
         if gated:
             # Only the candidates' own pixels are ever looked at (one pixel in twenty of a frame): the render goes through the object
             # gate with every OTHER pixel ownerless — such a pixel starts finished, an entry that reaches no owned pixel of a quadrant is
-            # dropped by the quadrant's owner set, a quadrant without a candidate ends at once; the owned pixels blend exactly what the
-            # full-frame gated render blends for them (pixels are independent).  Everything stays on the device: no boolean indexing.
+            # dropped by the quadrant's owner set, a (Gaussian, tile) pair whose object owns no candidate pixel of the tile is dropped by
+            # the binning, a quadrant without a candidate ends at once; the owned pixels blend exactly what the full-frame gated
+            # render blends for them (pixels are independent).  Two launches around the render (csrc/map_attach.hip) instead of the
+            # reference's chain of boolean-index ops: the growth step is bound by the host's op issue rate.
             import diff_gaussian_rasterization_depth as dgr
-            uv, inside = mg.temp_points_pixels(temp_xyz, st.viewmatrix.T.contiguous(), K, W, H)
-            lin = uv[:, 1].clamp(0, H - 1) * W + uv[:, 0].clamp(0, W - 1)
-            po = self.pixel_object.reshape(-1)
-            if getattr(self, "_attach_pixels", None) is None or self._attach_pixels.numel() != po.numel():
-                self._attach_pixels = torch.empty_like(po)
-            sparse = self._attach_pixels
-            sparse.fill_(-1)
-            # (several candidates may share a pixel, and a candidate outside the image is clamped onto a border pixel: amax with -1)
-            sparse.scatter_reduce_(0, lin, torch.where(inside, po[lin], torch.full_like(po[lin], -1)), "amax")
+            lin, sparse, tile_sets = mg.attach_pixels(temp_xyz, st.viewmatrix, W / (2.0 * st.tanfovx), H / (2.0 * st.tanfovy), st.cx, st.cy,
+                                                      W, H, self.pixel_object)
             dgr.gate_ids_checked(sparse)  # (values of pixel_object, which has been checked, or -1)
-            # ... and the owners per tile (DqoObjectGate.tile_objects of `sparse`): the binning drops every (Gaussian, tile) pair whose
-            # object owns no candidate pixel of the tile.  Column 64 takes the candidates without an owner.
-            gx, gy = (W + 15) // 16, (H + 15) // 16
-            tile = (uv[:, 1].clamp(0, H - 1) // 16) * gx + uv[:, 0].clamp(0, W - 1) // 16
-            own = torch.where(inside, po[lin], torch.full_like(po[lin], -1)).long()
-            sets = torch.zeros((gx * gy, 65), dtype=torch.bool, device=dev)
-            sets[tile, torch.where(own >= 0, own, torch.full_like(own, 64))] = True
-            tile_sets = (sets[:, :64].long() << mg.const_tensor(list(range(64)), dev, torch.int64)).sum(dim=1)
             out = mapping.render(st, data, object_gate=(self.gaussian_object, sparse, tile_sets))
-            ok = mg.temp_points_attach_mask_per_object(temp_xyz, temp_opacity, temp_obj, uv, inside, W, H, out["color_index_map"],
-                                                       out["color_hit_weight"], self.xyz, lambda rows: self.normals(rows),
-                                                       self.gaussian_object, self.add_depth_thres, unstable_opacity_low)
+            ok = mg.attach_decide(temp_xyz, temp_opacity, temp_obj, lin, out["color_index_map"], out["color_hit_weight"], self.xyz,
+                                  self.scaling_raw, self.rotation_raw, self.gaussian_object, self.add_depth_thres, unstable_opacity_low)
             return ok.nonzero().reshape(-1)
         out = mapping.render(st, data, object_gate=None)
         cim = out["color_index_map"]

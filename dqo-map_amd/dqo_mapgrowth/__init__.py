@@ -232,12 +232,64 @@ def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius,
 
 def temp_points_pixels(temp_xyz, w2c, intrinsic, image_width, image_height):
     """scene/cameras.py:207-214 get_uv as mapper.py:1398-1404 uses it: pixel = trunc(K (R x + t) / z) of every point (long [N, 2]: u, v)
-    and whether it lies inside the image.  Row-wise arithmetic: a point's pixel does not depend on the other points of the batch."""
-    xyz_c = temp_xyz @ w2c[:3, :3].T + w2c[:3, 3]
-    uv = xyz_c @ intrinsic.T
-    uv = (uv[:, :2] / uv[:, 2:]).long()
-    inside = (uv[:, 0] >= 0) & (uv[:, 0] < image_width) & (uv[:, 1] >= 0) & (uv[:, 1] < image_height)
+    and whether it lies inside the image.  Written out element by element — separate multiplies and adds in a fixed order, K = [[fx, 0,
+    cx], [0, fy, cy], [0, 0, 1]] — so that a point's pixel does not depend on the other points of the batch (a matmul's blocking may)
+    and equals dqo_attach_pixels' bit for bit (csrc/map_attach.hip follows this function)."""
+    x, y, z = temp_xyz[:, 0], temp_xyz[:, 1], temp_xyz[:, 2]
+    R, t, K = w2c[:3, :3], w2c[:3, 3], intrinsic
+    xc = ((x * R[0, 0] + y * R[0, 1]) + z * R[0, 2]) + t[0]
+    yc = ((x * R[1, 0] + y * R[1, 1]) + z * R[1, 2]) + t[1]
+    zc = ((x * R[2, 0] + y * R[2, 1]) + z * R[2, 2]) + t[2]
+    uf, vf = (xc * K[0, 0] + zc * K[0, 2]) / zc, (yc * K[1, 1] + zc * K[1, 2]) / zc
+    inside = (uf > -1) & (uf < image_width) & (vf > -1) & (vf < image_height)  # (trunc toward zero: pixel >= 0 <=> coordinate > -1)
+    uv = torch.stack([torch.where(inside, uf, torch.zeros_like(uf)), torch.where(inside, vf, torch.zeros_like(vf))], dim=1).long()
     return uv, inside
+
+
+def attach_pixels(temp_xyz, viewmatrix, fx, fy, cx, cy, image_width, image_height, pixel_object):
+    """dqo_attach_pixels (include/dqo_raster.h): (lin int32 [N] — the candidates' pixels v * W + u, -1 = outside the image;
+    sparse pixel_object int32 [H * W]; tile_objects int64 [tiles]) — the sparse object gate of the attach render, in two launches."""
+    import _dqo_native as N
+    n, dev = int(temp_xyz.shape[0]), temp_xyz.device
+    W, H = int(image_width), int(image_height)
+    N.require_gpu(temp_xyz, viewmatrix, pixel_object)
+    if temp_xyz.dtype != torch.float32 or viewmatrix.dtype != torch.float32 or pixel_object.dtype != torch.int32:
+        raise RuntimeError("attach_pixels: float32 points / viewmatrix, int32 pixel_object")
+    if pixel_object.numel() != W * H or viewmatrix.numel() != 16:
+        raise RuntimeError("attach_pixels: pixel_object must have H x W elements, viewmatrix 16")
+    temp_xyz, viewmatrix, pixel_object = temp_xyz.contiguous(), viewmatrix.contiguous(), pixel_object.contiguous()
+    with torch.cuda.device(dev):
+        lin = torch.empty((n,), dtype=torch.int32, device=dev)
+        sparse = torch.empty((W * H,), dtype=torch.int32, device=dev)
+        tiles = torch.empty((((H + 15) // 16) * ((W + 15) // 16),), dtype=torch.int64, device=dev)
+        N.check(N.lib().dqo_attach_pixels(n, N.ptr(temp_xyz), N.ptr(viewmatrix), fx, fy, cx, cy, W, H, N.ptr(pixel_object), N.ptr(lin),
+                                          N.ptr(sparse), N.ptr(tiles), N.current_stream()))
+    return lin, sparse, tiles
+
+
+def attach_decide(temp_xyz, temp_opacity, temp_obj, lin, hit_index, hit_weight, stable_xyz, scaling_raw, rotation_raw, stable_obj,
+                  add_depth_thres, unstable_opacity_low=0.1):
+    """dqo_attach_decide (include/dqo_raster.h): uint8 [N], 1 = the candidate attaches — temp_points_attach_mask_per_object in one
+    launch (normals from the raw quaternion and raw scales inside)."""
+    import _dqo_native as N
+    n, dev = int(temp_xyz.shape[0]), temp_xyz.device
+    f32 = (temp_xyz, temp_opacity, hit_weight, stable_xyz, scaling_raw, rotation_raw)
+    i32 = (temp_obj, lin, hit_index, stable_obj)
+    N.require_gpu(*f32, *i32)
+    if any(a.dtype != torch.float32 for a in f32) or any(a.dtype != torch.int32 for a in i32):
+        raise RuntimeError("attach_decide: float32 points / opacities / weights / parameters, int32 ids / pixels / hit indices")
+    P = int(stable_xyz.shape[0])
+    if (temp_opacity.numel() != n or temp_obj.numel() != n or lin.numel() != n or hit_index.numel() != hit_weight.numel()
+            or scaling_raw.numel() != 3 * P or rotation_raw.numel() != 4 * P or stable_obj.numel() != P):
+        raise RuntimeError("attach_decide: sizes do not agree")
+    c = lambda a: a.contiguous()
+    with torch.cuda.device(dev):
+        out = torch.empty((n,), dtype=torch.uint8, device=dev)
+        N.check(N.lib().dqo_attach_decide(n, N.ptr(c(temp_xyz)), N.ptr(c(temp_opacity)), N.ptr(c(temp_obj)), N.ptr(c(lin)),
+                                          N.ptr(c(hit_index)), N.ptr(c(hit_weight)), N.ptr(c(stable_xyz)), N.ptr(c(scaling_raw)),
+                                          N.ptr(c(rotation_raw)), N.ptr(c(stable_obj)), 0.5 * add_depth_thres, unstable_opacity_low,
+                                          N.ptr(out), N.current_stream()))
+    return out
 
 
 def temp_points_attach_mask_per_object(temp_xyz, temp_opacity, temp_obj, uv, inside, image_width, image_height, hit_index, hit_weight,

@@ -303,6 +303,23 @@ int dqo_knn3_query_grouped(int32_t Q, const float* query_xyz, const int32_t* que
                            const int32_t* ref_group, const float* group_box, float max_dist, float* dist2, int32_t* idx3, void* workspace,
                            size_t workspace_bytes, void* hipStream);
 
+/* Row f, the per-object job's temp_points_attach (SLAM/multiprocess/mapper.py:1384-1430; not a reference binding: the reference runs the
+ * decision as a chain of torch ops) in two launches around the gated render of the stable cloud.
+ *   dqo_attach_pixels: candidate n -> lin[n] = its pixel v * W + u (get_uv, scene/cameras.py:207-214: trunc(K (R x + t) / z); -1 = outside
+ *     the image), and the sparse object gate of that render, both fully written: sparse_pixel_object [H*W] = pixel_object where a candidate
+ *     projects, -1 elsewhere; tile_objects [ceil(H/16) * ceil(W/16)] = per tile the 64-bit set of the owners among those pixels
+ *     (DqoObjectGate.pixel_object / .tile_objects).  viewmatrix: the 16 floats DqoRastInputs.viewmatrix takes; fx, fy, cx, cy: pixels.
+ *   dqo_attach_decide: out[n] = 1 iff opacity[n] > opacity_low, the candidate is inside the image, hit_index at its pixel names a
+ *     Gaussian s >= 0 (index 0 with hit_weight 0 = the op's zero fill: no hit) of the candidate's object, and
+ *     |(xyz[s] - temp_xyz[n]) . normal(s)| < plane_thr (normal: SLAM/gaussian_pointcloud.py:780-791 from the raw quaternion and raw
+ *     scales).  hit_index / hit_weight: DqoRastOutputs.out_hit_color / out_hit_color_weight of the gated render. */
+int dqo_attach_pixels(int32_t n, const float* temp_xyz, const float* viewmatrix, float fx, float fy, float cx, float cy, int32_t W, int32_t H,
+                      const int32_t* pixel_object, int32_t* lin, int32_t* sparse_pixel_object, uint64_t* tile_objects, void* hipStream);
+int dqo_attach_decide(int32_t n, const float* temp_xyz, const float* temp_opacity, const int32_t* temp_object, const int32_t* lin,
+                      const int32_t* hit_index, const float* hit_weight, const float* xyz, const float* scaling_raw,
+                      const float* rotation_raw, const int32_t* gaussian_object, float plane_thr, float opacity_low, uint8_t* out,
+                      void* hipStream);
+
 /* Batched dual-quadric residual over B independent (object, view) pairs: loss = 1 - IoU(obs, bbox(ellipsoid, P34)),
  * with gradients.  valid[b] = 0 when loss == 1 (the reference skips that Adam step). */
 int dqo_quadric_iou_fwd_bwd(int32_t B, const float* axes, const float* R, const float* center, const float* P34,

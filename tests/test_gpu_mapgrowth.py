@@ -448,12 +448,15 @@ def test_a_sharded_map_grows_exactly_like_the_unsharded_map(mg):
 
 
 def test_gated_attach_on_the_candidates_pixels_equals_the_full_frame_chain(mg):
-    """FusedMapper._temp_points_attach(temp_obj=...) renders the stable cloud for the candidates' own pixels only (every other pixel
-    ownerless in the object gate) and decides with masked arithmetic; the answer is the one of the reference's boolean-index chain
-    (dqo_mapgrowth.temp_points_attach_indices with temp_obj / stable_obj) over a FULL-frame gated render of the stable cloud."""
+    """FusedMapper._temp_points_attach(temp_obj=...) renders the stable cloud for the candidates' own pixels only (dqo_attach_pixels: every
+    other pixel ownerless in the object gate, per-tile owner sets for the binning) and decides in one launch (dqo_attach_decide).  Checked
+    link by link: the two launches against their torch restatements (dqo_mapgrowth.temp_points_pixels /
+    temp_points_attach_mask_per_object) bit for bit; the sparse render against the FULL-frame gated render at the candidates' pixels;
+    the answer against the reference's boolean-index chain (temp_points_attach_indices with temp_obj / stable_obj) over the full-frame
+    render — equal except where the chain's matmul projection and the element-wise one put a candidate into different pixels."""
     torch, M = mg
     from dqo_harness import mapping, scenes
-    from dqo_harness.fused_mapping import FusedMapper
+    from dqo_harness.fused_mapping import FusedMapper, tile_object_sets
     dev, cam, scene, settings, gt_color, gt_depth, mask = _growth_problem()
     go = np.asarray(scene["obj_id"], np.int32)
     with torch.no_grad():
@@ -465,27 +468,51 @@ def test_gated_attach_on_the_candidates_pixels_equals_the_full_frame_chain(mg):
     new = scenes.surfel_room(85, 5000, n_objects=8)
     t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
     nx, nop = t(new["xyz"]), t(new["opacity"]).reshape(-1, 1)
-    nop[7::11] = 0.05  # some candidates below unstable_opacity_low: never attached
+    nx[3::97] += 40.0  # some candidates far outside the image
+    nop[7::11] = 0.05  # some below unstable_opacity_low: never attached
     nobj = torch.tensor(np.asarray(new["obj_id"], np.int32), device=dev)
     got = fm._temp_points_attach(nx, nop, stable, 0.1, temp_obj=nobj)
-    # the chain, over the full-frame gated render of the same stable cloud
+    H, W = cam.H, cam.W
+    fx, fy = W / (2.0 * cam.tanfovx), H / (2.0 * cam.tanfovy)
+    K = torch.tensor([[fx, 0.0, cam.cx], [0.0, fy, cam.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    w2c = settings.viewmatrix.T.contiguous()
+    # (1) the pixels and the sparse gate
+    uv, inside = M.temp_points_pixels(nx, w2c, K, W, H)
+    assert 0 < int((~inside).sum().item()) < nx.shape[0]
+    lin_t = torch.where(inside, uv[:, 1] * W + uv[:, 0], torch.full_like(uv[:, 0], -1))
+    lin, sparse, tsets = M.attach_pixels(nx, settings.viewmatrix, fx, fy, cam.cx, cam.cy, W, H, fm.pixel_object)
+    assert torch.equal(lin.long(), lin_t)
+    sparse_t = torch.full((H * W,), -1, dtype=torch.int32, device=dev)
+    sparse_t[lin_t[inside]] = fm.pixel_object.reshape(-1)[lin_t[inside]]
+    assert torch.equal(sparse, sparse_t) and int((sparse >= 0).sum().item()) > 100
+    assert torch.equal(tsets, tile_object_sets(sparse_t.reshape(H, W)))
+    # (2) the sparse render is the full-frame gated render at the candidates' pixels
     sm = stable & fm.alive.bool()
     op, sc, rot = fm.activate()
     data = dict(xyz=torch.where(sm[:, None], fm.xyz, fm._park_position()[None, :]), opacity=op, scales=sc, rotations=rot, shs=fm.shs)
     with torch.no_grad():
-        out = mapping.render(settings, data, object_gate=(fm.gaussian_object, fm.pixel_object.reshape(-1)))
-    cim = out["color_index_map"]
-    cim = torch.where((cim == 0) & (out["color_hit_weight"] == 0), torch.full_like(cim, -1), cim)
-    H, W = cam.H, cam.W
-    K = torch.tensor([[W / (2.0 * cam.tanfovx), 0.0, cam.cx], [0.0, H / (2.0 * cam.tanfovy), cam.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
-    want = M.temp_points_attach_indices(nx, nop, settings.viewmatrix.T.contiguous(), K, W, H, cim, fm.xyz, lambda r: fm.normals(r),
-                                        fm.add_depth_thres, 0.1, temp_obj=nobj, stable_obj=fm.gaussian_object)
-    assert torch.equal(torch.sort(got).values, torch.sort(want).values) and 0 < got.numel() < nx.shape[0]
-    # ... and the maps at the candidates' pixels are the full frame's
-    uv, inside = M.temp_points_pixels(nx, settings.viewmatrix.T.contiguous(), K, W, H)
-    lin = (uv[:, 1].clamp(0, H - 1) * W + uv[:, 0].clamp(0, W - 1))[inside]
-    with torch.no_grad():
-        sparse = mapping.render(settings, data, object_gate=(fm.gaussian_object, fm._attach_pixels))
+        full = mapping.render(settings, data, object_gate=(fm.gaussian_object, fm.pixel_object.reshape(-1)))
+        thin = mapping.render(settings, data, object_gate=(fm.gaussian_object, sparse, tsets))
+    px = lin_t[inside]
     for k in ("color_index_map", "color_hit_weight", "depth_index_map", "depth", "render"):
-        a, b = out[k].reshape(out[k].shape[0], -1)[:, lin], sparse[k].reshape(sparse[k].shape[0], -1)[:, lin]
+        a, b = full[k].reshape(full[k].shape[0], -1)[:, px], thin[k].reshape(thin[k].shape[0], -1)[:, px]
         assert torch.equal(a, b), k
+    # (3) the decision: one launch = the masked torch arithmetic, on either render
+    want = M.temp_points_attach_mask_per_object(nx, nop, nobj, uv, inside, W, H, full["color_index_map"], full["color_hit_weight"], fm.xyz,
+                                                lambda r: fm.normals(r), fm.gaussian_object, fm.add_depth_thres, 0.1)
+    for r in (full, thin):
+        dec = M.attach_decide(nx, nop, nobj, lin, r["color_index_map"], r["color_hit_weight"], fm.xyz, fm.scaling_raw, fm.rotation_raw,
+                              fm.gaussian_object, fm.add_depth_thres, 0.1)
+        assert torch.equal(dec.bool(), want)
+    assert torch.equal(torch.sort(got).values, want.nonzero().reshape(-1)) and 0 < got.numel() < nx.shape[0]
+    # (4) ... and the reference's chain over the full frame
+    cim = torch.where((full["color_index_map"] == 0) & (full["color_hit_weight"] == 0), torch.full_like(full["color_index_map"], -1),
+                      full["color_index_map"])
+    chain = M.temp_points_attach_indices(nx, nop, w2c, K, W, H, cim, fm.xyz, lambda r: fm.normals(r), fm.add_depth_thres, 0.1,
+                                         temp_obj=nobj, stable_obj=fm.gaussian_object)
+    c_mask = torch.zeros_like(want)
+    c_mask[chain] = True
+    uv_mm = (nx @ w2c[:3, :3].T + w2c[:3, 3]) @ K.T
+    uv_mm = (uv_mm[:, :2] / uv_mm[:, 2:]).long()
+    moved = (uv_mm != uv).any(dim=1) & inside  # (the two projections differ in the last bit: a candidate on a pixel edge may move)
+    assert not bool(((c_mask != want) & ~moved).any()) and int(moved.sum().item()) < 10
