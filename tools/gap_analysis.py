@@ -13,9 +13,19 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
 rows.sort()
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
 # iterations = runs that start with zero_words_kernel followed by preprocess_kernel ... gaussian_tail_kernel
-seq = ["zero_words_kernel", "preprocess_kernel", "bin_count_kernel", "tile_sort_wave_kernel", "tile_sort_kernel", "blend_forward_kernel",
-       "blend_backward_kernel", "gaussian_tail_kernel"]
 names = [short(r[2]) for r in rows]
+# the iteration = the launches from one preprocess_kernel to the next gaussian_tail_kernel (the most frequent such run: the fused path's)
+from collections import Counter
+runs = Counter()
+for i, n in enumerate(names):
+    if n == "preprocess_kernel":
+        j = i
+        while j < len(names) and j - i < 16 and names[j] != "gaussian_tail_kernel":
+            j += 1
+        if j < len(names) and names[j] == "gaussian_tail_kernel":
+            runs[tuple(names[i:j + 1])] += 1
+seq = list(runs.most_common(1)[0][0]) if runs else ["preprocess_kernel"]
+print("iteration =", " -> ".join(seq), f"({runs.most_common(1)[0][1] if runs else 0} times in the trace)")
 dur, gap, n_it, it_len = defaultdict(float), defaultdict(float), 0, 0.0
 i = 0
 prev_end = None
