@@ -55,7 +55,8 @@ struct DqoGeomLayout {
     DqoRastHeader* header;   // 256 B reserved
     uint32_t* counters;      // [16] device scalars: [0] instance total (slot allocator of the packed-list mode), [1] long-list queue,
                              //      [3..5] split-list queue / tickets, [6] the forward's list_split, [7] bucket mode: a slot region ran out,
-                             //      [8] frame_prezeroed was promised but the per-frame scalars were not zero (preprocess_kernel)
+                             //      [8] frame_prezeroed was promised but the per-frame scalars were not zero (preprocess_kernel, bin_count_kernel<true>),
+                             //      [9] DQO_CLEARED_STAMP: the previous frame's tail has cleared scalars, tile histogram and flags (taken by bin_count_kernel<true>)
     uint32_t* spread;        // [DQO_SPREAD][64] statistics counters spread over DQO_SPREAD lines (same-address atomics serialise
                              //       memory-side): word 0 = visible Gaussians, word 1 = (Gaussian, tile) pairs in the tile rects,
                              //       words 2, 3 = longest list / non-empty tiles (keep_order frames), word 4 = bucket mode: the slot
@@ -357,12 +358,23 @@ static inline size_t dqo_frame_scalar_words(const DqoRastCtx* ctx) {
     return (256 + 256 * DQO_SPREAD) / 4 + obj_words;
 }
 
+// counters[9] after dqo_rast_backward_adam's per-Gaussian kernel (which also clears the tile histogram + flags of the context's image
+// buffer): the next frame on the context may start in bin_count_kernel<true> — no preprocess_kernel, no zero fill (dqo_fuse_k1).
+#define DQO_CLEARED_STAMP 0xC1EA5EDu
+// The early part of the per-Gaussian forward runs at the head of the binning kernel (dqo_k1_early.h) when the frame is pre-zeroed (a
+// replayed iteration of the fused mapping step), the lists live in per-tile buckets (that caller's mode) and the late part has a home
+// behind the sort kernels (dqo_k1_where != 0; 0 keeps everything in preprocess_kernel: the A/B baseline).  DQO_K1_FUSE=0 switches it off.
+bool dqo_fuse_k1(const DqoRastParams* p, const DqoRastCtx* ctx);
+
 // Zero fill of caller memory on the launch stream.  The library never uses hipMemsetAsync for this: as a memset NODE of a captured
 // hipGraph the fill was observed (ROCm 7.2, gfx950) to write garbage on replay once other runtime activity had happened since the
 // capture; a kernel node carries its arguments by value.  Defined in rast_forward.hip.
 int dqo_launch_zero_words(uint32_t* p, size_t n_words, hipStream_t s);
 
 // launchers (defined in the .hip files)
+int dqo_launch_bin_count_k1(const DqoView& v, const DqoRastInputs* in, const DqoRastOutputs* out, const int32_t* gobj, const DqoGeomLayout& g,
+                            const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, const unsigned long long* tile_objects,
+                            hipStream_t s);
 int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);
 int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s,
                               DqoRastHeader* header_host = nullptr, hipEvent_t header_event = nullptr);

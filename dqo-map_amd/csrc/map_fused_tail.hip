@@ -69,7 +69,8 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
                                                                         const float* scales, const float* rotations, const float* shs,
                                                                         const float4* __restrict__ partial,
                                                                         const uint32_t* __restrict__ valid, int64_t capacity, AdamArgs a,
-                                                                        uint8_t* __restrict__ moment_live, const uint32_t frame_words) {
+                                                                        uint8_t* __restrict__ moment_live, const uint32_t frame_words,
+                                                                        uint32_t* __restrict__ hist, const uint32_t hist_words) {
 #pragma clang fp contract(off)
     // This kernel is the last consumer of the frame's counters (its blocks only read header.overflow): each block clears a slice of
     // counters | statistics lines | loss-tap counters for the NEXT frame (DqoRastCtx.frame_prezeroed: a replayed iteration then has no
@@ -77,7 +78,15 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
     {
         const uint32_t per = (frame_words + gridDim.x - 1) / gridDim.x;
         const uint32_t z0 = blockIdx.x * per, z1 = min(frame_words, z0 + per);
-        for (uint32_t i = z0 + threadIdx.x; i < z1; i += TAIL_THREADS) g.counters[i] = 0u;
+        // (word 9 takes the stamp bin_count_kernel<true> asks for instead of a zero: "scalars, histogram and flags have been cleared")
+        for (uint32_t i = z0 + threadIdx.x; i < z1; i += TAIL_THREADS) g.counters[i] = i == 9u ? DQO_CLEARED_STAMP : 0u;
+    }
+    // ... and of the tile histogram + tile flags (nothing reads them behind the sort / blend kernels of this frame): the next frame may
+    // then start in bin_count_kernel<true>, without the preprocess_kernel launch that zeroes them (dqo_fuse_k1)
+    {
+        const uint32_t per = (hist_words + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = blockIdx.x * per, z1 = min(hist_words, z0 + per);
+        for (uint32_t i = z0 + threadIdx.x; i < z1; i += TAIL_THREADS) hist[i] = 0u;
     }
     // A frame flagged invalid by the forward must not train: nothing is read or written (adam_kernel's rule)
     if (a.frame_header != nullptr && a.frame_header->overflow != 0u) return;
@@ -504,9 +513,10 @@ int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, co
     const float4* partial = reinterpret_cast<const float4*>(recs);
     const uint32_t* vw = reinterpret_cast<const uint32_t*>(valid);
     const uint32_t frame_words = (uint32_t)dqo_frame_scalar_words(ctx);  // counters .. (per-object) loss counters, cleared for the next frame
+    const uint32_t hist_words = (uint32_t)((img.tile_flag + T) - img.tile_count);  // tile histogram (padded) + flags, likewise
 #define DQO_TAIL(SP, AT)                                                                                                              \
     DQO_LAUNCH("gaussian_tail_kernel", (gaussian_tail_kernel<SP, AT>), dim3(blocks), dim3(TAIL_THREADS), s, v, g, in->means3D, in->scales, \
-               in->rotations, in->shs, partial, vw, cap, a, st->moment_live, frame_words)
+               in->rotations, in->shs, partial, vw, cap, a, st->moment_live, frame_words, img.tile_count, hist_words)
     if (st->moment_live != nullptr) {
         if (attach) DQO_TAIL(true, true);
         else DQO_TAIL(true, false);

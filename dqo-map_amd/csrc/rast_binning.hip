@@ -19,6 +19,7 @@
 // thread keeps up to four of them in flight.
 #include "dqo_common.h"
 #include "dqo_cull.h"
+#include "dqo_k1_early.h"
 
 namespace {
 
@@ -69,12 +70,26 @@ struct Cand {
     int gi, tile;
 };
 
+// The raw parameters of the Gaussians for bin_count_kernel<true> (the early part of the per-Gaussian forward at its head, dqo_k1_early.h)
+struct DqoK1Raw {
+    DqoView v;
+    const float *means3D, *scales, *rotations, *opacities;
+    const int32_t* gobj;
+    int32_t *radii_out, *n_touched_out;
+};
+
 // tile_objects: DqoObjectGate.tile_objects or NULL — a candidate whose Gaussian's object (the spare word of its xy record) owns no pixel of
 // the tile is dropped like one whose footprint cannot reach the tile
+//
+// K1: the block first runs the early part of the per-Gaussian forward for its own 256 Gaussians (k1_early: the statements of
+// preprocess_kernel, which is then not launched) instead of reading their rect / conic / pixel position back from the tables — only for
+// a frame whose tile histogram, flags and per-frame scalars the previous frame's dqo_rast_backward_adam has cleared
+// (DqoRastCtx.frame_prezeroed: preprocess_kernel is also the launch that zeroes the histogram in front of this kernel's atomics).
+template <bool K1>
 __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
                                                                 uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
                                                                 DqoBinLayout bin, int64_t capacity,
-                                                                const unsigned long long* __restrict__ tile_objects) {
+                                                                const unsigned long long* __restrict__ tile_objects, const DqoK1Raw k1) {
     __shared__ uint32_t s_off[BIN_CHUNK + 1];  // exclusive prefix of the rect areas
     __shared__ uint2 s_rect[BIN_CHUNK];        // packed tile rects
     __shared__ float4 s_con[BIN_CHUNK];        // conic + opacity
@@ -96,7 +111,39 @@ __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P
     {
         uint2 rc = make_uint2(0u, 0u);
         float4 co = make_float4(0.f, 0.f, 0.f, 0.f), xy = co;
-        if (my_idx < P) {
+        if constexpr (K1) {
+            float view[16], proj[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) view[i] = k1.v.view[i], proj[i] = k1.v.proj[i];
+            if (blockIdx.x == 0 && tid == 0) {
+                g.header->stage = 1u;  // (the header still holds the previous frame: "stage 1" until the sort kernels rewrite it)
+                // the frame_prezeroed promise: the previous frame's tail leaves a stamp behind its clearing; a frame that finds none — a
+                // forward-only render, dqo_rast_backward, an error return in between — is flagged (folded into header.overflow)
+                if (g.counters[9] != DQO_CLEARED_STAMP) atomicOr(&g.counters[8], 1u);
+                g.counters[9] = 0u;
+            }
+            bool vis = false;
+            uint32_t ncand = 0;
+            if (my_idx < P) {
+                const K1Early e = k1_early<false>(k1.v, view, proj, 0.f, 0.f, 0.f, my_idx, k1.means3D, k1.scales, k1.rotations, k1.opacities,
+                                                  nullptr, nullptr, k1.gobj, g, k1.radii_out, k1.n_touched_out);
+                rc = make_uint2((uint32_t)e.rminx | ((uint32_t)e.rmaxx << 16), (uint32_t)e.rminy | ((uint32_t)e.rmaxy << 16));
+                co = e.co, xy = e.xy;
+                ncand = (uint32_t)((e.rmaxx - e.rminx) * (e.rmaxy - e.rminy));
+                area = ncand;
+                vis = e.radius > 0;
+            }
+            // visible count and (Gaussian, tile) pairs in the tile rects (the header's statistics): one pair of atomics per wave
+            const uint32_t nv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(vis));
+            uint32_t nc = ncand;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nc += (uint32_t)__shfl_xor((int)nc, off);
+            if (lane == 0 && (nv | nc) != 0u) {
+                uint32_t* const my_line = g.spread + (size_t)((blockIdx.x * (BIN_THREADS / 64) + wave) % DQO_SPREAD) * 64;
+                if (nv) atomicAdd(&my_line[0], nv);
+                if (nc) atomicAdd(&my_line[1], nc);
+            }
+        } else if (my_idx < P) {
             // all three loads together (the tables of a culled Gaussian hold stale values that are never looked at): loading the
             // conic only after the rect says "visible" would put two memory latencies in series at the head of every block
             rc = g.rect16[my_idx];
@@ -287,8 +334,21 @@ __global__ __launch_bounds__(256) void bin_place_kernel(DqoGeomLayout g, DqoImag
 
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                          int64_t capacity, const unsigned long long* tile_objects, hipStream_t s) {
-    DQO_LAUNCH("bin_count_kernel", bin_count_kernel, dim3(dqo_spread_blocks(P)), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
-               img.tile_count, img.tile_flag, bin, capacity, tile_objects);
+    DqoK1Raw none{};
+    DQO_LAUNCH("bin_count_kernel", bin_count_kernel<false>, dim3(dqo_spread_blocks(P)), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
+               img.tile_count, img.tile_flag, bin, capacity, tile_objects, none);
+    return DQO_OK;
+}
+
+// ... with the early part of the per-Gaussian forward at the head of every block (no preprocess_kernel launch in front)
+int dqo_launch_bin_count_k1(const DqoView& v, const DqoRastInputs* in, const DqoRastOutputs* out, const int32_t* gobj, const DqoGeomLayout& g,
+                            const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, const unsigned long long* tile_objects,
+                            hipStream_t s) {
+    DqoK1Raw k1;
+    k1.v = v, k1.means3D = in->means3D, k1.scales = in->scales, k1.rotations = in->rotations, k1.opacities = in->opacities;
+    k1.gobj = gobj, k1.radii_out = out->radii, k1.n_touched_out = out->n_touched;
+    DQO_LAUNCH("bin_count_kernel", bin_count_kernel<true>, dim3(dqo_spread_blocks(v.P)), dim3(BIN_THREADS), s, v.P, v.gx, in->tile_mask, g,
+               img.tile_count, img.tile_flag, bin, capacity, tile_objects, k1);
     return DQO_OK;
 }
 

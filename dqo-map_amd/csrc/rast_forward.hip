@@ -17,7 +17,7 @@
 #include "dqo_common.h"
 #include "dqo_cull.h"
 #include "dqo_gauss_chain.h"
-#include "dqo_k1_late.h"
+#include "dqo_k1_early.h"
 
 #ifndef K1_WAVES
 #define K1_WAVES 4     // preprocess_kernel: waves per SIMD the register allocation leaves room for
@@ -90,91 +90,9 @@ __global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const 
     for (int it = 0; it < K1_ITEMS; it++) {
         const int idx = blockIdx.x * (K1_THREADS * K1_ITEMS) + it * K1_THREADS + tid;
         if (idx >= P) continue;
-        int radius = 0;
-        int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
-        do {
-            const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
-            // in_frustum, auxiliary.h:139-165
-            const float hx = proj[0] * px + proj[4] * py + proj[8] * pz + proj[12];
-            const float hy = proj[1] * px + proj[5] * py + proj[9] * pz + proj[13];
-            const float hw = proj[3] * px + proj[7] * py + proj[11] * pz + proj[15];
-            const float p_w = 1.0f / (hw + 0.0000001f);
-            const float projx = hx * p_w, projy = hy * p_w;
-            const float tvx = view[0] * px + view[4] * py + view[8] * pz + view[12];
-            const float tvy = view[1] * px + view[5] * py + view[9] * pz + view[13];
-            const float tvz = view[2] * px + view[6] * py + view[10] * pz + view[14];
-            if (tvz <= 0.2f || (double)projx < -1.3 || (double)projx > 1.3 || (double)projy < -1.3 || (double)projy > 1.3) break;
-            const float opac = opacities[idx];  // (with the scales / rotation round: used only by the stores at the very end)
-            // DqoObjectGate: the Gaussian's object id travels to the blend kernels in the spare word of its xy record
-            const int obj_id = gobj != nullptr ? gobj[idx] : 0;
-            // computeCov3D, forward.cu:202-235
-            const float sx = scales[3 * idx], sy = scales[3 * idx + 1], sz = scales[3 * idx + 2];
-            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-            float Rm[3][3];
-            quat_to_R(q, Rm);
-            const float s[3] = {v.scale_mod * sx, v.scale_mod * sy, v.scale_mod * sz};
-            float Mm[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int i = 0; i < 3; i++) Mm[k][i] = s[k] * Rm[i][k];
-            float c3[6];
-            {
-                int o = 0;
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = i; j < 3; j++) c3[o++] = Mm[0][i] * Mm[0][j] + Mm[1][i] * Mm[1][j] + Mm[2][i] * Mm[2][j];
-            }
-            // computeCov2D, forward.cu:158-197
-            const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
-            const float txtz = tvx / tvz, tytz = tvy / tvz;
-            const float tx = fminf(limx, fmaxf(-limx, txtz)) * tvz;
-            const float ty = fminf(limy, fmaxf(-limy, tytz)) * tvz;
-            const float J00 = v.focal_x / tvz, J02 = -(v.focal_x * tx) / (tvz * tvz);
-            const float J11 = v.focal_y / tvz, J12 = -(v.focal_y * ty) / (tvz * tvz);
-            float A0[3], A1[3];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                A0[j] = J00 * view[j * 4 + 0] + J02 * view[j * 4 + 2];
-                A1[j] = J11 * view[j * 4 + 1] + J12 * view[j * 4 + 2];
-            }
-            const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
-            float VA0[3], VA1[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                VA0[i] = V[i][0] * A0[0] + V[i][1] * A0[1] + V[i][2] * A0[2];
-                VA1[i] = V[i][0] * A1[0] + V[i][1] * A1[1] + V[i][2] * A1[2];
-            }
-            const float ca = A0[0] * VA0[0] + A0[1] * VA0[1] + A0[2] * VA0[2] + 0.3f;
-            const float cb = A0[0] * VA1[0] + A0[1] * VA1[1] + A0[2] * VA1[2];
-            const float cc = A1[0] * VA1[0] + A1[1] * VA1[1] + A1[2] * VA1[2] + 0.3f;
-            const float det = ca * cc - cb * cb;
-            if (det == 0.0f) break;
-            const float det_inv = 1.f / det;
-            const float conx = cc * det_inv, cony = -cb * det_inv, conz = ca * det_inv;
-            const float mid = 0.5f * (ca + cc);
-            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-            const float my_radius = ceilf(v.color_sigma * sqrtf(fmaxf(lambda1, lambda2)));
-            // ndc2Pix(v, S, c) = v * S * 0.5 + c with double intermediate, auxiliary.h:44-47
-            const float pixx = (float)((double)(projx * (float)v.W) * 0.5 + (double)v.cx);
-            const float pixy = (float)((double)(projy * (float)v.H) * 0.5 + (double)v.cy);
-            // getRect, auxiliary.h:49-57
-            const int ir = (int)my_radius;
-            rminx = min(v.gx, max(0, (int)((pixx - (float)ir) / (float)DQO_TILE)));
-            rminy = min(v.gy, max(0, (int)((pixy - (float)ir) / (float)DQO_TILE)));
-            rmaxx = min(v.gx, max(0, (int)((pixx + (float)ir + (float)(DQO_TILE - 1)) / (float)DQO_TILE)));
-            rmaxy = min(v.gy, max(0, (int)((pixy + (float)ir + (float)(DQO_TILE - 1)) / (float)DQO_TILE)));
-            if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
-            if constexpr (LATE) k1_late_part(v, view, cam0, cam1, cam2, idx, px, py, pz, tvx, tvy, tvz, sx, sy, sz, Rm, shs, colors_precomp, g);
-            radius = ir;
-            g.conic_opacity[idx] = make_float4(conx, cony, conz, opac);
-            g.xy_depth[idx] = make_float4(pixx, pixy, tvz, __int_as_float(gobj != nullptr ? obj_id : ir));
-        } while (false);
-        radii_out[idx] = radius;
-        n_touched_out[idx] = 0;
-        g.rect16[idx] = make_uint2((uint32_t)rminx | ((uint32_t)rmaxx << 16), (uint32_t)rminy | ((uint32_t)rmaxy << 16));
+        const K1Early e = k1_early<LATE>(v, view, proj, cam0, cam1, cam2, idx, means3D, scales, rotations, opacities, shs, colors_precomp, gobj, g,
+                                         radii_out, n_touched_out);
+        const int radius = e.radius, rminx = e.rminx, rminy = e.rminy, rmaxx = e.rmaxx, rmaxy = e.rmaxy;
         nvis += radius > 0 ? 1u : 0u;
         ncand += (uint32_t)((rmaxx - rminx) * (rmaxy - rminy));
     }
@@ -907,7 +825,7 @@ int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, 
         int rc = dqo_launch_zero_words(img.tile_count, zero_words, s);
         if (rc) return rc;
     }
-    if (p->P > 0) {
+    if (p->P > 0 && !dqo_fuse_k1(p, ctx)) {  // (fused: bin_count_kernel<true> does this part, dqo_launch_forward_render)
         const int per_block = K1_THREADS * K1_ITEMS;
         const int grid = (p->P + per_block - 1) / per_block;
         const int32_t* gobj = ctx->object_gate ? ctx->object_gate->gaussian_object : nullptr;
@@ -938,8 +856,10 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     const int T = v.gx * v.gy;
     if (p->P > 0) {
         // footprint test, per-tile histogram + ranks, tiles_touched, gaussian-major slots (forward.cu:344-353, rasterizer_impl.cu:303)
-        int rc = dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap,
-                                      ctx->object_gate ? reinterpret_cast<const unsigned long long*>(ctx->object_gate->tile_objects) : nullptr, s);
+        const unsigned long long* tobj = ctx->object_gate ? reinterpret_cast<const unsigned long long*>(ctx->object_gate->tile_objects) : nullptr;
+        int rc = dqo_fuse_k1(p, ctx) ? dqo_launch_bin_count_k1(v, in, out, ctx->object_gate ? ctx->object_gate->gaussian_object : nullptr, g, img,
+                                                               bin, cap, tobj, s)
+                                     : dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap, tobj, s);
         if (rc) return rc;
     }
     // bucket mode with a tile_order kept from an earlier frame on the same image buffer: nothing of tile_scan_kernel is needed
@@ -974,6 +894,14 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     if (header_event != nullptr) DQO_CHECK_HIP(hipEventRecord(header_event, s));
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, dqo_tap_dev(ctx->loss_tap),
                                     dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s);
+}
+
+bool dqo_fuse_k1(const DqoRastParams* p, const DqoRastCtx* ctx) {
+    static const bool on = [] {
+        const char* e = getenv("DQO_K1_FUSE");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    return on && ctx->frame_prezeroed != 0 && p->P > 0 && ctx->tile_bucket_capacity > 0 && dqo_k1_where(p->P) != 0;
 }
 
 int dqo_launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present, hipStream_t s) {

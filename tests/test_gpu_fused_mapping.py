@@ -718,3 +718,52 @@ def test_adam_attach_term_vs_oracle(env):
     for k, want in (("xyz", g["xyz"].astype(np.float64) + a_xyz), ("sc", rg_sc + a_sc), ("rot", rg_rot + a_rot)):
         np.testing.assert_allclose(m[k].cpu().numpy() / 0.1, want, rtol=2e-5, atol=2e-6), k
     np.testing.assert_allclose(m["shs"].cpu().numpy() / 0.1, g["shs"], rtol=2e-5, atol=2e-6)
+
+
+def test_early_part_at_the_head_of_the_binning_kernel_gives_identical_bits(env):
+    """A replayed iteration runs the early part of the per-Gaussian forward at the head of bin_count_kernel (csrc/dqo_k1_early.h; the
+    previous frame's tail has cleared the tile histogram and left its stamp) instead of launching preprocess_kernel: the same statements
+    — parameters, moments, loss, outputs, radii and the header's statistics after a capture + 6 replays must agree bit for bit with the
+    two-launch sequence (DQO_K1_FUSE=0).  The switch is read once per process: each setting runs in a child process and reports a digest."""
+    import os, subprocess, sys
+    code = r'''
+import hashlib, sys, os
+import numpy as np, torch
+root = os.environ["DQO_TEST_ROOT"]
+sys.path[:0] = [root, root + "/dqo-map_amd", root + "/tests"]
+import test_gpu_fused_mapping as T
+from dqo_harness.fused_mapping import FusedMapper
+cam, scene, settings, gt_color, gt_depth, mask, dev = T._problem(torch, P=9000)
+h = hashlib.sha256()
+for gated in (False, True):
+    fm = FusedMapper(scene, settings, dev)
+    if gated:
+        go = (np.arange(9000) % 5).astype(np.int32)
+        po = (np.add.outer(np.arange(cam.H) // 40, np.arange(cam.W) // 50) % 6 - 1).astype(np.int32)
+        fm.set_object_gate(go, po)
+    fm.capture(gt_color, gt_depth, mask, fused_tail=True)
+    assert fm._g.cctx.frame_prezeroed == 1 and fm._g.cctx.tile_bucket_capacity > 0
+    for _ in range(6):
+        fm.replay()
+    torch.cuda.synchronize()
+    assert not fm.graph_overflowed()
+    hdr = fm._g.geom[:32].view(torch.int32).cpu().numpy()
+    assert hdr[4] > 0 and hdr[5] >= hdr[0] > 0
+    h.update(hdr[:6].tobytes())
+    for k, v in sorted(fm._params().items()):
+        h.update(v.cpu().numpy().tobytes())
+        for m in fm.state[k]:
+            h.update(m.cpu().numpy().tobytes())
+    h.update(fm.loss.cpu().numpy().tobytes())
+    for o in fm._g.out:
+        h.update(o.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for fuse in ("0", "1"):
+        e = dict(os.environ, DQO_K1_FUSE=fuse, DQO_TEST_ROOT=root)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
