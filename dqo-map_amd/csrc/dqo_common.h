@@ -366,6 +366,40 @@ static inline size_t dqo_frame_scalar_words(const DqoRastCtx* ctx) {
 // behind the sort kernels (dqo_k1_where != 0; 0 keeps everything in preprocess_kernel: the A/B baseline).  DQO_K1_FUSE=0 switches it off.
 bool dqo_fuse_k1(const DqoRastParams* p, const DqoRastCtx* ctx);
 
+// keep_order frames (DqoRastCtx.keep_tile_order: no tile_scan_kernel): the header that kernel would have written, from the spread statistics
+// lines — one wave, behind the per-tile sort launch: the first block of tile_sort_kernel, or (no long-list launch: dqo_skip_long_sort) an
+// extra block of blend_forward_kernel
+__device__ __forceinline__ void dqo_header_from_spread(const DqoGeomLayout& g, int64_t capacity, int bucket, int lane) {
+    uint32_t nv = 0, nc = 0, mx = 0, nt = 0, total = 0;
+    for (int j = lane; j < DQO_SPREAD; j += 64) {
+        const uint32_t* line = g.spread + (size_t)j * 64;
+        nv += line[0], nc += line[1], mx = max(mx, line[2]), nt += line[3], total += line[4];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        nv += __shfl_xor((int)nv, off), nc += __shfl_xor((int)nc, off), nt += __shfl_xor((int)nt, off);
+        total += __shfl_xor((int)total, off);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    }
+    if (lane == 0) {
+        // instances counted by bin_count_kernel's regional slot allocators (line word 4) = the sum of the list lengths
+        DqoRastHeader h;
+        h.num_rendered = total;
+        h.num_tiles = nt;
+        (void)capacity;
+        h.overflow = (g.counters[7] != 0u || g.counters[8] != 0u || mx > (uint32_t)bucket) ? 1u : 0u;
+        h.max_tile_count = mx;
+        h.num_visible = nv;
+        h.num_candidates = nc;
+        h.stage = 2u, h.reserved = 0u;
+        *g.header = h;
+    }
+}
+
+// The long-list sort launch is dropped when no list can outgrow the per-tile sort (buckets of at most DQO_SORTW_CAP entries, tile order kept,
+// the late part of the per-Gaussian forward not riding that launch, no list splitting); DQO_SKIP_LONG_SORT=0 keeps it.
+bool dqo_skip_long_sort(const DqoRastParams* p, const DqoRastCtx* ctx);
+
 // Zero fill of caller memory on the launch stream.  The library never uses hipMemsetAsync for this: as a memset NODE of a captured
 // hipGraph the fill was observed (ROCm 7.2, gfx950) to write garbage on replay once other runtime activity had happened since the
 // capture; a kernel node carries its arguments by value.  Defined in rast_forward.hip.

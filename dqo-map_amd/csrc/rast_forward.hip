@@ -529,34 +529,6 @@ constexpr int SORTL_RUN = SORTP_RUN;  // 512
 // frame left in the image buffer (any permutation of the tiles gives the same results), a list's range follows from its own
 // counter, and the frame statistics the header needs go to the spread lines (words 2..3), which tile_sort_kernel's first block
 // sums up (header_from_spread).
-// keep_order frames: the header tile_scan_kernel would have written, from the spread statistics lines (one wave)
-__device__ __forceinline__ void header_from_spread(const DqoGeomLayout& g, int64_t capacity, int bucket, int lane) {
-    uint32_t nv = 0, nc = 0, mx = 0, nt = 0, total = 0;
-    for (int j = lane; j < DQO_SPREAD; j += 64) {
-        const uint32_t* line = g.spread + (size_t)j * 64;
-        nv += line[0], nc += line[1], mx = max(mx, line[2]), nt += line[3], total += line[4];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        nv += __shfl_xor((int)nv, off), nc += __shfl_xor((int)nc, off), nt += __shfl_xor((int)nt, off);
-        total += __shfl_xor((int)total, off);
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
-    }
-    if (lane == 0) {
-        // instances counted by bin_count_kernel's regional slot allocators (line word 4) = the sum of the list lengths
-        DqoRastHeader h;
-        h.num_rendered = total;
-        h.num_tiles = nt;
-        (void)capacity;
-        h.overflow = (g.counters[7] != 0u || g.counters[8] != 0u || mx > (uint32_t)bucket) ? 1u : 0u;
-        h.max_tile_count = mx;
-        h.num_visible = nv;
-        h.num_candidates = nc;
-        h.stage = 2u, h.reserved = 0u;
-        *g.header = h;
-    }
-}
-
 template <bool LATE>
 __global__ __launch_bounds__(SORT_THREADS, LATE ? 4 : 6) void tile_sort_kernel(int T, DqoImageLayout img, DqoBinLayout bin, DqoGeomLayout g, int64_t capacity,
                                                                  int keep_order, const DqoK1Late late) {
@@ -569,7 +541,7 @@ __global__ __launch_bounds__(SORT_THREADS, LATE ? 4 : 6) void tile_sort_kernel(i
     const uint32_t sort_blocks = LATE ? (uint32_t)late.first_block : gridDim.x;
     __shared__ uint64_t s_keys[SORTL_SEG];
     __shared__ uint32_t s_vals[SORTL_SEG];
-    if (keep_order && blockIdx.x == 0 && threadIdx.x < 64) header_from_spread(g, capacity, bin.bucket, (int)threadIdx.x);
+    if (keep_order && blockIdx.x == 0 && threadIdx.x < 64) dqo_header_from_spread(g, capacity, bin.bucket, (int)threadIdx.x);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t n_long = min(g.counters[1], (uint32_t)T);  // tiles queued by tile_sort_wave_kernel
     for (uint32_t q = blockIdx.x; q < n_long; q += sort_blocks) {  // (block-uniform trip count; every helper ends with a barrier)
@@ -797,7 +769,8 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s);
+                             const DqoRastOutputs& out, int T, const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s,
+                             int64_t header_capacity);
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                          int64_t capacity, const unsigned long long* tile_objects, hipStream_t s);
 int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
@@ -882,7 +855,10 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
             DQO_LAUNCH("tile_sort_wave_kernel", tile_sort_wave_kernel<false>, dim3(slots), dim3(SORTW_THREADS), s, T, img, bin, g, cap, keep_order,
                        dqo_list_split(ctx), late);
         }
-        if (dqo_k1_where(p->P) == 2) {
+        if (dqo_skip_long_sort(p, ctx)) {
+            // no list can be longer than the per-tile sort reaches (a tile that outgrows its bucket is flagged): no long-list launch;
+            // the frame's header — that launch's first block forms it in keep_order frames — comes from an extra block of the blend launch
+        } else if (dqo_k1_where(p->P) == 2) {
             late.first_block = SORT_GRID;
             DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel<true>, dim3(SORT_GRID + (p->P + SORT_THREADS - 1) / SORT_THREADS), dim3(SORT_THREADS), s, T,
                        img, bin, g, cap, keep_order, late);
@@ -893,7 +869,16 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
     if (header_host != nullptr) DQO_CHECK_HIP(hipMemcpyAsync(header_host, g.header, sizeof(DqoRastHeader), hipMemcpyDeviceToHost, s));
     if (header_event != nullptr) DQO_CHECK_HIP(hipEventRecord(header_event, s));
     return dqo_launch_blend_forward(v, g, img, bin, *out, T, dqo_tap_dev(ctx->loss_tap),
-                                    dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s);
+                                    dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s, dqo_skip_long_sort(p, ctx) ? cap : (int64_t)-1);
+}
+
+bool dqo_skip_long_sort(const DqoRastParams* p, const DqoRastCtx* ctx) {
+    static const bool on = [] {
+        const char* e = getenv("DQO_SKIP_LONG_SORT");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    return on && p->P > 0 && ctx->tile_bucket_capacity > 0 && ctx->tile_bucket_capacity <= SORTW_CAP && ctx->keep_tile_order != 0 &&
+           dqo_k1_where(p->P) != 2 && dqo_list_split(ctx) == 0;
 }
 
 bool dqo_fuse_k1(const DqoRastParams* p, const DqoRastCtx* ctx) {

@@ -489,7 +489,14 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 template <bool GATE>
 __global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? 6 : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                                             DqoBinLayout bin, DqoRastOutputs out,
-                                                                                            const DqoTapDev tap, const DqoGateDev gate) {
+                                                                                            const DqoTapDev tap, const DqoGateDev gate,
+                                                                                            const int64_t header_capacity) {
+    // header_capacity >= 0: the launch has ONE extra block, which forms the frame's header from the statistics lines (frames without a
+    // long-list sort launch, whose first block does that otherwise: dqo_skip_long_sort); nothing in this kernel reads the header
+    if (header_capacity >= 0 && blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x < 64) dqo_header_from_spread(g, header_capacity, bin.bucket, (int)threadIdx.x);
+        return;
+    }
     __shared__ float4 lds[FWD_BLK * FWD_WPB];
     const int wave = FWD_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int xg = blockIdx.x & 7, jg = FWD_WPB > 1 ? ((int)(blockIdx.x >> 3) * FWD_WPB + wave) : (int)(blockIdx.x >> 3);
@@ -545,7 +552,8 @@ __global__ __launch_bounds__(FWD_THREADS * SPLIT_RUNS, 4) void blend_forward_spl
 }  // namespace
 
 int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                             const DqoRastOutputs& out, int T, const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s) {
+                             const DqoRastOutputs& out, int T, const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s,
+                             int64_t header_capacity) {
     const bool gt = gate.gobj != nullptr;
     if (list_split > 0) {
         const dim3 grid(2 * SPLIT_GRID + 8 * (((T + 7) / 8 + 1) / 2)), block(FWD_THREADS * SPLIT_RUNS);
@@ -553,8 +561,8 @@ int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const Dqo
         else DQO_LAUNCH("blend_forward_kernel", blend_forward_split_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate, list_split);
         return DQO_OK;
     }
-    const dim3 grid(8 * ((T + 7) / 8) * 4 / FWD_WPB), block(FWD_THREADS * FWD_WPB);
-    if (gt) DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<true>, grid, block, s, v, g, img, bin, out, tap, gate);
-    else DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate);
+    const dim3 grid(8 * ((T + 7) / 8) * 4 / FWD_WPB + (header_capacity >= 0 ? 1 : 0)), block(FWD_THREADS * FWD_WPB);
+    if (gt) DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<true>, grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
+    else DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
     return DQO_OK;
 }

@@ -673,6 +673,10 @@ class FusedMapper:
                 g.bucket = 256
                 while g.bucket < 2 * longest:
                     g.bucket *= 2
+                # 1024 entries are what the per-tile sort launch reaches: while no list can be longer, the long-list sort launch is
+                # dropped (6 us of launch on a map whose lists are all short) — worth a smaller margin (at least 1.3 x) to stay there
+                if g.bucket == 2048 and 1.3 * longest <= 1024:
+                    g.bucket = 1024
             for name, t_, shape in (("gt_color", gt_color, (3, H, W)), ("gt_depth", gt_depth, (1, H, W))):
                 if t_.dtype != torch.float32 or not t_.is_cuda or not t_.is_contiguous() or tuple(t_.shape) != shape:
                     raise RuntimeError(f"FusedMapper.capture: {name} must be a contiguous float32 GPU tensor of shape {shape} "
@@ -796,6 +800,12 @@ class FusedMapper:
                                    radii=out[8].data_ptr())
         cctx = N.DqoRastCtx(geom=geom.data_ptr(), geom_bytes=geom.numel(), binning=None, binning_bytes=0, image=img.data_ptr(),
                             image_bytes=img.numel(), inst_capacity=0)
+        if self.gaussian_object is not None:
+            # the lists of the gated job (the binning drops a pair whose object owns no pixel of the tile): its longest list, not the
+            # ungated frame's, sizes the buckets
+            gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(self.pixel_object),
+                                   tile_objects=N.ptr(self.tile_objects))
+            cctx.object_gate = ctypes.addressof(gate)
         stream = N.current_stream()
         hdr = N.DqoRastHeader()
         N.check(lib.dqo_rast_forward_prepare(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs), ctypes.byref(cctx), stream))
