@@ -177,7 +177,14 @@ typedef struct DqoRastCtx {
      * loss-tap counters) are zero — as dqo_rast_backward_adam leaves them: its per-Gaussian kernel, the LAST consumer of a frame's
      * counters, clears them for the next frame on the way — so the forward does not launch its zero-fill kernel.  For a captured iteration that is
      * replayed back to back (forward, dqo_rast_backward_adam, forward, ...) on one context: one launch less per iteration.  Ignored when
-     * P == 0.  The device header (num_rendered ... overflow) is never cleared: every frame rewrites it. */
+     * P == 0.  The device header (num_rendered ... overflow) is never cleared: every frame rewrites it.
+     * Round 5: that kernel also clears the tile histogram and tile flags of ctx.image and leaves a stamp behind; with per-tile buckets
+     * (tile_bucket_capacity > 0) a pre-zeroed frame then has no per-Gaussian preprocess launch either — its statements run at the head of
+     * the binning kernel (csrc/dqo_k1_early.h) — and, with buckets of at most 1024 entries and keep_tile_order, no long-list sort launch.
+     * A frame that finds no stamp (the promise was broken: a forward-only render, dqo_rast_backward or an error return in between) is
+     * flagged in header.overflow and trains nothing; the frame after it is valid again.  Between dqo_rast_forward_prepare and
+     * dqo_rast_forward_render of such a frame the stage-1 statistics are not available yet (dqo_rast_read_header reports zeros): use
+     * dqo_rast_forward / dqo_rast_forward_async. */
     int32_t frame_prezeroed;
 } DqoRastCtx;
 

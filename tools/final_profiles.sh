@@ -9,7 +9,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks --output-for
 cp $(find /tmp/ks -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
 echo "kernel stats done"
 for c in 2 4 5; do
-  steps=50; [ $c = 5 ] && steps=300   # cfg 5: three growth steps (every 100 iterations) inside the timed region
+  steps=50; [ $c = 5 ] && steps=1000   # cfg 5: ten growth steps (every 100 iterations) inside the timed region
   timeout -k 10 500 python bench.py --cfg $c --steps $steps --no-cpu-baseline > $out/bench_cfg$c.json 2> $out/bench_cfg$c.err || exit 1
   echo "cfg$c done"
 done
