@@ -58,3 +58,42 @@ def test_temp_points_attach_indices_vs_oracle():
     t = torch.tensor
     assert dqo_mapgrowth.temp_points_attach_indices(t(xyz), t(op), t(w2c), t(K), W, H, t(np.full_like(im, -1)), t(sx), t(sn), 0.1).numel() == 0
     assert dqo_mapgrowth.temp_points_attach_indices(t(xyz), t(np.full_like(op, 0.1)), t(w2c), t(K), W, H, t(im), t(sx), t(sn), 0.1).numel() == 0
+
+
+def test_per_object_mask_form_equals_the_chain():
+    """The per-object job's decision as ONE mask over the candidates (dqo_mapgrowth.temp_points_pixels +
+    temp_points_attach_mask_per_object: the statements csrc/map_attach.hip follows) against the reference's boolean-index chain with
+    temp_obj / stable_obj: the same candidates attach, except where the chain's matmul projection and the element-wise one put a candidate
+    into different pixels (none expected at these sizes; allowed for)."""
+    import dqo_mapgrowth
+    t = torch.tensor
+    for seed, n in ((5, 500), (6, 900)):
+        W, H, K, w2c, sx, sn, im, xyz, op = _case(seed, n, False)
+        rng = np.random.default_rng(seed + 100)
+        op[rng.uniform(size=n) < 0.15] = 0.05      # below unstable_opacity_low: never attached
+        sobj = rng.integers(0, 4, sx.shape[0]).astype(np.int32)
+        tobj = rng.integers(0, 4, n).astype(np.int32)
+        # most candidates carry the object of the Gaussian their pixel shows (otherwise nothing would attach)
+        u = (t(xyz) @ t(w2c)[:3, :3].T + t(w2c)[:3, 3]) @ t(K).T
+        uv_mm = (u[:, :2] / u[:, 2:]).long()
+        ok = (uv_mm[:, 0] >= 0) & (uv_mm[:, 0] < W) & (uv_mm[:, 1] >= 0) & (uv_mm[:, 1] < H)
+        for i in np.nonzero(ok.numpy())[0]:
+            s = im[0, uv_mm[i, 1], uv_mm[i, 0]]
+            if s >= 0 and rng.uniform() < 0.8:
+                tobj[i] = sobj[s]
+        weight = np.where(im >= 0, 0.5, 0.0).astype(np.float32)
+        im0 = im.copy()
+        im0[0, :4, :4] = 0      # a never-rendered tile: index 0 with weight 0 is the op's zero fill, no hit
+        weight[0, :4, :4] = 0
+        uv, inside = dqo_mapgrowth.temp_points_pixels(t(xyz), t(w2c), t(K), W, H)
+        mask = dqo_mapgrowth.temp_points_attach_mask_per_object(t(xyz), t(op), t(tobj), uv, inside, W, H, t(im0), t(weight), t(sx), t(sn),
+                                                                t(sobj), 0.1, 0.1)
+        cim = np.where((im0 == 0) & (weight == 0), -1, im0).astype(np.int32)
+        chain = dqo_mapgrowth.temp_points_attach_indices(t(xyz), t(op), t(w2c), t(K), W, H, t(cim), t(sx), t(sn), 0.1, 0.1,
+                                                         temp_obj=t(tobj), stable_obj=t(sobj))
+        c_mask = torch.zeros(n, dtype=torch.bool)
+        c_mask[chain] = True
+        moved = (uv_mm != uv).any(dim=1) & inside
+        assert not bool(((c_mask != mask) & ~moved).any()) and int(moved.sum()) <= 2
+        assert 0 < int(mask.sum()) < n and bool((mask & (t(op).reshape(-1) <= 0.1)).sum() == 0)
+        assert not bool(inside.all()) and bool((uv[inside] >= 0).all())
