@@ -273,6 +273,7 @@ def attach_decide(temp_xyz, temp_opacity, temp_obj, lin, hit_index, hit_weight, 
     launch (normals from the raw quaternion and raw scales inside)."""
     import _dqo_native as N
     n, dev = int(temp_xyz.shape[0]), temp_xyz.device
+    temp_obj, stable_obj = temp_obj.to(torch.int32), stable_obj.to(torch.int32)  # (object ids arrive as int32 or int64)
     f32 = (temp_xyz, temp_opacity, hit_weight, stable_xyz, scaling_raw, rotation_raw)
     i32 = (temp_obj, lin, hit_index, stable_obj)
     N.require_gpu(*f32, *i32)
