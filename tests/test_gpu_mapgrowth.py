@@ -516,3 +516,47 @@ def test_gated_attach_on_the_candidates_pixels_equals_the_full_frame_chain(mg):
     uv_mm = (uv_mm[:, :2] / uv_mm[:, 2:]).long()
     moved = (uv_mm != uv).any(dim=1) & inside  # (the two projections differ in the last bit: a candidate on a pixel edge may move)
     assert not bool(((c_mask != want) & ~moved).any()) and int(moved.sum().item()) < 10
+
+
+def test_attach_kernels_on_degenerate_candidates(mg):
+    """dqo_attach_pixels / dqo_attach_decide with no candidates and with non-finite / huge coordinates: such a candidate is outside the
+    image (lin = -1), owns no pixel of the sparse gate and never attaches; nothing is read or written out of bounds.  (A point BEHIND the
+    camera projects to a pixel like one in front of it — the reference's get_uv has no depth test, scene/cameras.py:207-214 — and is
+    judged like any other: the torch restatement says the same.)"""
+    torch, M = mg
+    from dqo_harness import mapping, scenes
+    dev = torch.device("cuda")
+    cam, scene = scenes.make_config(1, P=2000)
+    settings = mapping.make_settings(cam, dev)
+    H, W = cam.H, cam.W
+    fx, fy = W / (2.0 * cam.tanfovx), H / (2.0 * cam.tanfovy)
+    K = torch.tensor([[fx, 0.0, cam.cx], [0.0, fy, cam.cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    po = torch.zeros((H * W,), dtype=torch.int32, device=dev)
+    lin, sparse, tsets = M.attach_pixels(torch.empty((0, 3), device=dev), settings.viewmatrix, fx, fy, cam.cx, cam.cy, W, H, po)
+    assert lin.numel() == 0 and bool((sparse == -1).all()) and bool((tsets == 0).all())
+    campos = settings.campos.reshape(1, 3).float()
+    fwd = settings.viewmatrix[:3, 2].reshape(1, 3).float()  # camera z axis in world coordinates
+    inf, nan = float("inf"), float("nan")
+    pts = torch.cat([campos - 2.0 * fwd, campos + 2.0 * fwd,
+                     torch.tensor([[nan, 0.0, 1.0], [inf, 0.0, 1.0], [0.0, -inf, 1.0], [1e30, 1e30, 1e30]], device=dev)]).contiguous()
+    lin, sparse, tsets = M.attach_pixels(pts, settings.viewmatrix, fx, fy, cam.cx, cam.cy, W, H, po)
+    uv, inside = M.temp_points_pixels(pts, settings.viewmatrix.T.contiguous(), K, W, H)
+    assert torch.equal(lin >= 0, inside) and inside.tolist() == [True, True, False, False, False, False]
+    assert torch.equal(lin[:2].long(), uv[:2, 1] * W + uv[:2, 0]) and int((sparse >= 0).sum().item()) == int(torch.unique(lin[:2]).numel())
+    P = 5
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    rot = z(P, 4)
+    rot[:, 0] = 1
+    n = pts.shape[0]
+    ids = torch.zeros(n, dtype=torch.int32, device=dev)
+    hit = torch.full((1, H, W), -1, dtype=torch.int32, device=dev)
+    dec = M.attach_decide(pts, torch.full((n, 1), 0.99, device=dev), ids, lin, hit, z(1, H, W), z(P, 3), z(P, 3), rot,
+                          torch.zeros(P, dtype=torch.int32, device=dev), 0.1, 0.1)
+    assert int(dec.sum().item()) == 0
+    hit[:] = 2  # every pixel shows Gaussian 2, placed on the second candidate: that one attaches, the non-finite ones never do
+    sx = (campos + 2.0 * fwd).repeat(P, 1).contiguous()
+    dec = M.attach_decide(pts, torch.full((n, 1), 0.99, device=dev), ids, lin, hit, torch.ones((1, H, W), device=dev), sx, z(P, 3), rot,
+                          torch.zeros(P, dtype=torch.int32, device=dev), 0.1, 0.1)
+    assert dec.tolist()[1:] == [1, 0, 0, 0, 0]
+    assert M.attach_decide(pts[:0], z(0, 1), ids[:0], lin[:0], hit, z(1, H, W), z(P, 3), z(P, 3), rot,
+                           torch.zeros(P, dtype=torch.int32, device=dev), 0.1, 0.1).numel() == 0
