@@ -82,7 +82,7 @@ EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_e
            "dqo_rast_forward", "dqo_rast_forward_async", "dqo_rast_backward", "dqo_rast_backward_adam", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
            "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam", "dqo_tile_count_mask", "dqo_transmission_mask", "dqo_tile_color_error", "dqo_knn3_query_workspace_bytes",
            "dqo_knn3_query", "dqo_knn3_query_within", "dqo_knn3_query_grouped", "dqo_icp_workspace_bytes", "dqo_icp_normal_equations",
-           "dqo_attach_pixels", "dqo_attach_decide")
+           "dqo_attach_pixels", "dqo_attach_decide", "dqo_growth_scales", "dqo_growth_inside", "dqo_error_maps")
 
 _lib = None
 
@@ -145,6 +145,9 @@ def lib():
         L.dqo_knn3_query_grouped.argtypes = [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
         L.dqo_attach_pixels.argtypes = [c_i32, c_vp, c_vp, c_f, c_f, c_f, c_f, c_i32, c_i32] + [c_vp] * 5
         L.dqo_attach_decide.argtypes = [c_i32] + [c_vp] * 10 + [c_f, c_f, c_vp, c_vp]
+        L.dqo_growth_scales.argtypes = [c_i32] + [c_vp] * 7 + [c_f, c_f, c_f, c_vp, c_vp, c_vp]
+        L.dqo_growth_inside.argtypes = [c_i32] + [c_vp] * 5
+        L.dqo_error_maps.argtypes = [c_i32, c_i32] + [c_vp] * 9
         L.dqo_icp_workspace_bytes.restype = ctypes.c_size_t
         L.dqo_icp_workspace_bytes.argtypes = []
         L.dqo_icp_normal_equations.argtypes = [c_i32, c_i32] + [c_vp] * 5 + [c_f] * 6 + [c_vp] * 4 + [ctypes.c_size_t, c_vp]

@@ -52,6 +52,12 @@ int dqo_launch_icp(int H, int W, const float* vertex0, const float* vertex1, con
 int dqo_launch_tile_count(int W, int H, int mode, const uint8_t* mask_in, const float* T_map, uint8_t* mask_out, int32_t* tile_count,
                           int32_t* total, hipStream_t s);
 int dqo_launch_tile_color_error(int W, int H, const float* render, const float* gt, float* err_px, float* tile_sum, hipStream_t s);
+int dqo_launch_growth_scales(int n, const float* xyz, const int32_t* obj, const float* radius, const int32_t* i_new, const float* d2_old,
+                             const int32_t* i_old, const float* extra_radius, float reach2, float min_radius, float max_radius, float* scales,
+                             uint8_t* invalid, hipStream_t s);
+int dqo_launch_growth_inside(int n, const float* d2, const int32_t* idx, const float* radius, uint8_t* inside, hipStream_t s);
+int dqo_launch_error_maps(int64_t HW, const float* gt_color, const float* gt_depth, const float* render, const float* depth,
+                          const int32_t* depth_index, const uint8_t* mask, float* color_err, float* depth_err, hipStream_t s);
 int dqo_launch_attach_pixels(int n, const float* xyz, const float* V, float fx, float fy, float cx, float cy, int W, int H,
                              const int32_t* pixel_object, int32_t* lin, int32_t* sparse, unsigned long long* tile_objects, hipStream_t s);
 int dqo_launch_attach_decide(int n, const float* xyz, const float* opacity, const int32_t* obj, const int32_t* lin, const int32_t* hit_index,
@@ -539,6 +545,30 @@ DQO_API int dqo_attach_decide(int32_t n, const float* temp_xyz, const float* tem
                       gaussian_object && out, "null pointer");
     return dqo_launch_attach_decide(n, temp_xyz, temp_opacity, temp_object, lin, hit_index, hit_weight, xyz, scaling_raw, rotation_raw,
                                     gaussian_object, plane_thr, opacity_low, out, (hipStream_t)stream);
+}
+
+DQO_API int dqo_growth_scales(int32_t n, const float* xyz, const int32_t* object, const float* radius, const int32_t* i_new,
+                              const float* d2_old, const int32_t* i_old, const float* extra_radius, float reach2, float min_radius,
+                              float max_radius, float* scales, uint8_t* invalid, void* stream) {
+    DQO_CHECK_ARG(n >= 0, "bad size");
+    if (n == 0) return DQO_OK;
+    DQO_CHECK_ARG(xyz && object && radius && scales && invalid, "null pointer");
+    DQO_CHECK_ARG(i_old == nullptr || (d2_old && extra_radius), "i_old without d2_old / extra_radius");
+    return dqo_launch_growth_scales(n, xyz, object, radius, i_new, d2_old, i_old, extra_radius, reach2, min_radius, max_radius, scales, invalid,
+                                    (hipStream_t)stream);
+}
+
+DQO_API int dqo_growth_inside(int32_t n, const float* d2, const int32_t* idx, const float* radius, uint8_t* inside, void* stream) {
+    DQO_CHECK_ARG(n >= 0, "bad size");
+    if (n == 0) return DQO_OK;
+    DQO_CHECK_ARG(d2 && idx && radius && inside, "null pointer");
+    return dqo_launch_growth_inside(n, d2, idx, radius, inside, (hipStream_t)stream);
+}
+
+DQO_API int dqo_error_maps(int32_t H, int32_t W, const float* gt_color, const float* gt_depth, const float* render, const float* depth,
+                           const int32_t* depth_index, const uint8_t* mask, float* color_err, float* depth_err, void* stream) {
+    DQO_CHECK_ARG(W > 0 && H > 0 && gt_color && gt_depth && render && depth && depth_index && color_err && depth_err, "bad size / null pointer");
+    return dqo_launch_error_maps((int64_t)W * H, gt_color, gt_depth, render, depth, depth_index, mask, color_err, depth_err, (hipStream_t)stream);
 }
 
 DQO_API size_t dqo_icp_workspace_bytes(void) { return dqo_icp_ws_bytes(); }

@@ -24,7 +24,7 @@ import _dqo_native as N
 from simple_knn._C import distCUDA2
 
 
-def knn_points_k3(p1, p2, max_dist=None, groups=None, group_box=None):
+def knn_points_k3(p1, p2, max_dist=None, groups=None, group_box=None, int32_idx=False):
     """(dists [Q, 3] squared L2 ascending, idx [Q, 3] int64 into p2).  Fewer than 3 references: FLT_MAX / -1 in the tail.
     max_dist (not a pytorch3d argument): only references closer than that count (dqo_knn3_query_within).
     groups = (g1 [Q], g2 [R]) int32 ids in [0, 64) (any other value: the point belongs to no group): a reference only counts for a
@@ -39,7 +39,7 @@ def knn_points_k3(p1, p2, max_dist=None, groups=None, group_box=None):
     d = torch.empty((Q, 3), dtype=torch.float32, device=q.device)
     i = torch.empty((Q, 3), dtype=torch.int32, device=q.device)
     if Q == 0:
-        return d, i.long()
+        return d, (i if int32_idx else i.long())
     if R == 0:
         raise RuntimeError("knn_points_k3: empty reference set")
     lib = N.lib()
@@ -59,7 +59,7 @@ def knn_points_k3(p1, p2, max_dist=None, groups=None, group_box=None):
         else:
             N.check(lib.dqo_knn3_query_within(Q, N.ptr(q), R, N.ptr(r), float(max_dist), N.ptr(d), N.ptr(i), N.ptr(ws), ws.numel(),
                                               N.current_stream()))
-    return d, i.long()
+    return d, (i if int32_idx else i.long())  # (int32_idx: the kernel's own index type, for callers that hand it to another kernel)
 
 
 def bbox_filter(local_xyz, total_xyz, padding=0.05):
@@ -186,32 +186,61 @@ def _per_object_bbox_mask(query_xyz, query_obj, ref_xyz, ref_obj, padding=0.05, 
     return ok & (ref_xyz > box[ro, :3]).all(dim=-1) & (ref_xyz < box[ro, 3:]).all(dim=-1)
 
 
-def temp_points_filter_mask_per_object(temp_xyz, temp_obj, exist_xyz, exist_radius, exist_obj, cell=None):
+def temp_points_filter_mask_per_object(temp_xyz, temp_obj, exist_xyz, exist_radius, exist_obj, cell=None, fused=True):
     """temp_points_filter_mask with every candidate judged against the existing Gaussians of its own object: True for the temp points
-    that lie within 0.6 x radius of one of the (up to) 3 nearest existing centres of their object.  None: nothing to test against."""
+    that lie within 0.6 x radius of one of the (up to) 3 nearest existing centres of their object.  None: nothing to test against.
+    fused: the decision behind the search in one launch (dqo_growth_inside) instead of the torch chain below it — the same bits."""
     if torch.numel(exist_xyz) == 0 or torch.numel(temp_xyz) == 0:
         return None
     nn_d2, nn_idx = knn_points_k3(temp_xyz, exist_xyz, max_dist=NEIGHBOUR_REACH, groups=(temp_obj, exist_obj),
-                                  group_box=_per_object_boxes(temp_xyz, temp_obj))
+                                  group_box=_per_object_boxes(temp_xyz, temp_obj), int32_idx=fused)
+    if fused:
+        n = int(temp_xyz.shape[0])
+        er = exist_radius.reshape(-1).float().contiguous()
+        out = torch.empty((n,), dtype=torch.uint8, device=temp_xyz.device)
+        with torch.cuda.device(temp_xyz.device):
+            N.check(N.lib().dqo_growth_inside(n, N.ptr(nn_d2), N.ptr(nn_idx), N.ptr(er), N.ptr(out), N.current_stream()))
+        return out.bool()
     j = nn_idx.clamp(min=0)
     valid = nn_idx >= 0
     return ((torch.sqrt(nn_d2) < exist_radius.reshape(-1)[j] * 0.6) & valid).any(dim=-1)
 
 
-def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius, extra_obj, min_radius, max_radius, cell=None):
+def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius, extra_obj, min_radius, max_radius, cell=None, fused=True):
     """update_geometry_scales with every new point's three neighbours taken from its own object (the other new points of the object and
     the object's existing points inside the bounding box of the object's new points).  A point whose object offers fewer than three
-    neighbours keeps `inf` in the missing slots: its scale is clipped to max_radius, on every shard layout alike."""
+    neighbours keeps `inf` in the missing slots: its scale is clipped to max_radius, on every shard layout alike.
+    fused: everything behind the two searches in one launch (dqo_growth_scales) instead of the torch chain below — the same bits."""
     n = xyz.shape[0]
     xyz = xyz.float().contiguous()
     radius, extra_radius = radius.reshape(-1), extra_radius.reshape(-1)
+    if fused:
+        dev = xyz.device
+        obj32, rad = obj.to(torch.int32).contiguous(), radius.float().contiguous()
+        i_new = d2_old = i_old = er = None
+        if n > 1:
+            _, i_new = distCUDA2((xyz + object_offsets(obj, cell)).contiguous())
+        if torch.numel(extra_xyz) > 0:
+            d2_old, i_old = knn_points_k3(xyz, extra_xyz, max_dist=NEIGHBOUR_REACH, groups=(obj, extra_obj), group_box=_per_object_boxes(xyz, obj),
+                                          int32_idx=True)
+            er = extra_radius.float().contiguous()
+        scales = torch.empty((n,), dtype=torch.float32, device=dev)
+        invalid = torch.empty((n,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib().dqo_growth_scales(n, N.ptr(xyz), N.ptr(obj32), N.ptr(rad), N.ptr(i_new), N.ptr(d2_old), N.ptr(i_old), N.ptr(er),
+                                              NEIGHBOUR_REACH * NEIGHBOUR_REACH, float(min_radius), float(max_radius), N.ptr(scales),
+                                              N.ptr(invalid), N.current_stream()))
+        return scales, invalid.bool()
     inf = torch.full((n, 3), float("inf"), device=xyz.device)
     shifted = (xyz + object_offsets(obj, cell)).contiguous()
     cand_d, cand_r = [inf], [torch.zeros_like(inf)]
     if n > 1:
         _, i_new = distCUDA2(shifted)
         j = i_new.long().clamp(max=n - 1)
-        d2_new = (xyz[:, None, :] - xyz[j]).pow(2).sum(-1)
+        # (the three squares added in a fixed order — torch.sum over a dimension of three adds (0 + 2) + 1 in this build, another build
+        # may differ: the kernel and this chain spell the order out)
+        df = xyz[:, None, :] - xyz[j]
+        d2_new = (df[..., 0] * df[..., 0] + df[..., 1] * df[..., 1]) + df[..., 2] * df[..., 2]
         ok = (i_new < n) & (obj[j] == obj[:, None]) & (d2_new < NEIGHBOUR_REACH * NEIGHBOUR_REACH)
         cand_d.append(torch.where(ok, d2_new, inf))
         cand_r.append(radius[j])
@@ -228,6 +257,31 @@ def update_geometry_scales_per_object(xyz, obj, radius, extra_xyz, extra_radius,
     invalid = (d[0] < 0) | (d[1] < 0) | (d[2] < 0)
     scales = torch.sqrt((d[0] ** 2 + d[1] ** 2 + d[2] ** 2) / 3)
     return torch.clip(scales, min=min_radius, max=max_radius), invalid
+
+
+def error_maps(gt_color, gt_depth, render, depth, depth_index, render_mask=None, fused=True):
+    """The per-pixel error images of SLAM/multiprocess/mapper.py:1016-1033 that feed accumulate_gaussian_error: (color_err [1,H,W] = sum over
+    channels |gt_color - render|, depth_err [1,H,W] = max(gt_depth - depth, 0)), both zero where gt_depth == 0 or outside render_mask
+    ([H,W] bool / uint8, optional), depth_err also where the pixel has no depth hit (depth_index == -1).  fused: one launch
+    (dqo_error_maps) instead of the torch chain below — the same bits."""
+    H, W = int(gt_depth.shape[-2]), int(gt_depth.shape[-1])
+    if fused:
+        dev = gt_depth.device
+        c = lambda a: a.contiguous()
+        m = None if render_mask is None else render_mask.to(torch.uint8).contiguous()
+        color_err, depth_err = torch.empty((1, H, W), dtype=torch.float32, device=dev), torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib().dqo_error_maps(H, W, N.ptr(c(gt_color)), N.ptr(c(gt_depth)), N.ptr(c(render)), N.ptr(c(depth)), N.ptr(c(depth_index)),
+                                           N.ptr(m), N.ptr(color_err), N.ptr(depth_err), N.current_stream()))
+        return color_err, depth_err
+    off = gt_depth == 0
+    if render_mask is not None:
+        off = off | ~render_mask.bool()[None]
+    depth_err = (gt_depth - depth).clamp(min=0)
+    depth_err.masked_fill_(off | (depth_index == -1), 0)
+    color_err = (gt_color - render).abs().sum(0, keepdim=True)
+    color_err.masked_fill_(off, 0)
+    return color_err, depth_err
 
 
 def temp_points_pixels(temp_xyz, w2c, intrinsic, image_width, image_height):

@@ -327,6 +327,26 @@ int dqo_attach_decide(int32_t n, const float* temp_xyz, const float* temp_opacit
                       const float* rotation_raw, const int32_t* gaussian_object, float plane_thr, float opacity_low, uint8_t* out,
                       void* hipStream);
 
+/* Row f, small per-point kernels of the growth step (each replaces a chain of element-wise torch ops of the reference's callers; the
+ * step is bound by the host's op issue rate):
+ *   dqo_growth_scales: GaussianPointCloud.update_geometry's scale initialisation (SLAM/gaussian_pointcloud.py:519-556) behind its two
+ *     searches, per-object job: for new point i the candidates are i_new[i][0..2] (indices among the n new points from dqo_knn3 on
+ *     object-shifted coordinates; >= n: none; a neighbour counts if it has i's object id and lies within sqrt(reach2) — the distance is
+ *     recomputed from xyz) and (d2_old, i_old)[i][0..2] (dqo_knn3_query_grouped against the existing map; i_old < 0: none); the three
+ *     nearest give gaps g = dist - 3 * radius (radius / extra_radius of the neighbour); invalid = any g < 0; scale =
+ *     clip(sqrt(mean g^2), min_radius, max_radius).  i_new or i_old may be NULL (no such search).
+ *   dqo_growth_inside: Mapping.temp_points_filter's decision (SLAM/multiprocess/mapper.py:1372-1380): inside[i] = some idx[i][k] >= 0
+ *     with sqrt(d2[i][k]) < 0.6 * radius[idx[i][k]].
+ *   dqo_error_maps: the per-pixel error images of mapper.py:1016-1033 for dqo_accumulate_gaussian_error: depth_err = max(gt_depth -
+ *     depth, 0), color_err = sum over channels |gt_color - render|; both 0 where gt_depth == 0 or mask == 0 (mask NULL = all), depth_err
+ *     also where depth_index == -1.  Images are [C, H*W] planes. */
+int dqo_growth_scales(int32_t n, const float* xyz, const int32_t* object, const float* radius, const int32_t* i_new, const float* d2_old,
+                      const int32_t* i_old, const float* extra_radius, float reach2, float min_radius, float max_radius, float* scales,
+                      uint8_t* invalid, void* hipStream);
+int dqo_growth_inside(int32_t n, const float* d2, const int32_t* idx, const float* radius, uint8_t* inside, void* hipStream);
+int dqo_error_maps(int32_t H, int32_t W, const float* gt_color, const float* gt_depth, const float* render, const float* depth,
+                   const int32_t* depth_index, const uint8_t* mask, float* color_err, float* depth_err, void* hipStream);
+
 /* Batched dual-quadric residual over B independent (object, view) pairs: loss = 1 - IoU(obs, bbox(ellipsoid, P34)),
  * with gradients.  valid[b] = 0 when loss == 1 (the reference skips that Adam step). */
 int dqo_quadric_iou_fwd_bwd(int32_t B, const float* axes, const float* R, const float* center, const float* P34,

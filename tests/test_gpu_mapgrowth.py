@@ -560,3 +560,53 @@ def test_attach_kernels_on_degenerate_candidates(mg):
     assert dec.tolist()[1:] == [1, 0, 0, 0, 0]
     assert M.attach_decide(pts[:0], z(0, 1), ids[:0], lin[:0], hit, z(1, H, W), z(P, 3), z(P, 3), rot,
                            torch.zeros(P, dtype=torch.int32, device=dev), 0.1, 0.1).numel() == 0
+
+
+def test_fused_growth_decisions_equal_their_torch_chains(mg):
+    """dqo_growth_scales / dqo_growth_inside / dqo_error_maps (one launch each) against the torch chains they replace
+    (dqo_mapgrowth.*(fused=False): the reference's statements): identical masks, identical floats."""
+    torch, M = mg
+    from dqo_harness import mapping, scenes
+    dev = torch.device("cuda")
+    cam, scene = scenes.make_config(3, P=30000)
+    new = scenes.surfel_room(91, 7000, n_objects=8)
+    t = lambda a, dt=np.float32: torch.tensor(np.ascontiguousarray(a, dt), device=dev)
+    ex, eo = t(scene["xyz"]), t(scene["obj_id"], np.int32)
+    er = (torch.exp(t(scene["scales"]).log()).sum(1) - t(scene["scales"]).min(1).values) / 2
+    nx, no = t(new["xyz"]), t(new["obj_id"], np.int32)
+    nr = (t(new["scales"]).sum(1) - t(new["scales"]).min(1).values) / 2
+    eo2 = eo.clone()
+    eo2[::17] = -1                    # group-less rows (spare rows of a reserved map)
+    for cell in (None, (8.0, 4.0, 8.0)):
+        a = M.temp_points_filter_mask_per_object(nx, no, ex, er, eo2, cell=cell, fused=True)
+        b = M.temp_points_filter_mask_per_object(nx, no, ex, er, eo2, cell=cell, fused=False)
+        assert torch.equal(a, b) and 0 < int(a.sum().item()) < nx.shape[0]
+        sa, ia = M.update_geometry_scales_per_object(nx, no, nr, ex, er, eo2, 0.001, 0.05, cell=cell, fused=True)
+        sb, ib = M.update_geometry_scales_per_object(nx, no, nr, ex, er, eo2, 0.001, 0.05, cell=cell, fused=False)
+        assert torch.equal(ia, ib) and torch.equal(sa, sb)
+        assert 0 < int(ia.sum().item()) < nx.shape[0] and float(sa.min().item()) >= float(np.float32(0.001)) and float(sa.max().item()) <= float(np.float32(0.05))
+        assert int(((sa > 0.0011) & (sa < 0.0499)).sum().item()) > 100   # (not all clipped: the arithmetic in between is compared too)
+    # no existing map / a single new point / an object without neighbours
+    s1, i1 = M.update_geometry_scales_per_object(nx, no, nr, ex[:0], er[:0], eo[:0], 0.001, 0.05, fused=True)
+    s2, i2 = M.update_geometry_scales_per_object(nx, no, nr, ex[:0], er[:0], eo[:0], 0.001, 0.05, fused=False)
+    assert torch.equal(s1, s2) and torch.equal(i1, i2)
+    s1, i1 = M.update_geometry_scales_per_object(nx[:1], no[:1], nr[:1], ex, er, eo, 0.001, 0.05, fused=True)
+    s2, i2 = M.update_geometry_scales_per_object(nx[:1], no[:1], nr[:1], ex, er, eo, 0.001, 0.05, fused=False)
+    assert torch.equal(s1, s2) and torch.equal(i1, i2)
+    lone = torch.full_like(no, 63)
+    s1, i1 = M.update_geometry_scales_per_object(nx[:50], lone[:50], nr[:50], ex, er, eo, 0.001, 0.05, fused=True)
+    s2, i2 = M.update_geometry_scales_per_object(nx[:50], lone[:50], nr[:50], ex, er, eo, 0.001, 0.05, fused=False)
+    assert torch.equal(s1, s2) and torch.equal(i1, i2)
+    # the error images
+    settings = mapping.make_settings(cam, dev)
+    with torch.no_grad():
+        out = mapping.render(settings, mapping.GaussianParams(scene, dev).activated())
+    rng = np.random.default_rng(2)
+    gt_color = (out["render"] + t(rng.normal(0, 0.05, out["render"].shape))).contiguous()
+    gt_depth = (out["depth"] + t(rng.normal(0, 0.05, out["depth"].shape))).contiguous()
+    gt_depth[0, ::7] = 0
+    mask = torch.tensor(rng.uniform(size=(cam.H, cam.W)) < 0.8, device=dev)
+    for m in (mask, None):
+        ca, da = M.error_maps(gt_color, gt_depth, out["render"], out["depth"], out["depth_index_map"], m, fused=True)
+        cb, db = M.error_maps(gt_color, gt_depth, out["render"], out["depth"], out["depth_index_map"], m, fused=False)
+        assert torch.equal(ca, cb) and torch.equal(da, db) and float(da.max().item()) > 0 and float(ca.max().item()) > 0
