@@ -431,7 +431,14 @@ class FusedRunner:
                 dm = torch.zeros((mini.P,), dtype=torch.bool, device=self.device)
                 dm[5:m:97] = True
                 mini.grow({k: v[:1500] for k, v in b.items()}, delete_mask=dm, new_mapping_call=True, stable_mask=st)
-                del mini
+                del mini, dm, st
+                # ... and the map-sized temporaries of the step's in-place tail and of a new mapping call on the REAL map, so that the
+                # caching allocator has their blocks (a first-time device allocation is most of a millisecond)
+                live = fm.alive.bool()
+                tmp = [(fm.alive == 0).nonzero(), (self.stable_mask & live).nonzero(), torch.where(live, fm.gaussian_object, -1) if fm.gaussian_object is not None else None,
+                       ((torch.sigmoid(fm.opacity_raw) < 0.9).reshape(-1) & live).to(torch.uint8), torch.zeros((fm.P,), dtype=torch.bool, device=self.device) & live,
+                       torch.where(self.stable_mask[:, None] & live[:, None], fm.xyz, fm._park_position()[None, :])]
+                del tmp, live
             torch.cuda.synchronize()
 
     def grow(self):
