@@ -1,7 +1,8 @@
 // Forward pass of the depth-aware Gaussian rasteriser for gfx950 (MI355X).
 //
 // Replaces (semantics, not structure) /root/reference/submodules/diff-gaussian-rasterizer-depth/
-//   cuda_rasterizer/forward.cu:238-354   preprocessCUDA            -> preprocess_kernel
+//   cuda_rasterizer/forward.cu:238-354   preprocessCUDA            -> preprocess_kernel (its statements: dqo_k1_early.h / dqo_k1_late.h; a replayed
+//                                                                      iteration runs the early part at the head of bin_count_kernel<true>)
 //   cuda_rasterizer/rasterizer_impl.cu:70-142, 303-365 (cub scan, duplicateWithKeys, cub radix sort,
 //   identifyTileRanges, host tile compaction with two D2H syncs)   -> bin_count_kernel / bin_place_kernel (rast_binning.hip),
 //                                                                      tile_scan_kernel, tile_sort_wave_kernel, tile_sort_kernel
