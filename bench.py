@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--graph-unroll", type=int, default=4,
                     help="fused path, one rank: iterations per captured hipGraph (one launch call runs that many iterations back to back; "
                          "1 = one graph launch per iteration).  N > 1 always uses 1: the loss sums are all-reduced after every iteration")
+    ap.add_argument("--placement-trials", type=int, default=6,
+                    help="fused path: capture the iteration on this many placements of the context buffers and keep the fastest "
+                         "(FusedMapper.capture_placed: where the allocator puts them in physical memory moves the binning kernel and the "
+                         "per-Gaussian tail by several microseconds; results do not depend on it); 1 = plain capture")
     ap.add_argument("--growth-every", type=int, default=None,
                     help="map-growth step (knn on 40 800 new points + scale init + concat / delete + graph re-capture) every this many "
                          "iterations, inside the timed region; default: 100 for cfg 5 (its BASELINE workload), off otherwise")
@@ -329,8 +333,9 @@ class FusedRunner:
     the loss sums started asynchronously after it; optional growth step every `growth_every` iterations."""
 
     def __init__(self, prob, device, loss_buf, world, use_graph=True, growth_every=0, growth_seed=0, loss_tap=True, fused_tail=True, list_split=0,
-                 unroll=1, collective=None):
+                 unroll=1, collective=None, placement_trials=1):
         from dqo_harness.fused_mapping import FusedMapper
+        self.placement_trials = max(1, int(placement_trials))
         self.prob, self.device, self.loss_buf, self.world = prob, device, loss_buf, world
         # every iteration's loss sums go into the packed all-reduce (N > 1, or the one-rank group of --force-collective)
         self.collective = (world > 1) if collective is None else bool(collective)
@@ -359,8 +364,12 @@ class FusedRunner:
 
     def _capture(self, reuse_probe=False):
         p = self.prob
-        self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, tile_mask=p["tile_mask"], loss_tap=self.loss_tap, reuse_probe=reuse_probe,
-                        fused_tail=self.fused_tail, list_split=self.list_split, unroll=self.unroll)
+        kw = dict(tile_mask=p["tile_mask"], loss_tap=self.loss_tap, reuse_probe=reuse_probe, fused_tail=self.fused_tail, list_split=self.list_split,
+                  unroll=self.unroll)
+        if self.placement_trials > 1 and not reuse_probe:  # (the first capture of the run: a re-capture after a growth step stays quick)
+            self.fm.capture_placed(p["gt_color"], p["gt_depth"], self.mask_u8, trials=self.placement_trials, **kw)
+        else:
+            self.fm.capture(p["gt_color"], p["gt_depth"], self.mask_u8, **kw)
         if self.first_loss is None:
             self.first_loss = self.fm.loss.clone()  # loss of the initial state (the capture's own eager iteration)
 
@@ -985,7 +994,7 @@ def pmc_child(args, kernel_name, passes):
             inner += [flag]
     if args.as_shard:
         inner += ["--as-shard", args.as_shard]
-    inner += ["--list-split", args.list_split, "--graph-unroll", str(args.graph_unroll)]
+    inner += ["--list-split", args.list_split, "--graph-unroll", str(args.graph_unroll), "--placement-trials", "1"]
     res = {}
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("WORLD_SIZE", None)
@@ -1155,7 +1164,7 @@ def main():
     if args.path == "fused":
         runner = FusedRunner(prob, device, loss_buf, world, collective=coll, use_graph=not args.no_graph, growth_every=args.growth_every, growth_seed=rank,
                              loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail,
-                             list_split=parse_list_split(args.list_split), unroll=args.graph_unroll)
+                             list_split=parse_list_split(args.list_split), unroll=args.graph_unroll, placement_trials=args.placement_trials)
         step = runner.step
     else:
         step_dropin = make_dropin_step(prob, device, loss_buf)
@@ -1536,7 +1545,7 @@ def main():
                        "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if coll else "none (one rank)",
                        **({"backend_note": backend_note} if coll else {}),
                        "devices": rank_devices, **({"as_shard": args.as_shard} if args.as_shard else {}),
-                       **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "graph_unroll": (runner.unroll if runner is not None else None), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
+                       **({"list_split": int(runner.fm._g.ls_fwd), "list_split_backward": int(runner.fm._g.ls_bwd)} if (runner is not None and runner.fm._g is not None) else {}), "graph_unroll": (runner.unroll if runner is not None else None), "placement_trials_ms": (getattr(runner.fm, "placement_trials_ms", None) if runner is not None else None), "sync_mode": args.sync_mode, "selfcheck": ("skipped" if (args.no_selfcheck or runner is None) else
                                                                                    ("ok" if selfcheck_ok else "FAILED")), **stats},
             "loss": loss_now, "path": args.path,
         }

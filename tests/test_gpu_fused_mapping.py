@@ -767,3 +767,30 @@ print("DIGEST", h.hexdigest())
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert digests[0] == digests[1]
+
+
+def test_capture_placed_is_capture_on_other_buffers(env):
+    """FusedMapper.capture_placed captures on several placements of the context buffers and keeps the fastest; the trials' iterations are
+    undone: the mapper is exactly where capture() leaves it, and replays from there produce the same bits."""
+    torch = env
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch, P=8000)
+    a = FusedMapper(scene, settings, dev)
+    b = FusedMapper(scene, settings, dev)
+    a.capture(gt_color, gt_depth, mask, unroll=2)
+    b.capture_placed(gt_color, gt_depth, mask, trials=3, probe_replays=4, unroll=2)
+    assert len(b.placement_trials_ms) == 3 and a.step_count == b.step_count == 1
+    torch.cuda.synchronize()
+    assert torch.equal(a.loss, b.loss)
+    for _ in range(3):
+        a.replay(), b.replay()
+    torch.cuda.synchronize()
+    assert a.step_count == b.step_count == 7 and not a.graph_overflowed() and not b.graph_overflowed()
+    assert int(a._g.step_dev.item()) == int(b._g.step_dev.item()) == 8
+    for k, pa in a._params().items():
+        assert torch.equal(pa, b._params()[k]), k
+        for i in (0, 1):
+            assert torch.equal(a.state[k][i], b.state[k][i]), k
+    assert torch.equal(a.loss, b.loss)
+    for x, y in zip(a._g.out, b._g.out):
+        assert torch.equal(x, y)
