@@ -448,6 +448,10 @@ class FusedRunner:
                        ((torch.sigmoid(fm.opacity_raw) < 0.9).reshape(-1) & live).to(torch.uint8), torch.zeros((fm.P,), dtype=torch.bool, device=self.device) & live,
                        torch.where(self.stable_mask[:, None] & live[:, None], fm.xyz, fm._park_position()[None, :])]
                 del tmp, live
+                # ... and a large free block in the caching allocator's pool: the step's temporaries grow with the unstable cloud from step
+                # to step, and a request that fits no cached block is a device allocation (milliseconds) inside a timed growth step
+                tmp = torch.empty((768 << 20,), dtype=torch.uint8, device=self.device)
+                del tmp
             torch.cuda.synchronize()
 
     def grow(self):
