@@ -213,7 +213,9 @@ DQO_API int dqo_rast_forward_prepare(const DqoRastParams* p, const DqoRastInputs
     if (rc) return rc;
     rc = check_outputs(p, out);
     if (rc) return rc;
-    return dqo_launch_forward_prepare(p, in, out, ctx, (hipStream_t)stream);
+    rc = dqo_launch_forward_prepare(p, in, out, ctx, (hipStream_t)stream);
+    if (rc) return rc;
+    return dqo_launch_mark_header_stage0(p, ctx, (hipStream_t)stream);  // (a no-op unless the frame's first stage is fused into its second)
 }
 
 DQO_API int dqo_rast_read_header(const DqoRastCtx* ctx, DqoRastHeader* host_out, void* stream) {
@@ -265,9 +267,11 @@ DQO_API int dqo_rast_forward_render(const DqoRastParams* p, const DqoRastInputs*
 }
 
 DQO_API int dqo_rast_forward(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, void* stream) {
-    int rc = dqo_rast_forward_prepare(p, in, out, ctx, stream);
+    int rc = check_render(p, in, out, ctx);  // (covers the checks of the first stage)
     if (rc) return rc;
-    return dqo_rast_forward_render(p, in, out, ctx, stream);
+    rc = dqo_launch_forward_prepare(p, in, out, ctx, (hipStream_t)stream);
+    if (rc) return rc;
+    return dqo_launch_forward_render(p, in, out, ctx, (hipStream_t)stream);
 }
 
 DQO_API int dqo_rast_forward_async(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx,

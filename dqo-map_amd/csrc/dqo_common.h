@@ -268,9 +268,10 @@ struct __attribute__((aligned(16))) DqoGradRec {
     float m2[3];       // sum q dx^2, sum q dx dy, sum q dy^2
     float m0;          // sum q
     // depth-hit sums over the pixels whose depth this instance fixed (backward.cu:997-1065); the per-Gaussian factors of
-    // that gradient (normal, camera-space point, view matrix, quaternion Jacobian) are applied once per Gaussian by
+    // that gradient that are LINEAR (normal, view matrix, quaternion Jacobian) are applied once per Gaussian by
     // gaussian_backward_kernel:  hit[0] = sum dL/ddepth over pixels in the centre-depth branch,  hit[1] = sum of
-    // u = dL/ddepth * ray.z / (n.ray) over pixels in the ray/plane branch,  hit[2..4] = sum of u * ray / (n.ray)
+    // dL/ddepth * ray.z / (n.ray) over pixels in the ray/plane branch,  hit[2..4] = sum of dL/ddepth * d(depth)/d(n_c) =
+    // dL/ddepth * ray.z (nr p_c - np ray) / nr^2, evaluated per pixel with the reference's statements (backward.cu:1018-1041)
     float hit[5];
     float pad[2];
 };
@@ -410,6 +411,7 @@ int dqo_launch_bin_count_k1(const DqoView& v, const DqoRastInputs* in, const Dqo
                             const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, const unsigned long long* tile_objects,
                             hipStream_t s);
 int dqo_launch_forward_prepare(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s);
+int dqo_launch_mark_header_stage0(const DqoRastParams* p, DqoRastCtx* ctx, hipStream_t s);
 int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, DqoRastOutputs* out, DqoRastCtx* ctx, hipStream_t s,
                               DqoRastHeader* header_host = nullptr, hipEvent_t header_event = nullptr);
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,

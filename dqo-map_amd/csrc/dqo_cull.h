@@ -72,13 +72,8 @@ __device__ __forceinline__ float dqo_rcp(float x) { return __builtin_amdgcn_rcpf
 // 4x4 block of the quadrant — row r = lane >> 4 at ((r & 1) * 4, (r >> 1) * 4), lane s = lane & 15 of the row at (s & 3, s >> 2) inside
 // it.  The forward records per list entry WHICH rows saw it (a 4-bit row code in the entry's live byte), and the backward lets every
 // row walk its own sub-list (rast_backward_blend.hip): an entry costs a row a step only if one of ITS 16 pixels has work for it.
-#ifdef DQO_EXP_ROW_STRIPS  // (timing experiment only — the backward's row walk needs the 4x4 blocks: round 4's map, one 8x2 strip per DPP row)
-__device__ __forceinline__ uint32_t dqo_lane_x(int lane) { return (uint32_t)(lane & 7); }
-__device__ __forceinline__ uint32_t dqo_lane_y(int lane) { return (uint32_t)(lane >> 3); }
-#else
 __device__ __forceinline__ uint32_t dqo_lane_x(int lane) { return (uint32_t)(((lane >> 4) & 1) * 4 + (lane & 3)); }
 __device__ __forceinline__ uint32_t dqo_lane_y(int lane) { return (uint32_t)((lane >> 5) * 4 + ((lane >> 2) & 3)); }
-#endif
 // 64-bit lane mask -> 4-bit row code: bit r = some lane of DPP row r is set (two s_quadmask: 64 lanes -> 16 quads -> 4 rows)
 __device__ __forceinline__ uint32_t dqo_row_code(unsigned long long m) {
     unsigned long long q;

@@ -8,7 +8,9 @@
 //   backward.cu:997-1065  the per-Gaussian factors of the depth-hit gradient (+ propagateRotationGrad :100-148)
 // in the reference's statement order with separate IEEE multiplies and adds (no FMA contraction): the cov2D-inverse -> cov3D ->
 // (scale, quaternion) chain is ill-conditioned for thin surfels (denom^2, b^2 by cancellation), so its result depends on where the
-// roundings fall; evaluated like this it rounds where the oracle (and an uncontracted build of the reference) rounds.
+// roundings fall; evaluated like this it rounds where the oracle (and an uncontracted build of the reference) rounds — with ONE
+// exception since round 6: the ten statements of the 2x2 inverse's derivative run in double (see there), which is where those
+// cancellations sit.
 #pragma once
 #include "dqo_common.h"
 
@@ -137,15 +139,15 @@ __device__ __forceinline__ void dqo_gauss_chain(const DqoView& v, const float (&
     // ---- depth-hit gradient (backward.cu:997-1065 + propagateRotationGrad :100-148) ----
     // The blend kernel delivered the pixel sums hit[0..4] (DqoGradRec); everything that is constant per Gaussian — surfel
     // normal n_c, camera-space point p_c, view matrix, d(normal)/d(quaternion) — is applied here, once:
-    //   dL/dmean3D = hit1 * V^T n_c + hit0 * V^T e_z,   dL/dn_c = p_c * hit1 - (n_c . p_c) * hit[2..4],   dL/dq = (dn_w/dq)^T V^T dL/dn_c
+    //   dL/dmean3D = hit1 * V^T n_c + hit0 * V^T e_z,   dL/dn_c = hit[2..4] (cancelled per pixel, as the reference does),
+    //   dL/dq = (dn_w/dq)^T V^T dL/dn_c
     if (a[9] != 0.f || a[10] != 0.f || a[11] != 0.f || a[12] != 0.f || a[13] != 0.f) {
         const real h0 = a[9], h1 = a[10], h2x = a[11], h2y = a[12], h2z = a[13];
         const real nx = n_np.x, ny = n_np.y, nz = n_np.z;
-        const real np = nx * pc.x + ny * pc.y + nz * pc.z;
         mean_g[0] = (float)(h1 * (nx * view[0] + ny * view[1] + nz * view[2]) + h0 * view[2]);
         mean_g[1] = (float)(h1 * (nx * view[4] + ny * view[5] + nz * view[6]) + h0 * view[6]);
         mean_g[2] = (float)(h1 * (nx * view[8] + ny * view[9] + nz * view[10]) + h0 * view[10]);
-        const real n1c = pc.x * h1 - np * h2x, n2c = pc.y * h1 - np * h2y, n3c = pc.z * h1 - np * h2z;
+        const real n1c = h2x, n2c = h2y, n3c = h2z;
         const real n1w = n1c * view[0] + n2c * view[1] + n3c * view[2];
         const real n2w = n1c * view[4] + n2c * view[5] + n3c * view[6];
         const real n3w = n1c * view[8] + n2c * view[9] + n3c * view[10];
@@ -217,15 +219,31 @@ __device__ __forceinline__ void dqo_gauss_chain(const DqoView& v, const float (&
     const real ca = A0[0] * A0V[0] + A0[1] * A0V[1] + A0[2] * A0V[2] + RL(0.3f);
     const real cb = A0[0] * A1V[0] + A0[1] * A1V[1] + A0[2] * A1V[2];
     const real cc = A1[0] * A1V[0] + A1[1] * A1V[1] + A1[2] * A1V[2] + RL(0.3f);
-    const real denom = ca * cc - cb * cb;
+    // The derivative of the 2x2 inverse (backward.cu:331-340) in DOUBLE, from the float ca, cb, cc: denom = ac - b^2, (denom - ac) = -b^2
+    // and the three-term sums below cancel four to five digits for a thin elongated splat (ac / denom ~ 10^3), and in float that is
+    // where the chain's result is decided — two float evaluations whose inputs differ in the last bit land 1e-3 of the tensor's
+    // largest gradient apart (the reference against itself: its atomics change its sums from run to run, B10; rounds 2-5 of this
+    // library against the fp32 oracle: rows up to 5x further from the fp64 derivative than the oracle).  ~35 double operations per
+    // VISIBLE GAUSSIAN, three values in and three out; measured (round 6, profiles/r06_chain_precision.txt): rotation rows of the
+    // smoke case 1.6e-3 -> 2.0e-5 from fp64, the summed error 0.36 .. 0.86 of the fp32 oracle's own; every other section of the
+    // chain in double as well changes nothing.  What comes out is not the reference's float rounding of these ten statements — it is
+    // inside the reference's own run-to-run spread and closer to the exact derivative of the same formulas.
     real dL_da = 0, dL_db = 0, dL_dc = 0;
-    const real denom2inv = RL(1) / ((denom * denom) + RL(0.0000001f));
     real dcv[6];
-    const real dcx_ = RL(dcx), dcy_ = RL(dcy), dcz_ = RL(dcz);
-    if (denom2inv != 0) {
-        dL_da = denom2inv * (-cc * cc * dcx_ + RL(2) * cb * cc * dcy_ + (denom - ca * cc) * dcz_);
-        dL_dc = denom2inv * (-ca * ca * dcz_ + RL(2) * ca * cb * dcy_ + (denom - ca * cc) * dcx_);
-        dL_db = denom2inv * RL(2) * (cb * cc * dcx_ - (denom + RL(2) * cb * cb) * dcy_ + ca * cb * dcz_);
+    bool inv_ok;
+    {
+        const double ca_ = (double)ca, cb_ = (double)cb, cc_ = (double)cc;
+        const double dn = ca_ * cc_ - cb_ * cb_;
+        const double d2i = 1.0 / ((dn * dn) + (double)0.0000001f);
+        inv_ok = d2i != 0.0;
+        if (inv_ok) {
+            const double dx_ = (double)dcx, dy_ = (double)dcy, dz_ = (double)dcz;
+            dL_da = (real)(d2i * (-cc_ * cc_ * dx_ + 2.0 * cb_ * cc_ * dy_ + (dn - ca_ * cc_) * dz_));
+            dL_dc = (real)(d2i * (-ca_ * ca_ * dz_ + 2.0 * ca_ * cb_ * dy_ + (dn - ca_ * cc_) * dx_));
+            dL_db = (real)(d2i * 2.0 * (cb_ * cc_ * dx_ - (dn + 2.0 * cb_ * cb_) * dy_ + ca_ * cb_ * dz_));
+        }
+    }
+    if (inv_ok) {
         dcv[0] = A0[0] * A0[0] * dL_da + A0[0] * A1[0] * dL_db + A1[0] * A1[0] * dL_dc;
         dcv[3] = A0[1] * A0[1] * dL_da + A0[1] * A1[1] * dL_db + A1[1] * A1[1] * dL_dc;
         dcv[5] = A0[2] * A0[2] * dL_da + A0[2] * A1[2] * dL_db + A1[2] * A1[2] * dL_dc;

@@ -223,10 +223,6 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
             __syncthreads();  // (the staging area is overwritten — by the next trip or by phase C's rows)
         }
     }
-#if defined(TAIL_STOP) && TAIL_STOP == 1  // (timing experiment: phases A + B only)
-    if (a0.x + a1.y + a2.z + a3.w == 12345.678f) a.attach_partial[0] = 1.f;
-    return;
-#endif
     if (n_rows == 0) {  // (wave-uniform) nothing to update: no visible Gaussian, no live moment
         if (ATTACH && a.attach_partial != nullptr && tid == 0) a.attach_partial[blockIdx.x] = 0.f;
         adam_take_ticket(a);
@@ -252,10 +248,6 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
         row[ROW_ROT] = co.rot_g[0], row[ROW_ROT + 1] = co.rot_g[1], row[ROW_ROT + 2] = co.rot_g[2], row[ROW_ROT + 3] = co.rot_g[3];
     }
     __syncthreads();
-#if defined(TAIL_STOP) && TAIL_STOP == 2  // (timing experiment: phases A + B + C only)
-    if (s_g[tid] == 12345.678f) a.attach_partial[0] = 1.f;
-    return;
-#endif
 
     // ---- D: Adam over the wave's list, gradient from LDS (adam_kernel's statements) ----
     const int used = (v.D + 1) * (v.D + 1);

@@ -533,6 +533,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     const float3 ray = pixel_ray_b(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
     // ---- third round: the depth-hit entry's surfel normal and — row walk — the first group's records ----
     const float4 n_np_h = g.normal_c[gid_h];
+    const float4 pc_h = g.point_c[gid_h];
     // gather, second hop: entry j's records by its id, its instance slot, and its position / row code back from the collect's tables
     float4 g_co, g_xy, g_cs;
     int g_pos = 0;
@@ -560,17 +561,21 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
             const uint32_t slot_h = has_hit ? slot_h_ld : 0xffffffffu;
             if (has_hit) {
 #pragma clang fp contract(off)
-                const float4 n_np = n_np_h;
+                // The reference's statements per pixel (backward.cu:1018-1041), IEEE division included: d(depth)/d(n_c) =
+                // ray.z (nr p_c - np ray) / nr^2 cancels INSIDE the pixel (nr p_c - np ray = nr (p_c - hit point): the surfel's
+                // extent against its distance from the camera).  Rounds 2-5 summed ray.z / nr and ray.z ray / nr^2 over the pixels
+                // and cancelled the two SUMS per Gaussian, with v_rcp_f32: rotation rows 5x further from fp64 than the reference's
+                // own arithmetic is.  What is left to the per-Gaussian chain is linear: V^T and d(normal)/d(quaternion).
+                const float4 n_np = n_np_h, pc = pc_h;
                 const float nr_f = n_np.x * ray.x + n_np.y * ray.y + n_np.z * ray.z;
                 const float nr = (float)((double)nr_f + 1e-8);  // backward.cu:1018
-                const float inv_nr = dqo_rcp(nr);               // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
-                const float u = ddep * ray.z * inv_nr;
-                const float w = u * inv_nr;
+                const float inv_nr = 1.0f / nr, inv_nr2 = inv_nr * inv_nr;
+                const float np = n_np.x * pc.x + n_np.y * pc.y + n_np.z * pc.z;
                 h[0] = hit_plane ? 0.f : ddep;  // the forward decided backward.cu:1016's branch for this pixel
-                h[1] = hit_plane ? u : 0.f;
-                h[2] = hit_plane ? w * ray.x : 0.f;
-                h[3] = hit_plane ? w * ray.y : 0.f;
-                h[4] = hit_plane ? w * ray.z : 0.f;
+                h[1] = hit_plane ? ddep * (ray.z * inv_nr) : 0.f;
+                h[2] = hit_plane ? ddep * (ray.z * (nr * pc.x - np * ray.x) * inv_nr2) : 0.f;
+                h[3] = hit_plane ? ddep * (ray.z * (nr * pc.y - np * ray.y) * inv_nr2) : 0.f;
+                h[4] = hit_plane ? ddep * (ray.z * (nr * pc.z - np * ray.z) * inv_nr2) : 0.f;
             }
             int leader = lane;  // lowest lane with the same hit entry
             unsigned long long todo = hm;
@@ -761,9 +766,6 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     // of its dependency chains, not by the number of instructions: with a branch per entry the chain was one whole entry long.
     auto batch = [&](const int k0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-#ifdef DQO_EXP_FREE_FETCH
-        const float4 exp_co = s_co[0], exp_xy = s_xy[0], exp_cs = s_rgb[0];
-#endif
         constexpr int NV = BWD_NB == 7 ? 64 : 32;
         float v64[NV];
 #pragma unroll
@@ -774,15 +776,8 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
             const int k = k0 + b;
             float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_mx = 0.f, r_my = 0.f, r_ka = 0.f, r_kb = 0.f, r_kc = 0.f, r_op = 0.f;
             if (FULL || k < cnt) {  // wave-uniform
-#ifdef DQO_EXP_FREE_FETCH  // (timing experiment, results invalid: what would the walk cost if an entry's record were already in registers?
-                // every entry reuses the chunk's first record, opaque to the optimiser — no LDS read of the records in the loop)
-                float4 co = exp_co, xy = exp_xy, cs = exp_cs;
-                asm volatile("" : "+v"(co.x), "+v"(co.y), "+v"(co.z), "+v"(co.w), "+v"(xy.x), "+v"(xy.y), "+v"(xy.w), "+v"(cs.x), "+v"(cs.y), "+v"(cs.z));
-                const int c0 = s_pos[k];
-#else
                 const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
                 const int c0 = s_pos[k];  // 0-based list position == the reference's `contributor` after its --
-#endif
                 // ---- predicated per-pixel gradient terms (backward.cu:932-994) ----
                 // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
                 // and S + 0 * (c - S) = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.

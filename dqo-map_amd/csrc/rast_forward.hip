@@ -867,10 +867,31 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
             DQO_LAUNCH("tile_sort_kernel", tile_sort_kernel<false>, dim3(SORT_GRID), dim3(SORT_THREADS), s, T, img, bin, g, cap, keep_order, late);
         }
     }
-    if (header_host != nullptr) DQO_CHECK_HIP(hipMemcpyAsync(header_host, g.header, sizeof(DqoRastHeader), hipMemcpyDeviceToHost, s));
-    if (header_event != nullptr) DQO_CHECK_HIP(hipEventRecord(header_event, s));
-    return dqo_launch_blend_forward(v, g, img, bin, *out, T, dqo_tap_dev(ctx->loss_tap),
-                                    dqo_gate_dev(ctx->object_gate), dqo_list_split(ctx), s, dqo_skip_long_sort(p, ctx) ? cap : (int64_t)-1);
+    // In a frame without the long-list sort launch the header is formed by an extra block of the BLEND launch: the copy and the event
+    // go behind it there (the caller learns about an overflow one blend kernel later, never from a stale header).
+    const bool header_in_blend = dqo_skip_long_sort(p, ctx);
+    auto hand_over_header = [&]() -> int {
+        if (header_host != nullptr) DQO_CHECK_HIP(hipMemcpyAsync(header_host, g.header, sizeof(DqoRastHeader), hipMemcpyDeviceToHost, s));
+        if (header_event != nullptr) DQO_CHECK_HIP(hipEventRecord(header_event, s));
+        return DQO_OK;
+    };
+    if (!header_in_blend) {
+        const int rc = hand_over_header();
+        if (rc) return rc;
+    }
+    const int rc = dqo_launch_blend_forward(v, g, img, bin, *out, T, dqo_tap_dev(ctx->loss_tap), dqo_gate_dev(ctx->object_gate),
+                                            dqo_list_split(ctx), s, header_in_blend ? cap : (int64_t)-1);
+    if (rc) return rc;
+    return header_in_blend ? hand_over_header() : DQO_OK;
+}
+
+// A K1-fused frame launches nothing in its first stage, so the device header still shows the PREVIOUS frame's stage 2: a caller that
+// runs the two stages as separate calls gets the header marked "stage 1 not available" (dqo_rast_read_header then reports zeros, as
+// include/dqo_raster.h says) by one single-word launch; dqo_rast_forward / _async never pay it.
+int dqo_launch_mark_header_stage0(const DqoRastParams* p, DqoRastCtx* ctx, hipStream_t s) {
+    if (!dqo_fuse_k1(p, ctx)) return DQO_OK;
+    DqoGeomLayout g = dqo_geom_layout(ctx->geom, p->P);
+    return dqo_launch_zero_words(&g.header->stage, 1, s);
 }
 
 bool dqo_skip_long_sort(const DqoRastParams* p, const DqoRastCtx* ctx) {

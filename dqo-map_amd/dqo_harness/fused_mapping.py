@@ -97,8 +97,6 @@ class FusedMapper:
         self.rotation_raw = t(scene["rotations"]).clone()
         self.P, self.M = self.xyz.shape[0], self.shs.shape[1]
         self.lrs = dict(mapping.LRS if lrs is None else lrs)
-        if os.environ.get("DQO_EXP_LR0"):  # timing experiments on kernels whose results are invalid: the map must not move
-            self.lrs = {k: 0.0 for k in self.lrs}
         self.betas, self.eps = betas, eps
         self.color_weight, self.depth_weight, self.add_depth_thres = color_weight, depth_weight, add_depth_thres
         self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in self._params().items()}

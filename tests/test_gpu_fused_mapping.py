@@ -650,6 +650,52 @@ def test_read_header_after_the_fused_tail_and_the_prezeroed_guard(env):
     assert not fm.graph_overflowed() and int(g.step_dev.item()) == steps + 1
 
 
+def test_async_header_of_a_frame_without_the_long_sort_launch_and_the_stage_marker(env):
+    """(1) In a frame that skips the long-list sort launch (buckets <= 1024 entries, kept tile order, no list split) the header is formed
+    by an extra block of the BLEND launch: dqo_rast_forward_async must hand over THIS frame's header (copy and event behind the blend
+    launch), not the previous frame's.  (2) A K1-fused frame launches nothing in its first stage: between dqo_rast_forward_prepare and
+    dqo_rast_forward_render dqo_rast_read_header reports zeros at stage 1 (include/dqo_raster.h), not the previous frame's stage 2."""
+    torch = env
+    import ctypes
+    import _dqo_native as N
+    from dqo_harness.fused_mapping import FusedMapper
+    cam, scene, settings, gt_color, gt_depth, mask, dev = _problem(torch)
+    fm = FusedMapper(scene, settings, dev)
+    fm.capture(gt_color, gt_depth, mask, fused_tail=True)
+    g = fm._g
+    assert g.cctx.frame_prezeroed == 1 and 0 < g.cctx.tile_bucket_capacity <= 1024 and g.cctx.keep_tile_order == 1 and g.cctx.list_split == 0
+    fm.replay()
+    torch.cuda.synchronize()
+    lib = N.lib()
+    prev = g.geom[:32].view(torch.int32).cpu().numpy().copy()
+    # move the map so that this frame's header differs from the previous one's, then one frame through the async entry point
+    with torch.no_grad():
+        fm.xyz[: fm.P // 2] += 0.05
+    host = torch.zeros(8, dtype=torch.int32).pin_memory()
+    ev = torch.cuda.Event()
+    ev.record()
+    N.check(lib.dqo_rast_forward_async(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.outputs), ctypes.byref(g.cctx),
+                                       ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(ev.cuda_event), N.current_stream()))
+    ev.synchronize()
+    got = host.numpy().copy()
+    torch.cuda.synchronize()
+    now = g.geom[:32].view(torch.int32).cpu().numpy()
+    assert list(got[:7]) == list(now[:7]) and got[6] == 2, (got, now)
+    assert list(now[:6]) != list(prev[:6])
+    # the forward-only frame left dirty scalars: run the tail once (flagged frame, trains nothing, clears them), then a clean one
+    fm.replay()
+    fm.replay()
+    torch.cuda.synchronize()
+    assert not fm.graph_overflowed()
+    hdr = N.DqoRastHeader()
+    N.check(lib.dqo_rast_forward_prepare(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.outputs), ctypes.byref(g.cctx), N.current_stream()))
+    N.check(lib.dqo_rast_read_header(ctypes.byref(g.cctx), ctypes.byref(hdr), N.current_stream()))
+    assert hdr.stage == 1 and hdr.num_rendered == 0 and hdr.overflow == 0 and hdr.num_tiles == 0
+    N.check(lib.dqo_rast_forward_render(ctypes.byref(g.params), ctypes.byref(g.inputs), ctypes.byref(g.outputs), ctypes.byref(g.cctx), N.current_stream()))
+    N.check(lib.dqo_rast_read_header(ctypes.byref(g.cctx), ctypes.byref(hdr), N.current_stream()))
+    assert hdr.stage == 2 and hdr.num_rendered > 0 and hdr.overflow == 0
+
+
 def test_capture_takes_the_reference_cameras_noncontiguous_matrices(env):
     """scene/cameras.py:137-139 builds world_view_transform as torch.tensor(...).transpose(0, 1).cuda(): a non-contiguous view.  The
     op's forward makes it contiguous per call; the captured path must do the same once (its raw pointers would otherwise read the

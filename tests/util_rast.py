@@ -174,9 +174,9 @@ def _row_err(a, truth):
 
 
 def unexplained_cap(rows):
-    """Rows that may sit beyond the bar WITHOUT an explanation: max(1, 1e-5 x rows) — ONE row in every case below 200 000 rows (round 3's
-    max(4, ...) let four arbitrary rows pass in every small case), 5 of 500 k, 20 of 2 M (the data: 1 + 1 rows of 1 M, 2 + 8 of 2 M)."""
-    return max(1, int(1e-5 * rows))
+    """Rows that may sit beyond the bar WITHOUT an explanation: NONE (rounds 3-5 allowed max(1, 1e-5 x rows); since the derivative of the
+    2x2 inverse runs in double — csrc/dqo_gauss_chain.h — the HIP chain no longer adds float noise of its own to those rows)."""
+    return 0
 
 
 def _describe_rows(idx, e, e_o=None, e_h=None, limit=5):
@@ -195,9 +195,9 @@ def compare_grads(hg, og, og64=None, rtol=1e-3):
     ill-conditioned for thin surfels: on a few rows ANY two float32 evaluations disagree in the second digit, the reference with
     itself included (its float atomicAdd order changes from run to run, quirk B10).  A row beyond the bar must therefore be EXPLAINED:
     with the fp64 oracle beside (every full-size configuration runs it), the fp32 ORACLE ITSELF is off its fp64 twin by more than a
-    third of the bar on that row and the HIP result is no further from fp64 than 3x the oracle is — ill-conditioned, not wrong.
-    Unexplained rows (all rows beyond the bar when there is no fp64 oracle) are capped at unexplained_cap(rows) = max(1, 1e-5 x rows) and
-    named in the report / the assert message (row, its three errors).
+    third of the bar on that row and the HIP result is no further from fp64 than TWICE what the oracle is — ill-conditioned, not wrong.
+    Unexplained rows (all rows beyond the bar when there is no fp64 oracle) are not allowed (unexplained_cap = 0); they are named in the
+    assert message (row, its three errors).
     Returns per tensor a dict: max_row_err, q99 (99th percentile of the row error relative to the row's own magnitude), rows,
     beyond_bar, explained, unexplained, worst_explained, worst_unexplained."""
     stats = {}
@@ -211,7 +211,7 @@ def compare_grads(hg, og, og64=None, rtol=1e-3):
         if n_out and og64 is not None:
             e_o = _row_err(og[k], og64[k])
             e_h = _row_err(hg[k], og64[k])
-            expl = out & (e_o > 0.3 * rtol) & (e_h <= 3 * e_o + rtol)
+            expl = out & (e_o > 0.3 * rtol) & (e_h <= 2 * e_o)
         unexp = out & ~expl
         n_unexp = int(unexp.sum())
         stats[k] = dict(max_row_err=float(e.max()) if n else 0.0, q99=q99, rows=n, beyond_bar=n_out, explained=int(expl.sum()),
@@ -224,7 +224,7 @@ def compare_grads(hg, og, og64=None, rtol=1e-3):
             f"grad {k}: {n_unexp} of {n} rows are off the fp32 oracle by more than {rtol:.0e} of the largest magnitude"
             + (" with no fp64 oracle to explain them" if og64 is None else
                " and are NOT explained by the fp32 oracle's own error against fp64 (explained = fp32 oracle off fp64 by > 0.3 x bar on "
-               "the row AND hip no further from fp64 than 3 x that + bar)")
+               "the row AND hip no further from fp64 than 2 x that)")
             + f"; cap {unexplained_cap(n)} rows; worst rows: {stats[k]['unexplained_rows']}")
         if n >= 1000:
             assert q99 <= rtol, f"grad {k}: 99% row-wise error {q99:.3e} > {rtol:.1e} (vs fp32 oracle)"
@@ -234,15 +234,14 @@ def compare_grads(hg, og, og64=None, rtol=1e-3):
     return stats
 
 
-def assert_grads_match(ga, gb, what="", rtol=1e-3, worst=1e-2):
+def assert_grads_match(ga, gb, what="", rtol=1e-3):
     """Two HIP evaluations of the same gradients that differ by ROUNDING only (another summation order, a forward whose per-pixel state
-    differs in the last bits): every Gaussian row within `rtol` of the tensor's largest magnitude, except — the per-Gaussian chain of
-    backward.cu:331-355 is ill-conditioned for thin surfels and amplifies last-bit differences of its inputs ~1e4 times on a handful of
-    rows (compare_grads, which has the fp64 oracle to say which) — at most max(2, 2e-5 x rows) rows, none beyond `worst`."""
+    differs in the last bits): EVERY Gaussian row within `rtol` of the tensor's largest magnitude.  (Rounds 4-5 let max(2, 2e-5 x rows)
+    rows go up to 1e-2: the float evaluation of the 2x2 inverse's derivative amplified last-bit differences of its inputs ~1e4 times on a
+    handful of thin surfels; in double — csrc/dqo_gauss_chain.h — it does not.)"""
     for k in ga:
         e = _row_err(gb[k], ga[k])
-        n_out = int((e > rtol).sum())
-        assert n_out <= max(2, int(2e-5 * e.size)) and (e.max() if e.size else 0.0) < worst, (what, k, n_out, float(e.max()))
+        assert (e.max() if e.size else 0.0) <= rtol, (what, k, int((e > rtol).sum()), float(e.max()))
 
 
 def parity_case(ol, cam, sc, dL, fp64=False, device="cuda", **kw):
