@@ -21,7 +21,7 @@ class DqoRastParams(ctypes.Structure):
 
 class DqoRastInputs(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ("bg", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp",
-                                    "viewmatrix", "projmatrix", "campos", "tile_mask")]
+                                    "viewmatrix", "projmatrix", "campos", "tile_mask", "row_flags")]
 
 
 class DqoRastOutputs(ctypes.Structure):
@@ -67,7 +67,10 @@ class DqoAdamStep(ctypes.Structure):
                                      "g_scales", "g_rotations", "m_xyz", "m_shs", "m_opacity", "m_scaling", "m_rotation", "v_xyz",
                                      "v_shs", "v_opacity", "v_scaling", "v_rotation", "act_opacity", "act_scales", "act_rotations", "radii", "step_dev", "moment_live",
                                      "attach_mask", "init_xyz", "init_scaling_raw", "init_rotation_raw")] +
-                [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp), ("block_ticket", c_vp), ("bias_table", c_vp), ("attach_gains", c_vp)])
+                [("attach_count", c_i32), ("attach_partial", c_vp), ("frame_header", c_vp), ("block_ticket", c_vp), ("bias_table", c_vp), ("attach_gains", c_vp),
+                 ("row_flags", c_vp), ("confidence", c_vp), ("lr_table", c_vp)])
+
+ROW_FROZEN, ROW_HIDDEN = 1, 2  # DQO_ROW_FROZEN / DQO_ROW_HIDDEN (include/dqo_raster.h)
 
 
 class DqoAdamTensor(ctypes.Structure):
@@ -82,7 +85,7 @@ EXPORTS = ("dqo_abi_version", "dqo_abi_sizeof", "dqo_last_error", "dqo_profile_e
            "dqo_rast_forward", "dqo_rast_forward_async", "dqo_rast_backward", "dqo_rast_backward_adam", "dqo_mark_visible", "dqo_knn3_workspace_bytes", "dqo_knn3",
            "dqo_quadric_iou_fwd_bwd", "dqo_quadric_adam", "dqo_tile_count_mask", "dqo_transmission_mask", "dqo_tile_color_error", "dqo_knn3_query_workspace_bytes",
            "dqo_knn3_query", "dqo_knn3_query_within", "dqo_knn3_query_grouped", "dqo_icp_workspace_bytes", "dqo_icp_normal_equations",
-           "dqo_attach_pixels", "dqo_attach_decide", "dqo_growth_scales", "dqo_growth_inside", "dqo_error_maps")
+           "dqo_attach_pixels", "dqo_attach_decide", "dqo_growth_scales", "dqo_growth_inside", "dqo_error_maps", "dqo_map_history_merge")
 
 _lib = None
 
@@ -154,9 +157,10 @@ def lib():
         L.dqo_tile_count_mask.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp]
         L.dqo_transmission_mask.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
         L.dqo_tile_color_error.argtypes = [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]
+        L.dqo_map_history_merge.argtypes = [c_i32, c_i32, c_f, c_i32] + [c_vp] * 12
         L.dqo_profile_enable.argtypes = [ctypes.c_int]
         L.dqo_profile_collect.argtypes = [P(DqoProfileEntry), ctypes.c_int, ctypes.c_int]
-        if L.dqo_abi_version() != 4:
+        if L.dqo_abi_version() != 5:
             raise RuntimeError("libdqoraster.so ABI version mismatch")
         L.dqo_abi_sizeof.restype = ctypes.c_size_t
         L.dqo_abi_sizeof.argtypes = [c_i32]

@@ -36,6 +36,9 @@ struct AdamArgs {
     int32_t* block_ticket;                                                        // (with step_advance) blocks finished so far
     float* bias_table;                                                            // optional (with step_dev): DqoAdamStep.bias_table
     const float* attach_gains;                                                    // optional: DqoAdamStep.attach_gains (replaces attach_g3/4)
+    const uint8_t* row_flags;                                                     // optional: DqoAdamStep.row_flags (DQO_ROW_FROZEN rows are skipped)
+    float* confidence;                                                            // optional: DqoAdamStep.confidence
+    const float* lr_table;                                                        // optional (with step_dev): DqoAdamStep.lr_table
 };
 
 // a float beta as the double it was most likely written as: rounded to seven decimals (0.999f = 0.99900001287... -> 0.999)
@@ -109,6 +112,12 @@ struct AdamGradGlobal {
     __device__ __forceinline__ float sh(int, uint32_t, uint32_t ei, uint32_t e0, bool has_g) const { return ldnt(&a.g_shs[has_g ? ei : e0]); }
     __device__ __forceinline__ float opacity(int, uint32_t i, bool has_g) const { return ldsm(&a.g_opacity[has_g ? i : 0u]); }
     __device__ __forceinline__ float4 rot(int, uint32_t i, bool has_g) const { return reinterpret_cast<const float4*>(a.g_rot)[has_g ? i : 0u]; }
+    // does the row's f_dc gradient (SH coefficient 0) have a non-zero element?  (mapper.py:908-909; three loads at a clamped address)
+    __device__ __forceinline__ bool dc_nonzero(int, uint32_t i, bool has_g) const {
+        const size_t e = has_g ? (size_t)i * (size_t)(3 * a.M) : 0;
+        const float g0 = ldnt(&a.g_shs[e]), g1 = ldnt(&a.g_shs[e + 1]), g2 = ldnt(&a.g_shs[e + 2]);
+        return has_g && (g0 != 0.f || g1 != 0.f || g2 != 0.f);
+    }
 };
 
 // The bias corrections of step t (double, like the host path / torch's python floats): out[0] = sqrt(1 - beta2^t), out[1..6] = the six
@@ -117,9 +126,13 @@ __device__ __forceinline__ void adam_bias_compute(const AdamArgs& a, const int s
     const double t = (double)step;
     const double bc1 = 1.0 - pow(a.beta1_d, t), bc2 = 1.0 - pow(a.beta2_d, t);
     out[0] = (float)sqrt(bc2);
-    out[1] = (float)((double)a.lr_xyz / bc1), out[2] = (float)((double)a.lr_dc / bc1), out[3] = (float)((double)a.lr_rest / bc1);
-    out[4] = (float)((double)a.lr_opacity / bc1), out[5] = (float)((double)a.lr_scaling / bc1);
-    out[6] = (float)((double)a.lr_rotation / bc1);
+    float lr[6] = {a.lr_xyz, a.lr_dc, a.lr_rest, a.lr_opacity, a.lr_scaling, a.lr_rotation};
+    if (a.lr_table != nullptr) {  // DqoAdamStep.lr_table: the learning rates of THIS mapping call, from device memory (uniform loads)
+#pragma unroll
+        for (int i = 0; i < 6; i++) lr[i] = a.lr_table[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) out[1 + i] = (float)((double)lr[i] / bc1);
 }
 // ... of the launch's step (the device-resident count), by the calling thread(s): from DqoAdamStep.bias_table when it holds this step
 // (seven loads from uniform addresses), computed otherwise — the same function either way, so the same bits.
@@ -166,6 +179,8 @@ __device__ __forceinline__ void adam_xyz_update(const AdamArgs& a, const uint32_
 struct AdamRowVals {  // one row of the opacity / rotation pass
     float p, m, v, go_ld;
     float4 q, mq, vq, gr_ld, q0;
+    float conf;   // DqoAdamStep.confidence of the row (loaded with the others)
+    bool dc_nz;   // the row's f_dc gradient has a non-zero element
 };
 template <bool ATTACH>
 __device__ __forceinline__ void adam_row_update(const AdamArgs& a, const uint32_t r, AdamRowVals x, float& att_sum) {
@@ -202,6 +217,8 @@ __device__ __forceinline__ void adam_row_update(const AdamArgs& a, const uint32_
     }
     reinterpret_cast<float4*>(a.m_rotation)[i] = mq;
     reinterpret_cast<float4*>(a.v_rotation)[i] = vq;
+    // mapper.py:908-910: `_confidence[(f_dc.grad.abs() != 0).any(-1)] += 1` for the rows this launch trains
+    if (a.confidence != nullptr && x.dc_nz) a.confidence[i] = x.conf + 1.0f;
 }
 
 // One pass per parameter group over the block's list of rows (s_rows[k] = Gaussian index | has-gradient << 31 | attach-loss member
@@ -291,6 +308,8 @@ __device__ __forceinline__ float adam_passes(const AdamArgs& a, const uint32_t* 
         x.gr_ld = gsrc.rot(tid, i, has_g);
         x.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ATTACH) x.q0 = reinterpret_cast<const float4*>(a.init_rotation)[((r >> 30) & 1u) ? i : 0u];
+        x.conf = 0.f, x.dc_nz = false;
+        if (a.confidence != nullptr) x.conf = a.confidence[i], x.dc_nz = gsrc.dc_nonzero(tid, i, has_g);  // (kernel-uniform branch)
         adam_row_update<ATTACH>(a, r, x, att_sum);
     }
     return att_sum;
@@ -386,6 +405,8 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
         x.gr_ld = gsrc.rot(tid, i, has_g);
         x.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ATTACH) x.q0 = reinterpret_cast<const float4*>(a.init_rotation)[((r >> 30) & 1u) ? i : 0u];
+        x.conf = 0.f, x.dc_nz = false;
+        if (a.confidence != nullptr) x.conf = a.confidence[i], x.dc_nz = gsrc.dc_nonzero(tid, i, has_g);  // (kernel-uniform branch)
         adam_row_update<ATTACH>(a, r, x, att_sum);
     }
     return att_sum;

@@ -40,6 +40,9 @@ int dqo_launch_map_adam(const DqoAdamStep* st, hipStream_t s);
 size_t dqo_map_attach_ws_bytes(int P);
 int dqo_launch_adam_multi(const DqoAdamTensor* ts, int n_tensors, int step, double beta1, double beta2, double eps, hipStream_t s,
                           int32_t* step_dev = nullptr, int bump = 0);
+int dqo_launch_history_merge(int P, int M, float max_weight, int first_row, const uint8_t* row_flags, const float* conf0, const float* conf,
+                             const float* xyz0, const float* shs0, const float* scaling0, const float* rot0_unit, float* xyz, float* shs,
+                             float* scaling_raw, float* rotation_raw, hipStream_t s);
 int dqo_launch_map_attach(int P, const float* scaling, const float* xyz, const float* rotation, const float* scaling0, const float* xyz0,
                           const float* rotation0, const uint8_t* mask, int attach_count, float* loss, float* g_scaling, float* g_xyz,
                           float* g_rotation, void* ws, hipStream_t s);
@@ -444,6 +447,17 @@ DQO_API int dqo_map_ssim_fwd_bwd(int32_t W, int32_t H, const float* image, const
 }
 
 DQO_API size_t dqo_map_attach_workspace_bytes(int32_t P) { return dqo_map_attach_ws_bytes(P < 0 ? 0 : P); }
+
+DQO_API int dqo_map_history_merge(int32_t P, int32_t M, float max_weight, int32_t first_row, const uint8_t* row_flags, const float* conf0,
+                                  const float* conf, const float* xyz0, const float* shs0, const float* scaling0, const float* rot0_unit,
+                                  float* xyz, float* shs, float* scaling_raw, float* rotation_raw, void* stream) {
+    DQO_CHECK_ARG(P >= 0 && M >= 1 && M * 3 < 256, "bad P / M");
+    if (P == 0) return DQO_OK;
+    DQO_CHECK_ARG(first_row >= 0 && first_row < P, "first_row %d outside [0, %d)", first_row, P);
+    DQO_CHECK_ARG(conf0 && conf && xyz0 && shs0 && scaling0 && rot0_unit && xyz && shs && scaling_raw && rotation_raw, "null tensor");
+    return dqo_launch_history_merge(P, M, max_weight, first_row, row_flags, conf0, conf, xyz0, shs0, scaling0, rot0_unit, xyz, shs,
+                                    scaling_raw, rotation_raw, (hipStream_t)stream);
+}
 
 DQO_API int dqo_map_attach_loss_fwd_bwd(int32_t P, const float* scaling_raw, const float* xyz, const float* rotation_raw,
                                         const float* init_scaling_raw, const float* init_xyz, const float* init_rotation_raw,

@@ -313,6 +313,7 @@ struct DqoView {
     float scale_mod, color_sigma, opaque_thr, depth_thr, normal_thr, T_thr;
     int W, H, gx, gy;
     int P, D, M;
+    const uint8_t* row_flags;  // DqoRastInputs.row_flags (NULL = none): DQO_ROW_HIDDEN rows are culled by the per-Gaussian forward
 };
 
 // The inputs of the late part of the per-Gaussian forward (dqo_k1_late.h) for the extra blocks of a sort launch
@@ -325,6 +326,7 @@ struct DqoK1Late {
 static inline DqoView dqo_make_view(const DqoRastParams* p, const DqoRastInputs* in) {
     DqoView v;
     v.view = in->viewmatrix;
+    v.row_flags = in->row_flags;
     v.proj = in->projmatrix;
     v.campos = in->campos;
     v.bg = in->bg;

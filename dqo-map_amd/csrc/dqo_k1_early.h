@@ -32,6 +32,8 @@ __device__ __forceinline__ K1Early k1_early(const DqoView& v, const float (&view
     int radius = 0;
     int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
     do {
+        // a hidden row (DqoRastInputs.row_flags) is no Gaussian of this render: culled like one behind the camera
+        if (v.row_flags != nullptr && (v.row_flags[idx] & DQO_ROW_HIDDEN) != 0u) break;
         const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
         // in_frustum, auxiliary.h:139-165
         const float hx = proj[0] * px + proj[4] * py + proj[8] * pz + proj[12];

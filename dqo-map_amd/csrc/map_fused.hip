@@ -233,6 +233,72 @@ __global__ __launch_bounds__(ATT_THREADS) void attach_loss_sum_kernel(int n, con
     if (threadIdx.x == 0) loss[0] = (float)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 
+// ---------------------------------------------------------------- history merge ---------------------------------------
+// Mapping.history_merge (SLAM/multiprocess/mapper.py:607-650) + slerp (SLAM/utils.py:650-709) in one launch: a block owns HM_THREADS
+// Gaussians — a thread per Gaussian for xyz / scaling / rotation, then the block's SH rows element by element (coalesced).  The
+// reference's eager ops are separate IEEE operations: contraction off, same statement order (the lerps come out bit for bit; the
+// slerp's acos / sin differ from torch's CPU libm in the last bits).
+constexpr int HM_THREADS = 256;
+__device__ __forceinline__ float hm_weight(const float max_weight, const float c0, const float c) {
+#pragma clang fp contract(off)
+    return max_weight * c0 / (c + 0.000001f);  // mapper.py:610-614
+}
+// torch.lerp(start, end, weight): aten's lerp — weight < 0.5 ? start + weight * (end - start) : end - (end - start) * (1 - weight)
+__device__ __forceinline__ float hm_torch_lerp(const float a, const float b, const float w) {
+#pragma clang fp contract(off)
+    const float d = b - a;
+    return fabsf(w) < 0.5f ? a + w * d : b - d * (1.f - w);
+}
+__global__ __launch_bounds__(HM_THREADS) void history_merge_kernel(const int P, const int M, const float max_weight, const int first_row,
+                                                                   const uint8_t* __restrict__ row_flags, const float* __restrict__ conf0,
+                                                                   const float* __restrict__ conf, const float* __restrict__ xyz0,
+                                                                   const float* __restrict__ shs0, const float* __restrict__ scaling0,
+                                                                   const float* __restrict__ rot0, float* __restrict__ xyz,
+                                                                   float* __restrict__ shs, float* __restrict__ scaling,
+                                                                   float* __restrict__ rotation) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * HM_THREADS + threadIdx.x;
+    // `history_weight[0]` (mapper.py:620-637): ONE weight — the first trained row's — for f_dc, f_rest and scaling of every row
+    const float w0 = hm_weight(max_weight, conf0[first_row], conf[first_row]);
+    const float u0 = 1.f - w0;
+    if (i < P && !(row_flags != nullptr && (row_flags[i] & DQO_ROW_FROZEN) != 0u)) {
+        const float w = hm_weight(max_weight, conf0[i], conf[i]);
+        const float u = 1.f - w;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            xyz[3 * i + k] = xyz0[3 * i + k] * w + u * xyz[3 * i + k];                       // :615-618
+            scaling[3 * i + k] = scaling0[3 * i + k] * w0 + u0 * scaling[3 * i + k];         // :630-633
+        }
+        // slerp(history rotation, get_rotation, 1 - w), SLAM/utils.py:650-709; get_rotation = F.normalize(_rotation)
+        const float4 v0 = reinterpret_cast<const float4*>(rot0)[i];
+        const float4 qr = reinterpret_cast<const float4*>(rotation)[i];
+        const float nq = fmaxf(sqrtf(qr.x * qr.x + qr.y * qr.y + qr.z * qr.z + qr.w * qr.w), 1e-12f);
+        const float4 v1 = make_float4(qr.x / nq, qr.y / nq, qr.z / nq, qr.w / nq);
+        const float n0 = sqrtf(v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w);
+        const float n1 = sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w);
+        const float dot = (v0.x / n0) * (v1.x / n1) + (v0.y / n0) * (v1.y / n1) + (v0.z / n0) * (v1.z / n1) + (v0.w / n0) * (v1.w / n1);
+        const float t = u;  // 1 - history_weight
+        float4 o;
+        if (!(fabsf(dot) <= 0.9995f)) {  // NaN or nearly colinear -> torch.lerp(v0, v1, t), :677-691
+            o = make_float4(hm_torch_lerp(v0.x, v1.x, t), hm_torch_lerp(v0.y, v1.y, t), hm_torch_lerp(v0.z, v1.z, t), hm_torch_lerp(v0.w, v1.w, t));
+        } else {  // :694-707
+            const float th0 = acosf(dot), s_th0 = sinf(th0), tht = th0 * t;
+            const float s0 = sinf(th0 - tht) / s_th0, s1 = sinf(tht) / s_th0;
+            o = make_float4(s0 * v0.x + s1 * v1.x, s0 * v0.y + s1 * v1.y, s0 * v0.z + s1 * v1.z, s0 * v0.w + s1 * v1.w);
+        }
+        reinterpret_cast<float4*>(rotation)[i] = o;
+    }
+    // f_dc / f_rest (:620-628): rows of 3 M floats, the block's HM_THREADS rows as one run of elements
+    const int row = 3 * M;
+    const size_t e0 = (size_t)blockIdx.x * HM_THREADS * row;
+    const int n = min(HM_THREADS, P - blockIdx.x * HM_THREADS) * row;
+    for (int e = threadIdx.x; e < n; e += HM_THREADS) {
+        const int r = blockIdx.x * HM_THREADS + e / row;
+        if (row_flags != nullptr && (row_flags[r] & DQO_ROW_FROZEN) != 0u) continue;
+        shs[e0 + e] = shs0[e0 + e] * w0 + u0 * shs[e0 + e];
+    }
+}
+
 // ---------------------------------------------------------------- Adam ------------------------------------------------
 // (AdamArgs, adam1, the per-group passes: dqo_adam.h — shared with the fused per-Gaussian tail, map_fused_tail.hip)
 __global__ void adam_advance_kernel(int32_t* step_dev, const DqoRastHeader* frame_header) {
@@ -266,7 +332,7 @@ __device__ __forceinline__ void adam_block(AdamArgs a, uint8_t* __restrict__ mom
     if (a.step_dev != nullptr && tid == 0) adam_bias_to_lds(a, s_ss);
     const int idx = blockIdx.x * ADAM_THREADS + tid;
     bool hg = false, act = false, att = false;
-    if (idx < a.P) {
+    if (idx < a.P && !(a.row_flags != nullptr && (a.row_flags[idx] & DQO_ROW_FROZEN) != 0u)) {  // (a frozen row: DqoAdamStep.row_flags)
         hg = a.radii == nullptr || a.radii[idx] > 0;
         act = !SPARSE || hg || moment_live[idx] != 0;
         if (SPARSE && hg) moment_live[idx] = 1;  // only this thread ever looks at this byte
@@ -366,6 +432,8 @@ int dqo_adam_args(const DqoAdamStep* st, int blocks, AdamArgs* out, bool* attach
     a.bias_table = (advance_inside && st->step_dev != nullptr) ? st->bias_table : nullptr;
     const bool attach = st->attach_mask != nullptr && (st->attach_count > 0 || st->attach_gains != nullptr);
     a.attach_gains = attach ? st->attach_gains : nullptr;
+    a.row_flags = st->row_flags, a.confidence = st->confidence, a.lr_table = st->lr_table;
+    DQO_CHECK_ARG(st->lr_table == nullptr || st->step_dev != nullptr, "lr_table is read on the device: it needs step_dev");
     DQO_CHECK_ARG(!attach || (st->init_xyz && st->init_scaling_raw && st->init_rotation_raw), "attach_mask needs the three init_* tensors");
     DQO_CHECK_ARG(st->P < (1 << 30), "P must stay below 2^30");
     // d/dp of 1000 * mean((p - p0)^2) over |a| rows of 3 (scaling, xyz) / 4 (rotation) elements = 2000 (p - p0) / (len |a|)
@@ -498,5 +566,14 @@ int dqo_launch_map_attach(int P, const float* scaling, const float* xyz, const f
     DQO_LAUNCH("attach_loss_kernel", attach_loss_kernel, dim3(blocks), dim3(ATT_THREADS), s, P, scaling, xyz, rotation, scaling0, xyz0, rotation0,
                mask, g3, g4, g_scaling, g_xyz, g_rotation, partial);
     DQO_LAUNCH("attach_loss_sum_kernel", attach_loss_sum_kernel, dim3(1), dim3(ATT_THREADS), s, blocks, partial, loss);
+    return DQO_OK;
+}
+
+int dqo_launch_history_merge(int P, int M, float max_weight, int first_row, const uint8_t* row_flags, const float* conf0, const float* conf,
+                             const float* xyz0, const float* shs0, const float* scaling0, const float* rot0_unit, float* xyz, float* shs,
+                             float* scaling_raw, float* rotation_raw, hipStream_t s) {
+    if (P <= 0 || !(max_weight > 0.f)) return DQO_OK;  // mapper.py:608-609
+    DQO_LAUNCH("history_merge_kernel", history_merge_kernel, dim3((P + HM_THREADS - 1) / HM_THREADS), dim3(HM_THREADS), s, P, M, max_weight,
+               first_row, row_flags, conf0, conf, xyz0, shs0, scaling0, rot0_unit, xyz, shs, scaling_raw, rotation_raw);
     return DQO_OK;
 }

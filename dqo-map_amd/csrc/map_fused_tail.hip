@@ -59,6 +59,10 @@ struct AdamGradLds {
         const float* r = s_g + k * ROW_STRIDE + ROW_ROT;
         return make_float4(r[0], r[1], r[2], r[3]);
     }
+    // the f_dc gradient = elements 0..2 of the SH row (a row without a gradient holds stale LDS: has_g decides first)
+    __device__ __forceinline__ bool dc_nonzero(int k, uint32_t, bool has_g) const {
+        return has_g && (sh(k, 0u, 0u, 0u, true) != 0.f || sh(k, 1u, 0u, 0u, true) != 0.f || sh(k, 2u, 0u, 0u, true) != 0.f);
+    }
 };
 
 #ifndef DQO_TAIL_WAVES
@@ -113,14 +117,18 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
     // ---- A: first round of loads (rect, instance count, slot base, list flags); Adam's row list ----
     uint2 rc = make_uint2(0u, 0u);
     uint32_t base = 0, cnt = 0;
-    bool live_m = false, att = false;
+    bool live_m = false, att = false, trained = in_range;
     if (in_range) {
         rc = g.rect16[idx];
         cnt = g.tiles_touched[idx];
         base = g.slot_base[idx];
         if (SPARSE) live_m = moment_live[idx] != 0;
         if (ATTACH) att = a.attach_mask[idx] != 0;
+        // DqoAdamStep.row_flags: a frozen row is rendered and back-propagated THROUGH (its entries shape the pixels' T), but it is no
+        // parameter of this mapping call: no record sum, no chain, no Adam, no confidence (kernel-uniform branch, one byte per row)
+        if (a.row_flags != nullptr) trained = (a.row_flags[idx] & DQO_ROW_FROZEN) == 0u;
     }
+    if (!trained) cnt = 0u, live_m = false, att = false;
     float view[16], proj[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -128,8 +136,8 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
         proj[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.proj[i])));
     }
     // radii > 0 (backward.cu:285, 513; DqoAdamStep.radii)  <=>  the forward kept a non-empty tile rect for this Gaussian
-    const bool visible = in_range && ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
-    const bool act = in_range && (!SPARSE || visible || live_m);
+    const bool visible = trained && ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
+    const bool act = trained && (!SPARSE || visible || live_m);
     if (SPARSE && visible) moment_live[idx] = 1;  // only this thread ever looks at this byte
     const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
     if (lane == 0) s_wave_n[wave] = (int)__popcll(am);

@@ -220,11 +220,13 @@ def _params(rs, P, M):
                            T_threshold=float(rs.T_threshold))
 
 
-def _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask):
+def _inputs(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, tile_mask, row_flags=None):
+    """row_flags: DqoRastInputs.row_flags (uint8 [P], DQO_ROW_HIDDEN rows are not rendered) — None for the drop-in operator, whose
+    reference counterpart renders every row it is given."""
     return N.DqoRastInputs(bg=N.ptr(rs.bg), means3D=N.ptr(means3D), shs=N.ptr(sh), colors_precomp=N.ptr(colors_precomp),
                            opacities=N.ptr(opacities), scales=N.ptr(scales), rotations=N.ptr(rotations),
                            cov3D_precomp=N.ptr(cov3Ds_precomp), viewmatrix=N.ptr(rs.viewmatrix), projmatrix=N.ptr(rs.projmatrix),
-                           campos=N.ptr(rs.campos), tile_mask=N.ptr(tile_mask))
+                           campos=N.ptr(rs.campos), tile_mask=N.ptr(tile_mask), row_flags=N.ptr(row_flags))
 
 
 class _RasterizeGaussians(torch.autograd.Function):

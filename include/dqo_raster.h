@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DQO_ABI_VERSION 4
+#define DQO_ABI_VERSION 5
 
 typedef enum DqoStatus {
     DQO_OK = 0,
@@ -74,7 +74,15 @@ typedef struct DqoRastInputs {
     const float* projmatrix;     /* [16] */
     const float* campos;         /* [3] */
     const int32_t* tile_mask;    /* [ceil(H/16) * ceil(W/16)], non-zero = render; NULL = all ones */
+    /* ABI 5.  NULL (the drop-in behaviour: every row is rendered) or one byte per Gaussian; a row with DQO_ROW_HIDDEN set is treated
+     * as culled by the per-Gaussian forward (radii 0, no list entry, no gradient) — the reference's two clouds kept in ONE map:
+     * Mapping.global_optimization renders the stable cloud alone (SLAM/multiprocess/mapper.py:1199-1204, stable_params), local_optimize
+     * renders cat(unstable, stable) (:578, :1810-1840).  Device memory, read when the launch runs: a captured iteration follows a
+     * caller that rewrites the bytes in place between two mapping calls.  The same array serves DqoAdamStep.row_flags. */
+    const uint8_t* row_flags;
 } DqoRastInputs;
+#define DQO_ROW_FROZEN 1u /* DqoAdamStep.row_flags: the row is not trained (no gradient row, no Adam, no confidence count) */
+#define DQO_ROW_HIDDEN 2u /* DqoRastInputs.row_flags: the row is not rendered */
 
 /* Caller-allocated outputs; the forward writes EVERY element (masked / empty tiles get the reference's initial
  * fills: colour 0, depth 0, ids 0, weights 0, T 1 — rasterize_points.cu:79-89), so torch.empty is enough. */
@@ -530,8 +538,39 @@ typedef struct DqoAdamStep {
      * changes between replays: the caller rewrites attach_mask, init_* and these two numbers in place at the start of a mapping call
      * and replays the same graph.  With it, the attach term is on whenever attach_mask is given (|a| = 0: write two zeros). */
     const float* attach_gains;
+    /* ABI 5 — the reference trains ONE of its two clouds per mapping call while it renders both (local_optimize: pointcloud.parametrize,
+     * SLAM/multiprocess/mapper.py:533; global_optimization: stable_pointcloud.parametrize, :1119).  Optional (NULL = every row trains):
+     * one byte per Gaussian; a row with DQO_ROW_FROZEN set is no parameter of the optimiser: its gradient row is not formed, its
+     * parameters, moments, moment_live byte and confidence stay bit for bit as they are, it is no member of the attach set whatever
+     * attach_mask says.  Device memory, read when the launch runs (see DqoRastInputs.row_flags). */
+    const uint8_t* row_flags;
+    /* Optional (NULL = not counted): float [P], the reference's per-Gaussian confidence (SLAM/gaussian_pointcloud.py:42, :836).  A trained
+     * row whose f_dc gradient of this step has a non-zero element gains 1 — Mapping.loss_update's
+     *     grad_mask = (pointcloud._features_dc.grad.abs() != 0).any(dim=-1);  pointcloud._confidence[grad_mask] += 1   (mapper.py:908-910)
+     * — inside the launch that consumes the gradient (the fused tail never writes the row to HBM).  An invalid frame counts nothing. */
+    float* confidence;
+    /* Optional (NULL = the six lr_* fields above): six device floats { xyz, f_dc, f_rest, opacity, scaling, rotation }, read when the
+     * launch runs — global_optimization rescales the groups' learning rates per call (mapper.py:1120-1131: xyz 0, the others x 0.1 or
+     * x their *_lr_coef); a caller that rewrites the table (and zeroes bias_table) between two mapping calls keeps its captured graph. */
+    const float* lr_table;
 } DqoAdamStep;
 int dqo_map_adam_step(const DqoAdamStep*, void* hipStream);
+
+/* Mapping.history_merge (SLAM/multiprocess/mapper.py:607-650), the statement that closes every local_optimize call: the trained cloud is
+ * pulled back towards its state at the start of the call (`history_stat`, :535-545), weighted by how much of its confidence is old:
+ *     w[i] = max_weight * conf0[i] / (conf[i] + 1e-6)
+ *     xyz[i]      = xyz0[i] * w[i] + (1 - w[i]) * xyz[i]
+ *     f_dc, f_rest, scaling: the same lerp with w[first_row] FOR EVERY ROW — the reference indexes `history_weight[0]` (:620-637), a [1]
+ *                  tensor that broadcasts: the first Gaussian's weight serves the whole cloud (reproduced, not fixed)
+ *     rotation[i] = slerp(rot0_unit[i], normalize(rotation[i]), 1 - w[i])     (SLAM/utils.py:650-709: |dot| > 0.9995 or NaN -> torch.lerp,
+ *                  otherwise sin-weighted; no shortest-arc flip, no renormalisation) — the result replaces the RAW quaternion.
+ * One launch in place of ~40 eager torch ops.  All tensors are updated in place; rot0_unit = the ACTIVATED (normalised) rotation at the
+ * start of the call (`history_stat["rotation"]` = get_rotation), shs0 / shs are [P, M, 3] (coefficient 0 = f_dc, the rest f_rest).  rows:
+ * optional row_flags (NULL = all rows): rows with DQO_ROW_FROZEN are left untouched (they belong to the cloud the call did not train);
+ * first_row = the row whose weight serves the broadcast quirk (row 0 of the reference's trained cloud).  max_weight <= 0: no-op (:608-609). */
+int dqo_map_history_merge(int32_t P, int32_t M, float max_weight, int32_t first_row, const uint8_t* row_flags, const float* conf0,
+                          const float* conf, const float* xyz0, const float* shs0, const float* scaling0, const float* rot0_unit, float* xyz,
+                          float* shs, float* scaling_raw, float* rotation_raw, void* hipStream);
 
 /* Fused mapping iteration, backward half (ABI 3): the blend kernel of dqo_rast_backward followed by ONE kernel that, per block of 256
  * Gaussians, sums the per-instance gradient records, runs the per-Gaussian backward (rasterizer_impl.cu:445-564's K8 + K9,

@@ -35,7 +35,7 @@ def test_exports_every_declared_symbol(native):
 
 def test_size_queries_and_errors(native):
     lib = native.lib()
-    assert lib.dqo_abi_version() == 4
+    assert lib.dqo_abi_version() == 5
     g1, g2 = lib.dqo_rast_geom_bytes(1000, 640, 480), lib.dqo_rast_geom_bytes(2000, 640, 480)
     assert 0 < g1 < g2 and g1 % 256 == 0
     assert lib.dqo_rast_image_bytes(1200, 680) >= 12 * 1200 * 680

@@ -6,7 +6,7 @@ for v in ${LIBS:-m0 m4 m6 m7 m20 m22 m23 m31 m14 m3}; do
   cp .ab_old/$v.so $L/libdqoraster.so
   for c in "1 2000" "3 60000" "5 300000"; do
     echo "== $v cfg/P $c"
-    timeout -k 10 300 python tools/diag_row_error.py $c 2>&1 | grep -v "^   row\|amdgpu.ids" || { cp $L/ab_keep.so $L/libdqoraster.so; exit 1; }
+    timeout -k 10 300 python tests/diag_row_error.py $c 2>&1 | grep -v "^   row\|amdgpu.ids" || { cp $L/ab_keep.so $L/libdqoraster.so; exit 1; }
   done
 done
 cp $L/ab_keep.so $L/libdqoraster.so
