@@ -14,6 +14,13 @@ host synchronisation, the Adam step count, the attach set and its size kept on t
 eager path is otherwise longer than the GPU work.  `reserve()` + `grow()` + `begin_mapping_call()` keep the captured graph valid across
 map-growth steps and mapping calls (everything they change is rewritten in place).
 
+Round 6 — the reference's optimise LOOP, not one frame of it (mapper.py:531-605, 1105-1228): a frame set (`capture_window`: one graph
+per frame of the window / keyframe selection, each with its own context buffers and capacities, all sharing parameters, moments and the
+device-side step count; `replay(frame)` = the per-iteration frame choice, `run_window` = the reference's schedule), the two clouds in
+one map (`set_training_rows`: the rows the call trains and the rows it renders; frozen rows are rendered and back-propagated through
+but are no parameters of the call), per-call learning rates in device memory (`set_lrs`), the per-iteration confidence counter
+(`confidence`, mapper.py:908-910) inside the tail kernel, and `history_merge()` (mapper.py:607-650) as one kernel.
+
 With a render mask (every live call site of the reference) the loss is the masked L1 pair and the reference skips SSIM (B14); without
 one the SSIM term of mapper.py:839-845 is added by dqo_map_ssim_fwd_bwd (three launches; the loss tap is off then — the SSIM gradient
 is an image).  GPU only.
@@ -103,6 +110,28 @@ class FusedMapper:
         # exact sparse Adam (DqoAdamStep.moment_live): 0 = the Gaussian's moments are still identically zero
         self.moment_live = torch.zeros((self.xyz.shape[0],), dtype=torch.uint8, device=device) if sparse_moments else None
         self.step_count = 0
+        # Device-side step state SHARED by every captured graph of this mapper (one graph per frame of a window: capture_window):
+        # DqoAdamStep.step_dev / block_ticket / bias_table.  _expected_step = what step_dev holds while host and device counts agree.
+        i32 = dict(dtype=torch.int32, device=device)
+        self._step_dev = torch.full((1,), 1, **i32)
+        self._ticket = torch.zeros((1,), **i32)
+        self._bias = torch.zeros((8,), dtype=torch.float32, device=device)
+        self._expected_step, self._unsettled = 1, False
+        self._frames = []  # the captured graphs of a window (capture_window); self._g = the one replayed last / by default
+        # The reference keeps TWO clouds and trains one of them per mapping call while it renders one or both (mapper.py:533, 578,
+        # 1119, 1199-1204).  One map here: DqoAdamStep.row_flags / DqoRastInputs.row_flags (bit 0 = not trained, bit 1 = not rendered),
+        # rewritten in place by set_training_rows — a captured graph follows.
+        self.row_flags = torch.zeros((self.P,), dtype=torch.uint8, device=device)
+        self._first_trained_row = 0
+        # `_confidence` (SLAM/gaussian_pointcloud.py:42, 836): += 1 per iteration for every trained row with a non-zero f_dc gradient
+        # (mapper.py:908-910), counted by the Adam launch itself (DqoAdamStep.confidence)
+        self.confidence = torch.zeros((self.P,), dtype=torch.float32, device=device)
+        self.count_confidence = True
+        # the six groups' learning rates in device memory (DqoAdamStep.lr_table): set_lrs rewrites them between two mapping calls
+        self.lr_table = torch.zeros((6,), dtype=torch.float32, device=device)
+        self._write_lr_table()
+        self.history_merge_weight = 0.5  # history_merge_max_weight, configs/base.yaml:54
+        self.init_shs = self.init_confidence = None  # history_stat's other members (begin_mapping_call(history=True))
         self._act_valid = False  # opacity / scales / rotations hold the activations of the current raw parameters
         self.use_attach = bool(attach)
         # The attach loss is a mean over the attach set of the WHOLE map (mapper.py:812-829).  A mapper that holds a shard of the map
@@ -154,11 +183,89 @@ class FusedMapper:
                 raise RuntimeError("set_object_gate: object ids must lie in [0, 64)")
             self.gaussian_object, self.pixel_object, self.per_object_loss = go, po, bool(per_object_loss)
             self.tile_objects = tile_object_sets(po)  # DqoObjectGate.tile_objects: which objects own a pixel of each 16x16 tile
-        if getattr(self, "_g", None) is not None:
-            self._g.stale = True
+        for g in self._graphs():
+            g.stale = True
         return self
 
-    def begin_mapping_call(self, reset_optimizer=True):
+    # ------------------------------------------------------------------ the two clouds, per-call learning rates ---------
+    def _graphs(self):
+        gs = list(getattr(self, "_frames", []))
+        g = getattr(self, "_g", None)
+        if g is not None and all(g is not f for f in gs):
+            gs.append(g)
+        return gs
+
+    _LR_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+    def _write_lr_table(self):
+        # (fill_ carries the python float as a kernel argument: no pageable host copy, no synchronisation)
+        for i, k in enumerate(self._LR_ORDER):
+            self.lr_table[i:i + 1].fill_(float(self.lrs[k]))
+
+    def set_lrs(self, lrs=None, **scale):
+        """The learning rates of the NEXT mapping call, rewritten in device memory (DqoAdamStep.lr_table): captured graphs stay valid.
+        `lrs`: dict over xyz / f_dc / f_rest / opacity / scaling / rotation (missing keys keep their value); `scale`: factors on the
+        current values, e.g. Mapping.global_optimization's  l[0]["lr"] = 0; l[i]["lr"] *= 0.1  (mapper.py:1120-1123) is
+        set_lrs(dict(xyz=0.0), f_dc=0.1, f_rest=0.1, opacity=0.1, scaling=0.1, rotation=0.1).  The bias-correction table of the device
+        step is dropped (it holds products with the old rates)."""
+        if lrs:
+            self.lrs.update({k: float(v) for k, v in lrs.items()})
+        for k, f in scale.items():
+            self.lrs[k] = self.lrs[k] * float(f)
+        self._write_lr_table()
+        self._bias.zero_()
+        return self
+
+    @torch.no_grad()
+    def set_training_rows(self, trainable=None, rendered=None):
+        """Which rows the next mapping call TRAINS and which it RENDERS (bool [P] GPU tensors or None = all).  The reference's two clouds:
+          local_optimize        trains `pointcloud` (unstable), renders cat(unstable, stable)      (mapper.py:533, 578, 1810-1840)
+                                -> set_training_rows(trainable=~stable_mask)
+          global_optimization   trains and renders `stable_pointcloud` alone                        (mapper.py:1119, 1199-1204)
+                                -> set_training_rows(trainable=stable_mask, rendered=stable_mask)
+        A row that is not trained is rendered and back-propagated THROUGH (its list entries shape every pixel it touches) but is no
+        parameter of the call: no gradient row is formed, parameters, moments and confidence stay bit for bit, it is in no attach set.
+        A row that is not rendered is culled by the per-Gaussian forward (and not trained).  Written in place (DqoAdamStep.row_flags /
+        DqoRastInputs.row_flags live in device memory): captured graphs stay valid.  Call before begin_mapping_call (the attach set and
+        history_merge's "first row" follow the trained rows)."""
+        dev = self.device
+        fl = torch.zeros((self.P,), dtype=torch.uint8, device=dev)
+        if trainable is not None:
+            fl |= (~trainable.to(dev).bool().reshape(-1)).to(torch.uint8) * N.ROW_FROZEN
+        if rendered is not None:
+            fl |= (~rendered.to(dev).bool().reshape(-1)).to(torch.uint8) * (N.ROW_HIDDEN | N.ROW_FROZEN)
+        if self.alive is not None:  # a spare row is no Gaussian of the map, whichever camera looks its way
+            fl |= (self.alive == 0).to(torch.uint8) * (N.ROW_HIDDEN | N.ROW_FROZEN)
+        self.row_flags.copy_(fl)
+        # row 0 of the reference's trained cloud: its history weight serves every row's feature / scaling merge (mapper.py:620-637)
+        self._first_trained_row = int(torch.argmax(((fl & N.ROW_FROZEN) == 0).to(torch.uint8)).item())
+        return self
+
+    def trained_rows(self):
+        """bool [P]: the rows the current mapping call trains."""
+        return (self.row_flags & N.ROW_FROZEN) == 0
+
+    @torch.no_grad()
+    def history_merge(self, max_weight=None):
+        """Mapping.history_merge (mapper.py:607-650), the statement that closes every local_optimize call: the trained rows are pulled back
+        towards their state at the start of the call (begin_mapping_call(history=True) took `history_stat`), weighted by the share of
+        their confidence that is older than the call.  One launch (dqo_map_history_merge); the activations are recomputed."""
+        w = self.history_merge_weight if max_weight is None else float(max_weight)
+        if w <= 0:
+            return self
+        if self.init_shs is None or self.init_confidence is None or self.init_shs.shape[0] != self.P:
+            raise RuntimeError("FusedMapper.history_merge: begin_mapping_call(history=True) must have taken history_stat for this map")
+        rot0 = torch.nn.functional.normalize(self.init_rotation)  # history_stat["rotation"] = get_rotation (mapper.py:541)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().dqo_map_history_merge(self.P, self.M, w, self._first_trained_row, N.ptr(self.row_flags), N.ptr(self.init_confidence),
+                                                  N.ptr(self.confidence), N.ptr(self.init_xyz), N.ptr(self.init_shs), N.ptr(self.init_scaling),
+                                                  N.ptr(rot0), N.ptr(self.xyz), N.ptr(self.shs), N.ptr(self.scaling_raw),
+                                                  N.ptr(self.rotation_raw), N.current_stream()))
+        self._act_valid = False
+        self.activate()  # (a captured iteration starts from the activations of the current parameters)
+        return self
+
+    def begin_mapping_call(self, reset_optimizer=True, history=False):
         """Start of one `local_optimize` call (SLAM/multiprocess/mapper.py:531-548): snapshot `init_stat` (the raw parameters the
         attach loss pulls towards, :533-545, and the attach set `sigmoid(opacity) < 0.9`, :812-813) and — reset_optimizer — drop the
         Adam moments, because the reference builds a fresh torch.optim.Adam per call (:548, B13).  Everything is rewritten in place
@@ -167,6 +274,13 @@ class FusedMapper:
         mask = (torch.sigmoid(self.opacity_raw) < 0.9).reshape(-1)
         if self.alive is not None:
             mask &= self.alive.bool()  # (a spare row is no Gaussian of the map)
+        if getattr(self, "row_flags", None) is not None and self.row_flags.shape[0] == P:
+            mask &= (self.row_flags & N.ROW_FROZEN) == 0  # init_stat is the TRAINED cloud's (mapper.py:533-545, 1132-1137)
+        if history:  # history_stat's members that only history_merge reads (mapper.py:535-540)
+            if self.init_shs is not None and self.init_shs.shape[0] == P:
+                self.init_shs.copy_(self.shs), self.init_confidence.copy_(self.confidence)
+            else:
+                self.init_shs, self.init_confidence = self.shs.clone(), self.confidence.clone()
         same = getattr(self, "init_xyz", None) is not None and self.init_xyz.shape[0] == P and self.attach_mask.shape[0] == P
         if same:
             self.init_xyz.copy_(self.xyz), self.init_scaling.copy_(self.scaling_raw), self.init_rotation.copy_(self.rotation_raw)
@@ -185,12 +299,12 @@ class FusedMapper:
             if self.moment_live is not None:
                 self.moment_live.zero_()
             self.step_count = 0
-            if getattr(self, "_g", None) is not None:
-                self._g.step_dev.fill_(1)
-                self._g.expected_step = 1
-                self._g.unsettled = False
-        if getattr(self, "_g", None) is not None and not (same and getattr(self._g, "attach_in_place", False)):
-            self._g.stale = True  # the captured kernel arguments (attach set buffers) were fixed at capture time
+            if getattr(self, "_step_dev", None) is not None:
+                self._step_dev.fill_(1)
+                self._expected_step, self._unsettled = 1, False
+        for g in self._graphs():
+            if not (same and getattr(g, "attach_in_place", False)):
+                g.stale = True  # the captured kernel arguments (attach set buffers) were fixed at capture time
 
     def _count_attach_set(self):
         self.attach_count = int(self.attach_mask.sum().item()) if self.use_attach else 0
@@ -271,6 +385,9 @@ class FusedMapper:
         if self.gaussian_object is not None:
             self.gaussian_object = pad(self.gaussian_object, 0)
         self.attach_mask = pad(self.attach_mask, 0)
+        self.row_flags = pad(self.row_flags, N.ROW_HIDDEN | N.ROW_FROZEN)  # (a spare row: not rendered, not trained)
+        self.confidence = pad(self.confidence, 0.0)
+        self.init_shs = self.init_confidence = None
         self._spare_rows = n
         self._n_spare = int(self.alive.numel() - int(self.alive.sum().item()))  # (host copy of the spare-row count: grow() keeps it up to date)
         self.P = P = P0 + n
@@ -279,7 +396,7 @@ class FusedMapper:
         self.attach_partial = torch.zeros((4 * ((P + 255) // 256),), **f)
         self._attach_n = 0
         self._act_valid = False
-        self._g = None
+        self._g, self._frames = None, []
         return self
 
     @property
@@ -431,6 +548,8 @@ class FusedMapper:
                     self.alive.index_fill_(0, del_rows, 0)
                     self.xyz[del_rows] = self._park_position()
                     self.opacity_raw.index_fill_(0, del_rows, -10.0), self.scaling_raw.index_fill_(0, del_rows, -10.0)
+                    self.row_flags.index_fill_(0, del_rows, N.ROW_HIDDEN | N.ROW_FROZEN)  # a spare row again
+                    self.confidence.index_fill_(0, del_rows, 0.0)
                 self._n_spare += n_del - n_add
                 if n_add:
                     rows = (self.alive == 0).nonzero().reshape(-1)[:n_add]
@@ -439,6 +558,9 @@ class FusedMapper:
                     if self.gaussian_object is not None:
                         self.gaussian_object[rows] = nobj
                     self.alive.index_fill_(0, rows, 1)
+                    # what growth adds is rendered and trained by the next call (the unstable cloud, mapper.py:1438-1466), confidence 0
+                    self.row_flags.index_fill_(0, rows, 0)
+                    self.confidence.index_fill_(0, rows, 0.0)
                     stats["rows"] = rows
                     if stable_mask is not None:
                         # what growth adds belongs to the UNSTABLE cloud (mapper.py:1438-1466) — also when it lands in a row a deleted
@@ -472,6 +594,9 @@ class FusedMapper:
         self.rotation_raw = torch.cat([sel(self.rotation_raw), nrot]).contiguous()
         if self.gaussian_object is not None:
             self.gaussian_object = torch.cat([sel(self.gaussian_object), nobj]).contiguous()
+        self.row_flags = torch.cat([sel(self.row_flags), torch.zeros((nx.shape[0],), dtype=torch.uint8, device=dev)]).contiguous()
+        self.confidence = torch.cat([sel(self.confidence), torch.zeros((nx.shape[0],), dtype=torch.float32, device=dev)]).contiguous()
+        self.init_shs = self.init_confidence = None
         params = self._params()
         n_new = nx.shape[0]
         if new_mapping_call:
@@ -488,7 +613,7 @@ class FusedMapper:
         f = dict(dtype=torch.float32, device=dev)
         self.opacity, self.scales, self.rotations = torch.empty((P, 1), **f), torch.empty((P, 3), **f), torch.empty((P, 4), **f)
         self._act_valid = False
-        self._g = None
+        self._g, self._frames = None, []
         refill = stats.get("in_place") is False  # the map had spare rows and ran out of them: the same number again
         if new_mapping_call:
             self.init_xyz = None  # (sizes changed: begin_mapping_call takes fresh snapshots)
@@ -607,9 +732,15 @@ class FusedMapper:
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
-                loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0, unroll=1):
+                loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0, unroll=1, settings=None, pixel_object=None, frame=None):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
+
+        settings / pixel_object / frame (round 6, the frame set of a mapping call — capture_window drives them): the camera of THIS
+        graph (default: the mapper's), its pixel -> owner map when the object gate is on (default: set_object_gate's), and the slot of
+        the window it fills (None = a single-frame mapper: the graph replaces whatever was captured before).  Every graph has its own
+        context buffers, capacities and outputs; parameters, moments, activations, the device-side step count, the row flags, the
+        confidence counter and the learning-rate table are the mapper's and shared.
 
         The capture fixes two capacities from the state it is taken on: the instance capacity (candidates x capacity_margin)
         and, with tile_buckets, the per-tile list bucket (twice the longest list, power of two).  A replay that outgrows
@@ -630,19 +761,32 @@ class FusedMapper:
         iterations inside one graph follow each other without a gap); self._g.out / self.loss then show the last of them."""
         lib = N.lib()
         dev, P, M = self.device, self.P, self.M
-        st = self.settings
+        st = self.settings if settings is None else _normalised_settings(settings, dev)
+        if settings is not None:  # (the graph's own copies: set_frame rewrites them in place)
+            st = st._replace(bg=st.bg.clone(), viewmatrix=st.viewmatrix.clone(), projmatrix=st.projmatrix.clone(), campos=st.campos.clone())
         H, W = int(st.image_height), int(st.image_width)
+        if (H, W) != (int(self.settings.image_height), int(self.settings.image_width)):
+            raise RuntimeError("FusedMapper.capture: every frame of a mapper has the mapper's image size")
         f = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
         tile_mask = self.tile_mask if tile_mask is None else _checked_tile_mask(tile_mask, dev, H, W)
+        call_kw = dict(tile_mask=tile_mask, capacity_margin=capacity_margin, tile_buckets=tile_buckets, keep_tile_order=keep_tile_order,
+                       loss_tap=loss_tap, fused_tail=fused_tail, list_split=list_split, unroll=unroll, settings=settings,
+                       pixel_object=pixel_object, frame=frame)
+        pix_obj, tile_obj = self.pixel_object, self.tile_objects
+        if pixel_object is not None:
+            if self.gaussian_object is None:
+                raise RuntimeError("FusedMapper.capture: a per-frame pixel_object needs set_object_gate first")
+            pix_obj = torch.as_tensor(pixel_object).to(dev, torch.int32).contiguous().reshape(H, W)
+            tile_obj = tile_object_sets(pix_obj)
         with torch.cuda.device(dev):
-            if getattr(self, "_g", None) is not None:
-                # re-capture (e.g. after an overflow): replays of invalid frames did not advance the device-side step count
-                # (DqoAdamStep.frame_header), the host count assumed they did — _settle_replays takes exactly those back; eager step()
-                # calls since then advanced the host count alone (they never touch g.step_dev) and stay counted
-                self._settle_replays()
-                self._g = None
+            # re-capture (e.g. after an overflow): replays of invalid frames did not advance the device-side step count
+            # (DqoAdamStep.frame_header), the host count assumed they did — _settle_replays takes exactly those back; eager step()
+            # calls since then advanced the host count alone (they never touch the device count) and stay counted
+            self._settle_replays()
+            if frame is None:
+                self._g, self._frames = None, []
             if not self._act_valid:
                 N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
                                              N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
@@ -659,11 +803,17 @@ class FusedMapper:
                 cand, longest = int(last[0] * grown) + 1, int(last[1] * grown) + 1
             else:
                 reuse_probe = False
-                cand, longest = self._probe(tile_mask)
+                cand, longest = self._probe(tile_mask, st, pix_obj, tile_obj)
             self._last_probe = (cand, longest, P)
             cap = int(cand * capacity_margin) + 4096
             g = self._g = type("G", (), {})()
             g.cap = cap
+            g.settings, g.pixel_object, g.tile_objects = st, pix_obj, tile_obj
+            g.frame = frame
+            if frame is not None:
+                while len(self._frames) <= frame:
+                    self._frames.append(None)
+                self._frames[frame] = g
             # fixed per-tile list buckets (DqoRastCtx.tile_bucket_capacity): at least twice the longest list of the current state,
             # a power of two; a tile that outgrows it raises the same overflow flag as running out of instance capacity
             g.bucket = 0
@@ -695,12 +845,14 @@ class FusedMapper:
             # dL_dcolors / dL_dcov3D / dL_dmeans2D have no consumer in the mapping step: NULL = the backward does not store them
             g.grads = dict(means3D=torch.empty((P, 3), **f), sh=torch.empty((P, M, 3), **f),
                            opacity=torch.empty((P, 1), **f), scales=torch.empty((P, 3), **f), rot=torch.empty((P, 4), **f))
-            g.step_dev = torch.full((1,), self.step_count + 1, **i32)
-            g.expected_step = self.step_count + 1  # what step_dev holds while host and device counts agree
-            g.ticket = torch.zeros((1,), **i32)  # DqoAdamStep.block_ticket: the Adam launch advances step_dev itself
-            g.bias = torch.zeros((8,), **f)      # DqoAdamStep.bias_table: the bias corrections, computed once per step
+            # the step state is the mapper's, shared by all its graphs (DqoAdamStep.step_dev: the Adam launch advances it itself through
+            # block_ticket; bias_table: the bias corrections, computed once per step)
+            g.step_dev, g.ticket, g.bias = self._step_dev, self._ticket, self._bias
+            self._step_dev.fill_(self.step_count + 1)
+            self._expected_step = self.step_count + 1
             g.params = dgr._params(st, P, M)
-            g.inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, g.tile_mask)
+            g.inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, g.tile_mask,
+                                   row_flags=self.row_flags)
             o = g.out
             g.outputs = N.DqoRastOutputs(out_color=o[0].data_ptr(), out_depth=o[1].data_ptr(), out_hit_color=o[2].data_ptr(),
                                          out_hit_depth=o[3].data_ptr(), out_hit_color_weight=o[4].data_ptr(),
@@ -729,8 +881,7 @@ class FusedMapper:
                 g.cctx.loss_tap = ctypes.addressof(g.tap)
             g.gate = None
             if self.gaussian_object is not None:
-                g.gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(self.pixel_object),
-                                         tile_objects=N.ptr(self.tile_objects))
+                g.gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(pix_obj), tile_objects=N.ptr(tile_obj))
                 g.cctx.object_gate = ctypes.addressof(g.gate)
                 if self.per_object_loss and not loss_tap:
                     raise RuntimeError("FusedMapper.capture: the per-object loss is computed by the loss tap (loss_tap=True)")
@@ -751,7 +902,9 @@ class FusedMapper:
                                    v_rotation=N.ptr(stt["rotation"][1]), act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales),
                                    act_rotations=N.ptr(self.rotations), radii=o[8].data_ptr(), step_dev=g.step_dev.data_ptr(),
                                    moment_live=N.ptr(self.moment_live), frame_header=g.geom.data_ptr(), block_ticket=g.ticket.data_ptr(),
-                                   bias_table=g.bias.data_ptr(), **self._attach_fields())
+                                   bias_table=g.bias.data_ptr(), row_flags=N.ptr(self.row_flags),
+                                   confidence=N.ptr(self.confidence) if self.count_confidence else None, lr_table=N.ptr(self.lr_table),
+                                   **self._attach_fields())
             # one eager iteration on a side stream (warms every kernel up), then the capture
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
@@ -760,9 +913,7 @@ class FusedMapper:
             torch.cuda.current_stream().wait_stream(side)
             if self.graph_overflowed() and reuse_probe:  # the reused counts were too small after all: measure and start over
                 self._last_probe = None
-                return self.capture(gt_color, gt_depth, render_mask, tile_mask=tile_mask, capacity_margin=capacity_margin,
-                                    tile_buckets=tile_buckets, keep_tile_order=keep_tile_order, loss_tap=loss_tap, reuse_probe=False,
-                                    fused_tail=fused_tail, list_split=list_split, unroll=unroll)
+                return self.capture(gt_color, gt_depth, render_mask, reuse_probe=False, **call_kw)
             if not self.graph_overflowed():  # (an invalid frame is a no-op for the optimiser and its step count)
                 self.step_count += 1
             # the eager iteration left its tile launch order in g.img; the replays keep it (DqoRastCtx.keep_tile_order: the order is
@@ -777,7 +928,132 @@ class FusedMapper:
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
                 for _ in range(g.unroll):
                     self._static_iteration()
-            g.expected_step = self.step_count + 1
+            self._expected_step = self.step_count + 1
+        return self
+
+    # ------------------------------------------------------------------ the frame set of a mapping call -----------------
+    def _snapshot_state(self):
+        return dict(params={k: v.clone() for k, v in self._params().items()},
+                    state={k: (m.clone(), v.clone()) for k, (m, v) in self.state.items()},
+                    live=None if self.moment_live is None else self.moment_live.clone(), step=self.step_count,
+                    conf=self.confidence.clone())
+
+    def _restore_state(self, snap):
+        self._settle_replays()
+        for k, v in self._params().items():
+            v.copy_(snap["params"][k])
+        for k, (m, v) in self.state.items():
+            m.copy_(snap["state"][k][0]), v.copy_(snap["state"][k][1])
+        if self.moment_live is not None:
+            self.moment_live.copy_(snap["live"])
+        self.confidence.copy_(snap["conf"])
+        self.step_count = snap["step"]
+        self._step_dev.fill_(self.step_count + 1)
+        self._expected_step, self._unsettled = self.step_count + 1, False
+        self._bias.zero_()
+        self._act_valid = False
+        self.activate()
+
+    def capture_window(self, frames, **kw):
+        """One captured graph per frame of a mapping call's frame set — the five `processed_frames` of local_optimize (mapper.py:549-555)
+        or the selected keyframes of global_optimization (:1159-1180).  frames: list of dict(gt_color, gt_depth, render_mask=None,
+        tile_mask=None, settings=None, pixel_object=None); kw: capture()'s other arguments.  Each graph owns its context buffers and
+        capacities (a frame's tail clears ITS counters for ITS next replay: DqoRastCtx.frame_prezeroed holds per frame); they share the
+        map, the optimiser state and the device step count, so replay(k) in any order is the reference's loop with its per-iteration
+        frame choice = one graph launch.  The eager iterations the captures run are undone (parameters, moments, confidence, step
+        count are put back): the mapping call starts from the state it was given."""
+        snap = self._snapshot_state()
+        self._settle_replays()
+        self._g, self._frames = None, []
+        for k, fr in enumerate(frames):
+            if k:
+                self._restore_state(snap)  # every frame is sized on the call's initial state
+            self.capture(fr["gt_color"], fr["gt_depth"], fr.get("render_mask"), tile_mask=fr.get("tile_mask"), settings=fr.get("settings"),
+                         pixel_object=fr.get("pixel_object"), frame=k, **kw)
+            torch.cuda.synchronize()
+        self._restore_state(snap)
+        return self
+
+    @staticmethod
+    def window_schedule(n_iters, n_frames, rng, final=False, random_keyframes=False):
+        """The per-iteration frame choice of the reference's loops as a list of frame indices:
+          local_optimize (mapper.py:570-576):   random_index = random.randint(0, len - 1);  if iter > n / 2: random_index = -1
+          global_optimization (:1186-1199):     the same rule unless it is the final pass (`is_final`: random throughout)
+        rng: a random.Random (the reference draws from the global `random` module).  Index -1 = the last frame of the set (the newest
+        processed frame / select_frame[-1])."""
+        out = []
+        for it in range(int(n_iters)):
+            k = rng.randint(0, n_frames - 1)
+            if it > n_iters / 2 and not final and not random_keyframes:
+                k = n_frames - 1
+            out.append(k)
+        return out
+
+    def run_window(self, schedule, check_every=64, capacity_margin=1.5):
+        """The iterations of `schedule` (frame indices, see window_schedule) on the captured frame set: one graph launch each, one small
+        D2H read per `check_every` launches (device step count).  A frame that outgrew its captured capacities made its iterations
+        no-ops for the optimiser (parameters, moments, confidence, step count untouched): that frame is captured again on the current
+        state with `capacity_margin` and the lost iterations are replayed on it at the end of the batch.  Returns the re-captures."""
+        recaptures, i = 0, 0
+        while i < len(schedule):
+            batch = schedule[i:i + check_every]
+            start = self.step_count
+            for k in batch:
+                self.replay(frame=k)
+            lost = (start + len(batch)) - (int(self._step_dev.item()) - 1)
+            if lost > 0:
+                self._settle_replays()
+                bad = [k for k in sorted(set(batch)) if self.graph_overflowed(self._frames[k])]
+                if not bad or recaptures > 8 * max(1, len(self._frames)):
+                    raise RuntimeError("FusedMapper.run_window: the map keeps outgrowing the captured capacities")
+                for k in bad:
+                    g = self._frames[k]
+                    snap = self._snapshot_state()
+                    self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
+                                 tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0,
+                                 loss_tap=g.tap is not None, fused_tail=g.fused_tail, list_split=g.list_split, unroll=g.unroll,
+                                 settings=g.settings, pixel_object=g.pixel_object if self.gaussian_object is not None else None, frame=k)
+                    self._restore_state(snap)
+                    recaptures += 1
+                for j in range(lost):
+                    self.replay(frame=bad[j % len(bad)])
+                torch.cuda.synchronize()
+            i += len(batch)
+        return recaptures
+
+    @torch.no_grad()
+    def set_frame(self, frame, gt_color=None, gt_depth=None, render_mask=None, tile_mask=None, settings=None, pixel_object=None):
+        """New inputs for a captured frame WITHOUT a new capture: the next mapping call's window keeps four of its five frames and every
+        call re-evaluates the masks (mapper.py:549-555).  Everything a graph reads per frame lives in device buffers the capture fixed:
+        the camera's matrices / position / background, the ground-truth images, the render mask, the tile mask, the owner map — they
+        are overwritten in place (same shapes; a frame captured without a render mask cannot get one later, and the scalar intrinsics
+        — image size, tan(fov), principal point, thresholds — are kernel arguments: they must not change).  The captured capacities
+        were sized on the old view: check graph_overflowed(frame) / use run_window, which re-captures a frame that outgrew them."""
+        g = self._frames[frame]
+        if gt_color is not None:
+            g.gt_color.copy_(gt_color)
+        if gt_depth is not None:
+            g.gt_depth.copy_(gt_depth)
+        if render_mask is not None:
+            if g.mask is None:
+                raise RuntimeError("FusedMapper.set_frame: the frame was captured without a render mask")
+            g.mask.copy_(render_mask.to(torch.uint8))
+        if tile_mask is not None:
+            g.tile_mask.copy_(_checked_tile_mask(tile_mask, self.device, int(g.settings.image_height), int(g.settings.image_width)))
+        if settings is not None:
+            new = _normalised_settings(settings, self.device)
+            for name in ("image_height", "image_width", "tanfovx", "tanfovy", "cx", "cy", "sh_degree", "scale_modifier", "opaque_threshold",
+                         "depth_threshold", "normal_threshold", "color_sigma", "T_threshold"):
+                if getattr(new, name) != getattr(g.settings, name):
+                    raise RuntimeError(f"FusedMapper.set_frame: {name} is a captured kernel argument; capture the frame again")
+            for name in ("bg", "viewmatrix", "projmatrix", "campos"):
+                getattr(g.settings, name).copy_(getattr(new, name))
+        if pixel_object is not None:
+            if g.pixel_object is None:
+                raise RuntimeError("FusedMapper.set_frame: the frame was captured without an object gate")
+            po = torch.as_tensor(pixel_object).to(self.device, torch.int32).reshape(g.pixel_object.shape)
+            g.pixel_object.copy_(po)
+            g.tile_objects.copy_(tile_object_sets(g.pixel_object))
         return self
 
     def capture_placed(self, *args, trials=4, probe_replays=12, **kw):
@@ -791,21 +1067,11 @@ class FusedMapper:
         exactly capture()'s own eager iteration, re-run on the kept buffers.  Results do not depend on the placement (bit for bit)."""
         if int(trials) <= 1:
             return self.capture(*args, **kw)
-        snap = dict(params={k: v.clone() for k, v in self._params().items()},
-                    state={k: (m.clone(), v.clone()) for k, (m, v) in self.state.items()},
-                    live=None if self.moment_live is None else self.moment_live.clone(), step=self.step_count)
+        self._settle_replays()  # (the snapshot's step count is the settled one)
+        snap = self._snapshot_state()
 
         def restore():
-            if getattr(self, "_g", None) is not None:
-                self._settle_replays()
-            for k, v in self._params().items():
-                v.copy_(snap["params"][k])
-            for k, (m, v) in self.state.items():
-                m.copy_(snap["state"][k][0]), v.copy_(snap["state"][k][1])
-            if self.moment_live is not None:
-                self.moment_live.copy_(snap["live"])
-            self.step_count = snap["step"]
-            self._act_valid = False
+            self._restore_state(snap)
 
         cands = []
         for t in range(int(trials)):
@@ -822,20 +1088,29 @@ class FusedMapper:
                 self.replay()
             e1.record()
             torch.cuda.synchronize()
+            self._settle_replays()
+            if self.graph_overflowed():  # (an overflowed trial replays no-ops: fast, and worthless)
+                continue
             cands.append((e0.elapsed_time(e1) / probe_replays / self._g.unroll, self._g))
+        if not cands:
+            raise RuntimeError("FusedMapper.capture_placed: every trial overflowed its captured capacities")
         best = min(range(len(cands)), key=lambda i: cands[i][0])
         self.placement_trials_ms = [round(c[0], 4) for c in cands]
         restore()
         self._g = cands[best][1]
+        if self._g.frame is not None:
+            self._frames[self._g.frame] = self._g
         del cands
-        self.activate()       # (the kept graph's last replay left the activations of ITS last state)
         self.step_static()    # capture()'s eager iteration, on the kept buffers
         torch.cuda.synchronize()
         return self
 
-    def _probe(self, tile_mask):
+    def _probe(self, tile_mask, st=None, pixel_object=None, tile_objects=None):
         """(num_candidates, longest tile list) of the current state: one forward on scratch buffers with packed lists."""
-        lib, dev, P, M, st = N.lib(), self.device, self.P, self.M, self.settings
+        lib, dev, P, M = N.lib(), self.device, self.P, self.M
+        st = self.settings if st is None else st
+        if pixel_object is None:
+            pixel_object, tile_objects = self.pixel_object, self.tile_objects
         H, W = int(st.image_height), int(st.image_width)
         f, i32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev), dict(dtype=torch.uint8, device=dev)
         out = [torch.empty((3, H, W), **f), torch.empty((1, H, W), **f), torch.empty((1, H, W), **i32), torch.empty((1, H, W), **i32),
@@ -844,7 +1119,8 @@ class FusedMapper:
         geom = torch.empty((lib.dqo_rast_geom_bytes(P, W, H),), **u8)
         img = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
         params = dgr._params(st, P, M)
-        inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, tile_mask)
+        inputs = dgr._inputs(st, self.xyz, self.shs, self._empty, self.opacity, self.scales, self.rotations, self._empty, tile_mask,
+                             row_flags=self.row_flags)
         outputs = N.DqoRastOutputs(out_color=out[0].data_ptr(), out_depth=out[1].data_ptr(), out_hit_color=out[2].data_ptr(),
                                    out_hit_depth=out[3].data_ptr(), out_hit_color_weight=out[4].data_ptr(),
                                    out_hit_depth_weight=out[5].data_ptr(), out_T=out[6].data_ptr(), n_touched=out[7].data_ptr(),
@@ -854,8 +1130,7 @@ class FusedMapper:
         if self.gaussian_object is not None:
             # the lists of the gated job (the binning drops a pair whose object owns no pixel of the tile): its longest list, not the
             # ungated frame's, sizes the buckets
-            gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(self.pixel_object),
-                                   tile_objects=N.ptr(self.tile_objects))
+            gate = N.DqoObjectGate(gaussian_object=N.ptr(self.gaussian_object), pixel_object=N.ptr(pixel_object), tile_objects=N.ptr(tile_objects))
             cctx.object_gate = ctypes.addressof(gate)
         stream = N.current_stream()
         hdr = N.DqoRastHeader()
@@ -905,19 +1180,21 @@ class FusedMapper:
         N.check(lib.dqo_map_ssim_fwd_bwd(W, H, color_ptr, N.ptr(gt_color), self.ssim_weight, N.ptr(self.ssim_out), N.ptr(self.dL_dcolor), 1,
                                          N.ptr(self.loss), N.ptr(self.ssim_ws), self.ssim_ws.numel(), stream))
 
-    def replay(self):
-        """One mapping iteration (capture(unroll=k): k of them) by replaying the captured graph; outputs are the persistent tensors in
-        self._g.out."""
+    def replay(self, frame=None):
+        """One mapping iteration (capture(unroll=k): k of them) by replaying a captured graph — `frame`: which one of capture_window's
+        (None: the one replayed last / the single-frame mapper's); outputs are the persistent tensors in self._g.out."""
+        if frame is not None:
+            self._g = self._frames[frame]
         g = self._g
         if g.stale:
-            raise RuntimeError("FusedMapper: begin_mapping_call() changed the attach set since capture(); capture again")
-        if g.expected_step != self.step_count + 1:  # eager step() calls in between: resynchronise the device-side step count
+            raise RuntimeError("FusedMapper: the attach set / object gate changed since capture(); capture again")
+        if self._expected_step != self.step_count + 1:  # eager step() calls in between: resynchronise the device-side step count
             self._resync_step_count()
         g.graph.replay()
-        g.unsettled = True
+        self._unsettled = True
         self._attach_n = ((self.P + 255) // 256) * (4 if g.fused_tail else 1)  # (a new mapping call in between had reset it)
-        self.step_count += g.unroll  # (assumes valid frames; capture() re-reads the device-side count after an overflow)
-        g.expected_step = self.step_count + 1
+        self.step_count += g.unroll  # (assumes valid frames; _settle_replays re-reads the device-side count)
+        self._expected_step = self.step_count + 1
         return g.out
 
     def _settle_replays(self):
@@ -926,22 +1203,20 @@ class FusedMapper:
         expected after the last replay is the number of invalid replays — taken back here, BEFORE anything else (an eager step(), a
         re-capture, a resynchronisation) builds on the host count or overwrites the device count.  One 4-byte read, and only when
         replays happened since the last time."""
-        g = getattr(self, "_g", None)
-        if g is None or not getattr(g, "unsettled", False):
+        if not getattr(self, "_unsettled", False):
             return
-        dev_step = int(g.step_dev.item())
-        invalid = int(g.expected_step) - dev_step
+        dev_step = int(self._step_dev.item())
+        invalid = int(self._expected_step) - dev_step
         if invalid > 0:
             self.step_count -= invalid
-        g.expected_step = dev_step
-        g.unsettled = False
+        self._expected_step = dev_step
+        self._unsettled = False
 
     def _resync_step_count(self):
         """Eager step() calls between two replays advanced the host count alone: bring the device count up to it."""
         self._settle_replays()
-        g = self._g
-        g.step_dev.fill_(self.step_count + 1)
-        g.expected_step = self.step_count + 1
+        self._step_dev.fill_(self.step_count + 1)
+        self._expected_step = self.step_count + 1
 
     def run(self, n_iters, check_every=64, capacity_margin=1.5):
         """`n_iters` VALID mapping iterations on the captured graph: replays in batches of `check_every`, one small D2H read per batch
@@ -960,14 +1235,16 @@ class FusedMapper:
                 self.replay()
             # the device-side step count only advances on valid frames: one 4-byte read tells whether ANY replay of the batch was invalid
             # (the header's flag alone would only tell about the last one)
-            if int(self._g.step_dev.item()) - 1 != self.step_count or self.graph_overflowed():
+            if int(self._step_dev.item()) - 1 != self.step_count or self.graph_overflowed():
                 if recaptures > 8:
                     raise RuntimeError("FusedMapper.run: the map keeps outgrowing the captured capacities")
                 g = self._g
                 # (capture() re-reads the device-side step count: the valid replays of this batch stay counted, the others do not)
                 self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
                              tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0, loss_tap=g.tap is not None,
-                             fused_tail=g.fused_tail, list_split=g.list_split)
+                             fused_tail=g.fused_tail, list_split=g.list_split, settings=g.settings if g.settings is not self.settings else None,
+                             pixel_object=g.pixel_object if (self.gaussian_object is not None and g.pixel_object is not self.pixel_object) else None,
+                             frame=g.frame)
                 recaptures += 1
         return recaptures
 
@@ -975,23 +1252,24 @@ class FusedMapper:
         """One iteration over the persistent buffers issued eagerly — exactly the calls the captured graph holds (for per-kernel
         profiling: events cannot be recorded inside a replay)."""
         g = self._g
-        if g.expected_step != self.step_count + 1:
+        if self._expected_step != self.step_count + 1:
             self._resync_step_count()
         with torch.cuda.device(self.device):
             self._static_iteration()
-        g.unsettled = True
+        self._unsettled = True
         self.step_count += 1
-        g.expected_step = self.step_count + 1
+        self._expected_step = self.step_count + 1
         return g.out
 
-    def header(self):
+    def header(self, g=None):
         """Device header of the captured iteration's last forward (one small D2H read, synchronises)."""
-        h = self._g.geom[:32].view(torch.int32).cpu().tolist()
+        h = (self._g if g is None else g).geom[:32].view(torch.int32).cpu().tolist()
         return dict(num_rendered=h[0], num_tiles=h[1], overflow=h[2], max_tile_count=h[3], num_visible=h[4], num_candidates=h[5])
 
-    def graph_overflowed(self):
-        """True if the last replayed iteration produced more instances than the captured capacity (one small D2H read)."""
-        return bool(self._g.geom[:12].view(torch.int32)[2].item())
+    def graph_overflowed(self, g=None):
+        """True if the last replayed iteration (of graph g: a frame of the window; default the current one) produced more instances than
+        the captured capacity (one small D2H read)."""
+        return bool((self._g if g is None else g).geom[:12].view(torch.int32)[2].item())
 
     def _params(self):
         return dict(xyz=self.xyz, shs=self.shs, opacity=self.opacity_raw, scaling=self.scaling_raw, rotation=self.rotation_raw)
@@ -1051,6 +1329,7 @@ class FusedMapper:
                                v_scaling=N.ptr(self.state["scaling"][1]), v_rotation=N.ptr(self.state["rotation"][1]),
                                act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales), act_rotations=N.ptr(self.rotations),
                                radii=N.ptr(out[8]), moment_live=N.ptr(self.moment_live), frame_header=N.ptr(ctx.saved_tensors[8]),
+                               row_flags=N.ptr(self.row_flags), confidence=N.ptr(self.confidence) if self.count_confidence else None,
                                **self._attach_fields())
             N.check(lib.dqo_map_adam_step(ctypes.byref(st), stream))
             self._attach_n = (P + 255) // 256

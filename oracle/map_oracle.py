@@ -282,3 +282,47 @@ def icp_normal_equations(vertex0, vertex1, normal0, normal1, pose10, K, distance
     Jv = J[valid].astype(np.float64)
     rv = res[valid].astype(np.float64)
     return Jv.T @ Jv, Jv.T @ rv, valid
+
+
+def torch_lerp(a, b, w):
+    """aten lerp (torch.lerp): weight < 0.5 ? a + w (b - a) : b - (b - a) (1 - w), elementwise, in the arrays' dtype."""
+    d = b - a
+    return np.where(np.abs(w) < 0.5, a + w * d, b - d * (1 - w))
+
+
+def slerp(v0, v1, t, dot_threshold=0.9995):
+    """/root/reference/SLAM/utils.py:650-709 restated (v0, v1 [P, 4]; t [P, 1]): rows whose normalised dot product is NaN or beyond the
+    threshold in magnitude are torch.lerp'ed, the others sin-weighted — no shortest-arc flip, no renormalisation of the result."""
+    n0 = np.sqrt((v0 * v0).sum(-1, keepdims=True))
+    n1 = np.sqrt((v1 * v1).sum(-1, keepdims=True))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dot = ((v0 / n0) * (v1 / n1)).sum(-1)
+        lerp_rows = np.isnan(dot) | (np.abs(dot) > dot_threshold)
+        th0 = np.arccos(dot)[:, None]
+        s_th0 = np.sin(th0)
+        tht = th0 * t
+        s0, s1 = np.sin(th0 - tht) / s_th0, np.sin(tht) / s_th0
+        out = np.where(lerp_rows[:, None], torch_lerp(v0, v1, t), s0 * v0 + s1 * v1)
+    return out.astype(v0.dtype)
+
+
+def history_merge(hist, cur, max_weight=0.5, dtype=np.float32):
+    """Mapping.history_merge, /root/reference/SLAM/multiprocess/mapper.py:607-650, on ONE cloud (the trained one).  hist / cur: dicts with
+    confidence [P,1], xyz [P,3], features_dc [P,1,3], features_rest [P,M-1,3], scaling [P,3]; hist["rotation"] = the ACTIVATED rotation at
+    the start of the call, cur["rotation_raw"] the raw one now.  Returns dict(xyz, features_dc, features_rest, scaling, rotation) — the
+    new raw parameters.  Reproduces the reference's `history_weight[0]` quirk (:620-637): features and scaling of EVERY row are merged
+    with the FIRST row's weight.  PARITY: the slerp inside is pinned against the imported reference function
+    (tests/golden/make_history_merge_golden.py); the surrounding lerps are the ten statements restated here."""
+    f = lambda a: np.asarray(a, dtype)
+    if max_weight <= 0:
+        return dict(xyz=f(cur["xyz"]), features_dc=f(cur["features_dc"]), features_rest=f(cur["features_rest"]), scaling=f(cur["scaling"]),
+                    rotation=f(cur["rotation_raw"]))
+    w = dtype(max_weight) * f(hist["confidence"]) / (f(cur["confidence"]) + dtype(1e-6))          # [P,1]
+    w0 = w[0]                                                                                      # `history_weight[0]`: shape [1]
+    q = f(cur["rotation_raw"])
+    rot_now = q / np.maximum(np.sqrt((q * q).sum(-1, keepdims=True)), dtype(1e-12))               # get_rotation = F.normalize
+    return dict(xyz=f(hist["xyz"]) * w + (1 - w) * f(cur["xyz"]),
+                features_dc=f(hist["features_dc"]) * w0 + (1 - w0) * f(cur["features_dc"]),
+                features_rest=f(hist["features_rest"]) * w0 + (1 - w0) * f(cur["features_rest"]),
+                scaling=f(hist["scaling"]) * w0 + (1 - w0) * f(cur["scaling"]),
+                rotation=slerp(f(hist["rotation"]), rot_now, 1 - w))
