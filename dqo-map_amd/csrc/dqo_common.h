@@ -376,7 +376,7 @@ __device__ __forceinline__ void dqo_header_from_spread(const DqoGeomLayout& g, i
     uint32_t nv = 0, nc = 0, mx = 0, nt = 0, total = 0;
     for (int j = lane; j < DQO_SPREAD; j += 64) {
         const uint32_t* line = g.spread + (size_t)j * 64;
-        nv += line[0], nc += line[1], mx = max(mx, line[2]), nt += line[3], total += line[4];
+        nv += line[0], nc += line[1], mx = max(mx, line[2]), nt += line[3], total += line[4] + line[5];  // (5: list entries without a gradient slot)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

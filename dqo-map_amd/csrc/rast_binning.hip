@@ -89,7 +89,8 @@ template <bool K1>
 __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P, int gx, const int32_t* __restrict__ tile_mask, DqoGeomLayout g,
                                                                 uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_flag,
                                                                 DqoBinLayout bin, int64_t capacity,
-                                                                const unsigned long long* __restrict__ tile_objects, const DqoK1Raw k1) {
+                                                                const unsigned long long* __restrict__ tile_objects, const DqoK1Raw k1,
+                                                                const uint8_t* __restrict__ row_flags) {
     __shared__ uint32_t s_off[BIN_CHUNK + 1];  // exclusive prefix of the rect areas
     __shared__ uint2 s_rect[BIN_CHUNK];        // packed tile rects
     __shared__ float4 s_con[BIN_CHUNK];        // conic + opacity
@@ -223,7 +224,20 @@ __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P
         if (!one_window) __syncthreads();  // s_bits is rebuilt by the next window
     }
     // ---- tiles_touched + gaussian-major slot allocation: block scan of the live counts, one atomic per block ----
-    const uint32_t my_cnt = s_cnt[tid];
+    // A FROZEN row (DqoRastInputs.row_flags, bucket mode = the captured mapping iteration) is rendered — its list entries are written
+    // below like any other's — but it is no parameter of the mapping call: its instances get NO gradient slots (slot = 0xffffffff in the
+    // list record: every slot-indexed write of the backward is skipped, as it is for a slot beyond the capacity), so the backward's
+    // blend kernel stores no partial gradient record for it and the per-Gaussian tail has nothing to read.
+    const bool no_slots = bin.bucket > 0 && row_flags != nullptr && my_idx < P && (row_flags[my_idx] & DQO_ROW_FROZEN) != 0u;
+    const uint32_t my_cnt = no_slots ? 0u : s_cnt[tid];
+    __shared__ uint8_t s_noslot[BIN_CHUNK];
+    s_noslot[tid] = no_slots ? (uint8_t)1 : (uint8_t)0;
+    if (row_flags != nullptr && bin.bucket > 0) {  // (kernel-uniform) the header's num_rendered stays the sum of the LIST lengths
+        uint32_t nf = no_slots ? s_cnt[tid] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nf += (uint32_t)__shfl_xor((int)nf, off);
+        if (lane == 0 && nf != 0u) atomicAdd(&g.spread[(size_t)((blockIdx.x * (BIN_THREADS / 64) + wave) % DQO_SPREAD) * 64 + 5], nf);
+    }
     uint32_t block_live;
     const uint32_t my_gb = block_exclusive_scan(my_cnt, s_wave, lane, wave, &block_live);
     s_gb[tid] = my_gb;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P
                 if (ok[u]) {
                     const Cand c = decode(w);
                     const uint32_t first = max(s_off[c.gi], win);
-                    slot[u] = base + s_gb[c.gi] + s_prev[c.gi] + popcount_range(s_bits, first - win, w - win);
+                    slot[u] = s_noslot[c.gi] ? 0xffffffffu : base + s_gb[c.gi] + s_prev[c.gi] + popcount_range(s_bits, first - win, w - win);
                     tile[u] = c.tile;
                     gid[u] = dqo_spread_index(chunk0 + c.gi, P);
                     depth[u] = s_xyq[c.gi].w;
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P
             }
 #pragma unroll
             for (int u = 0; u < BIN_FLIGHT; u++) {
-                if (ok[u] && (int64_t)slot[u] < capacity) {
+                if (ok[u] && ((int64_t)slot[u] < capacity || slot[u] == 0xffffffffu)) {
                     if (bin.bucket > 0) {
                         // fixed per-tile buckets: the rank IS the list position (what bin_place_kernel derives from the scanned
                         // ranges in the packed mode); an instance beyond the bucket is dropped — tile_scan_kernel flags the frame
@@ -333,10 +347,10 @@ __global__ __launch_bounds__(256) void bin_place_kernel(DqoGeomLayout g, DqoImag
 }  // namespace
 
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                         int64_t capacity, const unsigned long long* tile_objects, hipStream_t s) {
+                         int64_t capacity, const unsigned long long* tile_objects, hipStream_t s, const uint8_t* row_flags) {
     DqoK1Raw none{};
     DQO_LAUNCH("bin_count_kernel", bin_count_kernel<false>, dim3(dqo_spread_blocks(P)), dim3(BIN_THREADS), s, P, gx, tile_mask, g,
-               img.tile_count, img.tile_flag, bin, capacity, tile_objects, none);
+               img.tile_count, img.tile_flag, bin, capacity, tile_objects, none, row_flags);
     return DQO_OK;
 }
 
@@ -348,7 +362,7 @@ int dqo_launch_bin_count_k1(const DqoView& v, const DqoRastInputs* in, const Dqo
     k1.v = v, k1.means3D = in->means3D, k1.scales = in->scales, k1.rotations = in->rotations, k1.opacities = in->opacities;
     k1.gobj = gobj, k1.radii_out = out->radii, k1.n_touched_out = out->n_touched;
     DQO_LAUNCH("bin_count_kernel", bin_count_kernel<true>, dim3(dqo_spread_blocks(v.P)), dim3(BIN_THREADS), s, v.P, v.gx, in->tile_mask, g,
-               img.tile_count, img.tile_flag, bin, capacity, tile_objects, k1);
+               img.tile_count, img.tile_flag, bin, capacity, tile_objects, k1, v.row_flags);
     return DQO_OK;
 }
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(K1_THREADS, K1_WAVES) void preprocess_kernel(const 
     // raises counters[8], which both header writers fold into header.overflow.
     if (check_prezeroed && blockIdx.x == 0 && tid < DQO_SPREAD) {
         const uint32_t* line = g.spread + (size_t)tid * 64;
-        uint32_t bad = line[2] | line[3] | line[4];
+        uint32_t bad = line[2] | line[3] | line[4] | line[5];
 #pragma unroll
         for (int i = 8; i < 16; i++) bad |= line[i];
         if (tid < 8) bad |= g.counters[tid];
@@ -773,7 +773,7 @@ int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const Dqo
                              const DqoRastOutputs& out, int T, const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s,
                              int64_t header_capacity);
 int dqo_launch_bin_count(int P, int gx, const int32_t* tile_mask, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
-                         int64_t capacity, const unsigned long long* tile_objects, hipStream_t s);
+                         int64_t capacity, const unsigned long long* tile_objects, hipStream_t s, const uint8_t* row_flags);
 int dqo_launch_bin_place(const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int64_t capacity, hipStream_t s);
 
 int dqo_launch_zero_words(uint32_t* p, size_t n_words, hipStream_t s) {
@@ -833,7 +833,7 @@ int dqo_launch_forward_render(const DqoRastParams* p, const DqoRastInputs* in, D
         const unsigned long long* tobj = ctx->object_gate ? reinterpret_cast<const unsigned long long*>(ctx->object_gate->tile_objects) : nullptr;
         int rc = dqo_fuse_k1(p, ctx) ? dqo_launch_bin_count_k1(v, in, out, ctx->object_gate ? ctx->object_gate->gaussian_object : nullptr, g, img,
                                                                bin, cap, tobj, s)
-                                     : dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap, tobj, s);
+                                     : dqo_launch_bin_count(p->P, v.gx, in->tile_mask, g, img, bin, cap, tobj, s, v.row_flags);
         if (rc) return rc;
     }
     // bucket mode with a tile_order kept from an earlier frame on the same image buffer: nothing of tile_scan_kernel is needed
