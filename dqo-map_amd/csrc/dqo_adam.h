@@ -413,21 +413,34 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
 }
 
 // DqoAdamStep.block_ticket: the device-side step count advances inside the launch — every block has read it at its start, so the
-// block that takes the last ticket may bump it (and hands the ticket counter back at zero for the next launch).
+// block that takes the last ticket may bump it (and hands the ticket counters back at zero for the next launch).
+// Two levels (round 6): a block takes a ticket on ONE OF UP TO 64 LINES (blockIdx % lines), the last block of a line takes one of the
+// `lines` tickets of word 0, the last of those advances the count.  A single counter is one address that all ~4 000 blocks of a
+// 500 k map add to, and same-address returning atomics are served one per ~11 ns memory-side: 43 us of queue — hidden while the
+// blocks are long and finish spread out, the kernel's floor when they are short (a mapping call that trains a tenth of the map:
+// 81 -> 58 us, profiles/r06_tail_ticket.txt).
 // (no fence: the only ordering needed is "read of the step count before the ticket", and that load has long been consumed)
+#define DQO_TICKET_LINES 64
+static_assert(DQO_TICKET_WORDS == 16 + 16 * DQO_TICKET_LINES, "DqoAdamStep.block_ticket: include/dqo_raster.h and the kernels disagree");
 __device__ __forceinline__ void adam_take_ticket(const AdamArgs& a) {
     if (a.step_advance != nullptr && threadIdx.x == 0) {
-        if (atomicAdd(a.block_ticket, 1) == (int)gridDim.x - 1) {
-            *a.block_ticket = 0;
-            const int next = *a.step_advance + 1;
-            *a.step_advance = next;
-            if (a.bias_table != nullptr) {  // the next launch's bias corrections, once, instead of once per block / wave there
-                float b[7];
-                adam_bias_compute(a, next, b);
+        const int grid = (int)gridDim.x;
+        const int lines = min(DQO_TICKET_LINES, max(1, grid / 16));
+        const int l = (int)blockIdx.x % lines;
+        const int on_line = (grid - l + lines - 1) / lines;  // blocks b < grid with b % lines == l
+        int* const line = a.block_ticket + 16 + 16 * l;
+        if (atomicAdd(line, 1) != on_line - 1) return;
+        *line = 0;
+        if (atomicAdd(a.block_ticket, 1) != lines - 1) return;
+        *a.block_ticket = 0;
+        const int next = *a.step_advance + 1;
+        *a.step_advance = next;
+        if (a.bias_table != nullptr) {  // the next launch's bias corrections, once, instead of once per block / wave there
+            float b[7];
+            adam_bias_compute(a, next, b);
 #pragma unroll
-                for (int i = 0; i < 7; i++) a.bias_table[i] = b[i];
-                a.bias_table[7] = __int_as_float(next);
-            }
+            for (int i = 0; i < 7; i++) a.bias_table[i] = b[i];
+            a.bias_table[7] = __int_as_float(next);
         }
     }
 }

@@ -577,3 +577,9 @@ int dqo_launch_history_merge(int P, int M, float max_weight, int first_row, cons
                first_row, row_flags, conf0, conf, xyz0, shs0, scaling0, rot0_unit, xyz, shs, scaling_raw, rotation_raw);
     return DQO_OK;
 }
+
+// the one-thread launch that advances the device step count when the Adam launch does not do it itself (DqoAdamStep.block_ticket == NULL)
+int dqo_launch_adam_advance(int32_t* step_dev, const DqoRastHeader* frame_header, hipStream_t s) {
+    DQO_LAUNCH("adam_advance_kernel", adam_advance_kernel, dim3(1), dim3(1), s, step_dev, frame_header);
+    return DQO_OK;
+}

@@ -487,6 +487,7 @@ int dqo_launch_gaussian_rows(const DqoView& v, const DqoGeomLayout& g, const Dqo
 int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin, int T,
                               const float* dL_dcolor, const float* dL_ddepth, DqoGradRec* recs, uint8_t* valid, int64_t capacity,
                               const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s);
+int dqo_launch_adam_advance(int32_t* step_dev, const DqoRastHeader* frame_header, hipStream_t s);
 
 // blend backward + the fused per-Gaussian tail.  The caller (dqo_rast_backward_adam) has checked the arguments.
 int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
@@ -525,5 +526,7 @@ int dqo_launch_backward_adam(const DqoRastParams* p, const DqoRastInputs* in, co
         else DQO_TAIL(false, false);
     }
 #undef DQO_TAIL
+    // (DqoAdamStep.block_ticket == NULL: the count is advanced by a launch of its own, as dqo_map_adam_step does)
+    if (st->step_dev != nullptr && a.step_advance == nullptr) return dqo_launch_adam_advance(st->step_dev, g.header, s);
     return DQO_OK;
 }

@@ -114,9 +114,11 @@ class FusedMapper:
         # DqoAdamStep.step_dev / block_ticket / bias_table.  _expected_step = what step_dev holds while host and device counts agree.
         i32 = dict(dtype=torch.int32, device=device)
         self._step_dev = torch.full((1,), 1, **i32)
-        self._ticket = torch.zeros((1,), **i32)
+        self._ticket = torch.zeros((16 + 16 * 64,), **i32)  # DQO_TICKET_WORDS
         self._bias = torch.zeros((8,), dtype=torch.float32, device=device)
         self._expected_step, self._unsettled = 1, False
+        # DqoAdamStep.block_ticket: the Adam launch advances the device step count itself (False: a one-thread launch behind it does)
+        self.use_block_ticket = True
         self._frames = []  # the captured graphs of a window (capture_window); self._g = the one replayed last / by default
         # The reference keeps TWO clouds and trains one of them per mapping call while it renders one or both (mapper.py:533, 578,
         # 1119, 1199-1204).  One map here: DqoAdamStep.row_flags / DqoRastInputs.row_flags (bit 0 = not trained, bit 1 = not rendered),
@@ -901,8 +903,9 @@ class FusedMapper:
                                    v_shs=N.ptr(stt["shs"][1]), v_opacity=N.ptr(stt["opacity"][1]), v_scaling=N.ptr(stt["scaling"][1]),
                                    v_rotation=N.ptr(stt["rotation"][1]), act_opacity=N.ptr(self.opacity), act_scales=N.ptr(self.scales),
                                    act_rotations=N.ptr(self.rotations), radii=o[8].data_ptr(), step_dev=g.step_dev.data_ptr(),
-                                   moment_live=N.ptr(self.moment_live), frame_header=g.geom.data_ptr(), block_ticket=g.ticket.data_ptr(),
-                                   bias_table=g.bias.data_ptr(), row_flags=N.ptr(self.row_flags),
+                                   moment_live=N.ptr(self.moment_live), frame_header=g.geom.data_ptr(),
+                                   block_ticket=g.ticket.data_ptr() if self.use_block_ticket else None,
+                                   bias_table=g.bias.data_ptr() if self.use_block_ticket else None, row_flags=N.ptr(self.row_flags),
                                    confidence=N.ptr(self.confidence) if self.count_confidence else None, lr_table=N.ptr(self.lr_table),
                                    **self._attach_fields())
             # one eager iteration on a side stream (warms every kernel up), then the capture

@@ -479,6 +479,7 @@ int dqo_icp_normal_equations(int32_t H, int32_t W, const float* vertex0, const f
                              float normal_threshold, float* JtJ, float* JtR, int32_t* valid_count, void* workspace,
                              size_t workspace_bytes, void* hipStream);
 
+#define DQO_TICKET_WORDS (16 + 16 * 64) /* int32 words behind DqoAdamStep.block_ticket */
 typedef struct DqoAdamStep {
     int32_t P, M;      /* Gaussians, SH coefficients per Gaussian (f_dc = coefficient 0, f_rest = the others) */
     int32_t step;      /* 1-based Adam step count */
@@ -525,8 +526,10 @@ typedef struct DqoAdamStep {
      * moments, moment_live and the device step count stay as they were, so the caller can re-capture with a larger capacity and
      * continue from a clean optimiser state. */
     const DqoRastHeader* frame_header;
-    /* Optional, with step_dev: one int32, zero before the first launch (it is zero again after every launch).  The block that
-     * finishes last advances *step_dev inside the Adam launch itself; NULL = a separate one-thread kernel does it afterwards. */
+    /* Optional, with step_dev: DQO_TICKET_WORDS int32 (ABI 5; one word until ABI 4), zero before the first launch (they are zero again
+     * after every launch).  The block that finishes last advances *step_dev inside the Adam launch itself — tickets are taken on up
+     * to 64 lines and then on word 0, so that no single address is hit by every block; NULL = a separate one-thread kernel does it
+     * afterwards. */
     int32_t* block_ticket;
     /* Optional, with step_dev and block_ticket (ABI 3): eight floats, zero before the first launch.  The bias corrections of a step
      * (two double-precision pow() calls + six divisions) are then computed ONCE per step — by the block that advances *step_dev, for the

@@ -172,3 +172,67 @@ def test_shards_of_one_map_add_up_to_the_unsharded_job(env):
         assert torch.equal(pw[ia], sa._params()[k]), k
         assert torch.equal(pw[ib], sb._params()[k]), k
     np.testing.assert_allclose((sa.attach_loss() + sb.attach_loss()).item(), whole.attach_loss().item(), rtol=1e-5)
+
+
+def test_shards_of_one_map_add_up_under_the_window_schedule(env):
+    """The N-invariance of the per-object job holds for the reference's LOOP as well (round 6): three frames — own camera, target and
+    pixel -> owner map each — replayed in the reference's schedule (mapper.py:570-576), a third of the rows frozen (the stable cloud),
+    the confidence counter on.  The whole map against its two object shards: losses add up at every iteration, every Gaussian's
+    parameters AND confidence end bit for bit where they end in the unsharded job."""
+    import random
+    torch = env
+    from dqo_harness import mapping, scenes
+    from dqo_harness.fused_mapping import FusedMapper
+    cam0, sc, go, _ = _scene(P=24000)
+    dev = torch.device("cuda")
+    P = len(go)
+    rng = np.random.default_rng(3)
+    pert = dict(sc)
+    pert["xyz"] = (sc["xyz"] + rng.normal(0, 0.004, sc["xyz"].shape)).astype(np.float32)
+    pert["shs"] = sc["shs"].copy()
+    pert["shs"][:, 0, :] += rng.normal(0, 0.15, (P, 3)).astype(np.float32)
+    cams = [scenes.replica_camera(yaw=12.0 - 3.0 * k, pitch=4.0 + 0.7 * k, pos=(0.3 - 0.08 * k, 0.1, -1.85 + 0.05 * k)) for k in (2, 1, 0)]
+    go_t = torch.tensor(go, device=dev)
+    frames = []
+    for cam in cams:
+        st = mapping.make_settings(cam, dev)
+        with torch.no_grad():  # the owner map of the frame: the object that fixes the pixel's depth in an ungated render of the target
+            t0 = mapping.render(st, mapping.GaussianParams(pert, dev).activated())
+            hit = t0["depth_index_map"][0]
+            po = torch.where(hit >= 0, go_t[hit.long().clamp(min=0)], torch.full_like(hit, -1)).to(torch.int32).contiguous()
+            tgt = mapping.render(st, mapping.GaussianParams(pert, dev).activated(), object_gate=(go_t, po))
+        frames.append(dict(settings=st, gt_color=tgt["render"].clone(), gt_depth=tgt["depth"].clone(), pixel_object=po))
+    objs_a = [0, 2, 5, 7]
+    in_a = np.isin(go, objs_a)
+    all_ids = sorted(set(np.unique(go).tolist()))
+    trainable = rng.uniform(size=P) < 0.67
+    sub = lambda m: {k: (v[m] if hasattr(v, "shape") and v.shape[:1] == (P,) else v) for k, v in sc.items()}
+
+    def build(rows, ids, n_attach=None):
+        fm = FusedMapper(sub(rows), frames[0]["settings"], dev, attach_count_reducer=(None if n_attach is None else (lambda n: n_attach)))
+        fm.set_object_gate(go[rows], frames[0]["pixel_object"])
+        fm.set_training_rows(trainable=torch.tensor(trainable[rows], device=dev))
+        fm.begin_mapping_call(reset_optimizer=True)
+        fr = [dict(f, render_mask=torch.isin(f["pixel_object"], torch.tensor(ids, device=dev, dtype=torch.int32)).to(torch.uint8).contiguous())
+              for f in frames]
+        return fm, fr
+
+    everything = np.ones(P, bool)
+    whole, fw = build(everything, all_ids)
+    n_attach = whole.attach_count
+    assert 0 < n_attach < int(trainable.sum())
+    sa, fa = build(in_a, objs_a, n_attach)
+    sb, fb = build(~in_a, [k for k in all_ids if k not in objs_a], n_attach)
+    for fm, fr in ((whole, fw), (sa, fa), (sb, fb)):
+        fm.capture_window(fr, loss_tap=True, fused_tail=True)
+    sched = FusedMapper.window_schedule(8, 3, random.Random(2))
+    for k in sched:
+        whole.replay(frame=k), sa.replay(frame=k), sb.replay(frame=k)
+        torch.cuda.synchronize()
+        assert not (whole.graph_overflowed() or sa.graph_overflowed() or sb.graph_overflowed())
+        np.testing.assert_allclose((sa.loss[:3].double() + sb.loss[:3].double()).tolist(), whole.loss[:3].double().tolist(), rtol=2e-6)
+    ia, ib = torch.tensor(np.nonzero(in_a)[0], device=dev), torch.tensor(np.nonzero(~in_a)[0], device=dev)
+    for k, pw in whole._params().items():
+        assert torch.equal(pw[ia], sa._params()[k]) and torch.equal(pw[ib], sb._params()[k]), k
+    assert torch.equal(whole.confidence[ia], sa.confidence) and torch.equal(whole.confidence[ib], sb.confidence)
+    assert float(whole.confidence.max()) >= 4 and float(whole.confidence[torch.tensor(~trainable, device=dev)].max()) == 0

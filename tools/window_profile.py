@@ -33,6 +33,7 @@ for cam in cams:
 for frac in fracs:
     fm = FusedMapper(prob["scene"], frames[-1]["settings"], device)
     fm.set_object_gate(prob["gate"][0], frames[-1]["pixel_object"])
+    fm.use_block_ticket = not os.environ.get("WP_NO_TICKET")
     if frac < 1.0:
         g_ = torch.Generator(device="cpu").manual_seed(11)
         fm.set_training_rows(trainable=(torch.rand(fm.P, generator=g_) < frac).to(device))
