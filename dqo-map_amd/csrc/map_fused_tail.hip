@@ -65,6 +65,9 @@ struct AdamGradLds {
     }
 };
 
+#ifndef DQO_TAIL_SH_U
+#define DQO_TAIL_SH_U 4  // float4s per lane and trip of the SH pass
+#endif
 #ifndef DQO_TAIL_WAVES
 #define DQO_TAIL_WAVES 4  // waves per SIMD the register allocation leaves room for (128 VGPRs since the SH row left the chain)
 #endif
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
     const bool vec4 = v.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) | reinterpret_cast<uintptr_t>(a.m_shs) |
                                      reinterpret_cast<uintptr_t>(a.v_shs)) & 15u) == 0u;
     float att_sum;
-    if (vec4) att_sum = adam_passes_tail<ATTACH, TAIL_THREADS, true, 4>(a, s_rows, n_rows, AdamGradLds{s_g, 3 * used});
+    if (vec4) att_sum = adam_passes_tail<ATTACH, TAIL_THREADS, true, DQO_TAIL_SH_U>(a, s_rows, n_rows, AdamGradLds{s_g, 3 * used});
     else att_sum = adam_passes<ATTACH, TAIL_THREADS>(a, s_rows, n_rows, AdamGradLds{s_g, 3 * used});
     if (ATTACH && a.attach_partial != nullptr) {  // fixed-order sum of the attach loss (the reported "scale_loss")
         att_sum = adam_wave_red(att_sum);
