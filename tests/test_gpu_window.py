@@ -337,3 +337,76 @@ def test_set_frame_rewrites_a_captured_frame_in_place(env):
     assert torch.equal(a.confidence, b.confidence) and torch.equal(a.loss, b.loss)
     for x, y in zip(a._g.out, b._g.out):
         assert torch.equal(x, y)
+
+
+def test_run_window_recaptures_a_frame_that_outgrew_its_capacities(env):
+    """run_window(): one frame of the window is captured with room for 5 % of its candidate pairs — its replays are invalid frames, no-ops
+    for the optimiser (parameters, moments, confidence, step count untouched); run_window notices from the device step count, captures
+    THAT frame again with room and replays the lost iterations on it: the call delivers len(schedule) valid iterations, and the
+    frames that were fine keep their graphs."""
+    torch, _ = env
+    from dqo_harness.fused_mapping import FusedMapper
+    P = 12000
+    sc, cams, frames, dev = _window_problem(torch, P, 3, seed=5)
+    fm = FusedMapper(sc, frames[0]["settings"], dev)
+    fm.begin_mapping_call(reset_optimizer=True)
+    fm.capture_window(frames, loss_tap=True, fused_tail=True)
+    good = [fm._frames[0], fm._frames[2]]
+    snap = fm._snapshot_state()
+    f1 = frames[1]
+    fm.capture(f1["gt_color"], f1["gt_depth"], f1["render_mask"], settings=f1["settings"], frame=1, capacity_margin=0.05)  # too small
+    fm._restore_state(snap)
+    assert fm.step_count == 0
+    sched = [0, 1, 2, 1, 1, 0, 2, 1, 0, 2]
+    n_recap = fm.run_window(sched, check_every=4)
+    torch.cuda.synchronize()
+    assert n_recap >= 1 and fm.step_count == len(sched) and int(fm._step_dev.item()) == len(sched) + 1
+    assert fm._frames[0] is good[0] and fm._frames[2] is good[1]
+    assert not any(fm.graph_overflowed(g) for g in fm._frames)
+    conf = fm.confidence.cpu().numpy()
+    assert conf.max() <= len(sched) and conf.max() >= 3
+
+
+def test_in_place_growth_keeps_the_captured_window(env):
+    """A growth step between two mapping calls (FusedMapper.grow with spare rows: in place) under a captured WINDOW: every frame's graph
+    stays valid, the new Gaussians are rendered and trained by the next call (row flags 0, confidence 0), deleted rows become spare rows
+    (hidden + frozen for every camera of the window, whatever side of it they are parked on)."""
+    torch, _ = env
+    import _dqo_native as N
+    from dqo_harness.fused_mapping import FusedMapper
+    P = 12000
+    sc, cams, frames, dev = _window_problem(torch, P, 2, seed=6)
+    fm = FusedMapper(sc, frames[0]["settings"], dev)
+    fm.reserve(2000)
+    assert int((fm.row_flags[P:] == (N.ROW_HIDDEN | N.ROW_FROZEN)).all())
+    fm.begin_mapping_call(reset_optimizer=True)
+    fm.capture_window(frames, loss_tap=True, fused_tail=True, capacity_margin=1.5)
+    graphs = list(fm._frames)
+    for k in (0, 1, 1, 0):
+        fm.replay(frame=k)
+    rng = np.random.default_rng(8)
+    src = rng.choice(P, 700, replace=False)
+    new = dict(xyz=(sc["xyz"][src] + rng.normal(0, 0.02, (700, 3))).astype(np.float32), scales=sc["scales"][src], rotations=sc["rotations"][src],
+               opacity=sc["opacity"][src], shs=sc["shs"][src])
+    delete = torch.zeros(fm.P, dtype=torch.bool, device=dev)
+    delete[torch.tensor(rng.choice(P, 300, replace=False), device=dev)] = True
+    st = fm.grow(new, delete_mask=delete, new_mapping_call=True)
+    assert st["in_place"] and st["deleted"] == 300 and st["added"] > 0
+    assert all(a is b for a, b in zip(fm._frames, graphs)) and not any(g.stale for g in fm._frames)
+    rows = st["rows"]
+    assert int(fm.row_flags[rows].max()) == 0 and float(fm.confidence[rows].abs().max()) == 0
+    gone = delete.clone()
+    gone[rows] = False  # (spare rows are handed out lowest index first: the new Gaussians took some of the rows just freed)
+    assert int(gone.sum()) > 0 or st["added"] >= 300
+    assert int((fm.row_flags[gone] == (N.ROW_HIDDEN | N.ROW_FROZEN)).all()) and float(fm.confidence[delete].abs().max()) == 0
+    before = fm.xyz[rows].clone()
+    for k in (1, 0, 1):
+        fm.replay(frame=k)
+    torch.cuda.synchronize()
+    assert not any(fm.graph_overflowed(g) for g in fm._frames) and fm.step_count == 3
+    moved = (fm.xyz[rows] != before).any(1)
+    seen = fm._frames[1].out[8][rows] > 0
+    assert bool(seen.any()) and bool(moved[seen].float().mean() > 0.9)          # the new Gaussians train
+    spare = fm.alive == 0
+    assert int(fm._frames[1].out[8][spare].abs().max()) == 0 and int(fm._frames[0].out[8][spare].abs().max()) == 0   # spare rows are not rendered
+    assert float(fm.confidence[rows].max()) >= 1
