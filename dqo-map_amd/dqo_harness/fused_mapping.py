@@ -120,6 +120,7 @@ class FusedMapper:
         # DqoAdamStep.block_ticket: the Adam launch advances the device step count itself (False: a one-thread launch behind it does)
         self.use_block_ticket = True
         self._frames = []  # the captured graphs of a window (capture_window); self._g = the one replayed last / by default
+        self._mixed = {}   # (k, m) -> graph of frame k's camera and target under frame m's masks (global_optimization's quirk)
         # The reference keeps TWO clouds and trains one of them per mapping call while it renders one or both (mapper.py:533, 578,
         # 1119, 1199-1204).  One map here: DqoAdamStep.row_flags / DqoRastInputs.row_flags (bit 0 = not trained, bit 1 = not rendered),
         # rewritten in place by set_training_rows — a captured graph follows.
@@ -191,7 +192,7 @@ class FusedMapper:
 
     # ------------------------------------------------------------------ the two clouds, per-call learning rates ---------
     def _graphs(self):
-        gs = list(getattr(self, "_frames", []))
+        gs = [g for g in getattr(self, "_frames", []) if g is not None] + list(getattr(self, "_mixed", {}).values())
         g = getattr(self, "_g", None)
         if g is not None and all(g is not f for f in gs):
             gs.append(g)
@@ -398,7 +399,7 @@ class FusedMapper:
         self.attach_partial = torch.zeros((4 * ((P + 255) // 256),), **f)
         self._attach_n = 0
         self._act_valid = False
-        self._g, self._frames = None, []
+        self._g, self._frames, self._mixed = None, [], {}
         return self
 
     @property
@@ -615,7 +616,7 @@ class FusedMapper:
         f = dict(dtype=torch.float32, device=dev)
         self.opacity, self.scales, self.rotations = torch.empty((P, 1), **f), torch.empty((P, 3), **f), torch.empty((P, 4), **f)
         self._act_valid = False
-        self._g, self._frames = None, []
+        self._g, self._frames, self._mixed = None, [], {}
         refill = stats.get("in_place") is False  # the map had spare rows and ran out of them: the same number again
         if new_mapping_call:
             self.init_xyz = None  # (sizes changed: begin_mapping_call takes fresh snapshots)
@@ -734,7 +735,8 @@ class FusedMapper:
 
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
-                loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0, unroll=1, settings=None, pixel_object=None, frame=None):
+                loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0, unroll=1, settings=None, pixel_object=None, frame=None,
+                short_bucket_margin=1.3):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
 
@@ -775,7 +777,7 @@ class FusedMapper:
         tile_mask = self.tile_mask if tile_mask is None else _checked_tile_mask(tile_mask, dev, H, W)
         call_kw = dict(tile_mask=tile_mask, capacity_margin=capacity_margin, tile_buckets=tile_buckets, keep_tile_order=keep_tile_order,
                        loss_tap=loss_tap, fused_tail=fused_tail, list_split=list_split, unroll=unroll, settings=settings,
-                       pixel_object=pixel_object, frame=frame)
+                       pixel_object=pixel_object, frame=frame, short_bucket_margin=short_bucket_margin)
         pix_obj, tile_obj = self.pixel_object, self.tile_objects
         if pixel_object is not None:
             if self.gaussian_object is None:
@@ -788,7 +790,7 @@ class FusedMapper:
             # calls since then advanced the host count alone (they never touch the device count) and stay counted
             self._settle_replays()
             if frame is None:
-                self._g, self._frames = None, []
+                self._g, self._frames, self._mixed = None, [], {}
             if not self._act_valid:
                 N.check(lib.dqo_map_activate(P, N.ptr(self.opacity_raw), N.ptr(self.scaling_raw), N.ptr(self.rotation_raw),
                                              N.ptr(self.opacity), N.ptr(self.scales), N.ptr(self.rotations), N.current_stream()))
@@ -812,7 +814,9 @@ class FusedMapper:
             g.cap = cap
             g.settings, g.pixel_object, g.tile_objects = st, pix_obj, tile_obj
             g.frame = frame
-            if frame is not None:
+            if isinstance(frame, tuple):  # (camera / target of frame k, masks of frame m): global_optimization's second half
+                self._mixed[frame] = g
+            elif frame is not None:
                 while len(self._frames) <= frame:
                     self._frames.append(None)
                 self._frames[frame] = g
@@ -824,8 +828,10 @@ class FusedMapper:
                 while g.bucket < 2 * longest:
                     g.bucket *= 2
                 # 1024 entries are what the per-tile sort launch reaches: while no list can be longer, the long-list sort launch is
-                # dropped (6 us of launch on a map whose lists are all short) — worth a smaller margin (at least 1.3 x) to stay there
-                if g.bucket == 2048 and 1.3 * longest <= 1024:
+                # dropped (6 us of launch on a map whose lists are all short) — worth a smaller margin (short_bucket_margin, default
+                # 1.3 x the longest list; pass 2.0 to never trade margin for that launch) to stay there.  A tile that outgrows its
+                # bucket flags the frame (graph_overflowed(); run() / run_window() re-capture; the replays in between train nothing).
+                if g.bucket == 2048 and float(short_bucket_margin) * longest <= 1024:
                     g.bucket = 1024
             for name, t_, shape in (("gt_color", gt_color, (3, H, W)), ("gt_depth", gt_depth, (1, H, W))):
                 if t_.dtype != torch.float32 or not t_.is_cuda or not t_.is_contiguous() or tuple(t_.shape) != shape:
@@ -967,7 +973,8 @@ class FusedMapper:
         count are put back): the mapping call starts from the state it was given."""
         snap = self._snapshot_state()
         self._settle_replays()
-        self._g, self._frames = None, []
+        self._g, self._frames, self._mixed = None, [], {}
+        self._window_kw, self._window_frames = dict(kw), list(frames)
         for k, fr in enumerate(frames):
             if k:
                 self._restore_state(snap)  # every frame is sized on the call's initial state
@@ -978,19 +985,40 @@ class FusedMapper:
         return self
 
     @staticmethod
-    def window_schedule(n_iters, n_frames, rng, final=False, random_keyframes=False):
+    def window_schedule(n_iters, n_frames, rng, final=False, random_keyframes=False, global_opt=False):
         """The per-iteration frame choice of the reference's loops as a list of frame indices:
           local_optimize (mapper.py:570-576):   random_index = random.randint(0, len - 1);  if iter > n / 2: random_index = -1
-          global_optimization (:1186-1199):     the same rule unless it is the final pass (`is_final`: random throughout)
+          global_optimization (:1186-1199):     the same draw — but the camera and the target images are taken BEFORE the index is
+                                                overwritten (`frame_input = select_frame[random_index]` at :1188-1190, the `= -1` at
+                                                :1194-1195), only the tile mask and the render mask follow it: in the second half of a
+                                                (non-final) call a RANDOM keyframe is rendered and compared under the LAST keyframe's
+                                                masks.  global_opt=True reproduces that: those entries are pairs (k, n_frames - 1) —
+                                                replay() / run_window() capture such a mixed graph on first use.
         rng: a random.Random (the reference draws from the global `random` module).  Index -1 = the last frame of the set (the newest
-        processed frame / select_frame[-1])."""
+        processed frame / select_frame[-1]); final = the `is_final` pass (random throughout)."""
         out = []
         for it in range(int(n_iters)):
             k = rng.randint(0, n_frames - 1)
             if it > n_iters / 2 and not final and not random_keyframes:
-                k = n_frames - 1
+                k = (k, n_frames - 1) if (global_opt and k != n_frames - 1) else n_frames - 1
             out.append(k)
         return out
+
+    def _graph_of(self, frame):
+        """The captured graph of a schedule entry: a frame index, or a pair (k, m) = frame k's camera and target under frame m's render
+        mask and tile mask (captured on first use from the window's frames, state untouched)."""
+        if not isinstance(frame, tuple):
+            return self._frames[frame]
+        if frame not in self._mixed:
+            k, m = frame
+            fk, fm_ = self._window_frames[k], self._window_frames[m]
+            snap = self._snapshot_state()
+            cur = self._g
+            self.capture(fk["gt_color"], fk["gt_depth"], fm_.get("render_mask"), tile_mask=fm_.get("tile_mask"), settings=fk.get("settings"),
+                         pixel_object=fk.get("pixel_object"), frame=frame, **self._window_kw)
+            self._restore_state(snap)
+            self._g = cur
+        return self._mixed[frame]
 
     def run_window(self, schedule, check_every=64, capacity_margin=1.5):
         """The iterations of `schedule` (frame indices, see window_schedule) on the captured frame set: one graph launch each, one small
@@ -1006,11 +1034,11 @@ class FusedMapper:
             lost = (start + len(batch)) - (int(self._step_dev.item()) - 1)
             if lost > 0:
                 self._settle_replays()
-                bad = [k for k in sorted(set(batch)) if self.graph_overflowed(self._frames[k])]
+                bad = [k for k in sorted(set(batch), key=str) if self.graph_overflowed(self._graph_of(k))]
                 if not bad or recaptures > 8 * max(1, len(self._frames)):
                     raise RuntimeError("FusedMapper.run_window: the map keeps outgrowing the captured capacities")
                 for k in bad:
-                    g = self._frames[k]
+                    g = self._graph_of(k)
                     snap = self._snapshot_state()
                     self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
                                  tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0,
@@ -1032,31 +1060,45 @@ class FusedMapper:
         are overwritten in place (same shapes; a frame captured without a render mask cannot get one later, and the scalar intrinsics
         — image size, tan(fov), principal point, thresholds — are kernel arguments: they must not change).  The captured capacities
         were sized on the old view: check graph_overflowed(frame) / use run_window, which re-captures a frame that outgrew them."""
-        g = self._frames[frame]
-        if gt_color is not None:
-            g.gt_color.copy_(gt_color)
-        if gt_depth is not None:
-            g.gt_depth.copy_(gt_depth)
-        if render_mask is not None:
-            if g.mask is None:
-                raise RuntimeError("FusedMapper.set_frame: the frame was captured without a render mask")
-            g.mask.copy_(render_mask.to(torch.uint8))
-        if tile_mask is not None:
-            g.tile_mask.copy_(_checked_tile_mask(tile_mask, self.device, int(g.settings.image_height), int(g.settings.image_width)))
+        cams = [self._frames[frame]] + [g for (k, m), g in self._mixed.items() if k == frame]    # graphs that render frame's camera / target
+        masks = [self._frames[frame]] + [g for (k, m), g in self._mixed.items() if m == frame]   # graphs that use frame's masks
+        done = set()
+
+        def once(t):  # (graphs of one window share the tensors they were given: write each buffer once)
+            if t.data_ptr() in done:
+                return False
+            done.add(t.data_ptr())
+            return True
+
+        for g in cams:
+            if gt_color is not None and once(g.gt_color):
+                g.gt_color.copy_(gt_color)
+            if gt_depth is not None and once(g.gt_depth):
+                g.gt_depth.copy_(gt_depth)
+        for g in masks:
+            if render_mask is not None:
+                if g.mask is None:
+                    raise RuntimeError("FusedMapper.set_frame: the frame was captured without a render mask")
+                if once(g.mask):
+                    g.mask.copy_(render_mask.to(torch.uint8))
+            if tile_mask is not None and once(g.tile_mask):
+                g.tile_mask.copy_(_checked_tile_mask(tile_mask, self.device, int(g.settings.image_height), int(g.settings.image_width)))
         if settings is not None:
             new = _normalised_settings(settings, self.device)
-            for name in ("image_height", "image_width", "tanfovx", "tanfovy", "cx", "cy", "sh_degree", "scale_modifier", "opaque_threshold",
-                         "depth_threshold", "normal_threshold", "color_sigma", "T_threshold"):
-                if getattr(new, name) != getattr(g.settings, name):
-                    raise RuntimeError(f"FusedMapper.set_frame: {name} is a captured kernel argument; capture the frame again")
-            for name in ("bg", "viewmatrix", "projmatrix", "campos"):
-                getattr(g.settings, name).copy_(getattr(new, name))
+            for g in cams:
+                for name in ("image_height", "image_width", "tanfovx", "tanfovy", "cx", "cy", "sh_degree", "scale_modifier", "opaque_threshold",
+                             "depth_threshold", "normal_threshold", "color_sigma", "T_threshold"):
+                    if getattr(new, name) != getattr(g.settings, name):
+                        raise RuntimeError(f"FusedMapper.set_frame: {name} is a captured kernel argument; capture the frame again")
+                for name in ("bg", "viewmatrix", "projmatrix", "campos"):
+                    getattr(g.settings, name).copy_(getattr(new, name))
         if pixel_object is not None:
-            if g.pixel_object is None:
-                raise RuntimeError("FusedMapper.set_frame: the frame was captured without an object gate")
-            po = torch.as_tensor(pixel_object).to(self.device, torch.int32).reshape(g.pixel_object.shape)
-            g.pixel_object.copy_(po)
-            g.tile_objects.copy_(tile_object_sets(g.pixel_object))
+            for g in cams:
+                if g.pixel_object is None:
+                    raise RuntimeError("FusedMapper.set_frame: the frame was captured without an object gate")
+                if once(g.pixel_object):
+                    g.pixel_object.copy_(torch.as_tensor(pixel_object).to(self.device, torch.int32).reshape(g.pixel_object.shape))
+                    g.tile_objects.copy_(tile_object_sets(g.pixel_object))
         return self
 
     def capture_placed(self, *args, trials=4, probe_replays=12, **kw):
@@ -1187,7 +1229,7 @@ class FusedMapper:
         """One mapping iteration (capture(unroll=k): k of them) by replaying a captured graph — `frame`: which one of capture_window's
         (None: the one replayed last / the single-frame mapper's); outputs are the persistent tensors in self._g.out."""
         if frame is not None:
-            self._g = self._frames[frame]
+            self._g = self._graph_of(frame)
         g = self._g
         if g.stale:
             raise RuntimeError("FusedMapper: the attach set / object gate changed since capture(); capture again")

@@ -314,6 +314,23 @@ def test_global_optimisation_trains_and_renders_the_stable_cloud_alone(env):
         _check_iteration(s0, s1, it + 1, stable, grads, fm.lrs, sub_of_row, report)
         assert np.array_equal(s0["xyz"], s1["xyz"])  # lr 0 (mapper.py:1120)
     print("global optimisation", report)
+    # the reference's second half (mapper.py:1188-1204): a RANDOM keyframe's camera and target under the LAST keyframe's masks
+    sched = FusedMapper.window_schedule(12, 2, random.Random(3), global_opt=True)
+    assert all(not isinstance(k, tuple) for k in sched[:7]) and (0, 1) in sched[7:] and all(k in (1, (0, 1)) for k in sched[7:]), sched
+    fm.set_frame(0, render_mask=base_masks[0]), fm.set_frame(1, render_mask=base_masks[1])
+    twin = FusedMapper(sc, frames[0]["settings"], dev)
+    twin.set_training_rows(trainable=st_t, rendered=st_t)
+    twin.set_lrs(dict(fm.lrs))
+    for k in twin._params():
+        twin._params()[k].copy_(fm._params()[k])
+    twin.begin_mapping_call(reset_optimizer=True), fm.begin_mapping_call(reset_optimizer=True)
+    mixed = dict(frames[0], render_mask=frames[1]["render_mask"], tile_mask=frames[1].get("tile_mask"))
+    twin.capture_window([mixed], loss_tap=True, fused_tail=True)      # frame 0's camera and images, frame 1's masks — captured directly
+    fm.replay(frame=(0, 1)), twin.replay(frame=0)
+    torch.cuda.synchronize()
+    assert (0, 1) in fm._mixed and not fm.graph_overflowed() and torch.equal(fm.loss, twin.loss)
+    for k in fm._params():
+        assert torch.equal(fm._params()[k], twin._params()[k]), k
 
 
 def test_set_frame_rewrites_a_captured_frame_in_place(env):
