@@ -45,6 +45,81 @@ __device__ __forceinline__ HitEval eval_hit(const float3 ray, const float4 n_np)
 
 constexpr int FWD_THREADS = 64;
 
+// ---- lane masks as scalar values (round 6) ----
+// The entry loop below keeps every per-pixel PREDICATE of forward.cu:750-842 (pixel unfinished, depth fixed, valid, blend, finish, new
+// maximum) as a 64-bit lane mask in a scalar register pair: a compare writes its mask straight into the pair (VOP3 v_cmp), masks are
+// combined on the scalar unit, and a select reads the pair (v_cndmask).  Written as C++ bools / 0-1 floats the same statements cost 50
+// VALU instructions per (wave, entry) step — the compiler materialises ballots as v_cndmask + v_cmp, keeps `finished` / `depth fixed`
+// as floats that are multiplied in, and moves the wave-uniform LDS address into a VGPR before every read; in mask form a step is 37.
+// Every value that reaches an output is produced by the same IEEE operation on the same operands as before.
+typedef unsigned long long lanemask;
+#define DQO_CMP_F(name, op, ca, cb)                                                                \
+    __device__ __forceinline__ lanemask name(float a, float b) {                                   \
+        lanemask m;                                                                                \
+        asm(op " %0, %1, %2" : "=s"(m) : ca(a), cb(b));                                            \
+        return m;                                                                                  \
+    }
+// (_sv / _vs: that operand is wave-uniform and read from a scalar register — a loop-invariant threshold then costs no v_mov per trip)
+DQO_CMP_F(m_le_sv, "v_cmp_le_f32", "s", "v")    // a <= b (ordered)
+DQO_CMP_F(m_ge_vs, "v_cmp_ge_f32", "v", "s")    // a >= b
+DQO_CMP_F(m_gt, "v_cmp_gt_f32", "v", "v")       // a >  b
+DQO_CMP_F(m_nlt_vs, "v_cmp_nlt_f32", "v", "s")  // !(a < b): true for NaN, like the C++ negation
+#undef DQO_CMP_F
+__device__ __forceinline__ lanemask m_ge0(float b) {  // 0 >= b
+    lanemask m;
+    asm("v_cmp_ge_f32 %0, 0, %1" : "=s"(m) : "v"(b));
+    return m;
+}
+__device__ __forceinline__ lanemask m_lt_half(float b) {  // 0.5 < b
+    lanemask m;
+    asm("v_cmp_lt_f32 %0, 0.5, %1" : "=s"(m) : "v"(b));
+    return m;
+}
+__device__ __forceinline__ lanemask m_ne_i(int a, int b) {
+    lanemask m;
+    asm("v_cmp_ne_u32 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+// m ? t : f
+__device__ __forceinline__ float sel_f(lanemask m, float t, float f) {
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel0_f(lanemask m, float t) {  // m ? t : 0
+    float r;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(t), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t sel_u(lanemask m, uint32_t t, uint32_t f) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+// LDS reads at a byte address held in a VGPR (+ an immediate offset): one address register serves a whole record
+typedef float dqo_lf4 __attribute__((ext_vector_type(4)));
+typedef int dqo_li2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 lds_ld4(uint32_t a) {
+    const dqo_lf4 t = *reinterpret_cast<const __attribute__((address_space(3))) dqo_lf4*>((uintptr_t)a);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ int2 lds_ld2i(uint32_t a) {
+    const dqo_li2 t = *reinterpret_cast<const __attribute__((address_space(3))) dqo_li2*>((uintptr_t)a);
+    return make_int2(t.x, t.y);
+}
+__device__ __forceinline__ void lds_st1i(uint32_t a, int x) {
+    *reinterpret_cast<__attribute__((address_space(3))) int*>((uintptr_t)a) = x;
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// dqo_power (dqo_cull.h) on a conic whose A and C arrive multiplied by -0.5: scaling by a power of two commutes with every rounding,
+// so (A' dx) dx + (C' dy) dy - (B dx) dy is bit for bit -0.5 (A dx dx + C dy dy) - B dx dy, one multiply shorter
+__device__ __forceinline__ float fwd_power_pre(float Ah, float B, float Ch, float dx, float dy) {
+#pragma clang fp contract(off)
+    return (Ah * dx * dx + Ch * dy * dy) - B * dx * dy;
+}
+
 // DqoLossTap, forward half: this wave's share of the masked loss sums from the values it has just written for its 64 pixels, added to
 // the frame's 64-bit counters (one set per spread line) with fire-and-forget atomics — nothing waits for them; the backward's blend
 // kernel, a kernel boundary later, reads the totals (dqo_tap_totals).  A first version finished the loss here (the wave with the last
@@ -120,9 +195,11 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
 // The products are grouped by chunk instead of strictly front to back, so T differs from the serial order's in the last bits (and a
 // pixel sitting exactly on a threshold may fall on the other side): splitting is opt-in (DqoRastCtx.list_split), not a default.
 //
-// LDS: one block of FWD_BLK float4 per wave — the compaction buffers of its chunk; with SEGS > 1 the same block holds the wave's
+// LDS: one block of FWD_BLK float4 per wave — the compacted entries of its chunk; with SEGS > 1 the same block holds the wave's
 // merge record at the end (a wave only ever writes its own block), and SEGS * 64 more float4 behind the blocks the pass-1 results.
-constexpr int FWD_BLK = 4 * FWD_THREADS - FWD_THREADS / 4;  // 3 float4 tables + 3 int tables of 64 entries = 240 float4 = 3840 B
+// one 64-byte record per compacted entry — conic (A, C pre-multiplied by -0.5) + opacity | xy, depth, object id | rgb, smax | id,
+// list position + 1 — and an id table for the chunk's n_touched atomics: 4352 B
+constexpr int FWD_BLK = 4 * FWD_THREADS + FWD_THREADS / 4;
 constexpr int PART_STRIDE = FWD_BLK * 4;                    // floats per wave block
 constexpr int PART_WORDS = 14;                              // merge record of one (run, pixel): 13 x 64 floats <= PART_STRIDE
 static_assert(PART_WORDS * FWD_THREADS <= PART_STRIDE, "the merge record lives in the wave's own LDS block");
@@ -131,12 +208,9 @@ template <bool GATE, int SEGS, bool PF>
 __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                                                const DqoRastOutputs& out, const DqoTapDev& tap, const DqoGateDev& gate, const int tile,
                                                const int quad, const int wave, const int lane, float4* const lds, const int skip_over) {
-    float4* const s_co = lds + wave * FWD_BLK;
-    float4* const s_xy = s_co + FWD_THREADS;
-    float4* const s_rgb = s_xy + FWD_THREADS;
-    int* const s_id = reinterpret_cast<int*>(s_rgb + FWD_THREADS);
-    int* const s_pos = s_id + FWD_THREADS;
-    int* const s_half = s_pos + FWD_THREADS;
+    float4* const s_ent = lds + wave * FWD_BLK;                                  // entry k: s_ent[4 k .. 4 k + 3]
+    int* const s_idt = reinterpret_cast<int*>(s_ent + 4 * FWD_THREADS);          // entry k's Gaussian index
+    const uint32_t ent_addr = lds_addr_of(s_ent);
     float* const s_part = reinterpret_cast<float*>(lds);  // run j, word k, lane l: s_part[j * PART_STRIDE + k * 64 + l]
 
     const int tile_x = tile % v.gx, tile_y = tile / v.gx;
@@ -198,9 +272,11 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     const float qx0 = (float)(tile_x * DQO_TILE + (quad & 1) * 8), qy0 = (float)(tile_y * DQO_TILE + (quad >> 1) * 8);
     const float pixfx = (float)px, pixfy = (float)py;
     const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
-    float pix_gate = (inside && (!GATE || owner >= 0)) ? 1.f : 0.f;   // 0 = this pixel is finished (outside the image; no owner)
-    float nohit = 1.f;                 // 0 = the pixel's depth has been fixed by an opaque hit
+    const float static_gate = (inside && (!GATE || owner >= 0)) ? 1.f : 0.f;   // 0 = this pixel starts finished (outside the image; no owner)
+    lanemask alive_m = __builtin_amdgcn_ballot_w64(static_gate != 0.f);        // pixels that are not finished
+    lanemask fixed_m = 0ull;                                                   // pixels whose depth has been fixed by an opaque hit
     const float hit_thr = fmaxf(v.opaque_thr, 1.0f / 255.0f);
+    const float thr255 = 1.0f / 255.0f, T_thr = v.T_thr;
     float T = 1.0f, end_T = 1.0f;
     uint32_t last_contributor = 0, hit_pos = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -211,46 +287,42 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 
     const int chunks_all = (n + FWD_THREADS - 1) / FWD_THREADS;
     // the chunk in flight (written by the chunk loops below, read by entries())
-    int cnt = 0;                       // compacted entries of the chunk
-    unsigned long long live_m = 0ull;  // compacted entries of this chunk that were live (wave-uniform)
-    bool all_done = false;             // wave-uniform: none of the wave's pixels is unfinished
-    uint32_t wmax_pos = 0;             // SEGS > 1: list position of the entry that holds color_weight_max
-    // per-entry results of compacted entry k: was it live for this quadrant (bit k of live_m), and how many of the
-    // quadrant's pixels saw it with T' > 0.5 (s_half[k]; n_touched, forward.cu:833-835, quirk B8)
+    int cnt = 0;          // compacted entries of the chunk
+    // per-entry result, word 14 of the entry's record: how many of the quadrant's pixels saw it with T' > 0.5 (n_touched,
+    // forward.cu:833-835, quirk B8) | its row code << 8 (0: the entry was not live for this quadrant)
+    uint32_t wmax_pos = 0;  // SEGS > 1: list position of the entry that holds color_weight_max
     auto entries = [&]() {
+        const uint32_t ea0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent_addr);
         // PF: the next entry's records are read from LDS while this one is blended (a read one past the chunk's last entry stays
         // inside the wave's own block and is never used)
-        float4 xy_pf = make_float4(0.f, 0.f, 0.f, 0.f), co_pf = xy_pf, cs_pf = xy_pf;
-        int id_pf = 0, pos_pf = 0;
-        if (PF) xy_pf = s_xy[0], co_pf = s_co[0], cs_pf = s_rgb[0], id_pf = s_id[0], pos_pf = s_pos[0];
-        for (int k = 0; k < cnt && !all_done; k++) {
-            const float4 xy_cur = PF ? xy_pf : s_xy[k], co_cur = PF ? co_pf : s_co[k];
-            const float4 cs_now = cs_pf;
-            const int id_now = id_pf, pos_now = pos_pf;
-            if (PF) xy_pf = s_xy[k + 1], co_pf = s_co[k + 1], cs_pf = s_rgb[k + 1], id_pf = s_id[k + 1], pos_pf = s_pos[k + 1];
-            // ---- per-pixel update (forward.cu:750-842), arithmetic gating instead of per-lane control flow ----
-            // gate = 0 for a finished pixel, nohit = 0 once its depth is fixed: multiplying by them keeps the lane's
-            // predicates in VGPRs (a lane mask that lives across the loop costs scalar bookkeeping in every trip).  An
-            // entry that is not valid for a pixel acts on it with alpha = 0: T (1 - 0) = T, weight 0.
+        float4 xy_pf = make_float4(0.f, 0.f, 0.f, 0.f), co_pf = xy_pf;
+        if (PF) co_pf = lds_ld4(ea0), xy_pf = lds_ld4(ea0 + 16);
+        for (int k = 0; k < cnt && alive_m != 0ull; k++) {
+            // the record address: formed on the scalar unit, moved into ONE vector register; the loads carry the field offsets
+            uint32_t ea = ea0 + ((uint32_t)k << 6);
+            asm("" : "+v"(ea));
+            const float4 co_cur = PF ? co_pf : lds_ld4(ea), xy_cur = PF ? xy_pf : lds_ld4(ea + 16);
+            if (PF) co_pf = lds_ld4(ea + 64), xy_pf = lds_ld4(ea + 80);
+            // ---- per-pixel update (forward.cu:750-842) ----
             const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
-            const float power = dqo_power(co_cur.x, co_cur.y, co_cur.z, dx, dy);
+            const float power = fwd_power_pre(co_cur.x, co_cur.y, co_cur.z, dx, dy);
             const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
+            // forward.cu:763-772 (and the pixel is not finished): power <= 0, alpha >= 1/255
+            lanemask valid_m = m_ge0(power) & m_le_sv(thr255, alpha) & alive_m;
             // (object gate, mixed quadrants only: the entry acts on the pixels of its own object)
-            const bool other = GATE && mixed && __float_as_int(xy_cur.w) != owner;
-            const float a_g = (power <= 0.0f && !other) ? alpha * pix_gate : 0.f;
-            const bool valid = a_g >= 1.0f / 255.0f;  // forward.cu:763-772 (and the pixel is not finished)
-            const unsigned long long valid_m = __builtin_amdgcn_ballot_w64(valid);
+            if (GATE && mixed) valid_m &= ~m_ne_i(__float_as_int(xy_cur.w), owner);
             if (valid_m != 0ull) {
-                const uint32_t contributor = (uint32_t)(PF ? pos_now : s_pos[k]);
-                const float4 cs = PF ? cs_now : s_rgb[k];
-                const int gid = PF ? id_now : s_id[k];
-                const float a_v = valid ? alpha : 0.f;
-                const bool newhit = a_v * nohit >= hit_thr;  // valid, no depth yet, alpha >= opaque_threshold
-                if (__builtin_amdgcn_ballot_w64(newhit) != 0ull) {
+                const float4 cs = lds_ld4(ea + 32);
+                const int2 ip = lds_ld2i(ea + 48);
+                const int gid = ip.x;
+                const uint32_t contributor = (uint32_t)ip.y;
+                const float a_v = sel0_f(valid_m, alpha);  // an entry that is not valid for a pixel acts on it with alpha = 0
+                const lanemask hit_m = m_ge_vs(a_v, hit_thr) & ~fixed_m;  // valid, no depth yet, alpha >= opaque_threshold
+                if (hit_m != 0ull) {
                     // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
                     const float4 n_np = g.normal_c[gid];
                     const float raw_smax = g.point_c[gid].w;
-                    if (newhit) {
+                    if ((hit_m >> lane) & 1ull) {
                         const HitEval h = eval_hit(ray, n_np);
                         hit_id = gid;
                         hit_depth_weight = alpha * T;
@@ -260,38 +332,32 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
                         // the backward repeats the test with the raw scales (backward.cu:1009-1016): decide it here once
                         const bool plane_b = depth_distance <= v.depth_thr * raw_smax && angle_distance >= v.normal_thr;
                         hit_pos = contributor | (plane_b ? 0x80000000u : 0u);
-                        nohit = 0.f;
                     }
+                    fixed_m |= hit_m;
                 }
                 const float test_T = T * (1.f - a_v);  // == T when the entry is not valid for this pixel
-                const bool blend = valid && !(test_T < v.T_thr);       // forward.cu:818-840
-                const bool finish = valid && !blend && nohit == 0.f;   // forward.cu:813-817: done, T NOT updated
-                const float w = blend ? a_v * T : 0.f;
+                const lanemask nlt_m = m_nlt_vs(test_T, T_thr);
+                const lanemask blend_m = valid_m & nlt_m;             // forward.cu:818-840
+                const lanemask finish_m = valid_m & ~nlt_m & fixed_m;  // forward.cu:813-817: done, T NOT updated
+                const float w = sel0_f(blend_m, a_v * T);
                 C0 += cs.x * w;
                 C1 += cs.y * w;
                 C2 += cs.z * w;
-                const bool newmax = blend && w > color_weight_max;
-                color_weight_max = newmax ? w : color_weight_max;
-                hit_color_id = newmax ? gid : hit_color_id;
-                if (SEGS > 1) wmax_pos = newmax ? contributor : wmax_pos;  // (the waves' maxima are merged by list position)
-                last_contributor = blend ? contributor : last_contributor;
-                end_T = blend ? test_T : end_T;
-                T = finish ? T : test_T;  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
-                pix_gate = finish ? 0.f : pix_gate;
+                const lanemask newmax_m = blend_m & m_gt(w, color_weight_max);
+                color_weight_max = sel_f(newmax_m, w, color_weight_max);
+                hit_color_id = (int)sel_u(newmax_m, (uint32_t)gid, (uint32_t)hit_color_id);
+                if (SEGS > 1) wmax_pos = sel_u(newmax_m, contributor, wmax_pos);  // (the waves' maxima are merged by list position)
+                last_contributor = sel_u(blend_m, contributor, last_contributor);
+                end_T = sel_f(blend_m, test_T, end_T);
+                T = sel_f(finish_m, T, test_T);  // keeps decaying below T_thr until an opaque hit appears (forward.cu:841)
+                alive_m &= ~finish_m;
                 // live for the backward: some pixel of the quadrant saw the entry with alpha >= 1/255 while unfinished — a
                 // superset of "blended it or took it as its depth hit" (equal except when every such pixel is saturated
                 // below T_threshold), so the backward never misses a pair it has work for.  The per-entry results are
-                // wave-uniform: the live flag goes into a scalar mask, the n_touched count into LDS (uniform store).
-                // (the compare writes its lane mask straight into a scalar pair: through __builtin_amdgcn_ballot_w64 the
-                // compiler materialises the predicate as 0/1 and compares it again)
-                const float t_half = blend ? test_T : 0.f;
-                unsigned long long half_m;
-                asm volatile("v_cmp_lt_f32 %0, 0.5, %1" : "=s"(half_m) : "v"(t_half));
-                // ... and with it WHICH 16-lane rows (4x4 pixel blocks, dqo_lane_x / _y) saw the entry: the backward's rows walk their
-                // own sub-lists
-                s_half[k] = (int)__popcll(half_m) | (int)(dqo_row_code(valid_m) << 8);
-                live_m |= 1ull << k;
-                all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;
+                // wave-uniform: n_touched count | WHICH 16-lane rows (4x4 pixel blocks, dqo_lane_x / _y) saw the entry (the backward's
+                // rows walk their own sub-lists), one word of the entry's record.
+                const lanemask half_m = blend_m & m_lt_half(test_T);
+                lds_st1i(ea + 56, (int)__popcll(half_m) | (int)(dqo_row_code(valid_m) << 8));
             }
         }
     };
@@ -305,21 +371,24 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         cnt = (int)__popcll(rm);
         const int myk = (int)__popcll(rm & ((1ull << lane) - 1ull));
         if (reach) {
-            s_co[myk] = co;
-            s_xy[myk] = xy;
-            s_rgb[myk] = cs_me;
-            s_id[myk] = id;
-            s_pos[myk] = pos + 1;  // the reference's running counter `contributor` = list position + 1
+            float4* const e = s_ent + 4 * myk;
+            e[0] = make_float4(-0.5f * co.x, co.y, -0.5f * co.z, co.w);  // (fwd_power_pre)
+            e[1] = xy;
+            e[2] = cs_me;
+            // (the reference's running counter `contributor` = list position + 1; the result word starts at "not live")
+            *reinterpret_cast<int4*>(e + 3) = make_int4(id, pos + 1, 0, 0);
+            s_idt[myk] = id;
         }
         return myk;
     };
     // what the chunk leaves behind: one scattered integer atomic per touched Gaussian, and the live byte of every list position
     // (coalesced 64-byte store)
     auto chunk_results = [&](int pos, bool reach, int myk) {
-        const int half_k = ((live_m >> lane) & 1ull) ? (s_half[lane] & 0xff) : 0;
-        if (half_k > 0) atomicAdd(&out.n_touched[s_id[lane]], half_k);
+        const int* const res = reinterpret_cast<const int*>(s_ent) + 14;  // entry k: res[16 k]
+        const int half_k = lane < cnt ? (res[16 * lane] & 0xff) : 0;
+        if (half_k > 0) atomicAdd(&out.n_touched[s_idt[lane]], half_k);
         // live byte = the entry's row code (0: no pixel of the quadrant has work for it)
-        if (pos < n) live[pos] = (reach && ((live_m >> myk) & 1ull)) ? (uint8_t)((s_half[myk] >> 8) & 0xf) : (uint8_t)0;
+        if (pos < n) live[pos] = reach ? (uint8_t)((res[16 * myk] >> 8) & 0xf) : (uint8_t)0;
     };
 
     // prologue: loads of the wave's first chunk (chunk `wave`; SEGS == 1: chunk 0)
@@ -333,8 +402,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         cs_nx = g.rgb_smax[id_nx];
     }
     if (SEGS == 1) {
-        all_done = __builtin_amdgcn_ballot_w64(pix_gate != 0.f) == 0ull;
-        for (int c = 0; c < chunks_all && !all_done; c++) {  // a finished quadrant never looks at the entries further back
+        for (int c = 0; c < chunks_all && alive_m != 0ull; c++) {  // a finished quadrant never looks at the entries further back
             const int pos = c * FWD_THREADS + lane;
             const int id = id_nx;
             const float4 co = co_nx, xy = xy_nx, cs_me = cs_nx;
@@ -351,14 +419,12 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             }
             bool reach;
             const int myk = compact(pos, id, co, xy, cs_me, reach);
-            live_m = 0ull;
             if (cnt > 0) entries();
             chunk_results(pos, reach, myk);
         }
     } else {
         // ---- rounds of SEGS chunks, chunk r * SEGS + w to wave w ----
         float* const s_ph = reinterpret_cast<float*>(lds + SEGS * FWD_BLK);  // [round parity][wave][P | H][lane]
-        const float static_gate = pix_gate;
         float Tg = 1.f;     // transmittance at the start of the round (every wave computes the same bits)
         bool hitg = false;  // the depth was fixed before the round
         float T_last = 1.f; // running T behind the last chunk of this wave that the pixel entered unfinished
@@ -384,9 +450,9 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             bool H = false;
 #pragma unroll 2
             for (int k = 0; k < cnt; k++) {
-                const float4 xy_cur = s_xy[k], co_cur = s_co[k];
+                const float4 xy_cur = s_ent[4 * k + 1], co_cur = s_ent[4 * k];
                 const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
-                const float power = dqo_power(co_cur.x, co_cur.y, co_cur.z, dx, dy);
+                const float power = fwd_power_pre(co_cur.x, co_cur.y, co_cur.z, dx, dy);
                 const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
                 const bool other = GATE && mixed && __float_as_int(xy_cur.w) != owner;
                 const float a_g = (power <= 0.0f && !other) ? alpha * static_gate : 0.f;
@@ -411,11 +477,9 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             // pass 2: the blend of the chunk from that state.  A pixel is finished before the chunk iff T_in < T_threshold and a hit
             // lies before it (forward.cu:813-817: it finishes at the first valid entry at or behind both)
             T = T_in;
-            nohit = h_in ? 0.f : 1.f;
-            pix_gate = (h_in && T_in < v.T_thr) ? 0.f : static_gate;
-            const bool alive_in = pix_gate != 0.f;
-            all_done = __builtin_amdgcn_ballot_w64(alive_in) == 0ull;
-            live_m = 0ull;
+            fixed_m = __builtin_amdgcn_ballot_w64(h_in);
+            const bool alive_in = static_gate != 0.f && !(h_in && T_in < v.T_thr);
+            alive_m = __builtin_amdgcn_ballot_w64(alive_in);
             if (cnt > 0) entries();
             chunk_results(pos, reach, myk);
             if (alive_in && c < chunks_all) T_last = T, last_alive = c;
