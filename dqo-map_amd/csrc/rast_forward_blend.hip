@@ -113,6 +113,39 @@ __device__ __forceinline__ void lds_st1i(uint32_t a, int x) {
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
+// The quadrant's own footprint test (dqo_splat_hits_rect + dqo_q_threshold, dqo_cull.h) with v_rcp_f32 / v_log_f32 in place of the two
+// IEEE divisions and logf: ~40 instructions shorter per (quadrant, entry).  Still conservative — an entry is dropped only if the bound
+// on q over the quadrant exceeds the 1/255 cut-off by dqo_cull.h's margin (0.05 + 1 % in q), against which one ulp in 1 / C or 1e-6 in
+// the logarithm is nothing: q is stationary at the minimiser the reciprocal feeds — so every dropped entry is one the walk would have
+// found `valid` for no pixel: the outputs, live bytes and n_touched cannot tell the two tests apart.  (The BINNING keeps the IEEE form:
+// its two passes must take bit-identical decisions, and its lists are compared against the oracle's.)
+__device__ __forceinline__ bool fwd_hits_quadrant(float mx, float my, float A, float B, float C, float opacity, float x0, float y0,
+                                                  float x1, float y1) {
+#pragma clang fp contract(off)
+    const float qthr = 2.0f * __logf(255.0f * fmaxf(opacity, 1e-30f));
+    if (qthr < 0.f) return false;  // opacity < 1/255: alpha < 1/255 even at the centre
+    const float dx0 = x0 - mx, dx1 = x1 - mx, dy0 = y0 - my, dy1 = y1 - my;
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;  // centre inside: q_min = 0
+    float qmin = 3.0e38f;
+    {
+        const float invC = __builtin_amdgcn_rcpf(C);
+        float dy = fminf(dy1, fmaxf(dy0, -B * dx0 * invC));
+        qmin = fminf(qmin, A * dx0 * dx0 + 2.0f * B * dx0 * dy + C * dy * dy);
+        dy = fminf(dy1, fmaxf(dy0, -B * dx1 * invC));
+        qmin = fminf(qmin, A * dx1 * dx1 + 2.0f * B * dx1 * dy + C * dy * dy);
+    }
+    {
+        const float invA = __builtin_amdgcn_rcpf(A);
+        float dx = fminf(dx1, fmaxf(dx0, -B * dy0 * invA));
+        qmin = fminf(qmin, A * dx * dx + 2.0f * B * dx * dy0 + C * dy0 * dy0);
+        dx = fminf(dx1, fmaxf(dx0, -B * dy1 * invA));
+        qmin = fminf(qmin, A * dx * dx + 2.0f * B * dx * dy1 + C * dy1 * dy1);
+    }
+    const float ddx = fmaxf(fabsf(dx0), fabsf(dx1)), ddy = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float tmax = fabsf(A) * ddx * ddx + 2.0f * fabsf(B) * ddx * ddy + fabsf(C) * ddy * ddy;
+    const float margin = 0.05f + 0.01f * qthr + 4.0e-6f * tmax;
+    return !(qmin > qthr + margin);  // NaN-safe: keeps the entry
+}
 // dqo_power (dqo_cull.h) on a conic whose A and C arrive multiplied by -0.5: scaling by a power of two commutes with every rounding,
 // so (A' dx) dx + (C' dy) dy - (B dx) dy is bit for bit -0.5 (A dx dx + C dy dy) - B dx dy, one multiply shorter
 __device__ __forceinline__ float fwd_power_pre(float Ah, float B, float Ch, float dx, float dy) {
@@ -201,7 +234,7 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
 // list position + 1 — and an id table for the chunk's n_touched atomics: 4352 B
 constexpr int FWD_BLK = 4 * FWD_THREADS + FWD_THREADS / 4;
 constexpr int PART_STRIDE = FWD_BLK * 4;                    // floats per wave block
-constexpr int PART_WORDS = 14;                              // merge record of one (run, pixel): 13 x 64 floats <= PART_STRIDE
+constexpr int PART_WORDS = 15;                              // merge record of one (run, pixel): 15 x 64 floats <= PART_STRIDE
 static_assert(PART_WORDS * FWD_THREADS <= PART_STRIDE, "the merge record lives in the wave's own LDS block");
 
 template <bool GATE, int SEGS, bool PF>
@@ -281,6 +314,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     uint32_t last_contributor = 0, hit_pos = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float depth_ = 0.f;
+    float hit_zc = 0.f, hit_smax = 0.f;  // of the entry that fixed the pixel's depth: its view depth, its (modified) largest scale
     int hit_id = -1, hit_color_id = -1;
     float color_weight_max = -1.f, hit_depth_weight = 0.f;
     uint8_t* live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;  // this quadrant's live bytes of this tile's segment
@@ -319,20 +353,15 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
                 const float a_v = sel0_f(valid_m, alpha);  // an entry that is not valid for a pixel acts on it with alpha = 0
                 const lanemask hit_m = m_ge_vs(a_v, hit_thr) & ~fixed_m;  // valid, no depth yet, alpha >= opaque_threshold
                 if (hit_m != 0ull) {
-                    // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth
-                    const float4 n_np = g.normal_c[gid];
-                    const float raw_smax = g.point_c[gid].w;
-                    if ((hit_m >> lane) & 1ull) {
-                        const HitEval h = eval_hit(ray, n_np);
-                        hit_id = gid;
-                        hit_depth_weight = alpha * T;
-                        const float angle_distance = fabsf(h.den);
-                        const float depth_distance = fabsf(h.hit_z - xy_cur.z);
-                        depth_ = (depth_distance <= cs.w * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : xy_cur.z;
-                        // the backward repeats the test with the raw scales (backward.cu:1009-1016): decide it here once
-                        const bool plane_b = depth_distance <= v.depth_thr * raw_smax && angle_distance >= v.normal_thr;
-                        hit_pos = contributor | (plane_b ? 0x80000000u : 0u);
-                    }
+                    // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth.  Only what the step
+                    // alone knows is kept here (five selects); the ray / surfel-plane intersection with its double-precision division
+                    // and its two gathers runs ONCE per pixel behind the walk (finish_hit) — inside the loop it ran once per distinct
+                    // hit entry of the quadrant, each time behind a vmcnt(0) wait that also drained the next chunk's prefetch
+                    hit_id = (int)sel_u(hit_m, (uint32_t)gid, (uint32_t)hit_id);
+                    hit_depth_weight = sel_f(hit_m, alpha * T, hit_depth_weight);
+                    hit_zc = sel_f(hit_m, xy_cur.z, hit_zc);
+                    hit_smax = sel_f(hit_m, cs.w, hit_smax);
+                    hit_pos = sel_u(hit_m, contributor, hit_pos);
                     fixed_m |= hit_m;
                 }
                 const float test_T = T * (1.f - a_v);  // == T when the entry is not valid for this pixel
@@ -365,7 +394,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     // the chunk's cull test and compaction into LDS; returns the lane's slot among the survivors (reach: this lane's entry survived)
     auto compact = [&](int pos, int id, const float4& co, const float4& xy, const float4& cs_me, bool& reach) {
         // which entries of this chunk can reach this quadrant at all (conservative, dqo_cull.h); compact them into LDS
-        reach = pos < n && dqo_splat_hits_rect(xy.x, xy.y, co.x, co.y, co.z, dqo_q_threshold(co.w), qx0, qy0, qx0 + 7.f, qy0 + 7.f);
+        reach = pos < n && fwd_hits_quadrant(xy.x, xy.y, co.x, co.y, co.z, co.w, qx0, qy0, qx0 + 7.f, qy0 + 7.f);
         if (GATE) reach = reach && ((present >> (__float_as_int(xy.w) & 63)) & 1ull) != 0ull;
         const unsigned long long rm = __builtin_amdgcn_ballot_w64(reach);
         cnt = (int)__popcll(rm);
@@ -493,7 +522,8 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         rec[3 * FWD_THREADS] = color_weight_max, rec[4 * FWD_THREADS] = __int_as_float(hit_color_id);
         rec[5 * FWD_THREADS] = __uint_as_float(last_contributor), rec[6 * FWD_THREADS] = end_T;
         rec[7 * FWD_THREADS] = __int_as_float(hit_id), rec[8 * FWD_THREADS] = __uint_as_float(hit_pos);
-        rec[9 * FWD_THREADS] = depth_, rec[10 * FWD_THREADS] = hit_depth_weight;
+        rec[9 * FWD_THREADS] = hit_zc, rec[10 * FWD_THREADS] = hit_depth_weight;
+        rec[14 * FWD_THREADS] = hit_smax;
         rec[11 * FWD_THREADS] = T_last, rec[12 * FWD_THREADS] = __int_as_float(last_alive);
         rec[13 * FWD_THREADS] = __uint_as_float(wmax_pos);
         __syncthreads();
@@ -501,7 +531,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         C0 = C1 = C2 = 0.f;
         color_weight_max = -1.f, hit_color_id = -1, wmax_pos = 0;
         last_contributor = 0, end_T = 1.f;
-        hit_id = -1, hit_pos = 0, depth_ = 0.f, hit_depth_weight = 0.f;
+        hit_id = -1, hit_pos = 0, hit_zc = 0.f, hit_smax = 0.f, hit_depth_weight = 0.f;
         T = 1.f, last_alive = -1;
         for (int j = 0; j < SEGS; j++) {
             const float* q = s_part + j * PART_STRIDE + lane;
@@ -516,10 +546,25 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             if (hp != 0u && (hit_pos == 0u || (hp & 0x7fffffffu) < (hit_pos & 0x7fffffffu))) {
                 // (one wave holds the hit: the chunks behind it start with the depth fixed)
                 hit_pos = hp, hit_id = __float_as_int(q[7 * FWD_THREADS]);
-                depth_ = q[9 * FWD_THREADS], hit_depth_weight = q[10 * FWD_THREADS];
+                hit_zc = q[9 * FWD_THREADS], hit_depth_weight = q[10 * FWD_THREADS], hit_smax = q[14 * FWD_THREADS];
             }
             const int la = __float_as_int(q[12 * FWD_THREADS]);
             if (la > last_alive) last_alive = la, T = q[11 * FWD_THREADS];  // the running transmittance behind the last chunk entered
+        }
+    }
+    // finish_hit (forward.cu:784-810, once per pixel): the hit entry's surfel plane against this pixel's ray
+    if (__builtin_amdgcn_ballot_w64(hit_id != -1) != 0ull) {
+        const int hid = max(hit_id, 0);  // (pixels without a hit read Gaussian 0 and discard it: one round of loads for the wave)
+        const float4 n_np = g.normal_c[hid];
+        const float raw_smax = g.point_c[hid].w;
+        if (hit_id != -1) {
+            const HitEval h = eval_hit(ray, n_np);
+            const float angle_distance = fabsf(h.den);
+            const float depth_distance = fabsf(h.hit_z - hit_zc);
+            depth_ = (depth_distance <= hit_smax * v.depth_thr && angle_distance >= v.normal_thr) ? h.hit_z : hit_zc;
+            // the backward repeats the test with the raw scales (backward.cu:1009-1016): decide it here once
+            const bool plane_b = depth_distance <= v.depth_thr * raw_smax && angle_distance >= v.normal_thr;
+            hit_pos |= plane_b ? 0x80000000u : 0u;
         }
     }
     const float oc0 = C0 + T * v.bg[0], oc1 = C1 + T * v.bg[1], oc2 = C2 + T * v.bg[2];  // running T, not end_T (quirk B2, forward.cu:852)
@@ -550,8 +595,14 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 #ifndef FWD_WPB
 #define FWD_WPB 1  // waves (= quadrants of ONE tile) per workgroup; independent of each other either way
 #endif
+#ifndef FWD_PF
+#define FWD_PF false  // the next entry's records read one step ahead (a register rotation)
+#endif
+#ifndef FWD_MINW
+#define FWD_MINW 6
+#endif
 template <bool GATE>
-__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? 6 : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? FWD_MINW : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                                             DqoBinLayout bin, DqoRastOutputs out,
                                                                                             const DqoTapDev tap, const DqoGateDev gate,
                                                                                             const int64_t header_capacity) {
@@ -567,7 +618,7 @@ __global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? 6 : 1) void blend_for
     const int T8 = (v.gx * v.gy + 7) / 8;
     const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
     if (tile_u == 0xffffffffu) return;  // unused slot
-    blend_quadrant<GATE, 1, false>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, wave, (int)(threadIdx.x & 63), lds, 0x7fffffff);
+    blend_quadrant<GATE, 1, FWD_PF>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, wave, (int)(threadIdx.x & 63), lds, 0x7fffffff);
 }
 
 // DqoRastCtx.list_split: blocks of SPLIT_RUNS waves.  The first SPLIT_GRID blocks take the long lists (longer than list_split entries: the
