@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 __device__ __forceinline__ bool fwd_hits_quadrant(float mx, float my, float A, float B, float C, float opacity, float x0, float y0,
                                                   float x1, float y1) {
 #pragma clang fp contract(off)
-    const float qthr = 2.0f * __logf(255.0f * fmaxf(opacity, 1e-30f));
+    const float qthr = 2.0f * (0.693147181f * __builtin_amdgcn_logf(255.0f * fmaxf(opacity, 1e-30f)));  // v_log_f32 = log2; the argument is a normal number
     if (qthr < 0.f) return false;  // opacity < 1/255: alpha < 1/255 even at the centre
     const float dx0 = x0 - mx, dx1 = x1 - mx, dy0 = y0 - my, dy1 = y1 - my;
     if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;  // centre inside: q_min = 0
@@ -420,16 +420,32 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         if (pos < n) live[pos] = reach ? (uint8_t)((res[16 * myk] >> 8) & 0xf) : (uint8_t)0;
     };
 
-    // prologue: loads of the wave's first chunk (chunk `wave`; SEGS == 1: chunk 0)
-    int id_nx = 0;
+    // prologue: loads of the wave's first chunk (chunk `wave`; SEGS == 1: chunk 0).  The list is read TWO chunks ahead of the walk: a
+    // chunk's records are gathered by Gaussian index, so its indices must have arrived before the gathers can be issued — with one
+    // chunk of lookahead the wave sat on a vmcnt(0) at the head of every chunk (index load -> wait -> three gathers); now the head of
+    // chunk c issues the gathers of chunk c + 1 from indices loaded a whole chunk ago, and the index load of chunk c + 2.
+    constexpr int STRIDE = SEGS * FWD_THREADS;  // list positions between two chunks of this wave
+    int id_nx = 0, id_n2 = 0;
     float4 co_nx = make_float4(0.f, 0.f, 0.f, 0.f), xy_nx = co_nx, cs_nx = co_nx;
     const int first = (SEGS > 1 ? wave : 0) * FWD_THREADS + lane;
+    if (first < n) id_nx = (int)bin.point_list[range.x + first];
+    if (first + STRIDE < n) id_n2 = (int)bin.point_list[range.x + first + STRIDE];
     if (first < n) {
-        id_nx = (int)bin.point_list[range.x + first];
         co_nx = g.conic_opacity[id_nx];
         xy_nx = g.xy_depth[id_nx];
         cs_nx = g.rgb_smax[id_nx];
     }
+    // the next chunk's gathers (indices: id_n2, here since the previous chunk's head) and the index load of the chunk behind it
+    auto fetch_ahead = [&](const int pos) {
+        const int pn = pos + STRIDE;
+        if (pn < n) {
+            id_nx = id_n2;
+            co_nx = g.conic_opacity[id_nx];
+            xy_nx = g.xy_depth[id_nx];
+            cs_nx = g.rgb_smax[id_nx];
+        }
+        if (pn + STRIDE < n) id_n2 = (int)bin.point_list[range.x + pn + STRIDE];
+    };
     if (SEGS == 1) {
         for (int c = 0; c < chunks_all && alive_m != 0ull; c++) {  // a finished quadrant never looks at the entries further back
             const int pos = c * FWD_THREADS + lane;
@@ -437,15 +453,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             const float4 co = co_nx, xy = xy_nx, cs_me = cs_nx;
             // issue the next chunk's loads now; they complete while this chunk is blended (all three records: a gather left for the
             // compaction below would sit, unhidden, between the cull test and the first entry of every chunk)
-            {
-                const int pn = pos + FWD_THREADS;
-                if (pn < n) {
-                    id_nx = (int)bin.point_list[range.x + pn];
-                    co_nx = g.conic_opacity[id_nx];
-                    xy_nx = g.xy_depth[id_nx];
-                    cs_nx = g.rgb_smax[id_nx];
-                }
-            }
+            fetch_ahead(pos);
             bool reach;
             const int myk = compact(pos, id, co, xy, cs_me, reach);
             if (cnt > 0) entries();
@@ -463,15 +471,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             const int pos = c * FWD_THREADS + lane;
             const int id = id_nx;
             const float4 co = co_nx, xy = xy_nx, cs_me = cs_nx;
-            {
-                const int pn = pos + SEGS * FWD_THREADS;  // the wave's chunk of the next round
-                if (pn < n) {
-                    id_nx = (int)bin.point_list[range.x + pn];
-                    co_nx = g.conic_opacity[id_nx];
-                    xy_nx = g.xy_depth[id_nx];
-                    cs_nx = g.rgb_smax[id_nx];
-                }
-            }
+            fetch_ahead(pos);  // the wave's chunk of the next round
             bool reach;
             const int myk = compact(pos, id, co, xy, cs_me, reach);  // (a chunk past the end of the list: cnt = 0)
             // pass 1: the chunk's product of (1 - alpha) and "holds an opaque hit", for a pixel that enters it unfinished
