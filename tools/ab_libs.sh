@@ -5,7 +5,7 @@ L=dqo-map_amd/lib
 libs="$1"; flags="$2"; shift; shift
 cp $L/libdqoraster.so $L/ab_keep.so
 for c in ${@:-3}; do
-  for i in 1 2 3; do
+  for i in $(seq 1 ${AB_REPS:-3}); do
     for v in $libs; do
       cp $L/$v $L/libdqoraster.so
       timeout -k 10 300 python bench.py --cfg $c --growth-every 0 --steps 200 --warmup 20 --no-cpu-baseline --no-pmc --no-aux --no-selfcheck $flags 2>/dev/null \
