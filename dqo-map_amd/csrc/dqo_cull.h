@@ -61,6 +61,14 @@ __device__ __forceinline__ float dqo_power(float A, float B, float C, float dx, 
     return -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
 }
 
+// dqo_power on a conic whose A and C arrive multiplied by -0.5 (the blend kernels pre-scale them where an entry's record goes into
+// LDS): scaling by a power of two commutes with every rounding, so (A' dx) dx + (C' dy) dy - (B dx) dy is bit for bit
+// -0.5 (A dx dx + C dy dy) - B dx dy, one multiply per (pixel, entry) pair shorter
+__device__ __forceinline__ float dqo_power_pre(float Ah, float B, float Ch, float dx, float dy) {
+#pragma clang fp contract(off)
+    return (Ah * dx * dx + Ch * dy * dy) - B * dx * dy;
+}
+
 // exp(power) of the blend loops (forward.cu:770, backward.cu:943).  One v_exp_f32 (|rel err| ~1e-7 for power in [-5.6, 0],
 // the only range that survives the 1/255 cut) instead of the ~15-instruction libm expf; forward and backward share it so
 // the backward reproduces the forward's alpha bit for bit.

@@ -629,7 +629,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
             if (lane < cnt) {
                 const uint32_t slot_j = g_slot;
                 float4* e = reinterpret_cast<float4*>(ent_base + lane * (R_ENT_W * 4));
-                e[0] = g_co;
+                e[0] = make_float4(-0.5f * g_co.x, g_co.y, -0.5f * g_co.z, g_co.w);  // (dqo_power_pre)
                 e[1] = make_float4(g_xy.x, g_xy.y, g_xy.w, __int_as_float(g_pos));
                 e[2] = make_float4(g_cs.x, g_cs.y, g_cs.z, __uint_as_float(slot_j));
             }
@@ -689,7 +689,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
                         const int c0 = __float_as_int(xy.w);  // 0-based list position == the reference's `contributor` after its --
                         // ---- predicated per-pixel gradient terms (backward.cu:932-994): the statements of the union walk below ----
                         const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-                        const float power = dqo_power(co.x, co.y, co.z, dx, dy);
+                        const float power = dqo_power_pre(co.x, co.y, co.z, dx, dy);
                         const float Gx = dqo_gauss(power);
                         const float alpha_x = fminf(0.99f, co.w * Gx);
                         const bool did_color = (c0 < last_contrib) & (power <= 0.0f) & (alpha_x >= 1.0f / 255.0f) & (!GATE || __float_as_int(xy.z) == owner);
@@ -782,7 +782,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
                 // A pixel that did not blend this entry runs the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) = T
                 // and S + 0 * (c - S) = S leave its state untouched bit for bit, and all its gradient terms are exact zeros.
                 const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-                const float power = dqo_power(co.x, co.y, co.z, dx, dy);
+                const float power = dqo_power_pre(co.x, co.y, co.z, dx, dy);
                 const float Gx = dqo_gauss(power);
                 const float alpha_x = fminf(0.99f, co.w * Gx);
                 const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f && (!GATE || __float_as_int(xy.w) == owner);
@@ -843,7 +843,8 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
             s_id[myk] = id;
             s_pos[myk] = pos;
             s_slot[myk] = bin.slot_list[range.x + pos];
-            s_co[myk] = g.conic_opacity[id];
+            const float4 co_g = g.conic_opacity[id];
+            s_co[myk] = make_float4(-0.5f * co_g.x, co_g.y, -0.5f * co_g.z, co_g.w);  // (dqo_power_pre)
             s_xy[myk] = g.xy_depth[id];
             s_rgb[myk] = g.rgb_smax[id];
         }
@@ -888,7 +889,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
                 const float4 co = s_co[k], xy = s_xy[k], cs = s_rgb[k];
                 const int c0 = s_pos[k];
                 const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-                const float power = dqo_power(co.x, co.y, co.z, dx, dy);
+                const float power = dqo_power_pre(co.x, co.y, co.z, dx, dy);
                 const float alpha_x = fminf(0.99f, co.w * dqo_gauss(power));
                 const bool did_color = c0 < last_contrib && power <= 0.0f && alpha_x >= 1.0f / 255.0f && (!GATE || __float_as_int(xy.w) == owner);
                 const float alpha = did_color ? alpha_x : 0.f;

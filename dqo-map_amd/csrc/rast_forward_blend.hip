@@ -146,12 +146,6 @@ __device__ __forceinline__ bool fwd_hits_quadrant(float mx, float my, float A, f
     const float margin = 0.05f + 0.01f * qthr + 4.0e-6f * tmax;
     return !(qmin > qthr + margin);  // NaN-safe: keeps the entry
 }
-// dqo_power (dqo_cull.h) on a conic whose A and C arrive multiplied by -0.5: scaling by a power of two commutes with every rounding,
-// so (A' dx) dx + (C' dy) dy - (B dx) dy is bit for bit -0.5 (A dx dx + C dy dy) - B dx dy, one multiply shorter
-__device__ __forceinline__ float fwd_power_pre(float Ah, float B, float Ch, float dx, float dy) {
-#pragma clang fp contract(off)
-    return (Ah * dx * dx + Ch * dy * dy) - B * dx * dy;
-}
 
 // DqoLossTap, forward half: this wave's share of the masked loss sums from the values it has just written for its 64 pixels, added to
 // the frame's 64-bit counters (one set per spread line) with fire-and-forget atomics — nothing waits for them; the backward's blend
@@ -339,7 +333,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             if (PF) co_pf = lds_ld4(ea + 64), xy_pf = lds_ld4(ea + 80);
             // ---- per-pixel update (forward.cu:750-842) ----
             const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
-            const float power = fwd_power_pre(co_cur.x, co_cur.y, co_cur.z, dx, dy);
+            const float power = dqo_power_pre(co_cur.x, co_cur.y, co_cur.z, dx, dy);
             const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
             // forward.cu:763-772 (and the pixel is not finished): power <= 0, alpha >= 1/255
             lanemask valid_m = m_ge0(power) & m_le_sv(thr255, alpha) & alive_m;
@@ -481,7 +475,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             for (int k = 0; k < cnt; k++) {
                 const float4 xy_cur = s_ent[4 * k + 1], co_cur = s_ent[4 * k];
                 const float dx = xy_cur.x - pixfx, dy = xy_cur.y - pixfy;
-                const float power = fwd_power_pre(co_cur.x, co_cur.y, co_cur.z, dx, dy);
+                const float power = dqo_power_pre(co_cur.x, co_cur.y, co_cur.z, dx, dy);
                 const float alpha = fminf(0.99f, co_cur.w * dqo_gauss(power));
                 const bool other = GATE && mixed && __float_as_int(xy_cur.w) != owner;
                 const float a_g = (power <= 0.0f && !other) ? alpha * static_gate : 0.f;
