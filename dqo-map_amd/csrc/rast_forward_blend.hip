@@ -2,15 +2,18 @@
 // cuda_rasterizer/forward.cu:636-866 (renderCUDA_withMask) with its helpers :54-100.
 //
 // Structure: ONE wave64 per (tile, 8x8 quadrant) — four single-wave workgroups per 16x16 tile, no __syncthreads anywhere.
-// The wave streams its tile's depth-sorted list in chunks of 64 positions (one per lane: coalesced id load + two 16-byte
-// record gathers), tests each entry's footprint against its own quadrant (dqo_cull.h), compacts the survivors into a
-// wave-private LDS buffer with one ballot, and blends them front to back (the entry record is read from LDS at the top of each
-// trip: at 7 waves per SIMD the other waves cover that latency, a register rotation for a software prefetch costs more).
-// The next chunk's global loads are issued before the current chunk is blended, so the gather latency hides behind compute.
-// The kernel is bound by VALU issue: predicates are kept as 0/1 floats where that saves a compare + select pair, and the
-// per-entry results that are wave-uniform (live flag, n_touched count) live in a scalar mask / one uniform LDS store.
+// The wave streams its tile's depth-sorted list in chunks of 64 positions (one per lane: coalesced index load two chunks ahead, three
+// 16-byte record gathers one chunk ahead), tests each entry's footprint against its own quadrant (fwd_hits_quadrant), compacts the
+// survivors into wave-private LDS with one ballot — one 64-byte record per entry — and blends them front to back.
+// The kernel is bound by VALU issue (SQ counters: the SIMDs issue vector instructions for ~80 % of its cycles), so the entry loop is
+// written for its instruction count (round 6: 54 -> 35 VALU instructions per wave step, profiles/r06_ab_fwd_mask_form.txt):
+//   * every per-pixel PREDICATE of forward.cu:750-842 (unfinished, depth fixed, valid, blend, finish, new maximum) is a 64-bit lane mask
+//     in a scalar register pair — compares write it there, the scalar unit combines masks, selects read them (the helpers below);
+//   * an entry's record is read through ONE vector address register with immediate field offsets, its conic arrives pre-scaled;
+//   * the opaque hit that fixes a pixel's depth leaves five selects in the loop; the ray / surfel-plane intersection (a double
+//     division, two gathers) runs once per pixel behind the walk (finish_hit).
 // A wave stops as soon as its own 64 pixels are finished (the reference keeps a whole 256-thread block alive until its
-// last pixel is done, and so did the previous 4-wave version of this kernel, paying a block barrier per batch).
+// last pixel is done, and so did the first 4-wave version of this kernel, paying a block barrier per batch).
 //
 // Per (quadrant, list position) the wave records a live byte: non-zero iff some unfinished pixel of the quadrant saw the entry with
 // alpha >= 1/255 (bit r: some pixel of DPP row r = 4x4 block r did) — a superset of "blended it or took it as its depth hit", i.e. of the (pixel, entry) pairs the backward has
@@ -298,7 +301,6 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 
     const float qx0 = (float)(tile_x * DQO_TILE + (quad & 1) * 8), qy0 = (float)(tile_y * DQO_TILE + (quad >> 1) * 8);
     const float pixfx = (float)px, pixfy = (float)py;
-    const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);
     const float static_gate = (inside && (!GATE || owner >= 0)) ? 1.f : 0.f;   // 0 = this pixel starts finished (outside the image; no owner)
     lanemask alive_m = __builtin_amdgcn_ballot_w64(static_gate != 0.f);        // pixels that are not finished
     lanemask fixed_m = 0ull;                                                   // pixels whose depth has been fixed by an opaque hit
@@ -552,6 +554,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         const float4 n_np = g.normal_c[hid];
         const float raw_smax = g.point_c[hid].w;
         if (hit_id != -1) {
+            const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);  // (here, not in the prologue: three registers less across the walk)
             const HitEval h = eval_hit(ray, n_np);
             const float angle_distance = fabsf(h.den);
             const float depth_distance = fabsf(h.hit_z - hit_zc);
