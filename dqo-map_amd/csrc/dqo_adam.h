@@ -160,6 +160,11 @@ struct AdamXyzVals {  // one element of the xyz / scaling pass
 };
 template <bool ATTACH>
 __device__ __forceinline__ void adam_xyz_update(const AdamArgs& a, const uint32_t r, const size_t i, AdamXyzVals x, float& att_sum) {
+    // Separate IEEE operations, like adam1: the gradient of the raw scaling is a sum of two products (g exp(s) + gain ds) — torch forms
+    // it with two roundings (the exp Jacobian is an op of its own, the attach term arrives through another autograd edge), and under
+    // -ffp-contract=fast WHICH product an fma would swallow depends on the code around the inlined call: the fused tail and adam_kernel
+    // must not differ by that (profiles/r06_ab_tail_small_rows.txt).
+#pragma clang fp contract(off)
     const bool has_g = (r >> 31) != 0u;
     float p = x.p, m = x.m, v = x.v, ps = x.ps, ms = x.ms, vs = x.vs;
     float gx = has_g ? x.gx_ld : 0.f, gs = (has_g ? x.gs_ld : 0.f) * expf(ps);  // d exp(x)/dx = exp(x)
@@ -184,6 +189,7 @@ struct AdamRowVals {  // one row of the opacity / rotation pass
 };
 template <bool ATTACH>
 __device__ __forceinline__ void adam_row_update(const AdamArgs& a, const uint32_t r, AdamRowVals x, float& att_sum) {
+#pragma clang fp contract(off)  // (see adam_xyz_update)
     const uint32_t i = r & 0x3fffffffu;
     const bool has_g = (r >> 31) != 0u;
     float p = x.p, m = x.m, v = x.v;
