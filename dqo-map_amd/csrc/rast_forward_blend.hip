@@ -206,7 +206,7 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
 
 // GATE: DqoObjectGate — a list entry acts on a pixel only if the Gaussian's object id equals the pixel's owner id.  A template
 // parameter, so that the ungated kernel (the reference's semantics, the drop-in op) keeps its instruction stream.  (The gated
-// instantiation is held to 80 registers: left alone it takes 83-92 and loses two waves per SIMD, which is where its time goes — the
+// instantiation is held to 72 registers (FWD_MINW): left alone it takes more and loses waves per SIMD, which is where its time goes — the
 // instruction counts of the two kernels are equal to 0.1 %; a duplicate of the entry loop without the owner comparison for the
 // one-owner quadrants measured nothing.)
 //
@@ -231,7 +231,7 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
 // list position + 1 — and an id table for the chunk's n_touched atomics: 4352 B
 constexpr int FWD_BLK = 4 * FWD_THREADS + FWD_THREADS / 4;
 constexpr int PART_STRIDE = FWD_BLK * 4;                    // floats per wave block
-constexpr int PART_WORDS = 15;                              // merge record of one (run, pixel): 15 x 64 floats <= PART_STRIDE
+constexpr int PART_WORDS = 14;                              // merge record of one (run, pixel): 14 x 64 floats <= PART_STRIDE (word 9 unused)
 static_assert(PART_WORDS * FWD_THREADS <= PART_STRIDE, "the merge record lives in the wave's own LDS block");
 
 template <bool GATE, int SEGS, bool PF>
@@ -310,7 +310,6 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     uint32_t last_contributor = 0, hit_pos = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float depth_ = 0.f;
-    float hit_zc = 0.f, hit_smax = 0.f;  // of the entry that fixed the pixel's depth: its view depth, its (modified) largest scale
     int hit_id = -1, hit_color_id = -1;
     float color_weight_max = -1.f, hit_depth_weight = 0.f;
     uint8_t* live = bin.live_q + (size_t)quad * (size_t)bin.list_cap + range.x;  // this quadrant's live bytes of this tile's segment
@@ -350,13 +349,11 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
                 const lanemask hit_m = m_ge_vs(a_v, hit_thr) & ~fixed_m;  // valid, no depth yet, alpha >= opaque_threshold
                 if (hit_m != 0ull) {
                     // forward.cu:792-810: the first Gaussian with alpha >= opaque_threshold fixes this pixel's depth.  Only what the step
-                    // alone knows is kept here (five selects); the ray / surfel-plane intersection with its double-precision division
+                    // alone knows is kept here (three selects); the ray / surfel-plane intersection with its double-precision division
                     // and its two gathers runs ONCE per pixel behind the walk (finish_hit) — inside the loop it ran once per distinct
                     // hit entry of the quadrant, each time behind a vmcnt(0) wait that also drained the next chunk's prefetch
                     hit_id = (int)sel_u(hit_m, (uint32_t)gid, (uint32_t)hit_id);
                     hit_depth_weight = sel_f(hit_m, alpha * T, hit_depth_weight);
-                    hit_zc = sel_f(hit_m, xy_cur.z, hit_zc);
-                    hit_smax = sel_f(hit_m, cs.w, hit_smax);
                     hit_pos = sel_u(hit_m, contributor, hit_pos);
                     fixed_m |= hit_m;
                 }
@@ -518,8 +515,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         rec[3 * FWD_THREADS] = color_weight_max, rec[4 * FWD_THREADS] = __int_as_float(hit_color_id);
         rec[5 * FWD_THREADS] = __uint_as_float(last_contributor), rec[6 * FWD_THREADS] = end_T;
         rec[7 * FWD_THREADS] = __int_as_float(hit_id), rec[8 * FWD_THREADS] = __uint_as_float(hit_pos);
-        rec[9 * FWD_THREADS] = hit_zc, rec[10 * FWD_THREADS] = hit_depth_weight;
-        rec[14 * FWD_THREADS] = hit_smax;
+        rec[10 * FWD_THREADS] = hit_depth_weight;
         rec[11 * FWD_THREADS] = T_last, rec[12 * FWD_THREADS] = __int_as_float(last_alive);
         rec[13 * FWD_THREADS] = __uint_as_float(wmax_pos);
         __syncthreads();
@@ -527,7 +523,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         C0 = C1 = C2 = 0.f;
         color_weight_max = -1.f, hit_color_id = -1, wmax_pos = 0;
         last_contributor = 0, end_T = 1.f;
-        hit_id = -1, hit_pos = 0, hit_zc = 0.f, hit_smax = 0.f, hit_depth_weight = 0.f;
+        hit_id = -1, hit_pos = 0, hit_depth_weight = 0.f;
         T = 1.f, last_alive = -1;
         for (int j = 0; j < SEGS; j++) {
             const float* q = s_part + j * PART_STRIDE + lane;
@@ -542,7 +538,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
             if (hp != 0u && (hit_pos == 0u || (hp & 0x7fffffffu) < (hit_pos & 0x7fffffffu))) {
                 // (one wave holds the hit: the chunks behind it start with the depth fixed)
                 hit_pos = hp, hit_id = __float_as_int(q[7 * FWD_THREADS]);
-                hit_zc = q[9 * FWD_THREADS], hit_depth_weight = q[10 * FWD_THREADS], hit_smax = q[14 * FWD_THREADS];
+                hit_depth_weight = q[10 * FWD_THREADS];
             }
             const int la = __float_as_int(q[12 * FWD_THREADS]);
             if (la > last_alive) last_alive = la, T = q[11 * FWD_THREADS];  // the running transmittance behind the last chunk entered
@@ -553,6 +549,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
         const int hid = max(hit_id, 0);  // (pixels without a hit read Gaussian 0 and discard it: one round of loads for the wave)
         const float4 n_np = g.normal_c[hid];
         const float raw_smax = g.point_c[hid].w;
+        const float hit_zc = g.xy_depth[hid].z, hit_smax = g.rgb_smax[hid].w;  // the hit entry's view depth and (modified) largest scale
         if (hit_id != -1) {
             const float3 ray = pixel_ray(px, py, v.focal_x, v.focal_y, v.cx, v.cy);  // (here, not in the prologue: three registers less across the walk)
             const HitEval h = eval_hit(ray, n_np);
@@ -588,7 +585,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 }
 
 // One wave64 per (tile, quadrant), block b: XCD group x = b % 8 (blocks b and b + 8 share an XCD), within the group item
-// j = b / 8 = (tile slot, quadrant).  (The gated instantiation is held to 80 registers, see above.)
+// j = b / 8 = (tile slot, quadrant).  (Both instantiations are held to FWD_MINW waves per SIMD, see below.)
 #ifndef FWD_WPB
 #define FWD_WPB 1  // waves (= quadrants of ONE tile) per workgroup; independent of each other either way
 #endif
@@ -596,10 +593,12 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 #define FWD_PF false  // the next entry's records read one step ahead (a register rotation)
 #endif
 #ifndef FWD_MINW
-#define FWD_MINW 6
+#define FWD_MINW 7  // waves per SIMD the register allocation leaves room for (72 VGPRs).  The kernel's time follows its occupancy —
+                    // 5 / 6 / 7 waves: 121 / 112 / 109 us before, 106 / 103 us (6 / 7) after the hit entry's depth and scale left the
+                    // loop's registers; at 8 (64 registers) it spills 19 and loses what it gains
 #endif
 template <bool GATE>
-__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? FWD_MINW : 1) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, FWD_MINW) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                                             DqoBinLayout bin, DqoRastOutputs out,
                                                                                             const DqoTapDev tap, const DqoGateDev gate,
                                                                                             const int64_t header_capacity) {
