@@ -595,10 +595,11 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 #ifndef FWD_MINW
 #define FWD_MINW 7  // waves per SIMD the register allocation leaves room for (72 VGPRs).  The kernel's time follows its occupancy —
                     // 5 / 6 / 7 waves: 121 / 112 / 109 us before, 106 / 103 us (6 / 7) after the hit entry's depth and scale left the
-                    // loop's registers; at 8 (64 registers) it spills 19 and loses what it gains
+                    // loop's registers; at 8 (64 registers) the gated instantiation spills 15 and loses what it gains — the ungated
+                    // one (the drop-in operator's) fits 64 without a spill and runs at 8
 #endif
 template <bool GATE>
-__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, FWD_MINW) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? FWD_MINW : 8) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                                             DqoBinLayout bin, DqoRastOutputs out,
                                                                                             const DqoTapDev tap, const DqoGateDev gate,
                                                                                             const int64_t header_capacity) {
