@@ -6,7 +6,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_LDS"; do
   i=$((i+1))
   rm -rf /tmp/pmb$i
-  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmb$i -o p --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-aux --no-selfcheck --no-graph > /tmp/pmb$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace -d /tmp/pmb$i -o p --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-aux --no-selfcheck --sustained 0 --no-graph > /tmp/pmb$i.log 2>&1
   echo "== set $i rc=$? (EXP=$DQO_BWD_EXP NB=$DQO_BWD_NB)"
   python tools/pmc_summary.py /tmp/pmb$i blend_
 done
