@@ -10,7 +10,7 @@
 //   * every per-pixel PREDICATE of forward.cu:750-842 (unfinished, depth fixed, valid, blend, finish, new maximum) is a 64-bit lane mask
 //     in a scalar register pair — compares write it there, the scalar unit combines masks, selects read them (the helpers below);
 //   * an entry's record is read through ONE vector address register with immediate field offsets, its conic arrives pre-scaled;
-//   * the opaque hit that fixes a pixel's depth leaves five selects in the loop; the ray / surfel-plane intersection (a double
+//   * the opaque hit that fixes a pixel's depth leaves three selects in the loop; the ray / surfel-plane intersection (a double
 //     division, two gathers) runs once per pixel behind the walk (finish_hit).
 // A wave stops as soon as its own 64 pixels are finished (the reference keeps a whole 256-thread block alive until its
 // last pixel is done, and so did the first 4-wave version of this kernel, paying a block barrier per batch).
@@ -596,10 +596,11 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
 #define FWD_MINW 7  // waves per SIMD the register allocation leaves room for (72 VGPRs).  The kernel's time follows its occupancy —
                     // 5 / 6 / 7 waves: 121 / 112 / 109 us before, 106 / 103 us (6 / 7) after the hit entry's depth and scale left the
                     // loop's registers; at 8 (64 registers) the gated instantiation spills 15 and loses what it gains — the ungated
-                    // one (the drop-in operator's) fits 64 without a spill and runs at 8
+                    // one (the drop-in operator's) fits 64 without a spill and runs at 8; maps beyond 768 Ki Gaussians run the gated
+                    // kernel at 6 (dqo_launch_blend_forward)
 #endif
-template <bool GATE>
-__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, GATE ? FWD_MINW : 8) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
+template <bool GATE, int MINW>
+__global__ __launch_bounds__(FWD_THREADS * FWD_WPB, MINW) void blend_forward_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                                             DqoBinLayout bin, DqoRastOutputs out,
                                                                                             const DqoTapDev tap, const DqoGateDev gate,
                                                                                             const int64_t header_capacity) {
@@ -674,7 +675,12 @@ int dqo_launch_blend_forward(const DqoView& v, const DqoGeomLayout& g, const Dqo
         return DQO_OK;
     }
     const dim3 grid(8 * ((T + 7) / 8) * 4 / FWD_WPB + (header_capacity >= 0 ? 1 : 0)), block(FWD_THREADS * FWD_WPB);
-    if (gt) DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<true>, grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
-    else DQO_LAUNCH("blend_forward_kernel", blend_forward_kernel<false>, grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
+    // waves per SIMD the register allocation leaves room for: what the walk gains from a seventh wave on a 500 k map (-3 us) it loses on
+    // a 1 M one (+5 us: more waves gathering from a bigger set of records) — same-box A/B, profiles/r06_ab_fwd_seven_waves.txt
+    const bool small_map = v.P <= 786432;
+    if (gt && small_map) DQO_LAUNCH("blend_forward_kernel", (blend_forward_kernel<true, FWD_MINW>), grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
+    else if (gt) DQO_LAUNCH("blend_forward_kernel", (blend_forward_kernel<true, 6>), grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
+    else if (small_map) DQO_LAUNCH("blend_forward_kernel", (blend_forward_kernel<false, 8>), grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
+    else DQO_LAUNCH("blend_forward_kernel", (blend_forward_kernel<false, 6>), grid, block, s, v, g, img, bin, out, tap, gate, header_capacity);
     return DQO_OK;
 }
