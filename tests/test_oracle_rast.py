@@ -361,3 +361,35 @@ def test_object_gate_of_the_oracle(oracle):
         _, rk, _ = U.run_oracle(oracle, cam, sub)
         px = po2 == k_obj
         assert np.array_equal(r2["color"][:, px], rk["color"][:, px]) and np.array_equal(r2["depth"][:, px], rk["depth"][:, px])
+
+
+def test_prescaled_conic_gives_the_reference_power_bit_for_bit():
+    """The blend kernels keep an entry's conic in LDS with A and C multiplied by -0.5 and evaluate
+    (A' dx) dx + (C' dy) dy - (B dx) dy   (dqo_power_pre, csrc/dqo_cull.h)
+    instead of the reference's -0.5 (A dx dx + C dy dy) - B dx dy (forward.cu:758-760, backward.cu:937-939; dqo_power): scaling by a
+    power of two commutes with every IEEE rounding, so the two are the same float — checked here on a million draws of the ranges the
+    blend loops see, with numpy's float32 operations (one rounding per operation, no contraction: the kernels compile both forms with
+    fp contract off)."""
+    rng = np.random.default_rng(7)
+    n = 1_000_000
+    f = np.float32
+    A = rng.uniform(1e-3, 40.0, n).astype(f)
+    C = rng.uniform(1e-3, 40.0, n).astype(f)
+    B = (rng.uniform(-0.99, 0.99, n) * np.sqrt(A.astype(np.float64) * C)).astype(f)
+    dx = rng.uniform(-40.0, 40.0, n).astype(f)
+    dy = rng.uniform(-40.0, 40.0, n).astype(f)
+    half = f(-0.5)
+    ref = half * (A * dx * dx + C * dy * dy) - B * dx * dy
+    Ah, Ch = half * A, half * C
+    pre = (Ah * dx * dx + Ch * dy * dy) - B * dx * dy
+    assert ref.dtype == np.float32 and pre.dtype == np.float32
+    assert np.array_equal(ref.view(np.uint32), pre.view(np.uint32))
+    # ... and on splats seen far from their centre, where the three terms cancel to a result 1e4 times smaller than they are
+    t = rng.uniform(-30.0, 30.0, n).astype(f)
+    dx2, dy2 = t, (t * f(0.999) + rng.uniform(-0.05, 0.05, n).astype(f)).astype(f)
+    A2 = np.full(n, 25.0, f)
+    C2 = np.full(n, 25.0, f)
+    B2 = np.full(n, -24.99, f)
+    ref2 = half * (A2 * dx2 * dx2 + C2 * dy2 * dy2) - B2 * dx2 * dy2
+    pre2 = ((half * A2) * dx2 * dx2 + (half * C2) * dy2 * dy2) - B2 * dx2 * dy2
+    assert np.array_equal(ref2.view(np.uint32), pre2.view(np.uint32))
