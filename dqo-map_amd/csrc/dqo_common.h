@@ -145,6 +145,58 @@ static inline DqoTapDev dqo_tap_dev(const DqoLossTap* t) {
 }
 constexpr double DQO_TAP_FIXED = 4294967296.0;  // 2^32
 #ifdef __HIPCC__
+// The value of lane ^ D (D a power of two) without the LDS crossbar: a ds_bpermute costs 20-60 cycles per dependent use and shares the
+// CU's LDS pipe; DPP moves 3-5, the gfx950 row / half swaps 4-9 (tools/ubench_valu.hip).  D = 1, 2: DPP quad_perm; D = 4: row_shl:4 /
+// row_shr:4 on alternate banks; D = 8: row_ror:8; D = 16, 32: v_permlane16/32_swap of the register with a copy of itself.
+typedef unsigned dqo_swap_uint2 __attribute__((ext_vector_type(2)));
+template <int D>
+__device__ __forceinline__ uint32_t dqo_lane_xor(uint32_t x, int lane) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+    else if constexpr (D == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);  // banks 0, 2 read lane + 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);  // banks 1, 3 read lane - 4
+    } else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);
+    else if constexpr (D == 16) {
+        const dqo_swap_uint2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r.x: even rows' values, r.y: odd rows'
+        return (lane & 16) ? r.x : r.y;
+    } else {
+        static_assert(D == 32, "power of two up to 32");
+        const dqo_swap_uint2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r.x: lower half's values, r.y: upper half's
+        return (lane & 32) ? r.x : r.y;
+    }
+}
+// wave64 float sum in the order of the xor butterfly 32, 16, 8, 4, 2, 1 (every lane ends with the same total, bit for bit what the
+// __shfl_xor loop of that order gives), and integer maximum — vector instructions only
+__device__ __forceinline__ float dqo_wave_sum_xor(float x, int lane) {
+    x += __uint_as_float(dqo_lane_xor<32>(__float_as_uint(x), lane));
+    x += __uint_as_float(dqo_lane_xor<16>(__float_as_uint(x), lane));
+    x += __uint_as_float(dqo_lane_xor<8>(__float_as_uint(x), lane));
+    x += __uint_as_float(dqo_lane_xor<4>(__float_as_uint(x), lane));
+    x += __uint_as_float(dqo_lane_xor<2>(__float_as_uint(x), lane));
+    x += __uint_as_float(dqo_lane_xor<1>(__float_as_uint(x), lane));
+    return x;
+}
+__device__ __forceinline__ uint32_t dqo_wave_max_u32(uint32_t x, int lane) {
+    x = max(x, dqo_lane_xor<32>(x, lane)), x = max(x, dqo_lane_xor<16>(x, lane)), x = max(x, dqo_lane_xor<8>(x, lane));
+    x = max(x, dqo_lane_xor<4>(x, lane)), x = max(x, dqo_lane_xor<2>(x, lane)), x = max(x, dqo_lane_xor<1>(x, lane));
+    return x;
+}
+__device__ __forceinline__ uint32_t dqo_wave_sum_u32(uint32_t x, int lane) {
+    x += dqo_lane_xor<32>(x, lane), x += dqo_lane_xor<16>(x, lane), x += dqo_lane_xor<8>(x, lane);
+    x += dqo_lane_xor<4>(x, lane), x += dqo_lane_xor<2>(x, lane), x += dqo_lane_xor<1>(x, lane);
+    return x;
+}
+// The two pixel counts of the frame's loss tap (mask pixels, valid depth pixels: at most W x H < 2^32 each) — all a wave of the
+// backward needs for its gradient scales; the sums of dqo_tap_totals below are for the report
+__device__ __forceinline__ void dqo_tap_counts(const uint32_t* spread, int lane, uint32_t& n_col, uint32_t& n_dep) {
+    uint32_t a = 0u, b = 0u;
+    for (int j = lane; j < DQO_SPREAD; j += 64) {
+        const unsigned long long* l = reinterpret_cast<const unsigned long long*>(spread + (size_t)j * 64 + 8);
+        a += (uint32_t)l[1], b += (uint32_t)l[3];
+    }
+    n_col = dqo_wave_sum_u32(a, lane), n_dep = dqo_wave_sum_u32(b, lane);
+}
 // The frame totals of the loss tap, by one wave: lane j reads line j, the wave adds up (fixed order).  tot[0..3] = colour error sum,
 // mask pixels, depth error sum, valid depth pixels.  Called a kernel boundary after the forward blend kernel wrote them.
 __device__ __forceinline__ void dqo_tap_totals(const uint32_t* spread, int lane, double tot[4]) {

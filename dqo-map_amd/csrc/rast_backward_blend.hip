@@ -39,6 +39,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// sum of a 32-bit word over the lanes of DPP row 0 (lanes 0..15), as a wave-uniform value
+__device__ __forceinline__ uint32_t row0_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror: every lane of a row holds its row's sum
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+}
+
 // Reduce-scatter butterfly over the wave for EIGHT values at once: afterwards every lane l holds the 64-lane total of
 // v[l & 7].  Each of the first three stages halves the number of live values per lane (the lane keeps the half selected by
 // one bit of its id and ships the other half to its partner), so the whole thing costs ~35 VALU instead of 8 x 11 for eight
@@ -334,10 +343,17 @@ struct BwdTap {  // DqoLossTap, backward half: the two gradient scales of the fr
 };
 // ... from the frame totals in the spread lines (one whole wave; report: lane 0 also writes the loss and the scales out)
 __device__ __forceinline__ BwdTap tap_frame_scales(const DqoGeomLayout& g, const DqoTapDev& tap, int lane, bool report) {
+    BwdTap t;
+    if (!report) {  // every wave with work: the two pixel counts alone (32-bit sums, no LDS crossbar)
+        uint32_t c1, c3;
+        dqo_tap_counts(g.spread, lane, c1, c3);
+        const float n_col = fmaxf((float)c1, 1.f), n_dep = fmaxf((float)c3, 1.f);
+        t.gc = tap.color_weight / (3.f * n_col), t.gdw = tap.depth_weight / n_dep;  // = loss_grad_kernel's gc / gdw
+        return t;
+    }
     double tot[4];
     dqo_tap_totals(g.spread, lane, tot);
     const float n_col = fmaxf((float)tot[1], 1.f), n_dep = fmaxf((float)tot[3], 1.f);
-    BwdTap t;
     t.gc = tap.color_weight / (3.f * n_col), t.gdw = tap.depth_weight / n_dep;  // = loss_grad_kernel's gc / gdw
     if (report && lane == 0) {
         const float color_loss = (float)(tot[0] / (3.0 * (double)n_col)), depth_loss = (float)(tot[2] / (double)n_dep);
@@ -480,13 +496,11 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
                 const int f = (int)__builtin_ctzll(todo);
                 const int o = __builtin_amdgcn_readlane(owner, f);
                 const unsigned long long* l = g.obj_tap + ((size_t)(lane & (DQO_OBJ_SPREAD - 1)) * DQO_GATE_OBJECTS + (size_t)(o & (DQO_GATE_OBJECTS - 1))) * 4;
-                unsigned long long n1 = lane < DQO_OBJ_SPREAD ? l[1] : 0ull, n3 = lane < DQO_OBJ_SPREAD ? l[3] : 0ull;
-#pragma unroll
-                for (int off = DQO_OBJ_SPREAD / 2; off > 0; off >>= 1) {
-                    n1 += (unsigned long long)__shfl_xor((long long)n1, off);
-                    n3 += (unsigned long long)__shfl_xor((long long)n3, off);
-                }
-                n1 = (unsigned long long)__shfl((long long)n1, 0), n3 = (unsigned long long)__shfl((long long)n3, 0);
+                // (pixel counts: at most W x H < 2^32 — summed as 32-bit words over the first DPP row, four DPP adds each instead of the
+                // ten 64-bit trips through the LDS crossbar that __shfl_xor / __shfl on a long long cost: 20 dependent ds_bpermute)
+                static_assert(DQO_OBJ_SPREAD <= 16, "the copies sit in one DPP row");
+                const uint32_t n1 = row0_sum_u32(lane < DQO_OBJ_SPREAD ? (uint32_t)l[1] : 0u);
+                const uint32_t n3 = row0_sum_u32(lane < DQO_OBJ_SPREAD ? (uint32_t)l[3] : 0u);
                 const float n_col = fmaxf((float)n1, 1.f), n_dep = fmaxf((float)n3, 1.f);
                 const bool mine = owner == o;
                 tap_gc = mine ? tap.color_weight / (3.f * n_col) : tap_gc;

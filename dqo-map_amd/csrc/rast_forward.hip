@@ -299,24 +299,8 @@ constexpr int SORTW_CAP = DQO_SORTW_CAP;
 // the LDS pipe of the CU; DPP moves 3-5, the gfx950 row / half swaps 4-9: tools/ubench_valu.hip):
 //   D = 1, 2 : DPP quad_perm;  D = 4 : row_shl:4 / row_shr:4 on alternate banks;  D = 8 : row_ror:8
 //   D = 16, 32 : v_permlane16/32_swap of the register with a copy of itself leaves (own rows, partner rows) in the two results
-typedef unsigned dqo_sort_uint2 __attribute__((ext_vector_type(2)));
 template <int D>
-__device__ __forceinline__ uint32_t lane_xor_value(uint32_t x, int lane) {
-    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
-    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
-    else if constexpr (D == 4) {
-        const int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);  // banks 0, 2 read lane + 4
-        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);  // banks 1, 3 read lane - 4
-    } else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);
-    else if constexpr (D == 16) {
-        const dqo_sort_uint2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r.x: even rows' values, r.y: odd rows'
-        return (lane & 16) ? r.x : r.y;
-    } else {
-        static_assert(D == 32, "power of two up to 32");
-        const dqo_sort_uint2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r.x: lower half's values, r.y: upper half's
-        return (lane & 32) ? r.x : r.y;
-    }
-}
+__device__ __forceinline__ uint32_t lane_xor_value(uint32_t x, int lane) { return dqo_lane_xor<D>(x, lane); }  // (dqo_common.h)
 
 // one cross-lane step of the network: every register r meets register r of lane ^ D
 template <int E, int D>

@@ -155,10 +155,8 @@ __device__ __forceinline__ bool fwd_hits_quadrant(float mx, float my, float A, f
 // kernel, a kernel boundary later, reads the totals (dqo_tap_totals).  A first version finished the loss here (the wave with the last
 // ticket wrote loss_out and grad_scale): 13 k tickets on one address cost 140 us (same-address atomics are served one per ~11 ns), and
 // with two-level tickets the returning atomics + their s_waitcnt at the end of every wave still cost what the two loss kernels had.
-__device__ __forceinline__ float tap_wave_sum(float x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);  // fixed order: reproducible
-    return x;
+__device__ __forceinline__ float tap_wave_sum(float x, int lane) {
+    return dqo_wave_sum_xor(x, lane);  // fixed order: reproducible (the xor butterfly 32 .. 1, without the LDS crossbar)
 }
 // owner: the pixel's object id (DqoObjectGate.pixel_object; only read when tap.per_object)
 __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeomLayout& g, bool inside, size_t pid, size_t HW, float c0,
@@ -183,7 +181,7 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
             const int o = __builtin_amdgcn_readlane(owner, f);
             const bool sel = m && owner == o, selv = valid && owner == o;
             const unsigned long long sm = __builtin_amdgcn_ballot_w64(sel), sv = __builtin_amdgcn_ballot_w64(selv);
-            const float se = tap_wave_sum(sel ? e : 0.f), sd = tap_wave_sum(selv ? de : 0.f);
+            const float se = tap_wave_sum(sel ? e : 0.f, lane), sd = tap_wave_sum(selv ? de : 0.f, lane);
             if (lane == 0) {
                 unsigned long long* line = g.obj_tap + ((size_t)(blockIdx.x % DQO_OBJ_SPREAD) * DQO_GATE_OBJECTS + (size_t)(o & (DQO_GATE_OBJECTS - 1))) * 4;
                 atomicAdd(&line[0], dqo_tap_fixed(se)), atomicAdd(&line[1], (unsigned long long)__popcll(sm));
@@ -195,7 +193,7 @@ __device__ __forceinline__ void loss_tap_wave(const DqoTapDev& tap, const DqoGeo
     }
     const unsigned long long nm = __popcll(__builtin_amdgcn_ballot_w64(m)), nv = __popcll(__builtin_amdgcn_ballot_w64(valid));
     if (nm == 0ull) return;  // (wave-uniform; valid implies m)
-    const float se = tap_wave_sum(m ? e : 0.f), sd = tap_wave_sum(valid ? de : 0.f);
+    const float se = tap_wave_sum(m ? e : 0.f, lane), sd = tap_wave_sum(valid ? de : 0.f, lane);
     if (lane != 0) return;
     unsigned long long* line = reinterpret_cast<unsigned long long*>(g.spread + (size_t)(blockIdx.x % DQO_SPREAD) * 64 + 8);
     // (a non-finite sum — NaN / infinite colours — is not representable in fixed point: dqo_tap_fixed)
@@ -263,12 +261,14 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     if (GATE) {
         if (inside) owner = gate.pobj[pix_id];
         if (owner < 0) owner = (int)0x80000000;  // "no owner": equal to no Gaussian's (non-negative) object id
-        present = owner >= 0 ? 1ull << (owner & 63) : 0ull;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) present |= (unsigned long long)__shfl_xor((long long)present, off);
-        // (wave-uniform: keep the set in scalar registers)
-        present = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(present >> 32)) << 32) |
-                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)present);
+        // (one trip per distinct owner — usually one or two — on the scalar unit; an OR-butterfly of a 64-bit word over the wave is
+        // twelve dependent trips through the LDS crossbar)
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(owner >= 0);
+        while (todo != 0ull) {
+            const int o = __builtin_amdgcn_readlane(owner, (int)__builtin_ctzll(todo));
+            present |= 1ull << (o & 63);
+            todo &= ~__builtin_amdgcn_ballot_w64(owner == o);
+        }
         mixed = __popcll(present) > 1;
     }
 
@@ -578,8 +578,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     }
     // list positions the backward has to walk for this quadrant
     int w = inside ? (int)max(last_contributor, hit_pos & 0x7fffffffu) : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) w = max(w, __shfl_xor(w, off));
+    w = (int)dqo_wave_max_u32((uint32_t)w, lane);  // (w >= 0)
     if (lane == 0) img.walk4[tile * 4 + quad] = (uint32_t)w;
     if (tap.scale != nullptr) loss_tap_wave(tap, g, inside, pix_id, HW, oc0, oc1, oc2, depth_, hit_id, lane, owner);
 }
