@@ -46,12 +46,16 @@ __device__ __forceinline__ uint32_t popcount_range(const uint32_t* bits, uint32_
 
 // block-wide exclusive scan of one value per thread; returns the exclusive prefix, *total = block sum.  Two barriers.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t lane, uint32_t wave, uint32_t* total) {
+    // wave-level inclusive scan through DPP (four row_shr steps inside the 16-lane rows, then lane 15 / lane 31 broadcast into the rows
+    // behind them): six vector instructions instead of six dependent trips through the LDS crossbar (__shfl_up), on the critical path
+    // of every block, twice
     uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= (uint32_t)off) incl += o;
-    }
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);  // row_shr:1 (lanes without a source add 0)
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);  // row_shr:8  -> inclusive within each row
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
     __syncthreads();  // s_wave free for reuse
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
@@ -136,9 +140,7 @@ __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P
             }
             // visible count and (Gaussian, tile) pairs in the tile rects (the header's statistics): one pair of atomics per wave
             const uint32_t nv = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(vis));
-            uint32_t nc = ncand;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) nc += (uint32_t)__shfl_xor((int)nc, off);
+            const uint32_t nc = dqo_wave_sum_u32(ncand, (int)lane);
             if (lane == 0 && (nv | nc) != 0u) {
                 uint32_t* const my_line = g.spread + (size_t)((blockIdx.x * (BIN_THREADS / 64) + wave) % DQO_SPREAD) * 64;
                 if (nv) atomicAdd(&my_line[0], nv);
@@ -233,9 +235,7 @@ __global__ __launch_bounds__(BIN_THREADS, BIN_WAVES) void bin_count_kernel(int P
     __shared__ uint8_t s_noslot[BIN_CHUNK];
     s_noslot[tid] = no_slots ? (uint8_t)1 : (uint8_t)0;
     if (row_flags != nullptr && bin.bucket > 0) {  // (kernel-uniform) the header's num_rendered stays the sum of the LIST lengths
-        uint32_t nf = no_slots ? s_cnt[tid] : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nf += (uint32_t)__shfl_xor((int)nf, off);
+        const uint32_t nf = dqo_wave_sum_u32(no_slots ? s_cnt[tid] : 0u, (int)lane);
         if (lane == 0 && nf != 0u) atomicAdd(&g.spread[(size_t)((blockIdx.x * (BIN_THREADS / 64) + wave) % DQO_SPREAD) * 64 + 5], nf);
     }
     uint32_t block_live;
