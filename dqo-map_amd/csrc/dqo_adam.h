@@ -341,6 +341,34 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
     static_assert(VEC4, "the scalar form is adam_passes");
     const int tid = threadIdx.x;
     float att_sum = 0.f;
+    // Roles of the block's two waves (round 6; in-kernel stamps, profiles/r06_tail_stamps.txt: the row pass — a thread per list row,
+    // ~50 rows — ran on wave 0 alone behind the SH pass, 6 us during which wave 1 waited at the block's last barrier): wave 1 takes the
+    // row pass (rows 0..63; wave 0 the rows beyond, if any) and in exchange at most ONE trip of the SH pass, wave 0 the rest of it.
+    // Element for element the statements are unchanged: same bits (the attach loss is grouped differently: a reported scalar).
+#ifndef DQO_TAIL_ROLE_SPLIT
+#define DQO_TAIL_ROLE_SPLIT 1
+#endif
+    constexpr bool SPLIT = DQO_TAIL_ROLE_SPLIT && THREADS == 128;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int my_row = SPLIT ? (wave == 1 ? lane : 64 + lane) : tid;
+    auto rows_pass = [&]() {
+        // opacity (sigmoid) [P] and rotation (normalize) [P,4]
+        if (my_row < n_rows) {
+            const uint32_t r = s_rows[my_row], i = r & 0x3fffffffu;
+            const bool has_g = (r >> 31) != 0u;
+            AdamRowVals x;
+            x.p = a.opacity_raw[i], x.m = ldsm(&a.m_opacity[i]), x.v = ldsm(&a.v_opacity[i]);
+            x.q = reinterpret_cast<float4*>(a.rotation_raw)[i];
+            x.mq = reinterpret_cast<float4*>(a.m_rotation)[i], x.vq = reinterpret_cast<float4*>(a.v_rotation)[i];
+            x.go_ld = gsrc.opacity(my_row, i, has_g);
+            x.gr_ld = gsrc.rot(my_row, i, has_g);
+            x.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ATTACH) x.q0 = reinterpret_cast<const float4*>(a.init_rotation)[((r >> 30) & 1u) ? i : 0u];
+            x.conf = 0.f, x.dc_nz = false;
+            if (a.confidence != nullptr) x.conf = a.confidence[i], x.dc_nz = gsrc.dc_nonzero(my_row, i, has_g);  // (kernel-uniform branch)
+            adam_row_update<ATTACH>(a, r, x, att_sum);
+        }
+    };
     // xyz (identity activation) and scaling (exp): element-wise, [P,3]
     for (int e = tid; e < 3 * n_rows; e += THREADS) {
         const uint32_t k = (uint32_t)e / 3u, j = (uint32_t)e - 3u * k, r = s_rows[k];
@@ -364,12 +392,16 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
             uint32_t ei[U], fl[U];  // first element index of the float4; 1 = in range, 2 = has a gradient, 4 = elements 0..2 are f_dc
         };
         const int n4 = n_rows * 12;
+        // this wave's share of the float4s: [f_begin, f_end), walked with a stride of FSTRIDE lanes
+        constexpr int FSTRIDE = SPLIT ? 64 : THREADS;
+        const int s0 = n4 <= 2 * U * 64 ? (n4 + 1) / 2 : n4 - U * 64;  // (SPLIT) wave 1: one trip at most
+        const int f_begin = SPLIT ? (wave == 0 ? 0 : s0) : 0, f_end = SPLIT ? (wave == 0 ? s0 : n4) : n4;
         auto load_trip4 = [&](int f0) {
             ShTrip4 t;
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int f = f0 + u * THREADS;
-                const bool in = f < n4;
+                const int f = f0 + u * FSTRIDE;
+                const bool in = f < f_end;
                 const uint32_t fc = in ? (uint32_t)f : 0u;
                 const uint32_t k = (fc * 10923u) >> 17, j4 = fc - 12u * k, r = s_rows[k];  // fc / 12, exact for fc < 2^15
                 t.ei[u] = (r & 0x3fffffffu) * 48u + 4u * j4;
@@ -381,7 +413,8 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
             }
             return t;
         };
-        for (int f0 = tid; f0 < n4; f0 += U * THREADS) {
+        if (SPLIT && wave == 1) rows_pass();  // (its loads go out first; the SH share follows)
+        for (int f0 = f_begin + (SPLIT ? lane : tid); f0 < f_end; f0 += U * FSTRIDE) {
             const ShTrip4 cur = load_trip4(f0);
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -399,22 +432,7 @@ __device__ __forceinline__ float adam_passes_tail(const AdamArgs& a, const uint3
             }
         }
     }
-    // opacity (sigmoid) [P] and rotation (normalize) [P,4]
-    if (tid < n_rows) {
-        const uint32_t r = s_rows[tid], i = r & 0x3fffffffu;
-        const bool has_g = (r >> 31) != 0u;
-        AdamRowVals x;
-        x.p = a.opacity_raw[i], x.m = ldsm(&a.m_opacity[i]), x.v = ldsm(&a.v_opacity[i]);
-        x.q = reinterpret_cast<float4*>(a.rotation_raw)[i];
-        x.mq = reinterpret_cast<float4*>(a.m_rotation)[i], x.vq = reinterpret_cast<float4*>(a.v_rotation)[i];
-        x.go_ld = gsrc.opacity(tid, i, has_g);
-        x.gr_ld = gsrc.rot(tid, i, has_g);
-        x.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ATTACH) x.q0 = reinterpret_cast<const float4*>(a.init_rotation)[((r >> 30) & 1u) ? i : 0u];
-        x.conf = 0.f, x.dc_nz = false;
-        if (a.confidence != nullptr) x.conf = a.confidence[i], x.dc_nz = gsrc.dc_nonzero(tid, i, has_g);  // (kernel-uniform branch)
-        adam_row_update<ATTACH>(a, r, x, att_sum);
-    }
+    if (!(SPLIT && wave == 1)) rows_pass();
     return att_sum;
 }
 

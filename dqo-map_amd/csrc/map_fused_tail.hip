@@ -95,25 +95,31 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
         const uint32_t z0 = blockIdx.x * per, z1 = min(hist_words, z0 + per);
         for (uint32_t i = z0 + threadIdx.x; i < z1; i += TAIL_THREADS) hist[i] = 0u;
     }
-    // A frame flagged invalid by the forward must not train: nothing is read or written (adam_kernel's rule)
-    if (a.frame_header != nullptr && a.frame_header->overflow != 0u) return;
+    // Everything the block's head needs from memory goes out as ONE round (stamps of round 6, profiles/r06_tail_stamps.txt: the head took
+    // 6.8 us of a block's 48 — the overflow word, then the step count, then the bias table's tag, then its values, then the per-Gaussian
+    // loads: four dependent round trips): the frame's overflow word, the step count and the whole bias table unconditionally, the attach
+    // gains, and the first per-Gaussian loads; the decisions follow below.
+    const uint32_t ovf_ld = a.frame_header != nullptr ? a.frame_header->overflow : 0u;
+    int step_ld = 0;
+    float tb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.step_dev != nullptr) {
+        step_ld = *a.step_dev;
+        if (a.bias_table != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) tb[i] = a.bias_table[i];
+        }
+    }
+    if (ATTACH) adam_attach_gains(a);
     // one buffer: phase B's slot staging (4 KB), then phase C / D's gradient rows (7.75 KB)
     __shared__ float4 s_buf[(TAIL_THREADS * ROW_STRIDE * 4 + 15) / 16];
     float4* const s_rec = s_buf;
     float* const s_g = reinterpret_cast<float*>(s_buf);
     static_assert(sizeof(float4) * TAIL_THREADS * 4 <= sizeof(s_buf), "the slot staging must fit the buffer");
     __shared__ uint32_t s_rows[TAIL_THREADS];  // Gaussian index | has-gradient << 31 | attach-loss member << 30
-    __shared__ uint32_t s_lohi[2];
+    __shared__ uint32_t s_lohi[2 * (TAIL_THREADS / 64)];  // per wave: lowest slot, end of the highest
     __shared__ int s_wave_n[TAIL_THREADS / 64];
     __shared__ float s_att[TAIL_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.step_dev != nullptr) {  // bias corrections of this step (DqoAdamStep.bias_table, or computed: every thread, uniform)
-        float ss[7];
-        adam_bias_to_lds(a, ss);
-        adam_bias_from_lds(a, ss);
-    }
-    if (ATTACH) adam_attach_gains(a);
-    if (tid == 0) s_lohi[0] = 0xffffffffu, s_lohi[1] = 0u;
     const int idx = dqo_spread_index(blockIdx.x * TAIL_THREADS + tid, v.P);  // bin_count_kernel's thread -> Gaussian assignment
     const bool in_range = idx < v.P;
 
@@ -131,36 +137,50 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
         // parameter of this mapping call: no record sum, no chain, no Adam, no confidence (kernel-uniform branch, one byte per row)
         if (a.row_flags != nullptr) trained = (a.row_flags[idx] & DQO_ROW_FROZEN) == 0u;
     }
-    if (!trained) cnt = 0u, live_m = false, att = false;
+    // (the chain's camera matrices come from the kernel-argument segment: fetched in the same round)
     float view[16], proj[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         view[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.view[i])));
         proj[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.proj[i])));
     }
+    // A frame flagged invalid by the forward must not train: nothing is read or written (adam_kernel's rule; block-uniform, no barrier yet)
+    if (ovf_ld != 0u) return;
+    if (a.step_dev != nullptr) {  // bias corrections of this step: DqoAdamStep.bias_table when it holds this step, computed otherwise
+        float ss[7];              // (the same function either way: adam_bias_to_lds's rule, every thread, uniform)
+        if (a.bias_table != nullptr && __float_as_int(tb[7]) == step_ld) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) ss[i] = tb[i];
+        } else {
+            adam_bias_compute(a, step_ld, ss);
+        }
+        adam_bias_from_lds(a, ss);
+    }
+    if (!trained) cnt = 0u, live_m = false, att = false;
     // radii > 0 (backward.cu:285, 513; DqoAdamStep.radii)  <=>  the forward kept a non-empty tile rect for this Gaussian
     const bool visible = trained && ((rc.x >> 16) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.y & 0xffffu));
     const bool act = trained && (!SPARSE || visible || live_m);
     if (SPARSE && visible) moment_live[idx] = 1;  // only this thread ever looks at this byte
     const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
-    if (lane == 0) s_wave_n[wave] = (int)__popcll(am);
+    // the workgroup's slot range (its Gaussians' slots are one contiguous range, rast_binning.hip): per wave the minimum of the bases and
+    // the maximum of the ends through the crossbar-free butterflies of dqo_common.h, handed over with the row counts in ONE barrier —
+    // 128 LDS atomics on two words and a second barrier until round 6 (2 us of the block's head)
+    const uint32_t w_lo = ~dqo_wave_max_u32(cnt ? ~base : 0u, lane), w_hi = dqo_wave_max_u32(cnt ? base + cnt : 0u, lane);
+    if (lane == 0) s_wave_n[wave] = (int)__popcll(am), s_lohi[2 * wave] = w_lo, s_lohi[2 * wave + 1] = w_hi;
     __syncthreads();  // (a one-wave workgroup's __syncthreads is a wave-level fence, not an s_barrier)
-    if (cnt) {  // the workgroup's slot range: its Gaussians' slots are contiguous and in thread order (rast_binning.hip)
-        atomicMin(&s_lohi[0], base);
-        atomicMax(&s_lohi[1], base + cnt);
-    }
     int before = 0, n_rows = 0;
+    uint32_t lo = 0xffffffffu, hi_all = 0u;
 #pragma unroll
     for (int w = 0; w < TAIL_THREADS / 64; w++) {
         const int c = s_wave_n[w];
         before += w < wave ? c : 0;
         n_rows += c;
+        lo = min(lo, s_lohi[2 * w]), hi_all = max(hi_all, s_lohi[2 * w + 1]);
     }
     const int my_row = before + (int)__popcll(am & ((1ull << lane) - 1ull));  // this Gaussian's list row (if act)
+    // (s_rows is first read in phase D, behind the barrier that closes phase C: no barrier of its own)
     if (act) s_rows[my_row] = (uint32_t)idx | (visible ? 0x80000000u : 0u) | (att ? 0x40000000u : 0u);
-    __syncthreads();  // s_lohi, s_rows complete
-    const uint32_t lo = s_lohi[0];
-    const uint32_t hi = (uint32_t)min((int64_t)s_lohi[1], capacity);  // (an overflowed forward never gets here; belt and braces)
+    const uint32_t hi = (uint32_t)min((int64_t)hi_all, capacity);  // (an overflowed forward never gets here; belt and braces)
 
     // ---- second round of loads: everything the chain needs of this lane's Gaussian, issued as a whole before the record gather (the
     //      same round structure as gaussian_backward_kernel; in flight while phase B runs).  (Compacting the visible Gaussians of a
@@ -259,7 +279,6 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_tail_ke
         row[ROW_ROT] = co.rot_g[0], row[ROW_ROT + 1] = co.rot_g[1], row[ROW_ROT + 2] = co.rot_g[2], row[ROW_ROT + 3] = co.rot_g[3];
     }
     __syncthreads();
-
     // ---- D: Adam over the wave's list, gradient from LDS (adam_kernel's statements) ----
     const int used = (v.D + 1) * (v.D + 1);
     // SH pass in float4s (rows of 48 floats, 16-byte aligned tensors), four per lane and trip: 1024 floats per wave and trip instead of
@@ -477,7 +496,6 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_rows_ke
 }
 
 }  // namespace
-
 // the per-Gaussian half of dqo_rast_backward (dqo_launch_backward, rast_backward.hip)
 int dqo_launch_gaussian_rows(const DqoView& v, const DqoGeomLayout& g, const DqoRastInputs* in, const DqoGradRec* recs, const uint8_t* valid,
                              int64_t cap, const DqoRastGrads& gr, hipStream_t s) {
