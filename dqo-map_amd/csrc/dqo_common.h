@@ -232,6 +232,9 @@ struct DqoImageLayout {
     uint32_t* walk4;        // [4T] per (tile, 8x8 quadrant): entries the backward must walk = max over the quadrant's pixels of
                             //      max(n_contrib, hit position)
     uint32_t* tile_order;   // [8][ceil(T/8)] tile ids per XCD group (block b serves group b % 8), longest list first; ~0 = unused
+    uint4* slot_info;       // [8][ceil(T/8)] per tile_order slot, written by tile_sort_wave_kernel of THIS frame: (tile id or ~0, list
+                            //      start, list end, 0) — the blend kernels' waves read their slot's record in ONE round instead of
+                            //      tile_order -> ranges in two (a wave's head is a chain of dependent rounds)
     float* final_T;         // [HW] end_T  (forward.cu:849)
     uint32_t* n_contrib;    // [HW] last contributor, 1-based (forward.cu:850)
     uint32_t* hit_pos;      // [HW] bits 0..30: 1-based list position of the Gaussian that fixed the depth, 0 if none;
@@ -258,6 +261,7 @@ static inline DqoImageLayout dqo_image_layout(void* base, int W, int H) {
     L.ranges = (uint2*)take(8 * T);
     L.walk4 = (uint32_t*)take(16 * T);
     L.tile_order = (uint32_t*)take(4 * 8 * ((T + 7) / 8));
+    L.slot_info = (uint4*)take(16 * 8 * ((T + 7) / 8));
     L.final_T = (float*)take(4 * HW);
     L.n_contrib = (uint32_t*)take(4 * HW);
     L.hit_pos = (uint32_t*)take(4 * HW);

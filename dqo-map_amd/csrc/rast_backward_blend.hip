@@ -380,7 +380,8 @@ template <int BWD_NB, bool GATE, int SEGS, bool ROWS = false>
 __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                                                    const float* __restrict__ dL_dpixels, const float* __restrict__ dL_ddepths,
                                                    float* __restrict__ recs, uint8_t* __restrict__ valid, const int64_t capacity,
-                                                   const DqoTapDev& tap, const DqoGateDev& gate, const int tile, const int quad, const int wave, const int lane, uint32_t* const lds, const int skip_over) {
+                                                   const DqoTapDev& tap, const DqoGateDev& gate, const int tile, const int quad, const int wave, const int lane, uint32_t* const lds, const int skip_over,
+                                                   const uint2 range) {
     static_assert(!ROWS || (SEGS == 1 && BWD_NB == 7), "the row walk is the single-wave walk");
     uint32_t* const blk = lds + wave * (ROWS ? ROWS_BLK : BWD_BLK);
     float4* const s_co = reinterpret_cast<float4*>(blk);
@@ -390,8 +391,7 @@ __device__ __forceinline__ void blend_quadrant_bwd(const DqoView& v, const DqoGe
     uint32_t* const s_slot = reinterpret_cast<uint32_t*>(s_id + BWD_THREADS);
     int* const s_pos = reinterpret_cast<int*>(s_slot + BWD_THREADS);
     float* const s_hit = ROWS ? reinterpret_cast<float*>(blk + R_PART) : reinterpret_cast<float*>(s_pos + BWD_THREADS);
-    const uint2 range = img.ranges[tile];
-    const int n = (int)(range.y - range.x);
+    const int n = (int)(range.y - range.x);  // (range: the tile's list, img.ranges[tile] — the caller has it with the tile id)
     if (n == 0 || n > skip_over) return;  // (n > skip_over: SEGS == 1 beside the split blocks, which own the long lists)
     const int L = min((int)img.walk4[tile * 4 + quad], n);  // list positions [0, L) matter to this quadrant
     if (L == 0) return;
@@ -955,10 +955,11 @@ __global__ __launch_bounds__(BWD_THREADS * BWD_WPB, ROWS ? DQO_BWD_ROWS_WAVES : 
     }
     const int xg = blockIdx.x & 7, jg = BWD_WPB > 1 ? ((int)(blockIdx.x >> 3) * BWD_WPB + wave) : (int)(blockIdx.x >> 3);
     const int T8 = (v.gx * v.gy + 7) / 8;
-    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
+    const uint4 si = img.slot_info[xg * T8 + (jg >> 2)];  // (tile, list start, list end) of the slot: one round
+    const uint32_t tile_u = si.x;
     if (tile_u == 0xffffffffu) return;  // unused slot
     blend_quadrant_bwd<BWD_NB, GATE, 1, ROWS>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, jg & 3, wave,
-                                               lane, lds, 0x7fffffff);
+                                               lane, lds, 0x7fffffff, make_uint2(si.y, si.z));
 }
 
 // DqoRastCtx.list_split, the backward's half (the layout of blend_forward_split_kernel): blocks of eight waves; the first BSPLIT_GRID and
@@ -993,8 +994,9 @@ __global__ __launch_bounds__(BWD_THREADS * BSPLIT_RUNS, 4) void blend_backward_s
                 if (threadIdx.x == 0 && it == items + 2u * BSPLIT_GRID - 1u) g.counters[5] = 0u;
                 return;
             }
-            blend_quadrant_bwd<7, GATE, BSPLIT_RUNS>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate,
-                                                     (int)img.split_tiles[it >> 2], (int)(it & 3u), wave, lane, lds, 0x7fffffff);
+            const int tile_s = (int)img.split_tiles[it >> 2];
+            blend_quadrant_bwd<7, GATE, BSPLIT_RUNS>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, tile_s,
+                                                     (int)(it & 3u), wave, lane, lds, 0x7fffffff, img.ranges[tile_s]);
             __syncthreads();  // (everyone has read this trip's ticket and the last round's pass-1 results)
         }
     }
@@ -1006,7 +1008,7 @@ __global__ __launch_bounds__(BWD_THREADS * BSPLIT_RUNS, 4) void blend_backward_s
     const uint32_t tile_u = img.tile_order[(b & 7) * T8 + slot];
     if (tile_u == 0xffffffffu) return;
     blend_quadrant_bwd<7, GATE, 1>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, wave & 3, wave, lane,
-                                   lds, fwd_split > 0 ? fwd_split : 0x7fffffff);
+                                   lds, fwd_split > 0 ? fwd_split : 0x7fffffff, img.ranges[tile_u]);
 }
 
 }  // namespace

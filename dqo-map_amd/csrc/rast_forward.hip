@@ -190,8 +190,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
     constexpr int NSEG = 8, SEGB = LPT_BUCKETS + 1;
     const int T8 = (T + NSEG - 1) / NSEG;
     for (int i = tid; i < NSEG * SEGB; i += SCAN_THREADS) s_bucket[i] = 0;
-    for (int i = tid; i < NSEG * T8; i += SCAN_THREADS) img.tile_order[i] = 0xffffffffu;
-    __syncthreads();
+    for (int i = tid; i < NSEG * T8; i += SCAN_THREADS) img.tile_order[i] = 0xffffffffu, img.slot_info[i] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+    __syncthreads();  // (also: img.ranges of this launch are visible to the block from here on)
     const uint32_t mx = s_max, total = s_carry;
     int shift = 0;
     while ((mx >> shift) >= (uint32_t)LPT_BUCKETS) shift++;
@@ -261,6 +261,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(int T, DqoImage
             slot = (uint32_t)y * T8 + s_seg_len[y] + (o - s_free_pre[y]);
         }
         img.tile_order[slot] = (uint32_t)t;
+        // (DqoImageLayout.slot_info: tile_sort_wave_kernel writes it again for the frames it runs in; a frame without Gaussians has
+        // no sort launch, and its blend kernel still reads its slots)
+        const uint2 rg_t = img.ranges[t];
+        img.slot_info[slot] = make_uint4((uint32_t)t, rg_t.x, rg_t.y, 0u);
     }
     const uint32_t n_empty = s_n_empty;
     if (tid == 0) {
@@ -457,7 +461,10 @@ __global__ __launch_bounds__(SORTW_THREADS, LATE ? SORTW_LATE_WAVES : SORTW_WAVE
     // (whatever the caller's backward context says)
     if (ti == 0 && threadIdx.x == 0) g.counters[6] = (uint32_t)list_split;
     const uint32_t tile = img.tile_order[ti];  // [8][T8] slots, unused ones hold ~0
-    if (tile >= (uint32_t)T) return;
+    if (tile >= (uint32_t)T) {
+        if (threadIdx.x == 0) img.slot_info[ti] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+        return;
+    }
     uint2 rg;
     if (keep_order) {
         const uint32_t c = img.tile_count[(size_t)tile * DQO_TSTRIDE];
@@ -478,6 +485,7 @@ __global__ __launch_bounds__(SORTW_THREADS, LATE ? SORTW_LATE_WAVES : SORTW_WAVE
     } else {
         rg = img.ranges[tile];
     }
+    if (threadIdx.x == 0) img.slot_info[ti] = make_uint4(tile, rg.x, rg.y, 0u);  // (DqoImageLayout.slot_info: the blend kernels' one-round head)
     const int n = (int)(rg.y - rg.x);
     if (n <= 0) return;
     // DqoRastCtx.list_split: the blend kernels' queue of lists shared between eight waves (longest first, like the one below)

@@ -235,7 +235,8 @@ static_assert(PART_WORDS * FWD_THREADS <= PART_STRIDE, "the merge record lives i
 template <bool GATE, int SEGS, bool PF>
 __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLayout& g, const DqoImageLayout& img, const DqoBinLayout& bin,
                                                const DqoRastOutputs& out, const DqoTapDev& tap, const DqoGateDev& gate, const int tile,
-                                               const int quad, const int wave, const int lane, float4* const lds, const int skip_over) {
+                                               const int quad, const int wave, const int lane, float4* const lds, const int skip_over,
+                                               const uint2 range) {
     float4* const s_ent = lds + wave * FWD_BLK;                                  // entry k: s_ent[4 k .. 4 k + 3]
     int* const s_idt = reinterpret_cast<int*>(s_ent + 4 * FWD_THREADS);          // entry k's Gaussian index
     const uint32_t ent_addr = lds_addr_of(s_ent);
@@ -247,8 +248,7 @@ __device__ __forceinline__ void blend_quadrant(const DqoView& v, const DqoGeomLa
     const bool inside = px < (uint32_t)v.W && py < (uint32_t)v.H;
     const size_t HW = (size_t)v.W * v.H;
     const size_t pix_id = (size_t)v.W * py + px;
-    const uint2 range = img.ranges[tile];
-    const int n = (int)(range.y - range.x);
+    const int n = (int)(range.y - range.x);  // (range: the tile's list, img.ranges[tile] — handed in by the caller, who has it with the tile id)
     if (n > skip_over) return;  // (SEGS == 1 beside a split launch: the long lists belong to the split blocks)
     // object gate: this pixel's owner, and the owners present in the quadrant as a 64-bit set of (id mod 64) — an entry whose object's
     // bit is not in the set matches no pixel of the quadrant and is culled with the entries that cannot reach it
@@ -613,9 +613,11 @@ __global__ __launch_bounds__(FWD_THREADS * FWD_WPB, MINW) void blend_forward_ker
     const int wave = FWD_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int xg = blockIdx.x & 7, jg = FWD_WPB > 1 ? ((int)(blockIdx.x >> 3) * FWD_WPB + wave) : (int)(blockIdx.x >> 3);
     const int T8 = (v.gx * v.gy + 7) / 8;
-    const uint32_t tile_u = img.tile_order[xg * T8 + (jg >> 2)];
+    const uint4 si = img.slot_info[xg * T8 + (jg >> 2)];  // (tile, list start, list end) of the slot: one round
+    const uint32_t tile_u = si.x;
     if (tile_u == 0xffffffffu) return;  // unused slot
-    blend_quadrant<GATE, 1, FWD_PF>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, wave, (int)(threadIdx.x & 63), lds, 0x7fffffff);
+    blend_quadrant<GATE, 1, FWD_PF>(v, g, img, bin, out, tap, gate, (int)tile_u, jg & 3, wave, (int)(threadIdx.x & 63), lds, 0x7fffffff,
+                                    make_uint2(si.y, si.z));
 }
 
 // DqoRastCtx.list_split: blocks of SPLIT_RUNS waves.  The first SPLIT_GRID blocks take the long lists (longer than list_split entries: the
@@ -648,8 +650,9 @@ __global__ __launch_bounds__(FWD_THREADS * SPLIT_RUNS, 4) void blend_forward_spl
             __syncthreads();
             const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
             if (it >= items) return;
-            blend_quadrant<GATE, SPLIT_RUNS, SPLIT_PF>(v, g, img, bin, out, tap, gate, (int)img.split_tiles[it >> 2], (int)(it & 3u), wave, lane, lds,
-                                             0x7fffffff);
+            const int tile_s = (int)img.split_tiles[it >> 2];
+            blend_quadrant<GATE, SPLIT_RUNS, SPLIT_PF>(v, g, img, bin, out, tap, gate, tile_s, (int)(it & 3u), wave, lane, lds, 0x7fffffff,
+                                                       img.ranges[tile_s]);
             __syncthreads();  // wave 0 has read the other waves' merge records (and everyone this trip's ticket)
         }
     }
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(FWD_THREADS * SPLIT_RUNS, 4) void blend_forward_spl
     if (slot >= T8) return;
     const uint32_t tile_u = img.tile_order[(b & 7) * T8 + slot];
     if (tile_u == 0xffffffffu) return;
-    blend_quadrant<GATE, 1, SPLIT_PF>(v, g, img, bin, out, tap, gate, (int)tile_u, wave & 3, wave, lane, lds, list_split);
+    blend_quadrant<GATE, 1, SPLIT_PF>(v, g, img, bin, out, tap, gate, (int)tile_u, wave & 3, wave, lane, lds, list_split, img.ranges[tile_u]);
 }
 
 }  // namespace
