@@ -1496,6 +1496,11 @@ def main():
                 for t_ in (pr_._xyz, pr_._features_dc, pr_._features_rest, pr_._opacity, pr_._scaling, pr_._rotation):
                     t_.grad = None
             alt["op_only_ms"] = round(time_path(op_only) * 1e3, 4)
+            # ... and with a context allocated per call, as the reference does and as this op did until round 6's pool (zero fill,
+            # preprocess launch, tile scan and placement pass back in the pair; the same bits: tests/test_gpu_context_pool.py)
+            dgr.set_context_pool(False)
+            alt["op_only_fresh_contexts_ms"] = round(time_path(op_only) * 1e3, 4)
+            dgr.set_context_pool(True)
             alt["op_only_what"] = "drop-in op forward + backward (+ the six activation ops and their autograd), fixed incoming gradient"
             del pr_
         else:

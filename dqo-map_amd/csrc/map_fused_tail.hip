@@ -322,8 +322,21 @@ constexpr int RROW_MEAN = 0, RROW_W = 3, RROW_RGB = 19, RROW_OP = 22, RROW_SC = 
 __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_rows_kernel(const DqoView v, DqoGeomLayout g, const float* means3D,
                                                                     const float* scales, const float* rotations, const float* shs,
                                                                     const float4* __restrict__ partial,
-                                                                    const uint32_t* __restrict__ valid, int64_t capacity, DqoRastGrads gr) {
+                                                                    const uint32_t* __restrict__ valid, int64_t capacity, DqoRastGrads gr,
+                                                                    const uint32_t frame_words, uint32_t* __restrict__ hist,
+                                                                    const uint32_t hist_words) {
 #pragma clang fp contract(off)
+    // dqo_rast_backward on a context with frame_prezeroed (the drop-in op's pooled contexts): like gaussian_tail_kernel, the last
+    // consumer of the frame's counters clears them, the tile histogram and the tile flags for the NEXT frame on the context and leaves
+    // the stamp (frame_words == 0: nothing is cleared — the plain call)
+    if (frame_words != 0u) {
+        const uint32_t per = (frame_words + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = blockIdx.x * per, z1 = min(frame_words, z0 + per);
+        for (uint32_t i = z0 + threadIdx.x; i < z1; i += TAIL_THREADS) g.counters[i] = i == 9u ? DQO_CLEARED_STAMP : 0u;
+        const uint32_t perh = (hist_words + gridDim.x - 1) / gridDim.x;
+        const uint32_t h0 = blockIdx.x * perh, h1 = min(hist_words, h0 + perh);
+        for (uint32_t i = h0 + threadIdx.x; i < h1; i += TAIL_THREADS) hist[i] = 0u;
+    }
     __shared__ float4 s_buf[(TAIL_THREADS * RROW_STRIDE * 4 + 15) / 16];
     float4* const s_rec = s_buf;
     float* const s_g = reinterpret_cast<float*>(s_buf);
@@ -498,10 +511,10 @@ __global__ __launch_bounds__(TAIL_THREADS, DQO_TAIL_WAVES) void gaussian_rows_ke
 }  // namespace
 // the per-Gaussian half of dqo_rast_backward (dqo_launch_backward, rast_backward.hip)
 int dqo_launch_gaussian_rows(const DqoView& v, const DqoGeomLayout& g, const DqoRastInputs* in, const DqoGradRec* recs, const uint8_t* valid,
-                             int64_t cap, const DqoRastGrads& gr, hipStream_t s) {
+                             int64_t cap, const DqoRastGrads& gr, hipStream_t s, uint32_t frame_words, uint32_t* hist, uint32_t hist_words) {
     const int blocks = dqo_spread_blocks(v.P) * (256 / TAIL_THREADS);
     DQO_LAUNCH("gaussian_rows_kernel", gaussian_rows_kernel, dim3(blocks), dim3(TAIL_THREADS), s, v, g, in->means3D, in->scales, in->rotations,
-               in->shs, reinterpret_cast<const float4*>(recs), reinterpret_cast<const uint32_t*>(valid), cap, gr);
+               in->shs, reinterpret_cast<const float4*>(recs), reinterpret_cast<const uint32_t*>(valid), cap, gr, frame_words, hist, hist_words);
     return DQO_OK;
 }
 

@@ -233,7 +233,7 @@ int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const Dq
                               const float* dL_dcolor, const float* dL_ddepth, DqoGradRec* recs, uint8_t* valid, int64_t capacity,
                               const DqoTapDev& tap, const DqoGateDev& gate, int list_split, hipStream_t s);
 int dqo_launch_gaussian_rows(const DqoView& v, const DqoGeomLayout& g, const DqoRastInputs* in, const DqoGradRec* recs, const uint8_t* valid,
-                             int64_t cap, const DqoRastGrads& gr, hipStream_t s);
+                             int64_t cap, const DqoRastGrads& gr, hipStream_t s, uint32_t frame_words, uint32_t* hist, uint32_t hist_words);
 
 int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const DqoRastCtx* ctx, const float* dL_dcolor,
                         const float* dL_ddepth, const int32_t* hit_image, DqoRastGrads* gr, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -258,7 +258,13 @@ int dqo_launch_backward(const DqoRastParams* p, const DqoRastInputs* in, const D
         const char* e = getenv("DQO_ROWS_KERNEL");
         return e == nullptr || atoi(e) != 0;
     }();
-    if (rows_kernel) return dqo_launch_gaussian_rows(v, g, in, recs, valid, cap, *gr, s);
+    // DqoRastCtx.frame_prezeroed given to THIS call: the per-Gaussian kernel, the last consumer of the frame's counters, clears them
+    // (+ tile histogram and flags) for the next forward on the context and leaves the stamp — what dqo_rast_backward_adam always does.
+    // Not with list_split: a second backward over the same forward (retain_graph) would find the long-list queue's counters gone.
+    const bool clear = ctx->frame_prezeroed != 0 && dqo_list_split(ctx) == 0 && rows_kernel;
+    if (rows_kernel)
+        return dqo_launch_gaussian_rows(v, g, in, recs, valid, cap, *gr, s, clear ? (uint32_t)dqo_frame_scalar_words(ctx) : 0u, img.tile_count,
+                                        clear ? (uint32_t)((img.tile_flag + T) - img.tile_count) : 0u);
     DqoGradRec* sums = reinterpret_cast<DqoGradRec*>(g.grad_sum);  // [P], lives in the forward's geometry buffer
     DQO_LAUNCH("record_sum_kernel", record_sum_kernel, dim3(dqo_spread_blocks(p->P)), dim3(256), s, p->P, g, reinterpret_cast<const float4*>(recs),
                reinterpret_cast<const uint32_t*>(valid), reinterpret_cast<float4*>(sums), cap);

@@ -37,10 +37,97 @@ _lock = threading.RLock()
 _list_split = 0         # DqoRastCtx.list_split of the forwards issued through this module (set_list_split)
 _sync_mode = "exact"   # "exact": read N after the preprocess stage;  "lazy" / "deferred" / "graph": reuse the previous capacity, no sync
 _cap_hint = {}
-_pending = []          # lazy mode: (event, pinned header tensor, key, capacity) of forwards not yet verified
+_pending = []          # lazy mode: (event, pinned header tensor, key, capacity, pooled context?) of forwards not yet verified
 _last = {"num_rendered": None, "num_visible": None, "header": None}   # header: (event, pinned host copy) or a weak reference to the geometry buffer
 _ring = {}             # per device: pinned 32-byte header buffers + their events, reused round robin (no pin_memory() / Event() per call)
 _RING = 64
+# Context pool ('lazy' / 'deferred' modes: the modes that carry state from call to call).  The reference allocates its three context
+# buffers anew in every forward (rasterize_points.cu:37-155: resizeFunctional on fresh tensors); so did this op, and a fresh context knows
+# nothing: its counters must be zeroed, its tile launch order computed, its lists packed by a scan.  A pooled context keeps, per
+# (device, stream, P, W, H), what the fused mapping step keeps for its captured frames: per-tile list buckets sized from the headers of
+# earlier frames (no scan, no placement pass), the tile launch order of the previous frame on the same buffers (no tile_scan launch),
+# and counters that the previous BACKWARD on the context cleared on its way out (no zero-fill launch, the per-Gaussian preprocess at
+# the head of the binning kernel): DqoRastCtx.tile_bucket_capacity / keep_tile_order / frame_prezeroed, include/dqo_raster.h.
+# Who may reuse a context: the buffers are the autograd context of a call whose graph may still be alive (retain_graph=True, outputs
+# held by the caller), so every forward takes a LEASE that lives in its autograd ctx object and ends with it; a context is handed out
+# again only when its lease is gone.  A loop that holds the previous iteration's outputs across the next forward (DQO-MAP's does)
+# simply alternates between two contexts.
+_pool = {}             # (device index, stream handle, P, W, H) -> [_CtxSet]
+_pool_on = True        # set_context_pool
+_POOL_SETS = 3         # contexts per key; a forward that finds all of them leased takes the unpooled path
+_POOL_KEYS = 4         # shapes with pooled contexts, most recently used last: a map that grows changes P with every keyframe, and the
+                       # contexts of the sizes it has left behind are dropped (one still leased lives on with its graph)
+_shape_hint = {}       # (device index, P, W, H) -> [candidate pairs, longest tile list] of earlier frames (max over them)
+
+
+class _CtxSet:
+    __slots__ = ("geom", "img", "binning", "cap", "bucket", "order_valid", "clean", "leased")
+
+
+class _Lease:
+    """Held by the autograd ctx of the forward that uses a pooled context; the context is free again when the ctx object dies (the
+    graph was freed, or the forward ran without grad)."""
+    __slots__ = ("set",)
+
+    def __init__(self, s):
+        self.set = s
+        s.leased = True
+
+    def __del__(self):
+        self.set.leased = False
+
+
+def set_context_pool(on):
+    """True (default): forwards in 'lazy' / 'deferred' mode run on pooled contexts once the shape's list statistics are known (from
+    the second call of a shape on).  False: every forward allocates its context anew, like the reference.  Results are the same bits
+    either way (the lists, their order and every kernel that reads them are the same); switching it off also frees the pool."""
+    global _pool_on
+    with _lock:
+        _pool_on = bool(on)
+        if not _pool_on:
+            _pool.clear()
+
+
+def _bucket_for(longest):
+    """Per-tile bucket for lists up to `longest` entries in earlier frames: a power of two, at least twice that (FusedMapper.capture's
+    rule, and its exception: 1024 — what the per-tile sort reaches, so the long-list sort launch disappears — if 1.3 x longest fits)."""
+    b = 256
+    while b < 2 * longest:
+        b *= 2
+    if b == 2048 and 1.3 * longest <= 1024:
+        b = 1024
+    return b
+
+
+def _pooled_set(lib, key, stream, dev, W, H):
+    """A free pooled context for this shape with room for the shape's hints, or None (pool off, statistics not known yet, every
+    context leased).  Called under the module lock."""
+    if not _pool_on:
+        return None
+    hint = _shape_hint.get(key)
+    if hint is None or hint[1] <= 0:
+        return None
+    cap, bucket = int(hint[0] * 1.25) + 4096, _bucket_for(hint[1])
+    pkey = (key[0], stream) + key[1:]
+    sets = _pool.pop(pkey, [])
+    _pool[pkey] = sets  # (dicts keep insertion order: the shape just used is the last one)
+    while len(_pool) > _POOL_KEYS:
+        del _pool[next(iter(_pool))]
+    for cs in sets:
+        if not cs.leased and cs.cap >= cap and cs.bucket >= bucket:
+            return cs
+    sets[:] = [cs for cs in sets if cs.leased or (cs.cap >= cap and cs.bucket >= bucket)]  # (outgrown free contexts go)
+    if len(sets) >= _POOL_SETS:
+        return None
+    u8 = dict(dtype=torch.uint8, device=dev)
+    cs = _CtxSet()
+    cs.cap, cs.bucket = int(cap * 1.2), bucket  # (headroom: a context is replaced when the hints outgrow it)
+    cs.geom = torch.empty((lib.dqo_rast_geom_bytes(key[1], W, H),), **u8)
+    cs.img = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
+    cs.binning = torch.empty((lib.dqo_rast_binning_bytes_bucketed(cs.cap, W, H, cs.bucket),), **u8)
+    cs.order_valid = cs.clean = cs.leased = False
+    sets.append(cs)
+    return cs
 
 
 def _ring_slot(dev_index):
@@ -113,6 +200,9 @@ def set_sync_mode(mode):
     if _pending:
         _verify_pending(block=True)  # forwards issued in lazy mode are still checked (raises if one of them overflowed)
     _sync_mode = mode
+    if mode in ("exact", "graph"):
+        with _lock:
+            _pool.clear()  # (only the carrying modes use pooled contexts; one still leased lives on with its graph)
 
 
 def set_capacity(P, W, H, instances, device_index=None):
@@ -135,19 +225,30 @@ def _verify_pending(block):
     err = None
     with _lock:
         keep = []
-        for i, (ev, host, key, cap) in enumerate(_pending):
+        for i, (ev, host, key, cap, pooled) in enumerate(_pending):
             if not block and not ev.query():
-                keep.append((ev, host, key, cap))
+                keep.append((ev, host, key, cap, pooled))
                 continue
             ev.synchronize()
             n, overflow = int(host[0]), int(host[2])
             # the hint only grows: one key serves calls with different tile masks / camera poses, whose N differ
             _cap_hint[key] = max(_cap_hint.get(key, 0), int(n * 1.25) + 4096)
+            sh = _shape_hint.setdefault(key, [0, 0])  # (the context pool's sizing: candidate pairs and the longest list)
+            sh[0], sh[1] = max(sh[0], int(host[5])), max(sh[1], int(host[3]))
+            if overflow and pooled:
+                # a region of the map may have outgrown its share of the instance slots although the bucket and the total fitted
+                # (include/dqo_raster.h, tile_bucket_capacity) -> more instance slots next time (cap = 1.25 x this + 4096)
+                sh[0] = max(sh[0], int(cap * 1.2))
             if overflow:
                 keep.extend(_pending[i + 1:])  # (the later forwards stay pending: they are checked by the next call)
-                err = (n, cap)
+                err = (n, cap, pooled)
                 break
         _pending[:] = keep
+    if err is not None and err[2]:
+        raise RuntimeError(f"diff_gaussian_rasterization_depth (lazy mode, pooled context): a previous forward produced {err[0]} "
+                           f"Gaussian-tile instances or a tile list that did not fit its context ({err[1]} instance slots in per-tile "
+                           "buckets); its outputs are invalid. The sizes have been raised — re-run that iteration (or use "
+                           "set_sync_mode('exact')).")
     if err is not None:
         raise RuntimeError(f"diff_gaussian_rasterization_depth (lazy mode): a previous forward produced {err[0]} Gaussian-tile "
                            f"instances but only {err[1]} fitted its binning buffer; its outputs are invalid. The capacity has "
@@ -303,6 +404,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cctx.object_gate = ctypes.addressof(gate)
             key = (dev.index, P, W, H)
             cap = None
+            lease = None
             if _sync_mode == "graph":
                 with _lock:
                     cap = _cap_hint.get(key)
@@ -353,21 +455,38 @@ class _RasterizeGaussians(torch.autograd.Function):
                         host, ev, _, _ = _ring_slot(dev.index)
                         host.copy_(geomBuffer[:32].view(torch.int32), non_blocking=True)
                         ev.record()
-                        _pending.append((ev, host, key, cap))
+                        _pending.append((ev, host, key, cap, False))
                         _last["header"] = (ev, host)
             else:
                 # 'lazy' / 'deferred' with a carried-over capacity: ONE call — both stages, and between the sort and the blend kernel
                 # (where the frame's header is final) its asynchronous copy into a pinned ring slot + the slot's event: the deferred
                 # capacity check, available a blend kernel before the forward's end
                 num_rendered = -1
-                binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
-                cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
                 with _lock:
+                    pooled = _pooled_set(lib, key, stream, dev, W, H) if P > 0 else None
+                    if pooled is not None:
+                        # a pooled context (see _pool): its buffers instead of the fresh ones, lists in per-tile buckets, the tile
+                        # order of the previous frame on it, and — if that frame's backward cleared the counters — no zero fill and
+                        # no preprocess launch
+                        lease = _Lease(pooled)
+                        geomBuffer, imgBuffer, binningBuffer, cap = pooled.geom, pooled.img, pooled.binning, pooled.cap
+                        cctx.geom, cctx.geom_bytes = geomBuffer.data_ptr(), geomBuffer.numel()
+                        cctx.image, cctx.image_bytes = imgBuffer.data_ptr(), imgBuffer.numel()
+                        cctx.tile_bucket_capacity = pooled.bucket
+                        cctx.keep_tile_order = 1 if pooled.order_valid else 0
+                        cctx.frame_prezeroed = 1 if (pooled.clean and _list_split == 0) else 0
+                        pooled.clean = False  # (whatever happens below: this frame's counters are in use)
+                    else:
+                        binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
+                    cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
                     host, ev, host_ptr, ev_handle = _ring_slot(dev.index)
                     N.check(lib.dqo_rast_forward_async(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
                                                        ctypes.byref(cctx), host_ptr, ev_handle, stream))
-                    _pending.append((ev, host, key, cap))
+                    if pooled is not None:
+                        pooled.order_valid = True
+                    _pending.append((ev, host, key, cap, pooled is not None))
                     _last["header"] = (ev, host)
+        ctx.pooled = lease  # (None: a context of this call's own)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.inst_capacity = cap
@@ -421,6 +540,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cctx = N.DqoRastCtx(geom=geomBuffer.data_ptr(), geom_bytes=geomBuffer.numel(), binning=binningBuffer.data_ptr(),
                                     binning_bytes=binningBuffer.numel(), image=imgBuffer.data_ptr(), image_bytes=imgBuffer.numel(),
                                     inst_capacity=cap, list_split=getattr(ctx, "list_split", 0))
+                lease = getattr(ctx, "pooled", None)
+                if lease is not None:
+                    # a pooled context: its lists live in buckets, and this call — the last consumer of the frame's counters — clears
+                    # them for the next forward on the context (DqoRastCtx.frame_prezeroed as dqo_rast_backward reads it)
+                    cctx.tile_bucket_capacity = lease.set.bucket
+                    cctx.frame_prezeroed = 1 if cctx.list_split == 0 else 0
                 if getattr(ctx, "object_gate", None) is not None:
                     gate = N.DqoObjectGate(gaussian_object=N.ptr(ctx.object_gate[0]), pixel_object=N.ptr(ctx.object_gate[1]))
                     cctx.object_gate = ctypes.addressof(gate)
@@ -431,6 +556,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 N.check(lib.dqo_rast_backward(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(cctx),
                                               grad_out_color.data_ptr(), grad_out_depth.data_ptr(), hit_depth.data_ptr(),
                                               ctypes.byref(grads), ws.data_ptr(), ws.numel(), stream))
+                if lease is not None and cctx.frame_prezeroed:
+                    with _lock:
+                        lease.set.clean = True
         # gradient slots of the reference (__init__.py:273-283); inputs handed over as empty tensors get None
         def slot(g, inp):
             return g if (g is not None and inp.numel() != 0) else None

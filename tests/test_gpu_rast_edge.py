@@ -86,6 +86,7 @@ def test_lazy_mode_overflow_is_detected_and_recovers(torch_cuda, oracle):
     import diff_gaussian_rasterization_depth as dgr
     cam, sc = scenes.make_config(1, P=3000)
     try:
+        dgr.set_context_pool(False)  # (the carried instance capacity of contexts allocated per call; pooled: test_gpu_context_pool.py)
         dgr.set_sync_mode("lazy")
         h1, _ = U.run_hip(cam, sc)  # first call of this shape measures N and sets the capacity hint
         key = (0, 3000, cam.W, cam.H)
@@ -102,6 +103,7 @@ def test_lazy_mode_overflow_is_detected_and_recovers(torch_cuda, oracle):
             np.testing.assert_array_equal(h3[k], h1[k])
     finally:
         dgr.set_sync_mode("exact")
+        dgr.set_context_pool(True)
     o, r, _ = U.run_oracle(oracle, cam, sc)
     U.compare_forward(h3, r)
 
@@ -116,6 +118,7 @@ def test_deferred_mode_never_waits_and_raises_an_overflow_later(torch_cuda, orac
     dL = _dL(cam, 4)
     h0, g0 = U.run_hip(cam, sc, dL=dL)  # exact mode
     try:
+        dgr.set_context_pool(False)
         dgr.set_sync_mode("deferred")
         h1, g1 = U.run_hip(cam, sc, dL=dL)
         dgr.verify_pending()
@@ -135,6 +138,7 @@ def test_deferred_mode_never_waits_and_raises_an_overflow_later(torch_cuda, orac
             assert np.array_equal(g0[k], g3[k]), k
     finally:
         dgr.set_sync_mode("exact")
+        dgr.set_context_pool(True)
 
 
 @pytest.mark.parametrize("n", [64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8193])
