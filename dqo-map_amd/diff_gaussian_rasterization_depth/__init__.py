@@ -16,6 +16,9 @@ Differences that are not visible to callers:
     and raised at the next synchronisation point — never silent; the backward waits for its forward's header so that no gradient of
     an invalid frame is ever produced), `set_sync_mode("deferred")` also drops that wait (an overflow is then raised by a later call,
     after at most a few iterations whose gradients were zero: see set_sync_mode);
+  * in the 'lazy' / 'deferred' modes the three context tensors come from a pool per (device, stream, P, W, H) instead of being
+    allocated per call (rasterize_points.cu:37-155 allocates them per call): see `_pool` below — four launches less per forward +
+    backward pair, the same bits;
   * `tile_mask=None` is accepted and means "all tiles" (the reference requires a tensor).
 There is no CPU path: tensors must live on the GPU and the HIP library must be built.
 """

@@ -192,7 +192,11 @@ typedef struct DqoRastCtx {
      * A frame that finds no stamp (the promise was broken: a forward-only render, dqo_rast_backward or an error return in between) is
      * flagged in header.overflow and trains nothing; the frame after it is valid again.  Between dqo_rast_forward_prepare and
      * dqo_rast_forward_render of such a frame the stage-1 statistics are not available yet (dqo_rast_read_header reports zeros): use
-     * dqo_rast_forward / dqo_rast_forward_async. */
+     * dqo_rast_forward / dqo_rast_forward_async.
+     * Round 6: dqo_rast_backward reads the field too.  Non-zero there (and list_split == 0): its per-Gaussian kernel — the last
+     * consumer of the frame's counters in that call — clears the same words and leaves the same stamp, so the NEXT forward on the
+     * context may be given frame_prezeroed: the drop-in operator's pooled contexts (forward, dqo_rast_backward, forward, ...).  A second
+     * dqo_rast_backward over the same forward (retain_graph) is fine: nothing it reads is cleared.  0 (default): nothing is cleared. */
     int32_t frame_prezeroed;
 } DqoRastCtx;
 
