@@ -64,7 +64,8 @@ _shape_hint = {}       # (device index, P, W, H) -> [candidate pairs, longest ti
 
 
 class _CtxSet:
-    __slots__ = ("geom", "img", "binning", "cap", "bucket", "order_valid", "clean", "leased")
+    __slots__ = ("geom", "img", "binning", "cap", "bucket", "order_valid", "clean", "leased",
+                 "captured")  # captured: (keep_tile_order, frame_prezeroed) of the captured forward that pinned it ('graph' mode)
 
 
 class _Lease:
@@ -78,6 +79,31 @@ class _Lease:
 
     def __del__(self):
         self.set.leased = False
+
+
+class _Pinned:
+    """'graph' mode: the context a CAPTURED forward runs on belongs to the graph for good — its buffers are baked into the captured
+    launches — so it leaves the pool and is never handed out again.  It is kept alive by `_captured` until the owner of the graph takes
+    it over (take_captured_contexts)."""
+    __slots__ = ("set",)
+
+    def __init__(self, s):
+        self.set = s
+        s.leased = True
+
+
+_captured = []         # contexts pinned by captured forwards whose owner has not called take_captured_contexts() yet
+
+
+def take_captured_contexts():
+    """The contexts that forwards captured in 'graph' mode have pinned since the last call.  Whoever owns the torch.cuda.CUDAGraph keeps
+    the returned list for as long as the graph may be replayed and drops it with the graph (fused_ops.CapturedIteration does); until
+    somebody takes them the module keeps them alive — a caller that never calls this leaks one context per captured forward
+    instead of replaying a graph on freed memory."""
+    with _lock:
+        out = list(_captured)
+        del _captured[:]
+    return out
 
 
 def set_context_pool(on):
@@ -102,15 +128,26 @@ def _bucket_for(longest):
     return b
 
 
-def _pooled_set(lib, key, stream, dev, W, H):
+def _pooled_set(lib, key, stream, dev, W, H, pin=False):
     """A free pooled context for this shape with room for the shape's hints, or None (pool off, statistics not known yet, every
-    context leased).  Called under the module lock."""
+    context leased).  Called under the module lock.
+    pin ('graph' mode, a forward that is being captured): the context leaves the pool for good (_Pinned); a free one of ANY stream will
+    do — the warm-up iterations ran on a side stream and are complete (a capture starts from a synchronised device) — and is the one to
+    have: it holds a tile order and the counters the warm-up's last backward cleared, so the captured launches are the short sequence."""
     if not _pool_on:
         return None
     hint = _shape_hint.get(key)
     if hint is None or hint[1] <= 0:
         return None
     cap, bucket = int(hint[0] * 1.25) + 4096, _bucket_for(hint[1])
+    if pin:
+        for pkey, sets in _pool.items():
+            if (pkey[0],) + pkey[2:] != key:
+                continue
+            for cs in sets:
+                if not cs.leased and cs.cap >= cap and cs.bucket >= bucket:
+                    sets.remove(cs)
+                    return cs
     pkey = (key[0], stream) + key[1:]
     sets = _pool.pop(pkey, [])
     _pool[pkey] = sets  # (dicts keep insertion order: the shape just used is the last one)
@@ -129,7 +166,8 @@ def _pooled_set(lib, key, stream, dev, W, H):
     cs.img = torch.empty((lib.dqo_rast_image_bytes(W, H),), **u8)
     cs.binning = torch.empty((lib.dqo_rast_binning_bytes_bucketed(cs.cap, W, H, cs.bucket),), **u8)
     cs.order_valid = cs.clean = cs.leased = False
-    sets.append(cs)
+    if not pin:
+        sets.append(cs)
     return cs
 
 
@@ -203,9 +241,9 @@ def set_sync_mode(mode):
     if _pending:
         _verify_pending(block=True)  # forwards issued in lazy mode are still checked (raises if one of them overflowed)
     _sync_mode = mode
-    if mode in ("exact", "graph"):
+    if mode == "exact":
         with _lock:
-            _pool.clear()  # (only the carrying modes use pooled contexts; one still leased lives on with its graph)
+            _pool.clear()  # (only the other modes use pooled contexts; one still leased lives on with its graph)
 
 
 def set_capacity(P, W, H, instances, device_index=None):
@@ -417,7 +455,26 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        "set_capacity(P, W, H, instances)")
                 # nothing below touches the host: the launches of both stages, no header copy, no event
                 num_rendered = -1
-                binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
+                with _lock:
+                    # (only a forward that IS being captured pins a context: an eager call in this mode keeps contexts of its own)
+                    capturing = P > 0 and torch.cuda.is_current_stream_capturing()
+                    pooled = _pooled_set(lib, key, stream, dev, W, H, pin=True) if capturing else None
+                    if pooled is not None:
+                        # the context belongs to the graph from here on (_Pinned).  The counters' promise holds at every replay only if
+                        # the captured iteration also holds this frame's backward, which clears them: a forward that needs no gradient
+                        # is captured with its own zero fill
+                        lease = _Pinned(pooled)
+                        _captured.append(pooled)
+                        geomBuffer, imgBuffer, binningBuffer, cap = pooled.geom, pooled.img, pooled.binning, pooled.cap
+                        cctx.geom, cctx.geom_bytes = geomBuffer.data_ptr(), geomBuffer.numel()
+                        cctx.image, cctx.image_bytes = imgBuffer.data_ptr(), imgBuffer.numel()
+                        cctx.tile_bucket_capacity = pooled.bucket
+                        cctx.keep_tile_order = 1 if pooled.order_valid else 0
+                        cctx.frame_prezeroed = 1 if (pooled.clean and _list_split == 0 and any(ctx.needs_input_grad)) else 0
+                        pooled.clean = False
+                        pooled.captured = (int(cctx.keep_tile_order), int(cctx.frame_prezeroed))
+                    else:
+                        binningBuffer = torch.empty((lib.dqo_rast_binning_bytes(cap),), **u8)
                 cctx.binning, cctx.binning_bytes, cctx.inst_capacity = binningBuffer.data_ptr(), binningBuffer.numel(), cap
                 N.check(lib.dqo_rast_forward_async(ctypes.byref(params), ctypes.byref(inputs), ctypes.byref(outputs),
                                                    ctypes.byref(cctx), None, None, stream))

@@ -270,6 +270,8 @@ class CapturedIteration:
             with torch.cuda.graph(self.graph):
                 self.iteration()
             self._header = dgr._last["header"]  # the captured forward's own geometry buffer: its header is valid after every replay
+            # the op's pooled contexts that the captured forwards run on are this graph's now: they live and die with this object
+            self._contexts = dgr.take_captured_contexts()
         finally:
             dgr.set_sync_mode(mode)
 

@@ -117,6 +117,53 @@ def test_a_captured_iteration_replays_like_the_eager_loop(env, optin):
         assert int(opt._step_dev.item()) == n
 
 
+def test_a_capture_after_three_warm_up_iterations_runs_on_the_warm_ups_pooled_context(env):
+    """The op's context pool in 'graph' mode: the captured forward takes the context the warm-up iterations ran on — out of the pool for
+    good, owned by the CapturedIteration — with its tile order kept and its counters cleared by the (captured) backward: the short
+    launch sequence at every replay.  The replays train like the eager loop."""
+    torch, dgr = env
+    from dqo_harness import mapping, fused_ops
+    scene, settings, gt_color, gt_depth, mask, dev = _problem(torch, P=5000)
+    n = 7
+
+    def run(graph):
+        params = mapping.GaussianParams(scene, dev)
+        opt = fused_ops.DqoAdam(params.param_groups(), lr=0.0, eps=1e-15, capturable=True)
+        cell = torch.zeros((), device=dev)
+
+        def iteration():
+            out = mapping.render(settings, params.activated())
+            loss, _ = fused_ops.masked_mapping_loss(out, gt_color, gt_depth, mask)
+            loss.backward()
+            opt.step()
+            cell.copy_(loss.detach())
+
+        dgr.set_sync_mode("lazy")
+        losses = []
+        if graph:
+            cap = fused_ops.CapturedIteration(iteration, opt, warmup=3)
+            assert len(cap._contexts) == 1 and cap._contexts[0].captured == (1, 1) and cap._contexts[0].leased
+            assert all(cap._contexts[0] is not cs for sets in dgr._pool.values() for cs in sets)
+            for _ in range(n - 3):
+                cap.replay()
+                losses.append(float(cell))
+            assert cap.check()["overflow"] == 0
+        else:
+            for it in range(n):
+                opt.zero_grad(set_to_none=True)
+                iteration()
+                if it >= 3:
+                    losses.append(float(cell))
+            dgr.verify_pending()
+        torch.cuda.synchronize()
+        return np.array(losses), params._xyz.detach().cpu().numpy()
+
+    le, xe = run(False)
+    lg, xg = run(True)
+    np.testing.assert_allclose(lg, le, rtol=2e-5)
+    assert np.abs(xg - xe).max() <= 0.05 * 0.001 + 1e-7
+
+
 def test_graph_mode_needs_a_known_capacity(env):
     torch, dgr = env
     from dqo_harness import mapping
