@@ -119,7 +119,19 @@ def perturbed_target(full, settings, device, seed):
     pert["shs"] = full["shs"].copy()
     pert["shs"][:, 0, :] += rng.normal(0, 0.15, (P, 3)).astype(np.float32)
     with torch.no_grad():
-        tgt = render(settings, GaussianParams(pert, device).activated())
+        # a forward-only render: in the op's 'lazy' / 'deferred' modes nothing behind it would look at the frame's header, and a frame
+        # that outgrew the sizes carried over from earlier calls (a camera unlike any before) is a background image — check, and render
+        # again with the sizes the flagged frame has raised (why 'exact' is the op's default)
+        import diff_gaussian_rasterization_depth as dgr
+        act = GaussianParams(pert, device).activated()
+        for attempt in range(3):
+            tgt = render(settings, act)
+            try:
+                dgr.verify_pending()
+                break
+            except RuntimeError:
+                if attempt == 2:
+                    raise
         hit = tgt["depth_index_map"][0]
         obj_id = torch.tensor(np.asarray(full["obj_id"]), device=device)
         pix_obj = obj_id[hit.long().clamp(min=0)]
