@@ -165,3 +165,31 @@ def test_the_pool_forgets_the_shapes_a_growing_map_has_left_behind(torch_cuda):
     finally:
         dgr.set_sync_mode("exact")
     assert len(dgr._pool) == 0
+
+
+def test_a_forward_only_caller_checks_its_frame_and_renders_again(torch_cuda):
+    """dqo_harness.mapping.perturbed_target (the targets of bench.py and of the full-size parity tests) is a forward-only caller: in the
+    carrying modes nothing behind it would look at the frame's header, so it does — a frame that outgrew its pooled context (here: a
+    context sized for far shorter lists) is rendered again with the sizes the flagged frame raised, and the target is the exact mode's."""
+    import diff_gaussian_rasterization_depth as dgr
+    from dqo_harness import mapping
+    torch = torch_cuda
+    cam, sc = scenes.make_config(1, P=9000)
+    dev = torch.device("cuda")
+    st = mapping.make_settings(cam, dev)
+    full = dict(sc)
+    full["obj_id"] = np.zeros(9000, np.int32)
+    ref = mapping.perturbed_target(full, st, dev, 3)
+    try:
+        dgr.set_sync_mode("deferred")
+        mapping.perturbed_target(full, st, dev, 3)  # (the shape's statistics)
+        skey = (torch.cuda.current_device(), 9000, cam.W, cam.H)
+        dgr._shape_hint[skey] = [64, 1]
+        dgr._pool.clear()
+        got = mapping.perturbed_target(full, st, dev, 3)
+        assert dgr._shape_hint[skey][0] > 64
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), k
+        assert float(got["gt_color"].abs().sum()) > 0
+    finally:
+        dgr.set_sync_mode("exact")
