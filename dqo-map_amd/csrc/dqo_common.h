@@ -49,6 +49,15 @@ void dqo_profile_after(hipStream_t s);
         DQO_CHECK_LAUNCH();                                                      \
     } while (0)
 
+// ... with dynamic LDS
+#define DQO_LAUNCH_SMEM(name, kernel, grid, block, smem_bytes, stream, ...)       \
+    do {                                                                         \
+        if (g_dqo_profile_on) dqo_profile_before(name, stream);                  \
+        hipLaunchKernelGGL(kernel, grid, block, smem_bytes, stream, __VA_ARGS__); \
+        if (g_dqo_profile_on) dqo_profile_after(stream);                         \
+        DQO_CHECK_LAUNCH();                                                      \
+    } while (0)
+
 // ---- context buffer layouts (private) -------------------------------------------------------------------------
 // geom buffer: header + per-Gaussian SoA tables, every table 256-B aligned.
 struct DqoGeomLayout {

@@ -967,13 +967,20 @@ __global__ __launch_bounds__(BWD_THREADS * BWD_WPB, ROWS ? DQO_BWD_ROWS_WAVES : 
 // round; the blocks in between are eight independent single-wave walks, two tiles of one XCD band, skipping the long lists.
 constexpr int BSPLIT_RUNS = 8;
 constexpr int BSPLIT_GRID = 256;
-template <bool GATE>
+// LDS of a block: the eight waves' blocks + the pass-1 results of two round parities (long lists), or — ROWS: the short-list blocks walk
+// their lists like blend_backward_kernel<7, GATE, true>, the row walk — eight row-walk blocks: 72.7 KB, more than a kernel may declare
+// statically, so the array is the launch's dynamic LDS (two blocks per CU either way)
+constexpr int BSPLIT_LDS_SPLIT = BSPLIT_RUNS * BWD_BLK + 2 * BSPLIT_RUNS * BWD_XCH;
+constexpr int BSPLIT_LDS_ROWS = BSPLIT_RUNS * ROWS_BLK;
+template <bool ROWS>
+constexpr int bsplit_lds_words() { return (ROWS && BSPLIT_LDS_ROWS > BSPLIT_LDS_SPLIT) ? BSPLIT_LDS_ROWS : BSPLIT_LDS_SPLIT; }
+template <bool GATE, bool ROWS>
 __global__ __launch_bounds__(BWD_THREADS * BSPLIT_RUNS, 4) void blend_backward_split_kernel(const DqoView v, DqoGeomLayout g, DqoImageLayout img,
                                                                      DqoBinLayout bin, const float* __restrict__ dL_dpixels,
                                                                      const float* __restrict__ dL_ddepths,
                                                                      float* __restrict__ recs, uint8_t* __restrict__ valid,
                                                                      int64_t capacity, const DqoTapDev tap, const DqoGateDev gate) {
-    __shared__ uint32_t lds[BSPLIT_RUNS * BWD_BLK + 2 * BSPLIT_RUNS * BWD_XCH];  // the waves' blocks, then the pass-1 results (two parities)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bsplit_lds_words<ROWS>() words
     __shared__ uint32_t s_item;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
     if (tap.scale != nullptr && blockIdx.x == 0 && wave == 0) {
@@ -1007,8 +1014,8 @@ __global__ __launch_bounds__(BWD_THREADS * BSPLIT_RUNS, 4) void blend_backward_s
     if (slot >= T8) return;
     const uint32_t tile_u = img.tile_order[(b & 7) * T8 + slot];
     if (tile_u == 0xffffffffu) return;
-    blend_quadrant_bwd<7, GATE, 1>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, wave & 3, wave, lane,
-                                   lds, fwd_split > 0 ? fwd_split : 0x7fffffff, img.ranges[tile_u]);
+    blend_quadrant_bwd<7, GATE, 1, ROWS>(v, g, img, bin, dL_dpixels, dL_ddepths, recs, valid, capacity, tap, gate, (int)tile_u, wave & 3, wave, lane,
+                                         lds, fwd_split > 0 ? fwd_split : 0x7fffffff, img.ranges[tile_u]);
 }
 
 }  // namespace
@@ -1048,22 +1055,37 @@ int dqo_launch_blend_backward(const DqoView& v, const DqoGeomLayout& g, const Dq
         return e ? atoi(e) : 7;
     }();
     float* r = reinterpret_cast<float*>(recs);
-    if (list_split > 0) {
-        const dim3 grid(2 * BSPLIT_GRID + 8 * (((T + 7) / 8 + 1) / 2)), block(BWD_THREADS * BSPLIT_RUNS);
-        if (gate.gobj != nullptr)
-            DQO_LAUNCH("blend_backward_kernel", blend_backward_split_kernel<true>, grid, block, s, v, g, img, bin, dL_dcolor, dL_ddepth, r, valid,
-                       capacity, tap, gate);
-        else
-            DQO_LAUNCH("blend_backward_kernel", blend_backward_split_kernel<false>, grid, block, s, v, g, img, bin, dL_dcolor, dL_ddepth, r, valid,
-                       capacity, tap, gate);
-        return DQO_OK;
-    }
-    const dim3 grid(8 * ((T + 7) / 8) * 4 / BWD_WPB);
     // DQO_BWD_ROWS=0 (measurement / A-B only): the union walk (every entry on all 64 pixels of the quadrant) instead of the row walk
     static const bool rows = [] {
         const char* e = getenv("DQO_BWD_ROWS");
         return e ? atoi(e) != 0 : true;
     }();
+    if (list_split > 0) {
+        const dim3 grid(2 * BSPLIT_GRID + 8 * (((T + 7) / 8 + 1) / 2)), block(BWD_THREADS * BSPLIT_RUNS);
+        // (the row-walk variant's dynamic LDS is above the 64 KB a launch gets without asking: raised once per process and kernel)
+        static const int raised = [] {
+            const int bytes = bsplit_lds_words<true>() * 4;
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&blend_backward_split_kernel<true, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&blend_backward_split_kernel<false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            return (e1 == hipSuccess && e2 == hipSuccess) ? 1 : 0;
+        }();
+        const bool use_rows = rows && nb == 7 && raised != 0;
+#define DQO_BSPLIT(GT, RW)                                                                                                                 \
+    DQO_LAUNCH_SMEM("blend_backward_kernel", (blend_backward_split_kernel<GT, RW>), grid, block, (size_t)bsplit_lds_words<RW>() * 4, s, v, g, img, \
+                    bin, dL_dcolor, dL_ddepth, r, valid, capacity, tap, gate)
+        if (gate.gobj != nullptr) {
+            if (use_rows) DQO_BSPLIT(true, true);
+            else DQO_BSPLIT(true, false);
+        } else {
+            if (use_rows) DQO_BSPLIT(false, true);
+            else DQO_BSPLIT(false, false);
+        }
+#undef DQO_BSPLIT
+        return DQO_OK;
+    }
+    const dim3 grid(8 * ((T + 7) / 8) * 4 / BWD_WPB);
     if (rows && nb == 7) {
         if (gate.gobj != nullptr)
             DQO_LAUNCH("blend_backward_kernel", (blend_backward_kernel<7, true, true>), grid, dim3(BWD_THREADS * BWD_WPB), s, v, g, img, bin, dL_dcolor,

@@ -205,3 +205,24 @@ def test_fused_mapper_with_split_lists_and_a_partial_render_mask(env):
         outs.append((fm.xyz.detach().cpu().numpy().copy(), fm.shs.detach().cpu().numpy().copy(), float(fm.loss[0].item())))
     assert abs(outs[1][2] - outs[0][2]) <= 1e-5 * abs(outs[0][2])
     assert np.abs(outs[1][0] - outs[0][0]).mean() < 1e-6 and np.abs(outs[1][1] - outs[0][1]).mean() < 1e-6
+
+
+def test_the_split_kernels_walk_short_lists_exactly_like_the_unsplit_ones(env):
+    """With a threshold that no list reaches the split launch has no long list: its short-list blocks — the serial forward wave, and in
+    the backward the ROW walk of blend_backward_kernel<7, GATE, true> since round 6 (the union walk until then: last-bit differences
+    in the record sums) — must give the outputs and the gradients of list_split = 0 bit for bit."""
+    dgr = env
+    cam, sc = scenes.make_config(3, P=30000)
+    dL = _dL(cam, 9)
+    dgr.set_list_split(0)
+    a = U.HipRun(cam, sc)
+    ga = a.backward(dL, retain=False)
+    hdr = dgr.last_header()
+    dgr.set_list_split(max(64, 2 * int(hdr["max_tile_count"])))
+    b = U.HipRun(cam, sc)
+    gb = b.backward(dL, retain=False)
+    dgr.set_list_split(0)
+    for k in a.res:
+        assert np.array_equal(a.res[k], b.res[k]), k
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
