@@ -176,8 +176,8 @@ typedef struct DqoRastCtx {
      * opaque hit"; backward: the scale of T and the affine map of the colour blended behind), a scan over the round, then the blend /
      * walk of every chunk from its scanned start state — for launches that cannot fill the GPU, a strong-scaling shard of a few hundred
      * tiles, whose time is the time of the one longest list.  Read by the forward AND by the backward call: the forward builds the
-     * queue of long lists, the backward (given n > 0 too) walks that queue with eight waves per quadrant; a backward given 0 walks every
-     * list in one wave whatever the forward did.  The state is grouped by chunk, so results on those lists differ from the serial order
+     * queue of long lists, the backward (given n > 0 too) walks that queue with eight waves per quadrant (and every shorter list exactly
+     * like a backward given 0: same kernel code, same bits); a backward given 0 walks every list in one wave whatever the forward did.  The state is grouped by chunk, so results on those lists differ from the serial order
      * in the last bits (1e-7 relative; a pixel exactly on T_threshold may finish one entry earlier or later); shorter lists are treated
      * as with 0. */
     int32_t list_split;
