@@ -193,3 +193,41 @@ def test_a_forward_only_caller_checks_its_frame_and_renders_again(torch_cuda):
         assert float(got["gt_color"].abs().sum()) > 0
     finally:
         dgr.set_sync_mode("exact")
+
+
+@pytest.mark.parametrize("variant", ["gated", "colors_precomp", "sh_degree_1", "tile_mask"])
+def test_pooled_contexts_on_the_ops_other_inputs(torch_cuda, variant):
+    """The pooled path runs the per-Gaussian preprocess at the head of the binning kernel and its late part beside the sorts
+    (DqoRastCtx.frame_prezeroed + buckets): every input form of the op goes through those too — the object gate, precomputed colours,
+    a lower SH degree, a tile mask — and must give the bits of a context per call."""
+    import diff_gaussian_rasterization_depth as dgr
+    torch = torch_cuda
+    cam, sc = scenes.make_config(3, P=16000)
+    dL = _dL(cam, 11)
+    kw = {}
+    if variant == "gated":
+        res, _ = U.run_hip(cam, sc)
+        hit = res["hit_depth"][0]
+        go = np.asarray(sc["obj_id"], np.int32)
+        kw["object_gate"] = (go, np.where(hit >= 0, go[np.clip(hit, 0, None)], -1).astype(np.int32))
+    elif variant == "colors_precomp":
+        kw["colors_precomp"] = np.random.default_rng(2).uniform(0, 1, (16000, 3)).astype(np.float32)
+    elif variant == "sh_degree_1":
+        sc = dict(sc)
+        sc["shs"] = np.ascontiguousarray(sc["shs"][:, :4, :])
+        kw["sh_degree"] = 1
+    else:
+        tm = np.ones(((cam.H + 15) // 16, (cam.W + 15) // 16), np.int32)
+        tm[::3, :] = 0
+        kw["tile_mask"] = tm
+    ref = [U.run_hip(cam, _moved(sc, i), dL=dL, **kw) for i in range(4)]
+    try:
+        dgr.set_sync_mode("deferred")
+        for i in range(4):
+            h, g = U.run_hip(cam, _moved(sc, i), dL=dL, **kw)
+            dgr.verify_pending()
+            _same(ref[i][0], h), _same(ref[i][1], g)
+        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, 16000, cam.W, cam.H)
+        assert dgr._pool[key][0].order_valid and dgr._pool[key][0].clean
+    finally:
+        dgr.set_sync_mode("exact")
