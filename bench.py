@@ -1501,7 +1501,10 @@ def main():
             dgr.set_context_pool(False)
             alt["op_only_fresh_contexts_ms"] = round(time_path(op_only) * 1e3, 4)
             dgr.set_context_pool(True)
-            alt["op_only_what"] = "drop-in op forward + backward (+ the six activation ops and their autograd), fixed incoming gradient"
+            alt["op_only_what"] = ("drop-in op forward + backward (+ the six activation ops and their autograd), fixed incoming gradient; op_only_ms: "
+                                   "on the op's pooled contexts (its default in the 'lazy' / 'deferred' modes since round 6), "
+                                   "op_only_fresh_contexts_ms: a context allocated per call as the reference does (set_context_pool(False): the "
+                                   "figure op_only_ms_history was taken with)")
             del pr_
         else:
             other_runner = FusedRunner(prob, device, PackedAllReduce(LOSS_SPEC, device), 1, use_graph=not args.no_graph)
