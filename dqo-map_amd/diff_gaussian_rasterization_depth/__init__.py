@@ -546,6 +546,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                         pooled.order_valid = True
                     _pending.append((ev, host, key, cap, pooled is not None))
                     _last["header"] = (ev, host)
+        # Only grad_out_color and grad_out_depth are consumed by the backward (like the reference's, __init__.py:176-238): the engine need not
+        # fill zero images for the three float outputs nobody differentiated through (hit_color_weight, hit_depth_weight, T_map) — three
+        # fill launches per backward; an undefined colour / depth gradient arrives as None and is replaced by zeros there
+        if hasattr(ctx, "set_materialize_grads"):  # (callers that drive forward / backward by hand pass a plain object)
+            ctx.set_materialize_grads(False)
         ctx.pooled = lease  # (None: a context of this call's own)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
