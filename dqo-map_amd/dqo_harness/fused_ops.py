@@ -46,10 +46,13 @@ class _MaskedMappingLoss(torch.autograd.Function):
                                              N.ptr(dC), N.ptr(dD), N.ptr(ws), ws.numel(), N.current_stream()))
         ctx.save_for_backward(dC, dD)
         ctx.mark_non_differentiable(loss)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the gradient of `loss`, which nothing differentiates through)
         return loss[0].clone(), loss
 
     @staticmethod
     def backward(ctx, g_total, _g_loss):
+        if g_total is None:
+            return (None,) * 9
         dC, dD = ctx.saved_tensors
         return g_total * dC, g_total * dD, None, None, None, None, None, None, None
 
