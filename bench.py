@@ -1153,15 +1153,16 @@ def window_benchmark(args, prob, device, n_iters=400):
             g_ = torch.Generator(device="cpu").manual_seed(11)
             fm.set_training_rows(trainable=(torch.rand(fm.P, generator=g_) < frac).to(device))
         fm.begin_mapping_call(reset_optimizer=True)
-        fm.capture_window(frames, loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail, list_split=parse_list_split(args.list_split))
+        # (run_unroll: the stretches of the schedule that stay on one frame — its second half, the newest frame only — go as launches of
+        # --graph-unroll iterations, like the single-frame headline; where the frame changes between iterations: one launch each)
+        fm.capture_window(frames, loss_tap=not args.no_loss_tap, fused_tail=not args.no_fused_tail, list_split=parse_list_split(args.list_split),
+                          run_unroll=max(1, int(args.graph_unroll)))
         sched = FusedMapper.window_schedule(n_iters, K, random.Random(0))
-        for k in sched[:40]:
-            fm.replay(frame=k)
+        fm.replay_schedule(sched[:40])
         torch.cuda.synchronize()
         # the reference's call is 50-100 iterations (gaussian_update_iter); the schedule of ONE call of n_iters iterations is timed
         t0 = time.perf_counter()
-        for k in sched:
-            fm.replay(frame=k)
+        fm.replay_schedule(sched)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         fm._settle_replays()
@@ -1181,8 +1182,9 @@ def window_benchmark(args, prob, device, n_iters=400):
         torch.cuda.empty_cache()
     res["frames"] = K
     res["schedule"] = "mapper.py:570-576: random.randint(0, K - 1) per iteration, the newest frame once iter > n / 2; random.Random(0)"
-    res["what"] = ("one hipGraph launch per iteration (graph_unroll 1: the frame changes between iterations), one graph per frame with its own "
-                   "context buffers; per-object job as in the headline; confidence counter on")
+    res["what"] = ("one hipGraph launch per iteration while the frame changes between iterations, launches of --graph-unroll iterations on the "
+                   "stretches that stay on one frame (the schedule's second half: the newest frame only); one graph pair per frame with its own "
+                   "context buffers; per-object job as in the headline; confidence counter on; newest_frame_only_ms: one launch per iteration")
     return res
 
 

@@ -736,6 +736,7 @@ class FusedMapper:
     # ------------------------------------------------------------------ hipGraph path ------------------------------------
     def capture(self, gt_color, gt_depth, render_mask, tile_mask=None, capacity_margin=1.15, tile_buckets=True, keep_tile_order=True,
                 loss_tap=True, reuse_probe=False, fused_tail=True, list_split=0, unroll=1, settings=None, pixel_object=None, frame=None,
+                run_unroll=1,
                 short_bucket_margin=1.3):
         """Allocate persistent buffers for every intermediate of an iteration, run it once eagerly, then capture it into a
         hipGraph.  The inputs (gt images, masks) are read from the tensors passed here at every replay().
@@ -776,7 +777,7 @@ class FusedMapper:
         u8 = dict(dtype=torch.uint8, device=dev)
         tile_mask = self.tile_mask if tile_mask is None else _checked_tile_mask(tile_mask, dev, H, W)
         call_kw = dict(tile_mask=tile_mask, capacity_margin=capacity_margin, tile_buckets=tile_buckets, keep_tile_order=keep_tile_order,
-                       loss_tap=loss_tap, fused_tail=fused_tail, list_split=list_split, unroll=unroll, settings=settings,
+                       loss_tap=loss_tap, fused_tail=fused_tail, list_split=list_split, unroll=unroll, run_unroll=run_unroll, settings=settings,
                        pixel_object=pixel_object, frame=frame, short_bucket_margin=short_bucket_margin)
         pix_obj, tile_obj = self.pixel_object, self.tile_objects
         if pixel_object is not None:
@@ -937,6 +938,15 @@ class FusedMapper:
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
                 for _ in range(g.unroll):
                     self._static_iteration()
+            # run_unroll (capture_window): a SECOND graph over the same context buffers with that many iterations, for the stretches of a
+            # schedule that stay on one frame — the second half of local_optimize renders the newest frame only (mapper.py:574-576) —
+            # where one launch per iteration leaves the GPU idle for ~9 us between graphs (replay_run)
+            g.run_graph, g.run_unroll = None, max(1, int(run_unroll))
+            if g.run_unroll > 1:
+                g.run_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g.run_graph, capture_error_mode="thread_local"):
+                    for _ in range(g.run_unroll):
+                        self._static_iteration()
             self._expected_step = self.step_count + 1
         return self
 
@@ -1029,8 +1039,7 @@ class FusedMapper:
         while i < len(schedule):
             batch = schedule[i:i + check_every]
             start = self.step_count
-            for k in batch:
-                self.replay(frame=k)
+            self.replay_schedule(batch)
             lost = (start + len(batch)) - (int(self._step_dev.item()) - 1)
             if lost > 0:
                 self._settle_replays()
@@ -1043,6 +1052,7 @@ class FusedMapper:
                     self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
                                  tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0,
                                  loss_tap=g.tap is not None, fused_tail=g.fused_tail, list_split=g.list_split, unroll=g.unroll,
+                                 run_unroll=getattr(g, "run_unroll", 1),
                                  settings=g.settings, pixel_object=g.pixel_object if self.gaussian_object is not None else None, frame=k)
                     self._restore_state(snap)
                     recaptures += 1
@@ -1242,6 +1252,40 @@ class FusedMapper:
         self._expected_step = self.step_count + 1
         return g.out
 
+    def replay_run(self, frame, n):
+        """n consecutive iterations on ONE frame of the window: launches of the frame's run graph (capture_window(run_unroll=k): k
+        iterations each) while at least k remain, single launches for the rest — the same kernels in the same order as n replay(frame)
+        calls, bit for bit.  Returns the outputs like replay()."""
+        g = self._graph_of(frame)
+        k = getattr(g, "run_unroll", 1)
+        out = None
+        while n >= k and k > 1:
+            self._g = g
+            if g.stale:
+                raise RuntimeError("FusedMapper: the attach set / object gate changed since capture(); capture again")
+            if self._expected_step != self.step_count + 1:
+                self._resync_step_count()
+            g.run_graph.replay()
+            self._unsettled = True
+            self._attach_n = ((self.P + 255) // 256) * (4 if g.fused_tail else 1)
+            self.step_count += k
+            self._expected_step = self.step_count + 1
+            out = g.out
+            n -= k
+        for _ in range(n):
+            out = self.replay(frame=frame)
+        return out
+
+    def replay_schedule(self, schedule):
+        """The iterations of `schedule` (window_schedule) with every stretch on one frame handed to replay_run."""
+        i = 0
+        while i < len(schedule):
+            j = i
+            while j < len(schedule) and schedule[j] == schedule[i]:
+                j += 1
+            self.replay_run(schedule[i], j - i)
+            i = j
+
     def _settle_replays(self):
         """Make the host step count agree with what the device counted.  replay() assumes a valid frame; the device count only advances
         on valid ones (DqoAdamStep.frame_header: an overflowed frame is a no-op for the optimiser), so what it falls short of the count
@@ -1287,7 +1331,8 @@ class FusedMapper:
                 # (capture() re-reads the device-side step count: the valid replays of this batch stay counted, the others do not)
                 self.capture(g.gt_color, g.gt_depth, g.mask, tile_mask=g.tile_mask, capacity_margin=capacity_margin,
                              tile_buckets=g.bucket > 0, keep_tile_order=bool(g.cctx.keep_tile_order) or g.bucket > 0, loss_tap=g.tap is not None,
-                             fused_tail=g.fused_tail, list_split=g.list_split, settings=g.settings if g.settings is not self.settings else None,
+                             fused_tail=g.fused_tail, list_split=g.list_split, run_unroll=getattr(g, "run_unroll", 1),
+                             settings=g.settings if g.settings is not self.settings else None,
                              pixel_object=g.pixel_object if (self.gaussian_object is not None and g.pixel_object is not self.pixel_object) else None,
                              frame=g.frame)
                 recaptures += 1

@@ -427,3 +427,33 @@ def test_in_place_growth_keeps_the_captured_window(env):
     spare = fm.alive == 0
     assert int(fm._frames[1].out[8][spare].abs().max()) == 0 and int(fm._frames[0].out[8][spare].abs().max()) == 0   # spare rows are not rendered
     assert float(fm.confidence[rows].max()) >= 1
+
+
+def test_run_graphs_of_several_iterations_are_the_single_launches_bit_for_bit(env):
+    """capture_window(run_unroll=k): the stretches of a schedule that stay on one frame (the second half of local_optimize: the newest
+    frame only, mapper.py:574-576) go as launches of k iterations each — the same kernels in the same order as one launch per iteration:
+    parameters, moments, confidence, step count and losses must be the same bits."""
+    import random
+    torch, _ = env
+    from dqo_harness.fused_mapping import FusedMapper
+    P = 12000
+    sc, cams, frames, dev = _window_problem(torch, P, 3, seed=7)
+    sched = FusedMapper.window_schedule(21, 3, random.Random(2))
+    assert sched[-9:] == [2] * 9
+    res = []
+    for k in (1, 4):
+        fm = FusedMapper(sc, frames[0]["settings"], dev)
+        fm.begin_mapping_call(reset_optimizer=True)
+        fm.capture_window(frames, loss_tap=True, fused_tail=True, run_unroll=k)
+        assert (fm._frames[2].run_graph is not None) == (k > 1)
+        assert fm.run_window(sched, check_every=8) == 0
+        torch.cuda.synchronize()
+        assert fm.step_count == len(sched) and int(fm._step_dev.item()) == len(sched) + 1
+        res.append(([v.clone() for _, v in sorted(fm._params().items())], [m.clone() for _, (m, v) in sorted(fm.state.items())],
+                    [v.clone() for _, (m, v) in sorted(fm.state.items())], fm.confidence.clone(), fm.loss.clone()))
+    for a, b in zip(res[0], res[1]):
+        if isinstance(a, list):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+        else:
+            assert torch.equal(a, b)
